@@ -1,0 +1,217 @@
+"""Shared helpers for the tests and bench.py: .bin I/O, seeded problem generators,
+3x3-block CSR conversion, and the gauge-invariant parity metrics.
+
+Pure numpy; no GPU, no oracle, no reference imports.
+"""
+import os
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------------------
+# .bin matrix format (reference utils/io.py:17-54, XM_main.cu:18-33): int32 rows, int32 cols, f64 col-major
+# --------------------------------------------------------------------------------------------------
+
+
+def load_bin(fn):
+    with open(fn, "rb") as f:
+        r, c = (int(x) for x in np.fromfile(f, dtype="<i4", count=2))
+        d = np.fromfile(f, dtype="<f8", count=r * c)
+    if d.size != r * c:
+        raise IOError(f"{fn}: short file")
+    return d.reshape((r, c), order="F")
+
+
+def save_bin(fn, M):
+    M = np.atleast_2d(np.asarray(M, dtype=np.float64))
+    with open(fn, "wb") as f:
+        np.array(M.shape, dtype="<i4").tofile(f)
+        np.asfortranarray(M).T.tofile(f)  # == column-major bytes
+
+
+# --------------------------------------------------------------------------------------------------
+# generators
+# --------------------------------------------------------------------------------------------------
+
+
+def haar_so3(rng, n):
+    """n Haar-distributed rotations (QR of N(0,1) 3x3, sign-fixed, det -> +1).  Returns (n,3,3)."""
+    A = rng.standard_normal((n, 3, 3))
+    Qm, Rm = np.linalg.qr(A)
+    d = np.sign(np.diagonal(Rm, axis1=1, axis2=2))
+    d[d == 0] = 1.0
+    Qm = Qm * d[:, None, :]
+    det = np.linalg.det(Qm)
+    Qm[:, :, 2] *= det[:, None]
+    return Qm
+
+
+def so3_exp(w):
+    """Rodrigues; w (m,3) -> (m,3,3)"""
+    th = np.linalg.norm(w, axis=1)
+    K = np.zeros((w.shape[0], 3, 3))
+    K[:, 0, 1], K[:, 0, 2] = -w[:, 2], w[:, 1]
+    K[:, 1, 0], K[:, 1, 2] = w[:, 2], -w[:, 0]
+    K[:, 2, 0], K[:, 2, 1] = -w[:, 1], w[:, 0]
+    th2 = np.where(th < 1e-12, 1.0, th)
+    a = np.where(th < 1e-12, 1.0, np.sin(th2) / th2)
+    b = np.where(th < 1e-12, 0.5, (1 - np.cos(th2)) / th2**2)
+    return np.eye(3)[None] + a[:, None, None] * K + b[:, None, None] * (K @ K)
+
+
+def gen_dense(n, seed=None, eps=1e-3):
+    """G_dense(n, seed): fully dense 'Schur-complement-like' PSD Q with planted optimum U* (SURVEY §8d C2-C4).
+    eps = 0 gives the known-answer variant (f* = 0, R* = U*)."""
+    seed = n if seed is None else seed
+    rng = np.random.default_rng(seed)
+    Rs = haar_so3(rng, n)
+    U = Rs.reshape(3 * n, 3)
+    m = 3 * n
+    B = rng.standard_normal((m, m)) / np.sqrt(m)
+    M = B @ B.T
+    M[np.diag_indices(m)] += rng.uniform(0.5, 1.5, m)
+    Uo, _ = np.linalg.qr(U)                       # P = I - Uo Uo^T
+    MU = M @ Uo
+    Qm = M - Uo @ MU.T - MU @ Uo.T + Uo @ (Uo.T @ MU) @ Uo.T
+    if eps:
+        E = rng.standard_normal((m, m))
+        E = (E + E.T) * 0.5
+        Qm += (eps * np.linalg.norm(Qm) / np.linalg.norm(E)) * E
+    Qm = (Qm + Qm.T) * 0.5
+    return dict(Q=Qm, R_star=Rs, n=n)
+
+
+def gen_vg_edges(n, deg, seed):
+    """path 0-1-...-(n-1) union Erdos-Renyi G(n, p=(deg-2)/n); returns unique (i<j) edge array."""
+    rng = np.random.default_rng(seed)
+    path = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1)
+    p = max(deg - 2, 0) / n
+    m_expect = p * n * (n - 1) / 2
+    m = rng.poisson(m_expect) if m_expect > 0 else 0
+    e = rng.integers(0, n, size=(m, 2))
+    e = e[e[:, 0] != e[:, 1]]
+    e = np.sort(e, axis=1)
+    e = np.concatenate([path, e], axis=0)
+    key = e[:, 0].astype(np.int64) * n + e[:, 1]
+    _, idx = np.unique(key, return_index=True)
+    return e[np.sort(idx)], rng
+
+
+def gen_vg(n, deg=20, sigma=0.05, seed=None, dense=True):
+    """G_vg(n,deg,sigma,seed): view-graph connection-Laplacian Q.  Returns dict with BSR3 arrays
+    (rowptr int64, colidx int32, blocks (nb,3,3) row-major 3x3 = Q_ij) and optionally the dense matrix."""
+    seed = n if seed is None else seed
+    edges, rng = gen_vg_edges(n, deg, seed)
+    Rs = haar_so3(rng, n)
+    ne = edges.shape[0]
+    xi = rng.standard_normal((ne, 3)) * sigma
+    i, j = edges[:, 0], edges[:, 1]
+    Mij = Rs[i] @ so3_exp(xi) @ np.transpose(Rs[j], (0, 2, 1))
+    w = np.ones(ne)
+    degw = np.zeros(n)
+    np.add.at(degw, i, w)
+    np.add.at(degw, j, w)
+    rows = np.concatenate([np.arange(n), i, j])
+    cols = np.concatenate([np.arange(n), j, i])
+    blocks = np.concatenate([degw[:, None, None] * np.eye(3)[None], -w[:, None, None] * Mij,
+                             -w[:, None, None] * np.transpose(Mij, (0, 2, 1))], axis=0)
+    order = np.lexsort((cols, rows))
+    rows, cols, blocks = rows[order], cols[order], blocks[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    out = dict(n=n, rowptr=rowptr, colidx=cols.astype(np.int32), blocks=np.ascontiguousarray(blocks), R_star=Rs,
+               edges=edges)
+    if dense:
+        out["Q"] = bsr_to_dense(n, rowptr, out["colidx"], blocks)
+    return out
+
+
+def bsr_to_dense(n, rowptr, colidx, blocks):
+    Qm = np.zeros((3 * n, 3 * n))
+    for r in range(n):
+        for q in range(rowptr[r], rowptr[r + 1]):
+            c = colidx[q]
+            Qm[3 * r:3 * r + 3, 3 * c:3 * c + 3] = blocks[q]
+    return Qm
+
+
+def dense_to_bsr(Qm, tol=0.0):
+    n = Qm.shape[0] // 3
+    B = Qm.reshape(n, 3, n, 3).transpose(0, 2, 1, 3)
+    nz = np.abs(B).max(axis=(2, 3)) > tol
+    rows, cols = np.nonzero(nz)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    return np.cumsum(rowptr), cols.astype(np.int32), np.ascontiguousarray(B[rows, cols])
+
+
+def make_problem(kind, **kw):
+    if kind == "dense":
+        return gen_dense(**kw)
+    if kind == "vg":
+        return gen_vg(**kw)
+    raise ValueError(kind)
+
+
+# --------------------------------------------------------------------------------------------------
+# parity metrics (gauge invariant)
+# --------------------------------------------------------------------------------------------------
+
+
+def scale_rows(R, s):
+    s = np.asarray(s).reshape(-1)
+    return np.asarray(R) * np.repeat(s, 3)[:, None]
+
+
+def gram_sample_index(m, k=4096, seed=12345):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, m, size=(k, 2))
+
+
+def gram(R, s):
+    sR = scale_rows(R, s)
+    return sR @ sR.T
+
+
+def rel_fro(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def recover_rotations(R, s):
+    """Anchored O(3)/SO(3) rotations (3 x 3n) + scales — the quantity the pipeline consumes
+    (semantics of reference utils/recoversolution.py:22-86, re-implemented; r > 3 handled through the
+    r x r Gram matrix instead of the 3n x 3n one)."""
+    R = np.asarray(R, dtype=np.float64)
+    s = np.asarray(s, dtype=np.float64).reshape(-1)
+    n = s.shape[0]
+    sR = scale_rows(R, s)
+    if R.shape[1] > 3:
+        w, V = np.linalg.eigh(sR.T @ sR)
+        sR = sR @ V[:, ::-1][:, :3]
+    B = sR.reshape(n, 3, 3)                                   # B_i = camera block (3 x 3)
+    sc = np.linalg.norm(B, axis=(1, 2)) / np.sqrt(3.0)
+    Rt = np.transpose(B, (0, 2, 1)) / sc[:, None, None]       # reference works with B_i^T
+    Rt = Rt[0].T[None] @ Rt                                   # anchor to camera 0
+    U, _, Vt = np.linalg.svd(Rt)
+    P = U @ Vt
+    if (np.linalg.det(P) < 0).sum() > n / 2:
+        U, _, Vt = np.linalg.svd(-Rt)
+        P = U @ Vt
+    return np.concatenate(list(P), axis=1), sc
+
+
+def rotation_parity(Ra, sa, Rb, sb):
+    """relative Frobenius distance between the anchored rotations of two solutions"""
+    A, _ = recover_rotations(Ra, sa)
+    Bm, _ = recover_rotations(Rb, sb)
+    return rel_fro(A, Bm)
+
+
+def stiefel_defect(R):
+    n = R.shape[0] // 3
+    B = np.asarray(R).reshape(n, 3, -1)
+    G = B @ np.transpose(B, (0, 2, 1))
+    return float(np.abs(G - np.eye(3)[None]).max())
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
