@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py — BM iters/sec + wall-clock-to-KKT of the XM staircase solve on MI355X (BASELINE.json metric).
+
+One "step" = one complete Riemannian-staircase solve (rank 3.. max_rank, RTR-tCG + dual certificate) of the workload
+with Q already resident in HBM.  value = tCG inner iterations (each = one Q*W Hessian product, the reference's
+"Total iteration", trustregion.h:666/711) per second over the K timed solves; ms_per_step = wall-clock-to-KKT of one
+solve.  Workload at every N: the configuration the metric is quoted on, "Venice-1778": the reference ships no BAL Q
+(SURVEY.md F7), so it is the seeded dense SBA-like generator of SURVEY.md §8d with n = 1778 cameras
+(tests/xm_testlib.py:gen_dense).  For N > 1 the same problem is row-partitioned over the ranks (strong scaling) with an
+RCCL all-gather of the product input per Q*W.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]   (N > 1: via torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "xm-code_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+import xmamd  # noqa: E402  (loads libxm_amd.so before torch so that one HIP runtime serves the process)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def workload(name):
+    import xm_testlib as tl
+    if name == "venice1778":
+        return dict(kind="dense", n=1778, seed=1778, max_rank=5, tol=1e-6, lam=0.0,
+                    desc="Venice-1778-size dense SBA-like Q (G_dense(1778, seed 1778), SURVEY §8d C4), staircase max_rank 5, tol 1e-6")
+    if name == "dubrovnik356":
+        return dict(kind="dense", n=356, seed=356, max_rank=5, tol=1e-6, lam=0.0, desc="Dubrovnik-356-size dense Q")
+    if name == "ladybug49":
+        return dict(kind="dense", n=49, seed=49, max_rank=5, tol=1e-6, lam=0.0, desc="Ladybug-49-size dense Q")
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(Q, wl, budget_s):
+    """oracle (CPU restatement) on the SAME Q/options, bounded by the reference's own max_time mechanism."""
+    from oracle import xm_oracle as xo
+    n = Q.shape[0] // 3
+    R0 = np.tile(np.eye(3), (n, 1))
+    t0 = time.time()
+    _, _, primal, _, st = xo.trustregion(Q, R0, np.ones(n), lam=wl["lam"], gradtol=wl["tol"], maxtime=budget_s)
+    el = time.time() - t0
+    its = st["tcg_iters"]
+    return dict(value=its / max(st["seconds"], 1e-9), unit="tCG iters/s", cores=xo.num_threads(), kind="port",
+                sample=f"rank-3 trust region of the same Q on the host for <= {budget_s:.0f}s of its own max_time clock: "
+                       f"{its} tCG iters / {st['outer_iters']} outer in {st['seconds']:.1f}s (stop {st['stop_reason']}), "
+                       f"Q*W {st['qw_seconds'] / max(st['qw_products'], 1) * 1e3:.2f} ms each",
+                qw_ms=st["qw_seconds"] / max(st["qw_products"], 1) * 1e3, wall_s=el)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="venice1778")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    xmamd.require_gpu()
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only (id exchange, barrier, max)
+        uid = bytearray(128)
+        if rank == 0:
+            buf = (xmamd.C.c_char * 128)()
+            xmamd._chk(xmamd.lib().xm_comm_unique_id(buf))
+            uid = bytearray(buf.raw)
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0)
+        xmamd._chk(xmamd.lib().xm_comm_init(rank, world, local, box[0], None))   # data plane: RCCL over xGMI inside the C++ solver
+
+    wl = workload(args.workload)
+    import xm_testlib as tl
+    t0 = time.time()
+    Q = tl.gen_dense(wl["n"], seed=wl["seed"])["Q"]
+    gen_s = time.time() - t0
+    ctx = xmamd.Context(Q=Q)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def one_solve(flags=0):
+        return ctx.solve(wl["max_rank"], wl["tol"], wl["lam"], flags=flags)
+
+    for _ in range(args.warmup):
+        one_solve()
+    barrier()
+    t0 = time.perf_counter()
+    infos = []
+    for _ in range(args.steps):
+        infos.append(one_solve(flags=xmamd.FLAG_PROFILE_QW)[2])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    iters = sum(i["tcg_iters"] for i in infos)
+    last = infos[-1]
+    qw_ms = sum(i["qw_ms_sum"] for i in infos) / max(1, sum(i["qw_ms_count"] for i in infos))
+    # per-rank algorithmic bytes of one tCG product: this rank's rows of Q + W in/out (SURVEY §8d dense formula / world)
+    n = wl["n"]
+    o_fin = max(3, last["rank"])
+    alg_bytes = (8.0 * (3 * n) ** 2) / world + 2 * 8 * 3 * n * o_fin
+    achieved = alg_bytes / (qw_ms * 1e-3) / 1e9 if qw_ms > 0 else 0.0
+    out = {
+        "metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
+        "value": iters / elapsed, "unit": "tCG iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": wl["desc"], "n_cameras": n, "storage": "dense 3n x 3n f64 (%.1f MB)" % (72.0 * n * n / 1e6),
+                   "max_rank": wl["max_rank"], "tol": wl["tol"], "lam": wl["lam"],
+                   "parallelism": "single GPU" if world == 1 else f"camera row partition x{world}, RCCL all-gather of W per product"},
+        "solve": {"rank": last["rank"], "status": last["status"], "primal": last["primal"], "dual": last["dual"],
+                  "min_eig": last["min_eig"], "tcg_iters_per_solve": last["tcg_iters"], "outer_iters": last["outer_iters"],
+                  "qw_products": last["qw_products"], "lanczos_iters": last["lanczos_iters"],
+                  "tr_seconds": last["tr_seconds"], "cert_seconds": last["cert_seconds"], "setup_gen_s": gen_s},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "qw_dense_kernel<o, EPI_HESS>", "avg_launch_ms": qw_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves; Q (%.0f MB) fits the 256 MB "
+                             "Infinity Cache, so this is cache-assisted bandwidth, not pure HBM" % (72.0 * n * n / 1e6 / world)},
+    }
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(Q, wl, args.cpu_seconds)
+    ctx.close()
+    if world > 1:
+        xmamd.lib().xm_comm_finalize()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+/*
+ * xm_amd.h — C ABI of the MI355X-native XM solver (libxm_amd.so).
+ *
+ * Drop-in boundary for the Burer-Monteiro / Riemannian-staircase SDP solve of
+ * ComputationalRobotics/XM-code.  The reference exposes this path as three pybind11 functions
+ * (XM/src/XM_main.cu:403-408):
+ *      XM.solve(dataset_path, max_rank, tol, lam, max_time)           -> None   (XM_main.cu:180)
+ *      XM.solve_rank3(dataset_path, max_rank, tol, lam, max_time)     -> None   (XM_main.cu:312)
+ *      XM.solve_rebuttle(dataset_path, max_rank, tol, lam, max_time)  -> int    (XM_main.cu:35)
+ * Section 1 below are exactly those entry points (same argument meaning, same Q.bin/R.bin/s.bin
+ * files); the pybind11 module `XM` shipped in xm-code_amd/csrc/xm_pybind.cpp is a ~30-line shim
+ * over them (INTEGRATION.md shows the stub).  Sections 2-4 are additive: an in-memory context API
+ * (what bench.py times: Q already resident in HBM), kernel-level entry points on device pointers
+ * (what the parity tests call), and the multi-GPU row-partition hooks.
+ *
+ * Conventions: plain pointers and sizes only, no exceptions cross the ABI, 0 == success,
+ * negative == error (xm_last_error() gives the message).  All matrices float64.
+ * Host-side matrices use the reference's layouts (column-major; R is 3n x r, camera i = rows
+ * 3i..3i+2, XM_main.cu:231-237).  Device-side vectors use the solver's internal row-major
+ * "camera-major" layout: element (row r, column k) of a 3n x o matrix at r*o + k.
+ */
+#ifndef XM_AMD_H
+#define XM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ error codes */
+#define XM_OK              0
+#define XM_ERR_IO         -1   /* missing / short Q.bin etc. (reference: prints "cannot open file" and goes on, XM_main.cu:21-24) */
+#define XM_ERR_ARG        -2
+#define XM_ERR_HIP        -3   /* HIP runtime / no device / kernel failure */
+#define XM_ERR_COMM       -4   /* RCCL failure */
+#define XM_ERR_NOMEM      -5
+
+/* status codes of the staircase (solve_rebuttle's return value, XM_main.cu:35-178) */
+#define XM_STATUS_NONE          0
+#define XM_STATUS_CERTIFIED     1
+#define XM_STATUS_MAX_RANK      2
+#define XM_STATUS_LS_FAILED    -2
+
+const char *xm_last_error(void);
+const char *xm_version(void);
+
+/* ================================================================== 1. file-based surface == the reference's pybind functions */
+/* replaces XM_main.cu:180  solve(): reads <path>/Q.bin, writes <path>/R.bin and <path>/s.bin */
+int xm_solve(const char *dataset_path, unsigned int max_rank, double tol, double lam, double max_time);
+/* replaces XM_main.cu:312  solve_rank3() */
+int xm_solve_rank3(const char *dataset_path, unsigned int max_rank, double tol, double lam, double max_time);
+/* replaces XM_main.cu:35   solve_rebuttle(): also reads R_ini.bin / s_ini.bin; *status receives 1 / 2 / -2 / 0 */
+int xm_solve_rebuttle(const char *dataset_path, unsigned int max_rank, double tol, double lam, double max_time,
+                      int *status);
+
+/* ================================================================== 2. in-memory context API */
+typedef struct xm_ctx xm_ctx_t;
+
+#define XM_STORAGE_DENSE 0     /* dense symmetric 3n x 3n, column-major (the reference format, XM_main.cu:18-33,191) */
+#define XM_STORAGE_BSR3  1     /* 3x3-block CSR over view-graph edges, both triangles stored */
+
+typedef struct {
+    int64_t n;                 /* cameras */
+    int32_t storage;           /* XM_STORAGE_* */
+    int32_t q_on_device;       /* dense only: q is a DEVICE pointer already in the solver's padded row-major layout
+                                  (xm_dense_ld(n) doubles per row); the context borrows it (no copy) */
+    const double *q;           /* dense: host column-major (ldq >= 3n) unless q_on_device */
+    int64_t ldq;
+    int64_t nb;                /* BSR3: stored blocks */
+    const int64_t *rowptr;     /* n+1 */
+    const int32_t *colidx;     /* nb */
+    const double *blocks;      /* nb x 9, each block ROW-major (b[3*a+c] = Q[3i+a, 3j+c]) */
+} xm_problem_t;
+
+#define XM_MODE_SOLVE    0     /* XM_main.cu:180 */
+#define XM_MODE_RANK3    1     /* XM_main.cu:312 */
+#define XM_MODE_REBUTTLE 2     /* XM_main.cu:35 (s_ini honoured, R_ini overwritten by the identity stack like the reference) */
+
+#define XM_FLAG_VERBOSE        1u   /* reference-style progress lines on stdout (trustregion.h:504, checkeig.h:317-337) */
+#define XM_FLAG_FIX_STALE_SR   2u   /* recompute sR after the escalation line search (reference does not, trustregion.h:394-422) */
+#define XM_FLAG_PROFILE_QW     4u   /* time every 8th Q*W launch with HIP events (result.qw_*) */
+#define XM_FLAG_HOST_STEPPED   8u   /* debugging: synchronise after every tCG iteration instead of run-ahead polling */
+
+typedef struct {
+    uint32_t max_rank;
+    double tol, lam, max_time;
+    int32_t mode;
+    uint32_t flags;
+    const double *s_ini;       /* n values, XM_MODE_REBUTTLE only (may be NULL -> ones) */
+    int32_t trace_cap;         /* optional per-outer-iteration trace: records of 6 doubles */
+    double *trace;             /*   loss, gradnorm, inner_iters, endreason, trstatus, delta (same as the oracle) */
+} xm_options_t;
+
+typedef struct {
+    double *R;                 /* caller-allocated 3n x max(max_rank,3)+1, column-major, leading dim 3n */
+    double *s;                 /* caller-allocated n (s[0] == 1) */
+    int32_t rank;              /* columns of R that are valid (what R.bin would hold) */
+    int32_t status;            /* XM_STATUS_* */
+    double primal, dual, min_eig, gap;
+    int64_t tcg_iters;         /* sum over outer iterations of (i+1) — the reference's "Total iteration" */
+    int64_t outer_iters;
+    int64_t qw_products;       /* launches of the Q*W kernel (any epilogue) */
+    int64_t lanczos_iters;
+    double seconds;            /* wall clock of the whole solve (Q already resident) */
+    double tr_seconds;         /* time inside the trust-region loops */
+    double cert_seconds;       /* time inside the certificates */
+    double qw_ms_sum;          /* XM_FLAG_PROFILE_QW: summed duration of the sampled Q*W launches (HIP events) */
+    int64_t qw_ms_count;       /*   number of sampled launches */
+    int64_t qw_bytes;          /* algorithmic bytes of ONE tCG Q*W launch at the final rank */
+    int32_t trace_len;
+    int32_t last_stop_reason;
+} xm_result_t;
+
+int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out);          /* uploads / lays out Q on device 0 (or the rank's device) */
+int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res);
+void xm_ctx_destroy(xm_ctx_t *ctx);
+int64_t xm_dense_ld(int64_t n);                                       /* padded leading dimension (doubles) of the device layout */
+
+/* ================================================================== 3. kernel-level entry points (device pointers) */
+/* device memory helpers so that callers need no other GPU runtime */
+int xm_dev_count(int *count);
+int xm_dev_alloc(void **ptr, size_t bytes);
+int xm_dev_free(void *ptr);
+int xm_dev_h2d(void *dst, const void *src, size_t bytes);
+int xm_dev_d2h(void *dst, const void *src, size_t bytes);
+int xm_dev_sync(void);
+
+/* lay a host column-major symmetric Q out as the device row-major padded matrix (allocates *dq) */
+int xm_dense_upload(const double *q_host, int64_t ldq, int64_t n, double **dq);
+/* out = alpha * Q * W.  dq from xm_dense_upload; dW, dOut: device, row-major 3n x o (o in 1,3..10).
+ * Replaces cublasDgemm via DnMatDnMat (Dense/matmul.h:42-87). stream: hipStream_t or NULL. */
+int xm_qw_dense(const double *dq, int64_t n, int o, const double *dW, double *dOut, double alpha, void *stream);
+/* same product from 3x3-block CSR (device arrays; blocks row-major 9 doubles) */
+int xm_qw_bsr3(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o,
+               const double *dW, double *dOut, double alpha, void *stream);
+/* per-camera kernels (device, row-major 3n x o; s: n):
+ * Rout = MGS_rows(R + t*D) (Dense/batchedQR.h:42-67), sout = s*exp(t*ds/s) (trustregion.h:19-24), s[0] stays 1 */
+int xm_retract(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t,
+               double *dRout, double *dsout, void *stream);
+/* timing helper for bench.py: average milliseconds of `reps` back-to-back xm_qw_dense launches (HIP events) */
+int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
+
+/* ================================================================== 4. multi-GPU row partition (one process per GPU) */
+/* 128-byte unique id of the RCCL communicator: rank 0 calls xm_comm_unique_id and broadcasts the bytes
+ * (bench.py does that with torch.distributed); every rank then calls xm_comm_init before xm_ctx_create. */
+int xm_comm_unique_id(unsigned char id[128]);
+int xm_comm_init(int rank, int world, int device, const unsigned char id[128], const char *rccl_path /* NULL = default search */);
+int xm_comm_finalize(void);
+/* contiguous camera range [*c0, *c1) owned by `rank` (balanced by rows for dense, by stored blocks for BSR3) */
+int xm_partition(int64_t n, int world, int rank, int64_t *c0, int64_t *c1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XM_AMD_H */

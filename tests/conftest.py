@@ -19,3 +19,14 @@ def oracle():
     from oracle import xm_oracle as xo
     xo.lib()
     return xo
+
+
+@pytest.fixture(scope="session")
+def xmamd():
+    """ctypes binding of the product library (xm-code_amd/lib/libxm_amd.so)."""
+    p = os.path.join(ROOT, "xm-code_amd")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import xmamd as m
+    m.lib()
+    return m

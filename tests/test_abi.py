@@ -1,0 +1,92 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that include/xm_amd.h
+declares, the reference-named module `XM` exposes the reference's positional-only signatures, and the product
+path fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import xm_testlib as tl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported(xmamd):
+    hdr = open(os.path.join(ROOT, "include", "xm_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(xm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = xmamd.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, f"symbols declared in xm_amd.h but not exported: {missing}"
+    assert set(xmamd.EXPORTS) <= declared
+    assert b"gfx950" in L.xm_version()
+
+
+def test_struct_layout_matches_header(xmamd):
+    # POD structs cross the ABI by pointer: sizes must match what a C compiler produces for the header
+    import subprocess, tempfile
+    src = '#include "xm_amd.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n",sizeof(xm_problem_t),sizeof(xm_options_t),sizeof(xm_result_t));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        a, b, c = map(int, subprocess.check_output([os.path.join(d, "t")]).split())
+    assert (a, b, c) == (ctypes.sizeof(xmamd.Problem), ctypes.sizeof(xmamd.Options), ctypes.sizeof(xmamd.Result))
+
+
+def test_partition_is_contiguous_and_covers(xmamd):
+    L = xmamd.lib()
+    for n, w in [(1, 1), (7, 2), (1778, 8), (13682, 8), (100000, 8), (5, 8)]:
+        prev = 0
+        for r in range(w):
+            c0, c1 = ctypes.c_int64(), ctypes.c_int64()
+            assert L.xm_partition(n, w, r, ctypes.byref(c0), ctypes.byref(c1)) == 0
+            assert c0.value == prev and c1.value >= c0.value
+            prev = c1.value
+        assert prev == n
+    assert L.xm_partition(5, 0, 0, None, None) != 0
+
+
+def test_XM_module_surface(xmamd):
+    XM = xmamd.import_XM()
+    for f in ("solve", "solve_rebuttle", "solve_rank3"):
+        assert callable(getattr(XM, f))
+        doc = getattr(XM, f).__doc__
+        # five positional, unnamed arguments (no py::arg in the reference either, XM_main.cu:405-407)
+        assert all(f"arg{i}:" in doc for i in range(5)) and "arg5" not in doc and "arg0: str" in doc
+    assert "-> int" in XM.solve_rebuttle.__doc__ and "-> None" in XM.solve.__doc__
+    with pytest.raises(TypeError):
+        XM.solve("x")                                  # all five arguments are required
+    with pytest.raises(TypeError):
+        XM.solve("x", -3, 1e-6, 0.0, 10.0)             # unsigned max_rank
+    with pytest.raises(TypeError):
+        XM.solve(dataset_path="x", max_rank=3, tol=1e-6, lam=0.0, max_time=1.0)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only behaviour")
+def test_no_cpu_fallback(xmamd, tmp_path):
+    """Without a GPU every compute entry point must fail loudly instead of computing on the host."""
+    assert xmamd.device_count() == 0
+    Q = tl.gen_dense(5, seed=1)["Q"]
+    tl.save_bin(tmp_path / "Q.bin", Q)
+    XM = xmamd.import_XM()
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        XM.solve(str(tmp_path), 3, 1e-6, 0.0, 10.0)
+    assert not (tmp_path / "R.bin").exists()
+    with pytest.raises(xmamd.XmError):
+        xmamd.qw_dense(Q, np.ones((15, 3)))
+    with pytest.raises(xmamd.XmError):
+        xmamd.solve_dense(Q, 3, 1e-6, 0.0)
+    assert xmamd.lib().xm_solve(b"/nonexistent", 3, 1e-6, 0.0, 1.0) != 0
+
+
+def test_layout_helpers(xmamd):
+    M = np.arange(18.0).reshape(6, 3)
+    rm = xmamd.to_rm(M, rows=8)
+    assert rm.shape == (8, 3) and np.array_equal(xmamd.from_rm(rm, 6, 3), M)
+    M4 = np.arange(24.0).reshape(6, 4)
+    rm = xmamd.to_rm(M4)
+    assert rm.shape == (6, 5) and np.all(rm[:, 4] == 0) and np.array_equal(xmamd.from_rm(rm, 6, 4), M4)
+    assert xmamd.dense_ld(149) == 512 and xmamd.dense_ld(1778) == 5376

@@ -1,0 +1,189 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of libxm_amd.so and is checked
+against the CPU oracle on the same seeded inputs, against the golden fixtures, and through size-independent invariants."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import xm_testlib as tl
+
+pytestmark = pytest.mark.gpu
+G = tl.GOLDEN
+
+
+def _case(name):
+    d = os.path.join(G, name)
+    return tl.load_bin(os.path.join(d, "Q.bin")), json.load(open(os.path.join(d, "expected.json"))), d
+
+
+# ---------------------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("n,o", [(1, 3), (5, 3), (43, 3), (149, 3), (171, 4), (60, 5), (33, 7), (90, 10), (700, 3), (211, 1)])
+def test_qw_dense_matches_oracle(xmamd, oracle, n, o):
+    rng = np.random.default_rng(100 * n + o)
+    Q = rng.standard_normal((3 * n, 3 * n))          # deliberately NOT symmetric: rows of C must be used like cublasDgemm
+    W = rng.standard_normal((3 * n, o))
+    ref = oracle.qw(Q, W, 2.0)
+    got = xmamd.qw_dense(Q, W, 2.0)
+    assert tl.rel_fro(got, ref) < 1e-13
+
+
+@pytest.mark.parametrize("n,deg,o", [(1, 2, 3), (7, 3, 3), (200, 8, 3), (300, 20, 5), (150, 40, 10), (1000, 12, 4)])
+def test_qw_bsr3_matches_dense(xmamd, oracle, n, deg, o):
+    P = tl.gen_vg(n, deg=deg, sigma=0.3, seed=n + o)
+    W = np.random.default_rng(n).standard_normal((3 * n, o))
+    ref = oracle.qw(P["Q"], W, 1.0)
+    got = xmamd.qw_bsr3(P["rowptr"], P["colidx"], P["blocks"], W, 1.0)
+    assert tl.rel_fro(got, ref) < 1e-13
+
+
+def test_qw_empty_rows_bsr(xmamd):
+    # ragged: cameras without any stored block
+    n = 9
+    rowptr = np.array([0, 0, 2, 2, 2, 3, 3, 3, 3, 3], dtype=np.int64)
+    colidx = np.array([0, 8, 4], dtype=np.int32)
+    blocks = np.random.default_rng(3).standard_normal((3, 3, 3))
+    W = np.random.default_rng(4).standard_normal((3 * n, 3))
+    ref = tl.bsr_to_dense(n, rowptr, colidx, blocks) @ W
+    assert np.allclose(xmamd.qw_bsr3(rowptr, colidx, blocks, W), ref, atol=1e-13)
+
+
+@pytest.mark.parametrize("o", [3, 4, 6, 10])
+def test_retraction_matches_oracle(xmamd, oracle, o):
+    rng = np.random.default_rng(o)
+    n = 77
+    R = oracle.mgs_rows(rng.standard_normal((3 * n, o)))
+    D = 0.3 * rng.standard_normal((3 * n, o)); s = rng.uniform(0.5, 2.0, n); s[0] = 1.0
+    ds = rng.standard_normal(n)
+    Rn, sn = xmamd.retract(R, s, D, ds, 0.7)
+    assert np.allclose(Rn, oracle.mgs_rows(R + 0.7 * D), atol=1e-13)
+    exp = s * np.exp(0.7 * ds / s); exp[0] = 1.0      # the anchor's scale never moves
+    assert np.allclose(sn, exp, rtol=1e-14)
+    assert tl.stiefel_defect(Rn) < 1e-13
+
+
+# ---------------------------------------------------------------------------------------------- whole solves
+def _check_against_golden(R, s, info, exp, d, tol_rot=1e-6):
+    assert info["rank"] == exp["rank"] and info["status"] == exp["status"]
+    assert info["primal"] == pytest.approx(exp["f_star"], rel=1e-9, abs=1e-12)
+    assert tl.stiefel_defect(R) < 1e-12 and s[0] == 1.0
+    rot, _ = tl.recover_rotations(R, s)
+    assert tl.rel_fro(rot, np.load(os.path.join(d, "rot_anchor.npy"))) < tol_rot       # north_star: <= 1e-6
+    sR = tl.scale_rows(R, s)
+    idx = tl.gram_sample_index(sR.shape[0])
+    X = (sR[idx[:, 0]] * sR[idx[:, 1]]).sum(axis=1)
+    assert tl.rel_fro(X, np.load(os.path.join(d, "sR_gram_sample.npy"))) < tol_rot
+
+
+@pytest.mark.parametrize("name", ["simple1", "simple2", "synth/dense49", "synth/vg60_cert"])
+def test_solve_matches_golden_rank3(xmamd, name):
+    Q, exp, d = _case(name)
+    R, s, info = xmamd.solve_dense(Q, exp["max_rank"], exp["tol"], exp["lam"], trace=1000)
+    _check_against_golden(R, s, info, exp, d)
+    assert info["min_eig"] == pytest.approx(exp["cert"]["min_eig"], abs=1e-7)
+    assert info["dual"] == pytest.approx(exp["cert"]["dual"], rel=1e-8)
+    # early iterates agree with the oracle's trajectory (loss, gradnorm, inner count, exit reason)
+    head = np.array(exp["trace_head"])
+    got = info["trace"][: head.shape[0]]
+    assert np.allclose(got[:, 0], head[:, 0], rtol=1e-9) and np.allclose(got[:, 1], head[:, 1], rtol=1e-7)
+    assert np.array_equal(got[:, 2:5], head[:, 2:5])
+    # iteration counts are within a few of the oracle's (trajectories agree until round-off decides the last steps)
+    assert abs(info["outer_iters"] - exp["outer_iters"]) <= 2
+    assert abs(info["tcg_iters"] - exp["tcg_iters"]) <= 0.05 * exp["tcg_iters"] + 10
+
+
+def test_staircase_matches_oracle(xmamd, oracle):
+    """rank escalation 3 -> 6 with saddle escape along the certificate's eigenvector (XM_main.cu:223-277)"""
+    Q, exp, d = _case("synth/vg40_stair")
+    R, s, info = xmamd.solve_dense(Q, exp["max_rank"], exp["tol"], exp["lam"], trace=4000)
+    assert info["rank"] == exp["rank"] and info["status"] == 1
+    assert info["primal"] == pytest.approx(exp["f_star"], rel=1e-8)
+    # the certified optimum X = sR sR^T is unique -> gauge-invariant comparison with the oracle
+    Ro, so, io = oracle.solve(Q, exp["max_rank"], exp["tol"], exp["lam"], 1000.0)
+    assert tl.rel_fro(tl.gram(R, s), tl.gram(Ro, so)) < 1e-6
+    assert tl.rotation_parity(R, s, Ro, so) < 1e-6
+    # rank-3-only run stops at the saddle, like the oracle
+    R3, s3, i3 = xmamd.solve_dense(Q, 3, exp["tol"], exp["lam"])
+    assert i3["status"] == 2 and i3["min_eig"] < -1e-3
+
+
+def test_modes_rank3_and_rebuttle(xmamd, oracle):
+    Q, exp, d = _case("synth/dense49")
+    R, s, info = xmamd.solve_dense(Q, 7, 1e-3, 0.0, mode=xmamd.MODE_RANK3)
+    Ro, so, io = oracle.solve(Q, 7, 1e-3, 0.0, 1000.0, mode=1)
+    assert info["rank"] == 3 and tl.rel_fro(tl.gram(R, s), tl.gram(Ro, so)) < 1e-8
+    s_ini = np.linspace(0.9, 1.1, 49); s_ini[0] = 1.0
+    R2, s2, i2 = xmamd.solve_dense(Q, 5, 1e-12, 0.0, mode=xmamd.MODE_REBUTTLE, s_ini=s_ini)
+    Ro2, so2, io2 = oracle.solve(Q, 5, 1e-12, 0.0, 1000.0, mode=2, s_ini=s_ini)
+    assert i2["status"] == io2["status"] == 1
+    assert tl.rotation_parity(R2, s2, Ro2, so2) < 1e-6
+
+
+def test_host_stepped_equals_run_ahead(xmamd):
+    """the enqueue-ahead tCG must give bit-identical results to the fully synchronised debug mode"""
+    Q, exp, d = _case("simple2")
+    a = xmamd.solve_dense(Q, 3, 1e-16, 0.0, trace=100)
+    b = xmamd.solve_dense(Q, 3, 1e-16, 0.0, trace=100, flags=xmamd.FLAG_HOST_STEPPED)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2]["trace"], b[2]["trace"])
+
+
+def test_bsr_solve_equals_dense_solve(xmamd):
+    P = tl.gen_vg(300, deg=10, sigma=0.1, seed=5)
+    Rd, sd, idn = xmamd.solve_dense(P["Q"], 5, 1e-10, 10.0)
+    ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+    Rb, sb, ib = ctx.solve(5, 1e-10, 10.0)
+    ctx.close()
+    assert idn["status"] == ib["status"] == 1 and idn["rank"] == ib["rank"]
+    assert ib["primal"] == pytest.approx(idn["primal"], rel=1e-10)
+    assert tl.rotation_parity(Rb, sb, Rd, sd) < 1e-7
+    # planted rotations are recovered up to the noise level
+    rot, _ = tl.recover_rotations(Rb, sb)
+    Rs = P["R_star"]
+    ref = np.concatenate([Rs[0] @ Rs[i].T for i in range(300)], axis=1)
+    assert tl.rel_fro(rot, ref) < 0.2
+
+
+def test_file_surface_XM_module(xmamd, tmp_path):
+    """the reference's own entry point: XM.solve(path, ...) reading Q.bin, writing R.bin / s.bin (1_test_solve.py:42)"""
+    Q, exp, d = _case("simple1")
+    tl.save_bin(tmp_path / "Q.bin", Q)
+    os.environ["XM_QUIET"] = "1"
+    XM = xmamd.import_XM()
+    assert XM.solve(str(tmp_path) + "/", 3, 1e-16, 0.0, 1000) is None
+    R = tl.load_bin(tmp_path / "R.bin"); s = tl.load_bin(tmp_path / "s.bin")
+    assert R.shape == (447, 3) and s.shape == (149, 1) and s[0, 0] == 1.0
+    raw = open(tmp_path / "s.bin", "rb").read()
+    assert raw[:8] == np.array([149, 1], dtype="<i4").tobytes() and len(raw) == 8 + 8 * 149
+    rot, _ = tl.recover_rotations(R, s)
+    assert tl.rel_fro(rot, np.load(os.path.join(d, "rot_anchor.npy"))) < 1e-6
+    assert XM.solve_rebuttle is not None
+    tl.save_bin(tmp_path / "R_ini.bin", R); tl.save_bin(tmp_path / "s_ini.bin", s)
+    assert XM.solve_rebuttle(str(tmp_path), 3, 1e-10, 0.0, 1000) == 1
+    XM.solve_rank3(str(tmp_path), 3, 1e-3, 0.0, 1000)
+    assert tl.load_bin(tmp_path / "R.bin").shape == (447, 3)
+    with pytest.raises(RuntimeError):
+        XM.solve(str(tmp_path / "missing"), 3, 1e-6, 0.0, 10)
+
+
+@pytest.mark.parametrize("n", [356, 1778])
+def test_full_size_properties(xmamd, n):
+    """BASELINE configs at full size (Dubrovnik-356 / Venice-1778 camera counts, dense SBA-like Q): too big for the
+    oracle's O(n^3) certificate, so checked through size-independent properties: certificate closes (primal == dual,
+    lambda_min >= 0), iterate on the manifold, planted rotations recovered, product linearity."""
+    P = tl.gen_dense(n, seed=n)
+    R, s, info = xmamd.solve_dense(P["Q"], 5, 1e-9, 0.0)
+    assert info["status"] == 1 and info["rank"] == 3
+    assert abs(info["gap"]) <= 1e-6 * max(1.0, abs(info["primal"])) and info["min_eig"] > -1e-6
+    assert tl.stiefel_defect(R) < 1e-12
+    rot, sc = tl.recover_rotations(R, s)
+    Rs = P["R_star"]
+    ref = np.concatenate([Rs[0] @ Rs[i].T for i in range(n)], axis=1)
+    assert tl.rel_fro(rot, ref) < 5e-2 and abs(sc - 1).max() < 5e-2
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((3 * n, 3)); B = rng.standard_normal((3 * n, 3))
+    dq = xmamd.dense_upload(P["Q"])
+    lhs = xmamd.qw_dense(None, 2.0 * A - 0.5 * B, dq=dq)
+    rhs = 2.0 * xmamd.qw_dense(None, A, dq=dq) - 0.5 * xmamd.qw_dense(None, B, dq=dq)
+    assert tl.rel_fro(lhs, rhs) < 1e-13
+    assert tl.rel_fro(xmamd.qw_dense(None, A, dq=dq), P["Q"] @ A) < 1e-13
+    dq.free()

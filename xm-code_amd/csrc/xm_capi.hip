@@ -1,0 +1,223 @@
+// xm_capi.hip — extern "C" boundary (include/xm_amd.h).  No exceptions cross it.
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <vector>
+
+#include "xm_solver.h"
+
+struct xm_ctx {
+    std::unique_ptr<xm::Context> impl;
+};
+
+namespace {
+thread_local std::string g_err;
+int fail(const xm::Error &e) { g_err = e.what(); return e.code; }
+int fail(const std::exception &e) { g_err = e.what(); return XM_ERR_HIP; }
+
+#define XM_TRY try {
+#define XM_CATCH                                                       \
+    }                                                                  \
+    catch (const xm::Error &e) { return fail(e); }                     \
+    catch (const std::bad_alloc &) { g_err = "out of host memory"; return XM_ERR_NOMEM; } \
+    catch (const std::exception &e) { return fail(e); }
+
+void require_device() {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt < 1)
+        throw xm::Error(XM_ERR_HIP, "no HIP device available: the XM solver has no CPU fallback (it needs an MI355X / gfx950 GPU)");
+}
+
+// .bin matrix: int32 rows, int32 cols, float64 column-major (XM_main.cu:18-33, utils/io.py:17-54)
+void read_bin(const std::string &fn, std::vector<double> &d, int64_t &rows, int64_t &cols) {
+    std::ifstream f(fn, std::ios::binary);
+    if (!f) throw xm::Error(XM_ERR_IO, "cannot open file " + fn);
+    int32_t h[2];
+    f.read(reinterpret_cast<char *>(h), 8);
+    if (!f || h[0] < 0 || h[1] < 0) throw xm::Error(XM_ERR_IO, "bad header in " + fn);
+    rows = h[0]; cols = h[1];
+    d.resize((size_t)rows * (size_t)cols);
+    f.read(reinterpret_cast<char *>(d.data()), (std::streamsize)(d.size() * sizeof(double)));
+    if ((size_t)f.gcount() != d.size() * sizeof(double)) throw xm::Error(XM_ERR_IO, "short file " + fn);
+}
+void write_bin(const std::string &fn, const double *d, int32_t rows, int32_t cols) {
+    std::ofstream f(fn, std::ios::binary);
+    if (!f) throw xm::Error(XM_ERR_IO, "cannot write " + fn);
+    f.write(reinterpret_cast<const char *>(&rows), 4);
+    f.write(reinterpret_cast<const char *>(&cols), 4);
+    f.write(reinterpret_cast<const char *>(d), (std::streamsize)((size_t)rows * (size_t)cols * sizeof(double)));
+}
+
+int solve_path(const char *dataset_path, unsigned max_rank, double tol, double lam, double max_time, int mode, int *status) {
+    if (!dataset_path) throw xm::Error(XM_ERR_ARG, "dataset_path is NULL");
+    require_device();
+    const std::string base(dataset_path);
+    std::vector<double> Q, sini;
+    int64_t rows = 0, cols = 0;
+    read_bin(base + "/Q.bin", Q, rows, cols);           // XM_main.cu:185
+    if (rows != cols || rows % 3 != 0 || rows < 3) throw xm::Error(XM_ERR_IO, "Q.bin must be 3n x 3n");
+    const bool verbose = std::getenv("XM_QUIET") == nullptr;
+    if (verbose) printf("rows: %lld, cols: %lld\n", (long long)rows, (long long)cols);
+    const int64_t n = rows / 3;
+    if (mode == XM_MODE_REBUTTLE) {
+        int64_t r2, c2;
+        read_bin(base + "/s_ini.bin", sini, r2, c2);      // XM_main.cu:42,62
+        if ((int64_t)sini.size() < n) throw xm::Error(XM_ERR_IO, "s_ini.bin too short");
+        std::vector<double> rini;
+        read_bin(base + "/R_ini.bin", rini, r2, c2);      // read like the reference (XM_main.cu:41,61); its content is then
+                                                          // overwritten by the identity stack at rank 3 (XM_main.cu:95-103)
+    }
+    xm_problem_t prob;
+    std::memset(&prob, 0, sizeof(prob));
+    prob.n = n; prob.storage = XM_STORAGE_DENSE; prob.q = Q.data(); prob.ldq = rows;
+    xm::Context ctx(prob);
+    std::vector<double>().swap(Q);
+    const unsigned rmax = std::max(3u, max_rank);
+    std::vector<double> R((size_t)rows * (rmax + 1), 0.0), s((size_t)n, 1.0);
+    xm_options_t opt;
+    std::memset(&opt, 0, sizeof(opt));
+    opt.max_rank = max_rank; opt.tol = tol; opt.lam = lam; opt.max_time = max_time; opt.mode = mode;
+    opt.flags = verbose ? XM_FLAG_VERBOSE : 0;
+    opt.s_ini = sini.empty() ? nullptr : sini.data();
+    xm_result_t res;
+    std::memset(&res, 0, sizeof(res));
+    res.R = R.data(); res.s = s.data();
+    ctx.solve(opt, res);
+    if (xm::global_comm().rank == 0) {
+        write_bin(base + "/R.bin", R.data(), (int32_t)rows, res.rank);   // XM_main.cu:284-294
+        if (verbose) printf("saved R\n");
+        write_bin(base + "/s.bin", s.data(), (int32_t)n, 1);             // XM_main.cu:298-305
+    }
+    if (status) *status = res.status;
+    return XM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char *xm_last_error(void) { return g_err.c_str(); }
+const char *xm_version(void) { return "xm-amd 0.1 (gfx950)"; }
+
+int xm_solve(const char *p, unsigned int max_rank, double tol, double lam, double max_time) {
+    XM_TRY return solve_path(p, max_rank, tol, lam, max_time, XM_MODE_SOLVE, nullptr); XM_CATCH
+}
+int xm_solve_rank3(const char *p, unsigned int max_rank, double tol, double lam, double max_time) {
+    XM_TRY return solve_path(p, max_rank, tol, lam, max_time, XM_MODE_RANK3, nullptr); XM_CATCH
+}
+int xm_solve_rebuttle(const char *p, unsigned int max_rank, double tol, double lam, double max_time, int *status) {
+    XM_TRY return solve_path(p, max_rank, tol, lam, max_time, XM_MODE_REBUTTLE, status); XM_CATCH
+}
+
+int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out) {
+    XM_TRY
+    if (!prob || !out) throw xm::Error(XM_ERR_ARG, "null argument");
+    require_device();
+    auto *c = new xm_ctx;
+    try { c->impl.reset(new xm::Context(*prob)); } catch (...) { delete c; throw; }
+    *out = c;
+    return XM_OK;
+    XM_CATCH
+}
+int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res) {
+    XM_TRY
+    if (!ctx || !opt || !res) throw xm::Error(XM_ERR_ARG, "null argument");
+    ctx->impl->solve(*opt, *res);
+    return XM_OK;
+    XM_CATCH
+}
+void xm_ctx_destroy(xm_ctx_t *ctx) { delete ctx; }
+int64_t xm_dense_ld(int64_t n) { return xm::dense_ld(n); }
+
+int xm_dev_count(int *count) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    if (count) *count = c;
+    return XM_OK;
+}
+int xm_dev_alloc(void **ptr, size_t bytes) {
+    XM_TRY require_device(); XM_HIP_CHECK(hipMalloc(ptr, bytes ? bytes : 8)); XM_HIP_CHECK(hipMemset(*ptr, 0, bytes ? bytes : 8)); return XM_OK; XM_CATCH
+}
+int xm_dev_free(void *ptr) { XM_TRY XM_HIP_CHECK(hipFree(ptr)); return XM_OK; XM_CATCH }
+int xm_dev_h2d(void *dst, const void *src, size_t bytes) { XM_TRY XM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return XM_OK; XM_CATCH }
+int xm_dev_d2h(void *dst, const void *src, size_t bytes) { XM_TRY XM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return XM_OK; XM_CATCH }
+int xm_dev_sync(void) { XM_TRY XM_HIP_CHECK(hipDeviceSynchronize()); return XM_OK; XM_CATCH }
+
+int xm_dense_upload(const double *q_host, int64_t ldq, int64_t n, double **dq) {
+    XM_TRY
+    require_device();
+    if (!q_host || !dq || ldq < 3 * n) throw xm::Error(XM_ERR_ARG, "bad argument");
+    const int64_t ld = xm::dense_ld(n), m = 3 * n;
+    double *tmp = nullptr, *out = nullptr;
+    XM_HIP_CHECK(hipMalloc((void **)&tmp, (size_t)m * m * sizeof(double)));
+    XM_HIP_CHECK(hipMalloc((void **)&out, (size_t)m * ld * sizeof(double)));
+    XM_HIP_CHECK(hipMemcpy2D(tmp, (size_t)m * sizeof(double), q_host, (size_t)ldq * sizeof(double), (size_t)m * sizeof(double), (size_t)m,
+                             hipMemcpyHostToDevice));
+    xm::launch_transpose_pad(tmp, m, m, m, out, ld, nullptr);
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    XM_HIP_CHECK(hipFree(tmp));
+    *dq = out;
+    return XM_OK;
+    XM_CATCH
+}
+
+static xm::CamArgs plain_args(int64_t n, double *out) {
+    xm::CamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.nloc = (int)n;
+    a.out = out;
+    return a;
+}
+int xm_qw_dense(const double *dq, int64_t n, int o, const double *dW, double *dOut, double alpha, void *stream) {
+    XM_TRY
+    xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, xm::dense_ld(n), dW, alpha, plain_args(n, dOut), (hipStream_t)stream);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_qw_bsr3(const int64_t *rp, const int32_t *ci, const double *bl, int64_t n, int o, const double *dW, double *dOut, double alpha,
+               void *stream) {
+    XM_TRY
+    xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, alpha, plain_args(n, dOut), (hipStream_t)stream);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_retract(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t, double *dRout,
+               double *dsout, void *stream) {
+    XM_TRY
+    xm::launch_retract(o, (int)n, 0, dR, ds, dD, dds, t, dRout, dsout, nullptr, (hipStream_t)stream);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
+    XM_TRY
+    hipEvent_t e0, e1;
+    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+    const xm::CamArgs a = plain_args(n, dOut);
+    const int64_t ld = xm::dense_ld(n);
+    for (int i = 0; i < 3; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+    XM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_avg) *ms_avg = (double)ms / reps;
+    return XM_OK;
+    XM_CATCH
+}
+
+int xm_comm_unique_id(unsigned char id[128]) { XM_TRY xm::comm_unique_id(id); return XM_OK; XM_CATCH }
+int xm_comm_init(int rank, int world, int device, const unsigned char id[128], const char *rccl_path) {
+    XM_TRY require_device(); xm::comm_init(rank, world, device, id, rccl_path); return XM_OK; XM_CATCH
+}
+int xm_comm_finalize(void) { XM_TRY xm::comm_finalize(); return XM_OK; XM_CATCH }
+int xm_partition(int64_t n, int world, int rank, int64_t *c0, int64_t *c1) {
+    if (n < 0 || world < 1 || rank < 0 || rank >= world || !c0 || !c1) { g_err = "bad argument"; return XM_ERR_ARG; }
+    const int64_t per = (n + world - 1) / world;
+    *c0 = std::min<int64_t>(n, (int64_t)rank * per);
+    *c1 = std::min<int64_t>(n, (int64_t)(rank + 1) * per);
+    return XM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// xm_common.h — shared declarations of the MI355X-native XM solver (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace xm {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define XM_HIP_CHECK(expr)                                                                            \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            throw ::xm::Error(-3, std::string("HIP error: ") + hipGetErrorString(_e) + " at " +       \
+                                      __FILE__ + ":" + std::to_string(__LINE__) + " (" #expr ")");    \
+    } while (0)
+
+// Row pitch of every device "3n x o" matrix: o rounded up to an odd number.  An odd pitch makes the
+// per-lane ds_read_b128 of two consecutive W rows bank-conflict free (lane stride 4*OP dwords, OP odd).
+__host__ __device__ constexpr int pitch_of(int o) { return o | 1; }
+
+constexpr int kQwWaves = 4;       // cameras (wavefronts) per workgroup in the Q*W kernels
+constexpr int kQwTileCols = 512;  // columns of Q per LDS-staged W tile
+constexpr int kColPad = 128;      // dense leading dimension is a multiple of this (64 lanes x double2)
+constexpr int kMaxRank = 10;      // template instantiations cover o = 1 and 3..10
+constexpr int kMaxInner = 1000;   // trustregion.h:416
+constexpr int kMaxOuter = 1000;   // trustregion.h:417
+
+inline int64_t dense_ld(int64_t n_total) { return ((3 * n_total + kColPad - 1) / kColPad) * kColPad; }
+
+// Device-resident scalar state of the truncated CG (double-buffered by iteration parity; written only by
+// block 0 of the p-update kernel, read by everybody in the following launches).
+struct TcgScal {
+    double rr;        // <r,r>_metric of the current residual               (rdotr[i],   trustregion.h:484,626)
+    double vv, vp, pp;  // |v|^2, <v,p>, |p|^2 by recurrence                (trustregion.h:642-644)
+    double delta;     // trust-region radius
+    double gradnorm;  // sqrt(rdotr[0])                                     (trustregion.h:485)
+    double last_step; // alpha or tau of the last iteration (diagnostics)
+    int32_t status;   // 0 running | 1 negative curvature | 2 boundary | 3 norm tolerance | 5 rdotr<1e-15 | 6 max iterations
+    int32_t iter;     // inner iteration index i (== completed iterations)
+};
+
+// Everything the fused epilogues / per-camera kernels need.  All pointers are device pointers; matrices are
+// row-major with pitch OP = pitch_of(o); "local" arrays hold the cameras [cam0, cam0+nloc) owned by this GPU.
+struct CamArgs {
+    int nloc;            // local cameras
+    int cam0;            // global index of local camera 0 (camera 0 globally is the scale anchor, s == 1)
+    double lam;
+    // current point
+    const double *R;     // nloc*3*OP
+    const double *s;     // nloc
+    // point state produced by the gradient epilogue
+    double *G;           // 2*Q*sR rows
+    double *egs;         // Euclidean d f / d s   (0 for the anchor)
+    double *S0;          // nloc*9: sym(R_i egR_i^T), row-major 3x3
+    double *rgR;         // Riemannian gradient
+    double *rgs;
+    // tCG vectors
+    const double *pR;
+    const double *ps;
+    double *HpR;
+    double *Hps;
+    // generic
+    const double *Wloc;  // rows of the product input that belong to the local cameras (f partial)
+    double *out;         // plain epilogue output rows
+    double *partials;    // per-workgroup partial sums
+    // certificate operator  S x = Q x + dz.*x(row 3i) - Lam_i x_i
+    const double *Lam;   // nloc*9 row-major symmetric
+    const double *dz;    // nloc
+    const TcgScal *scal; // tCG kernels return immediately when scal->status != 0
+};
+
+enum Epilogue { EPI_PLAIN = 0, EPI_GRAD = 1, EPI_HESS = 2, EPI_CERT = 3 };
+
+// ---- launchers implemented in xm_kernels.hip -------------------------------------------------------------------
+// Q*W products.  grid = ceil(nloc / kQwWaves).  Q rows are the local cameras' rows; W has `ld` rows (all cameras).
+void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a,
+                     hipStream_t st);
+void launch_qw_bsr3(int o, int epi, const int64_t *rowptr, const int32_t *colidx, const double *blocks, const double *W,
+                    double alpha, const CamArgs &a, hipStream_t st);
+int qw_grid(int nloc);
+
+// layout helpers
+void launch_transpose_pad(const double *src_colmajor, int64_t lds, int64_t rows, int64_t cols, double *dst, int64_t ldd,
+                          hipStream_t st);  // dst[r*ldd + c] = src[r + c*lds]
+void launch_dense_from_bsr(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t nloc, int64_t cam0,
+                           double *dst, int64_t ldd, hipStream_t st);
+
+// flat / per-camera kernels
+int flat_grid(int64_t elems);
+void launch_scale_rows(int o, int nloc, const double *R, const double *s, double *Wloc, hipStream_t st);
+void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, const double *R, const double *s, double *rR,
+                     double *rs, double *pR, double *ps, double *vR, double *vs, double *HvR, double *Hvs, double *Wloc,
+                     TcgScal *scal0, double rr, double delta, unsigned long long *hstat, hipStream_t st);
+void launch_cg_update(int o, int nloc, const TcgScal *scal, const double *partsA, int nA, const double *pR, const double *ps,
+                      const double *HpR, const double *Hps, const double *s, double *vR, double *vs, double *HvR, double *Hvs,
+                      double *rR, double *rs, double *partsB, hipStream_t st);
+void launch_p_update(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *partsA, int nA,
+                     const double *partsB, int nB, const double *rR, const double *rs, const double *R, const double *s,
+                     double *pR, const double *ps_cur, double *ps_next, double *Wloc, unsigned long long *hstat,
+                     hipStream_t st);
+void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs,
+                        const double *rgR, const double *rgs, const double *s, double *parts, hipStream_t st);
+void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
+                    double *Rout, double *sout, double *Wloc, hipStream_t st);
+void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *QsR, const double *R, const double *s,
+                         double *Lam, double *dz, double *parts, hipStream_t st);
+// small vector kernels used by Lanczos
+void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, hipStream_t st);
+void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);
+void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hipStream_t st);
+void launch_gemv_n(double *y, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);  // y = V c
+
+}  // namespace xm

@@ -1,0 +1,882 @@
+// xm_kernels.hip — hand-written CDNA4 (gfx950) kernels of the XM Burer-Monteiro solve.
+//
+//   qw_dense_kernel   out = alpha * Q * W for the reference's dense Q (replaces cublasDgemm via DnMatDnMat,
+//                     Dense/matmul.h:42-87, call sites trustregion.h:165,187,237,553, checkeig.h:182).
+//                     HBM-bound (<= 2.5 flop/B): one wavefront per camera (3 rows of Q) streams its rows with
+//                     16-byte coalesced loads, the W tile is staged once per workgroup in LDS (odd row pitch ->
+//                     conflict-free ds_read_b128), fp64 FMA, wave-shuffle reduction, and the per-camera algebra that
+//                     the reference runs as ~40 extra launches (trustregion.h:227-295, 186-194, 307-317) is fused
+//                     into the epilogue.
+//   qw_bsr3_kernel    same product from 3x3-block CSR (coalesced reads of the block array, W gathered from L2).
+//   flat kernels      the tCG vector updates (trustregion.h:605-644) with device-side alpha/beta/tau and branch
+//                     logic, so the host never reads a scalar inside the inner loop.
+//   per-camera        MGS-QR retraction (Dense/batchedQR.h:42-67), scale retraction (trustregion.h:19-24),
+//                     certificate multipliers (closed form of checkeig.h:56-220).
+//
+// No MFMA on this path (no dense contraction with reuse); everything is float64 like the reference
+// (Optimization/optimization.h:9).
+#include "xm_common.h"
+
+namespace xm {
+
+// ----------------------------------------------------------------------------------------------------------------
+// wave / block reductions (deterministic: fixed shuffle tree, fixed block size 256)
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sum over the 256 threads of a block; result valid in every thread.  `sh` must hold >= 4 doubles.
+__device__ __forceinline__ double block_sum256(double v, double *sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// fixed-order sum of an array of partials by one 256-thread block (identical in every kernel that needs it)
+__device__ __forceinline__ double sum_partials256(const double *p, int count, double *sh) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) v += p[i];
+    return block_sum256(v, sh);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// fused epilogues, column-distributed: after the wave reduction lane k (< O) owns column k of the camera's 3 x O
+// block; every 3-vector below is "that column".  Reductions over k are wave_sum()s with lanes >= O contributing 0,
+// so the epilogue costs ~20 VGPRs whatever the rank (a lane-redundant version needs ~30*O).
+// ----------------------------------------------------------------------------------------------------------------
+struct Col3 {
+    double v[3];
+};
+template <int O>
+__device__ __forceinline__ Col3 load_col(const double *base, int cam, int lane) {
+    constexpr int OP = pitch_of(O);
+    Col3 c;
+    const double *p = base + (size_t)cam * 3 * OP + lane;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c.v[a] = (lane < O) ? p[a * OP] : 0.0;
+    return c;
+}
+template <int O>
+__device__ __forceinline__ void store_col(const Col3 &c, double *base, int cam, int lane) {
+    constexpr int OP = pitch_of(O);
+    double *p = base + (size_t)cam * 3 * OP + lane;
+    if (lane < O) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p[a * OP] = c.v[a];
+    }
+}
+__device__ __forceinline__ double dot3(const Col3 &x, const Col3 &y) { return x.v[0] * y.v[0] + x.v[1] * y.v[1] + x.v[2] * y.v[2]; }
+
+// S = sym(A B^T) with A, B 3 x O blocks held column-per-lane: 9 wave reductions, result uniform across the wave
+__device__ __forceinline__ void sym_abt(const Col3 &A, const Col3 &B, double (&S)[3][3]) {
+    double M[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) M[a][b] = wave_sum(A.v[a] * B.v[b]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) S[a][b] = (M[a][b] + M[b][a]) * 0.5;
+}
+// X -= S * Y   (column-wise, no communication)
+__device__ __forceinline__ void sub_s_times(Col3 &X, const double (&S)[3][3], const Col3 &Y) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) X.v[a] -= S[a][0] * Y.v[0] + S[a][1] * Y.v[1] + S[a][2] * Y.v[2];
+}
+
+// Gradient / point-state epilogue: trustregion.h:186-194 (grad), :307-317 (projection), :162-170 (objc) fused.
+// h = 2*C*sR rows.  Produces G, egs, S0, rg and this camera's share of {f, <rg,rg>_metric} (uniform on return).
+template <int O>
+__device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const CamArgs &a, double &p0, double &p1) {
+    const bool anchor = (a.cam0 + cam) == 0;
+    const double s = a.s[cam];
+    const Col3 R = load_col<O>(a.R, cam, lane);
+    const Col3 Wl = load_col<O>(a.Wloc, cam, lane);
+    store_col<O>(h, a.G, cam, lane);
+    // f = <C sR, sR> + lam * sum_{i>=1} (s_i^2-1)^2 ;  <C sR, sR> = 0.5 * <G, sR>
+    const double q = s * s - 1.0;
+    const double hW = wave_sum(dot3(h, Wl));
+    const double hR = wave_sum(dot3(h, R));
+    p0 = 0.5 * hW + (anchor ? 0.0 : a.lam * q * q);
+    const double egs = anchor ? 0.0 : hR + 4.0 * a.lam * (q * s);
+    Col3 eg;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) eg.v[r] = h.v[r] * s;
+    double S0[3][3];
+    sym_abt(R, eg, S0);
+    sub_s_times(eg, S0, R);  // eg is now the Riemannian gradient column
+    const double rgs = egs * (s * s);
+    store_col<O>(eg, a.rgR, cam, lane);
+    if (lane == 0) {
+        double *so = a.S0 + (size_t)cam * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) so[r * 3 + c] = S0[r][c];
+        a.egs[cam] = egs;
+        a.rgs[cam] = rgs;
+    }
+    const double rsds = rgs / s;
+    p1 = wave_sum(dot3(eg, eg)) + rsds * rsds;
+}
+
+// Hessian epilogue: trustregion.h:227-255 (ehess) + :277-295 (ehess2rhess) fused.  h = 2*C*(s.*Ru + su.*R) rows.
+// Produces Hp = (rhr, rhs) and this camera's share of <p, Hp>_metric.
+template <int O>
+__device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const CamArgs &a, double &p0) {
+    const bool anchor = (a.cam0 + cam) == 0;
+    const double s = a.s[cam];
+    const double ps = anchor ? 0.0 : a.ps[cam];
+    const Col3 R = load_col<O>(a.R, cam, lane);
+    const Col3 P = load_col<O>(a.pR, cam, lane);
+    const Col3 G = load_col<O>(a.G, cam, lane);
+    // hs = sum(CsRu.*R) + sum(CsR.*Ru) + 4 lam (3 s^2 - 1) su
+    const double hRGP = wave_sum(dot3(h, R)) + wave_sum(dot3(G, P));
+    const double hs = anchor ? 0.0 : hRGP + 4.0 * a.lam * ((3.0 * s * s - 1.0) * ps);
+    // hr = CsRu.*s + CsR.*su
+    Col3 rh;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) rh.v[r] = h.v[r] * s + G.v[r] * ps;
+    double S0[3][3], S1[3][3];
+    const double *sp = a.S0 + (size_t)cam * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) S0[r][c] = sp[r * 3 + c];
+    sub_s_times(rh, S0, P);   // rhr = ehessR - Ru * sym(R' egradR)
+    sym_abt(R, rh, S1);
+    sub_s_times(rh, S1, R);   // rhr -= R * sym(R' rhr)
+    const double rhs = anchor ? 0.0 : hs * (s * s) + (ps * s) * a.egs[cam];
+    store_col<O>(rh, a.HpR, cam, lane);
+    if (lane == 0) a.Hps[cam] = rhs;
+    p0 = wave_sum(dot3(P, rh)) + ps * (rhs / (s * s));
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// common tail of the Q*W kernels: wave reduction of the 3 x O accumulators, epilogue, per-workgroup partial sums
+// ----------------------------------------------------------------------------------------------------------------
+template <int O, int EPI>
+__device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool active, double (&acc)[3][O], double alpha,
+                                          const CamArgs &a, double (*red)[2]) {
+    constexpr int OP = pitch_of(O);
+    Col3 h;
+    h.v[0] = h.v[1] = h.v[2] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            const double t = alpha * wave_sum(acc[r][k]);
+            if (lane == k) h.v[r] = t;
+        }
+    double p0 = 0.0, p1 = 0.0;
+    if (active) {  // wave-uniform
+        if (EPI == EPI_PLAIN) {
+            store_col<O>(h, a.out, cam, lane);
+        } else if (EPI == EPI_GRAD) {
+            epi_grad<O>(cam, lane, h, a, p0, p1);
+        } else if (EPI == EPI_HESS) {
+            epi_hess<O>(cam, lane, h, a, p0);
+        } else if (EPI == EPI_CERT) {
+            // y_i = (Q x)_i + dz_i * x[3i] e_0 - Lam_i x_i      (O == 1, lane 0 owns the column)
+            const double *x = a.Wloc + (size_t)cam * 3 * OP;
+            const double *L = a.Lam + (size_t)cam * 9;
+            const double x0 = x[0], x1 = x[OP], x2 = x[2 * OP];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) h.v[r] -= L[r * 3 + 0] * x0 + L[r * 3 + 1] * x1 + L[r * 3 + 2] * x2;
+            h.v[0] += a.dz[cam] * x0;
+            store_col<O>(h, a.out, cam, lane);
+        }
+    }
+    if (EPI == EPI_GRAD || EPI == EPI_HESS) {
+        if (lane == 0) { red[wave][0] = p0; red[wave][1] = p1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.partials[blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+            if (EPI == EPI_GRAD) a.partials[gridDim.x + blockIdx.x] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// dense Q*W
+// ----------------------------------------------------------------------------------------------------------------
+template <int O, int EPI>
+__global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict__ Q, int64_t ld,
+                                                        const double *__restrict__ W, double alpha, CamArgs a) {
+    constexpr int OP = pitch_of(O);
+    constexpr int NSUB = kQwTileCols / 128;
+    if (EPI == EPI_HESS) {
+        if (a.scal->status != 0) return;  // tCG already terminated: enqueued-ahead launch becomes a no-op
+    }
+    __shared__ __attribute__((aligned(16))) double wt[kQwTileCols * OP];
+    __shared__ double red[kQwWaves][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cam = blockIdx.x * kQwWaves + wave;
+    const bool active = cam < a.nloc;
+    const double *q0 = Q + (size_t)(active ? cam : 0) * 3 * (size_t)ld + 2 * lane;
+
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+
+    for (int64_t c0 = 0; c0 < ld; c0 += kQwTileCols) {
+        // (1) issue this tile's Q loads first: 3 rows x NSUB x 16 B per lane, fully coalesced (1 KiB per wave-instruction)
+        double2 q[NSUB][3];
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            const int64_t c = c0 + u * 128;
+            if (active && c < ld) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) q[u][r] = *reinterpret_cast<const double2 *>(q0 + (size_t)r * ld + c);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) q[u][r] = make_double2(0.0, 0.0);
+            }
+        }
+        // (2) stage the W tile (rows c0..c0+511, pitch OP) in LDS: flat 16-byte copy, shared by the 4 wavefronts
+        const int64_t tile_cols = (ld - c0 < kQwTileCols) ? (ld - c0) : kQwTileCols;
+        const int n2 = (int)(tile_cols * OP / 2);
+        const double2 *wsrc = reinterpret_cast<const double2 *>(W + (size_t)c0 * OP);
+        double2 *wdst = reinterpret_cast<double2 *>(wt);
+        __syncthreads();
+        for (int j = threadIdx.x; j < n2; j += 256) wdst[j] = wsrc[j];
+        __syncthreads();
+        // (3) fp64 FMAs: per lane 2 columns x 3 rows x O
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            if (c0 + u * 128 < ld) {
+                const double2 *wp = reinterpret_cast<const double2 *>(wt) + (size_t)(u * 64 + lane) * OP;
+                double wv[2 * OP];
+#pragma unroll
+                for (int j = 0; j < OP; ++j) {
+                    const double2 t = wp[j];
+                    wv[2 * j] = t.x;
+                    wv[2 * j + 1] = t.y;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < O; ++k) acc[r][k] += q[u][r].x * wv[k] + q[u][r].y * wv[OP + k];
+            }
+        }
+    }
+    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, red);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// 3x3-block CSR Q*W: one wavefront per camera row; 63 lanes cover 7 blocks x 9 entries per step.
+// ----------------------------------------------------------------------------------------------------------------
+template <int O, int EPI>
+__global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                       const double *__restrict__ blocks, const double *__restrict__ W,
+                                                       double alpha, CamArgs a) {
+    constexpr int OP = pitch_of(O);
+    if (EPI == EPI_HESS) {
+        if (a.scal->status != 0) return;
+    }
+    __shared__ double red[kQwWaves][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cam = blockIdx.x * kQwWaves + wave;
+    const bool active = cam < a.nloc;
+    double part[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) part[k] = 0.0;
+    const int slot = lane / 9, e = lane - slot * 9;  // e = 3*row + col inside the block
+    const int ecol = e % 3;
+    if (active && lane < 63) {
+        const int64_t b0 = rowptr[cam], b1 = rowptr[cam + 1];
+        for (int64_t b = b0 + slot; b < b1; b += 7) {
+            const double qv = blocks[b * 9 + e];
+            const double *w = W + ((size_t)colidx[b] * 3 + ecol) * OP;
+#pragma unroll
+            for (int k = 0; k < O; ++k) part[k] += qv * w[k];
+        }
+    }
+    // reduce the 21 lanes (7 slots x 3 cols) that share a block row; every lane ends with the full 3 x O result
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const bool mine = (lane < 63) && (e / 3 == r);
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = mine ? part[k] : 0.0;
+    }
+    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, red);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// layout helpers
+// ----------------------------------------------------------------------------------------------------------------
+// dst[r*ldd + c] = src[r + c*lds]  (column-major host layout -> row-major padded device layout), 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const double *__restrict__ src, int64_t lds, int64_t rows,
+                                                             int64_t cols, double *__restrict__ dst, int64_t ldd) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int64_t r = r0 + tx, c = c0 + ty + j;
+        tile[ty + j][tx] = (r < rows && c < cols) ? src[r + c * lds] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int64_t r = r0 + ty + j, c = c0 + tx;
+        if (r < rows && c < ldd) dst[r * ldd + c] = (c < cols) ? tile[tx][ty + j] : 0.0;
+    }
+}
+
+__global__ void dense_from_bsr_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                      const double *__restrict__ blocks, int64_t nloc, int64_t cam0, double *dst, int64_t ldd) {
+    const int64_t cam = blockIdx.x;
+    if (cam >= nloc) return;
+    for (int64_t b = rowptr[cam0 + cam] + threadIdx.x / 9; b < rowptr[cam0 + cam + 1]; b += blockDim.x / 9) {
+        const int e = threadIdx.x % 9;
+        if (threadIdx.x / 9 < (int)(blockDim.x / 9))
+            dst[(cam * 3 + e / 3) * ldd + (int64_t)colidx[b] * 3 + e % 3] = blocks[b * 9 + e];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// flat kernels (grid-stride over the nloc*3*OP elements; the row -> camera map is idx / (3*OP))
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long pack_stat(int iter, int status) {
+    return ((unsigned long long)(unsigned)iter << 8) | (unsigned long long)(unsigned)(status & 0xff);
+}
+__device__ __forceinline__ void publish_host(unsigned long long *hstat, unsigned long long v) {
+    if (hstat) __hip_atomic_store(hstat, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct StepDecision {
+    int mode;     // 0 CG step (alpha) | 1 negative curvature (tau) | 2 boundary (tau) | 5 stop, residual below 1e-15
+    double step;
+};
+// trustregion.h:565-600, evaluated identically by every thread that needs it
+__device__ __forceinline__ StepDecision tcg_decide(const TcgScal &sc, double pHp) {
+    StepDecision d;
+    const double alpha = sc.rr / pHp;
+    if (sc.rr < 1e-15) { d.mode = 5; d.step = 0.0; return d; }
+    const bool neg = alpha <= 0.0;
+    if (neg || sc.vv + 2.0 * alpha * sc.vp + alpha * alpha * sc.pp > sc.delta * sc.delta) {
+        const double sq = sqrt(sc.vp * sc.vp + sc.pp * (sc.delta * sc.delta - sc.vv));
+        d.mode = neg ? 1 : 2;
+        d.step = (-sc.vp + sq) / sc.pp;
+        return d;
+    }
+    d.mode = 0; d.step = alpha;
+    return d;
+}
+
+template <int O>
+__global__ __launch_bounds__(256) void scale_rows_kernel(int nloc, const double *__restrict__ R, const double *__restrict__ s,
+                                                          double *__restrict__ Wloc) {
+    constexpr int OP = pitch_of(O);
+    const int64_t total = (int64_t)nloc * 3 * OP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        Wloc[i] = R[i] * s[i / (3 * OP)];
+}
+
+// r = rg, p = -rg, v = Hv = 0, W = s.*p + ps.*R   (trustregion.h:454-458, 476-482 and the first half of ehess :229-234)
+template <int O>
+__global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *__restrict__ rgR, const double *__restrict__ rgs,
+                                                        const double *__restrict__ R, const double *__restrict__ s,
+                                                        double *rR, double *rs, double *pR, double *ps, double *vR, double *vs,
+                                                        double *HvR, double *Hvs, double *Wloc, TcgScal *scal0, double rr,
+                                                        double delta, unsigned long long *hstat) {
+    constexpr int OP = pitch_of(O);
+    const int64_t total = (int64_t)nloc * 3 * OP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cam = (int)(i / (3 * OP));
+        const double g = rgR[i], gs = rgs[cam];
+        rR[i] = g; pR[i] = -g; vR[i] = 0.0; HvR[i] = 0.0;
+        Wloc[i] = s[cam] * (-g) + (-gs) * R[i];
+        if (i % (3 * OP) == 0) { rs[cam] = gs; ps[cam] = -gs; vs[cam] = 0.0; Hvs[cam] = 0.0; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        TcgScal sc;
+        sc.rr = rr; sc.vv = 0.0; sc.vp = 0.0; sc.pp = rr; sc.delta = delta; sc.gradnorm = sqrt(rr); sc.last_step = 0.0;
+        sc.status = 0; sc.iter = 0;
+        *scal0 = sc;
+        publish_host(hstat, pack_stat(0, 0));
+    }
+}
+
+// v += step p, Hv += step Hp, (CG step only) r += step Hp and the partial of <r,r>_metric   (trustregion.h:577-626)
+template <int O>
+__global__ __launch_bounds__(256) void cg_update_kernel(int nloc, const TcgScal *__restrict__ scal, const double *__restrict__ partsA,
+                                                         int nA, const double *__restrict__ pR, const double *__restrict__ ps,
+                                                         const double *__restrict__ HpR, const double *__restrict__ Hps,
+                                                         const double *__restrict__ s, double *vR, double *vs, double *HvR,
+                                                         double *Hvs, double *rR, double *rs, double *partsB) {
+    constexpr int OP = pitch_of(O);
+    __shared__ double sh[4];
+    const TcgScal sc = *scal;
+    if (sc.status != 0) return;
+    const double pHp = sum_partials256(partsA, nA, sh);
+    const StepDecision d = tcg_decide(sc, pHp);
+    if (d.mode == 5) return;
+    const int64_t total = (int64_t)nloc * 3 * OP;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const double hp = HpR[i];
+        vR[i] += d.step * pR[i];
+        HvR[i] += d.step * hp;
+        if (d.mode == 0) { const double r = rR[i] + d.step * hp; rR[i] = r; acc += r * r; }
+        if (i % (3 * OP) == 0) {
+            const int cam = (int)(i / (3 * OP));
+            const double hs = Hps[cam];
+            vs[cam] += d.step * ps[cam];
+            Hvs[cam] += d.step * hs;
+            if (d.mode == 0) { const double r = rs[cam] + d.step * hs; rs[cam] = r; const double q = r / s[cam]; acc += q * q; }
+        }
+    }
+    if (d.mode == 0) {
+        const double tot = block_sum256(acc, sh);
+        if (threadIdx.x == 0) partsB[blockIdx.x] = tot;
+    }
+}
+
+// beta, p = -r + beta p, W = s.*p + ps.*R for the next product, scalar recurrences, termination tests
+// (trustregion.h:625-644).  Block 0 owns the scalar state (written to the OTHER parity buffer).  The scale part of p
+// is ping-ponged too (ps_cur -> ps_next): every element thread of a camera reads it while one thread rewrites it.
+template <int O>
+__global__ __launch_bounds__(256) void p_update_kernel(int nloc, const TcgScal *__restrict__ scal_cur, TcgScal *scal_next,
+                                                        const double *__restrict__ partsA, int nA, const double *__restrict__ partsB,
+                                                        int nB, const double *__restrict__ rR, const double *__restrict__ rs,
+                                                        const double *__restrict__ R, const double *__restrict__ s, double *pR,
+                                                        const double *__restrict__ ps_cur, double *ps_next, double *Wloc,
+                                                        unsigned long long *hstat) {
+    constexpr int OP = pitch_of(O);
+    __shared__ double sh[4];
+    const TcgScal sc = *scal_cur;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (sc.status != 0) {
+        if (lead) *scal_next = sc;
+        return;
+    }
+    const double pHp = sum_partials256(partsA, nA, sh);
+    const StepDecision d = tcg_decide(sc, pHp);
+    if (d.mode != 0) {
+        if (lead) {
+            TcgScal nx = sc; nx.status = d.mode; nx.last_step = d.step;
+            *scal_next = nx;
+            publish_host(hstat, pack_stat(nx.iter, nx.status));
+        }
+        return;
+    }
+    const double rr2 = sum_partials256(partsB, nB, sh);
+    const double alpha = d.step;
+    if (sqrt(rr2) < sc.gradnorm * fmin(sc.gradnorm, 0.1)) {  // trustregion.h:627
+        if (lead) {
+            TcgScal nx = sc; nx.rr = rr2; nx.status = 3; nx.last_step = alpha;
+            *scal_next = nx;
+            publish_host(hstat, pack_stat(nx.iter, nx.status));
+        }
+        return;
+    }
+    const double beta = rr2 / sc.rr;
+    const int64_t total = (int64_t)nloc * 3 * OP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cam = (int)(i / (3 * OP));
+        const double pn = beta * pR[i] - rR[i];
+        const double psn = beta * ps_cur[cam] - rs[cam];
+        pR[i] = pn;
+        Wloc[i] = s[cam] * pn + psn * R[i];
+        if (i % (3 * OP) == 0) ps_next[cam] = psn;
+    }
+    if (lead) {
+        TcgScal nx = sc;
+        nx.rr = rr2;
+        nx.vv = sc.vv + 2.0 * alpha * sc.vp + alpha * alpha * sc.pp;  // trustregion.h:642-644
+        nx.vp = beta * (sc.vp + alpha * sc.pp);
+        nx.pp = beta * beta * sc.pp + rr2;
+        nx.last_step = alpha;
+        nx.iter = sc.iter + 1;
+        nx.status = (nx.iter >= kMaxInner) ? 6 : 0;
+        *scal_next = nx;
+        publish_host(hstat, pack_stat(nx.iter, nx.status));
+    }
+}
+
+// model decrease  m = <v,Hv>/2 + <v,rg>  in the product metric (trustregion.h:667-668)
+template <int O>
+__global__ __launch_bounds__(256) void model_value_kernel(int nloc, const double *__restrict__ vR, const double *__restrict__ vs,
+                                                           const double *__restrict__ HvR, const double *__restrict__ Hvs,
+                                                           const double *__restrict__ rgR, const double *__restrict__ rgs,
+                                                           const double *__restrict__ s, double *parts) {
+    constexpr int OP = pitch_of(O);
+    __shared__ double sh[4];
+    const int64_t total = (int64_t)nloc * 3 * OP;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        acc += vR[i] * (0.5 * HvR[i] + rgR[i]);
+        if (i % (3 * OP) == 0) {
+            const int cam = (int)(i / (3 * OP));
+            const double vsds = vs[cam] / (s[cam] * s[cam]);
+            acc += vsds * (0.5 * Hvs[cam] + rgs[cam]);
+        }
+    }
+    const double tot = block_sum256(acc, sh);
+    if (threadIdx.x == 0) parts[blockIdx.x] = tot;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// per-camera kernels (one thread per camera; 3 x O block in registers)
+// ----------------------------------------------------------------------------------------------------------------
+// Rout_i = MGS_rows(R_i + t D_i)  (Dense/batchedQR.h:42-67),  sout = s exp(t ds / s)  (trustregion.h:19-24),
+// Wloc_i = sout_i * Rout_i  (the next product's input, trustregion.h:677).  The anchor's scale stays untouched.
+template <int O>
+__global__ __launch_bounds__(256) void retract_kernel(int nloc, int cam0, const double *__restrict__ R, const double *__restrict__ s,
+                                                       const double *__restrict__ D, const double *__restrict__ ds, double t,
+                                                       double *Rout, double *sout, double *Wloc) {
+    constexpr int OP = pitch_of(O);
+    const int cam = blockIdx.x * 256 + threadIdx.x;
+    if (cam >= nloc) return;
+    const size_t base = (size_t)cam * 3 * OP;
+    double q[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) q[r][k] = R[base + r * OP + k] + t * D[base + r * OP + k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double qq = 0.0;
+#pragma unroll
+        for (int k = 0; k < O; ++k) qq += q[i][k] * q[i][k];
+        qq = sqrt(qq);
+#pragma unroll
+        for (int k = 0; k < O; ++k) q[i][k] /= qq;
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j) {
+            double uu = 0.0;
+#pragma unroll
+            for (int k = 0; k < O; ++k) uu += q[i][k] * q[j][k];
+#pragma unroll
+            for (int k = 0; k < O; ++k) q[j][k] -= uu * q[i][k];
+        }
+    }
+    const double so = s[cam];
+    const double sn = ((cam0 + cam) == 0 || ds == nullptr) ? so : so * exp(t * ds[cam] / so);
+    if (sout) sout[cam] = sn;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            Rout[base + r * OP + k] = q[r][k];
+            if (Wloc) Wloc[base + r * OP + k] = sn * q[r][k];
+        }
+        if (OP > O) { Rout[base + r * OP + O] = 0.0; if (Wloc) Wloc[base + r * OP + O] = 0.0; }
+    }
+}
+
+// Certificate multipliers, closed form per camera of the least-squares problem that the reference hands to Eigen's LSCG
+// (checkeig.h:56-220): generators of camera 0 are the six symmetric unit matrices, of camera i>=1 the five
+// traceless / off-diagonal ones.  Output: Lam_i = sum_k y_k A_k (row-major 3x3), dz_i = 2 lam (|sR row 3i|^2 - 1)
+// (checkeig.h:30-40), partials {tr(Lam_0) [dual], lam*(1 - xii^2) [checkeig.h:324-332]}.
+__device__ __forceinline__ void gen_matrix(int cam_is_anchor, int g, double (&A)[3][3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) A[a][b] = 0.0;
+    if (cam_is_anchor) {
+        // order (0,0),(0,1),(0,2),(1,1),(1,2),(2,2)   checkeig.h:71-98
+        const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+        const int i = ii[g], j = jj[g];
+        if (i == j) A[i][i] = 1.0; else { A[i][j] = 0.5; A[j][i] = 0.5; }
+    } else {
+        // 0.5(E00-E11), 0.5(E11-E22), 0.5(E01+E10), 0.5(E02+E20), 0.5(E12+E21)   checkeig.h:100-161
+        if (g == 0) { A[0][0] = 0.5; A[1][1] = -0.5; }
+        else if (g == 1) { A[1][1] = 0.5; A[2][2] = -0.5; }
+        else if (g == 2) { A[0][1] = 0.5; A[1][0] = 0.5; }
+        else if (g == 3) { A[0][2] = 0.5; A[2][0] = 0.5; }
+        else { A[1][2] = 0.5; A[2][1] = 0.5; }
+    }
+}
+
+template <int O>
+__global__ __launch_bounds__(256) void cert_prepare_kernel(int nloc, int cam0, double lam, const double *__restrict__ QsR,
+                                                            const double *__restrict__ R, const double *__restrict__ s,
+                                                            double *Lam, double *dz, double *parts) {
+    constexpr int OP = pitch_of(O);
+    __shared__ double sh[4];
+    const int cam = blockIdx.x * 256 + threadIdx.x;
+    double d0 = 0.0, d1 = 0.0;
+    if (cam < nloc) {
+        const size_t base = (size_t)cam * 3 * OP;
+        const bool anchor = (cam0 + cam) == 0;
+        const double sc = s[cam];
+        double B[3][O], Rt[3][O];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k) { B[r][k] = sc * R[base + r * OP + k]; Rt[r][k] = QsR[base + r * OP + k]; }
+        double xii = 0.0;
+#pragma unroll
+        for (int k = 0; k < O; ++k) xii += B[0][k] * B[0][k];
+        const double dzi = 2.0 * lam * (xii - 1.0);
+#pragma unroll
+        for (int k = 0; k < O; ++k) Rt[0][k] += dzi * B[0][k];  // Right = Z * sR with Z = C + diag term
+        // P = B B^T, M = sym(Right B^T)
+        double P[3][3], M[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                double tp = 0.0, tm = 0.0;
+#pragma unroll
+                for (int k = 0; k < O; ++k) { tp += B[a][k] * B[b][k]; tm += Rt[a][k] * B[b][k]; }
+                P[a][b] = tp; M[a][b] = tm;
+            }
+        const int ng = anchor ? 6 : 5;
+        double N[6][6], rhs[6];
+        for (int g = 0; g < ng; ++g) {
+            double A[3][3];
+            gen_matrix(anchor, g, A);
+            // rhs_g = <A_g B, Right> = <A_g, M>_F ;  AP = A_g P
+            double t = 0.0, AP[3][3];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    t += A[a][b] * M[a][b];
+                    AP[a][b] = A[a][0] * P[0][b] + A[a][1] * P[1][b] + A[a][2] * P[2][b];
+                }
+            rhs[g] = t;
+            for (int h = 0; h < ng; ++h) {
+                double A2[3][3];
+                gen_matrix(anchor, h, A2);
+                double u = 0.0;  // <A_g B, A_h B> = tr(A_g P A_h^T)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) u += AP[a][b] * A2[a][b];
+                N[g][h] = u;
+            }
+        }
+        // Gaussian elimination with partial pivoting (ng <= 6)
+        for (int c = 0; c < ng; ++c) {
+            int piv = c; double best = fabs(N[c][c]);
+            for (int r = c + 1; r < ng; ++r) if (fabs(N[r][c]) > best) { best = fabs(N[r][c]); piv = r; }
+            if (piv != c) {
+                for (int j = 0; j < ng; ++j) { const double tt = N[c][j]; N[c][j] = N[piv][j]; N[piv][j] = tt; }
+                const double tt = rhs[c]; rhs[c] = rhs[piv]; rhs[piv] = tt;
+            }
+            const double dd = N[c][c];
+            if (dd != 0.0)
+                for (int r = c + 1; r < ng; ++r) {
+                    const double f = N[r][c] / dd;
+                    for (int j = c; j < ng; ++j) N[r][j] -= f * N[c][j];
+                    rhs[r] -= f * rhs[c];
+                }
+        }
+        double y[6];
+        for (int c = ng - 1; c >= 0; --c) {
+            double acc = rhs[c];
+            for (int j = c + 1; j < ng; ++j) acc -= N[c][j] * y[j];
+            y[c] = (N[c][c] != 0.0) ? acc / N[c][c] : 0.0;
+        }
+        double L[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int g = 0; g < ng; ++g) {
+            double A[3][3];
+            gen_matrix(anchor, g, A);
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) L[a][b] += y[g] * A[a][b];
+        }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) Lam[(size_t)cam * 9 + a * 3 + b] = L[a][b];
+        dz[cam] = dzi;
+        d0 = anchor ? (y[0] + y[3] + y[5]) : 0.0;   // checkeig.h:322
+        d1 = (1.0 - xii * xii) * lam;               // checkeig.h:331
+    }
+    const double t0 = block_sum256(d0, sh);
+    const double t1 = block_sum256(d1, sh);
+    if (threadIdx.x == 0) { parts[blockIdx.x] = t0; parts[gridDim.x + blockIdx.x] = t1; }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// small vector kernels for the Lanczos eigen-solver of the certificate
+// ----------------------------------------------------------------------------------------------------------------
+// c[j] = V(:,j) . w   one block per column
+__global__ __launch_bounds__(256) void dots_multi_kernel(const double *__restrict__ V, int64_t ldv, const double *__restrict__ w,
+                                                          int64_t len, double *c) {
+    __shared__ double sh[4];
+    const double *v = V + (size_t)blockIdx.x * ldv;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < len; i += 256) acc += v[i] * w[i];
+    const double tot = block_sum256(acc, sh);
+    if (threadIdx.x == 0) c[blockIdx.x] = tot;
+}
+// w -= V c
+__global__ __launch_bounds__(256) void sub_vc_kernel(double *w, const double *__restrict__ V, int64_t ldv,
+                                                      const double *__restrict__ c, int m, int64_t len) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+        double acc = 0.0;
+        for (int j = 0; j < m; ++j) acc += V[(size_t)j * ldv + i] * c[j];
+        w[i] -= acc;
+    }
+}
+__global__ __launch_bounds__(256) void gemv_n_kernel(double *y, const double *__restrict__ V, int64_t ldv,
+                                                      const double *__restrict__ c, int m, int64_t len) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+        double acc = 0.0;
+        for (int j = 0; j < m; ++j) acc += V[(size_t)j * ldv + i] * c[j];
+        y[i] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void scale_copy_kernel(double *dst, const double *__restrict__ src, double a, int64_t len) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) dst[i] = a * src[i];
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// launchers (dispatch on the rank o)
+// ----------------------------------------------------------------------------------------------------------------
+int qw_grid(int nloc) { return (nloc + kQwWaves - 1) / kQwWaves; }
+int flat_grid(int64_t elems) {
+    int64_t g = (elems + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 1024) g = 1024;
+    return (int)g;
+}
+
+#define XM_DISPATCH_O(o, CALL)                                                         \
+    switch (o) {                                                                       \
+        case 1: { constexpr int O_ = 1; CALL; } break;                                 \
+        case 3: { constexpr int O_ = 3; CALL; } break;                                 \
+        case 4: { constexpr int O_ = 4; CALL; } break;                                 \
+        case 5: { constexpr int O_ = 5; CALL; } break;                                 \
+        case 6: { constexpr int O_ = 6; CALL; } break;                                 \
+        case 7: { constexpr int O_ = 7; CALL; } break;                                 \
+        case 8: { constexpr int O_ = 8; CALL; } break;                                 \
+        case 9: { constexpr int O_ = 9; CALL; } break;                                 \
+        case 10: { constexpr int O_ = 10; CALL; } break;                               \
+        default: throw Error(-2, "rank o must be 1 or 3..10, got " + std::to_string(o)); \
+    }
+
+static void check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Error(-3, std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
+}
+
+template <int O>
+static void qw_dense_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+    const dim3 g(qw_grid(a.nloc)), b(256);
+    switch (epi) {
+        case EPI_PLAIN: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_HESS>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        default: throw Error(-2, "bad epilogue");
+    }
+}
+void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+    if (a.nloc <= 0) return;
+    if (epi == EPI_CERT) {
+        if (o != 1) throw Error(-2, "certificate operator needs o == 1");
+        hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
+    } else {
+        XM_DISPATCH_O(o, (qw_dense_epi<O_>(epi, Q, ld, W, alpha, a, st)));
+    }
+    check_launch("qw_dense");
+}
+
+template <int O>
+static void qw_bsr3_epi(int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, double alpha,
+                        const CamArgs &a, hipStream_t st) {
+    const dim3 g(qw_grid(a.nloc)), b(256);
+    switch (epi) {
+        case EPI_PLAIN: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_PLAIN>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_HESS>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
+        default: throw Error(-2, "bad epilogue");
+    }
+}
+void launch_qw_bsr3(int o, int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, double alpha,
+                    const CamArgs &a, hipStream_t st) {
+    if (a.nloc <= 0) return;
+    if (epi == EPI_CERT) {
+        if (o != 1) throw Error(-2, "certificate operator needs o == 1");
+        hipLaunchKernelGGL((qw_bsr3_kernel<1, EPI_CERT>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, rp, ci, bl, W, alpha, a);
+    } else {
+        XM_DISPATCH_O(o, (qw_bsr3_epi<O_>(epi, rp, ci, bl, W, alpha, a, st)));
+    }
+    check_launch("qw_bsr3");
+}
+
+void launch_transpose_pad(const double *src, int64_t lds, int64_t rows, int64_t cols, double *dst, int64_t ldd, hipStream_t st) {
+    const dim3 g((unsigned)((ldd + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(transpose_pad_kernel, g, dim3(256), 0, st, src, lds, rows, cols, dst, ldd);
+    check_launch("transpose_pad");
+}
+void launch_dense_from_bsr(const int64_t *rp, const int32_t *ci, const double *bl, int64_t nloc, int64_t cam0, double *dst,
+                           int64_t ldd, hipStream_t st) {
+    hipLaunchKernelGGL(dense_from_bsr_kernel, dim3((unsigned)nloc), dim3(252), 0, st, rp, ci, bl, nloc, cam0, dst, ldd);
+    check_launch("dense_from_bsr");
+}
+
+void launch_scale_rows(int o, int nloc, const double *R, const double *s, double *Wloc, hipStream_t st) {
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((scale_rows_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
+                                        nloc, R, s, Wloc));
+    check_launch("scale_rows");
+}
+void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, const double *R, const double *s, double *rR, double *rs,
+                     double *pR, double *ps, double *vR, double *vs, double *HvR, double *Hvs, double *Wloc, TcgScal *scal0,
+                     double rr, double delta, unsigned long long *hstat, hipStream_t st) {
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((tcg_init_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
+                                        nloc, rgR, rgs, R, s, rR, rs, pR, ps, vR, vs, HvR, Hvs, Wloc, scal0, rr, delta, hstat));
+    check_launch("tcg_init");
+}
+void launch_cg_update(int o, int nloc, const TcgScal *scal, const double *partsA, int nA, const double *pR, const double *ps,
+                      const double *HpR, const double *Hps, const double *s, double *vR, double *vs, double *HvR, double *Hvs,
+                      double *rR, double *rs, double *partsB, hipStream_t st) {
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((cg_update_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
+                                        nloc, scal, partsA, nA, pR, ps, HpR, Hps, s, vR, vs, HvR, Hvs, rR, rs, partsB));
+    check_launch("cg_update");
+}
+void launch_p_update(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *partsA, int nA, const double *partsB,
+                     int nB, const double *rR, const double *rs, const double *R, const double *s, double *pR, const double *ps_cur,
+                     double *ps_next, double *Wloc, unsigned long long *hstat, hipStream_t st) {
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((p_update_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
+                                        nloc, scal_cur, scal_next, partsA, nA, partsB, nB, rR, rs, R, s, pR, ps_cur, ps_next, Wloc,
+                                        hstat));
+    check_launch("p_update");
+}
+void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs, const double *rgR,
+                        const double *rgs, const double *s, double *parts, hipStream_t st) {
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((model_value_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
+                                        nloc, vR, vs, HvR, Hvs, rgR, rgs, s, parts));
+    check_launch("model_value");
+}
+void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
+                    double *Rout, double *sout, double *Wloc, hipStream_t st) {
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_>), dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, R, s, D, ds, t,
+                                        Rout, sout, Wloc));
+    check_launch("retract");
+}
+void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *QsR, const double *R, const double *s, double *Lam,
+                         double *dz, double *parts, hipStream_t st) {
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((cert_prepare_kernel<O_>), dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, lam, QsR, R,
+                                        s, Lam, dz, parts));
+    check_launch("cert_prepare");
+}
+void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, hipStream_t st) {
+    if (m <= 0) return;
+    hipLaunchKernelGGL(dots_multi_kernel, dim3(m), dim3(256), 0, st, V, ldv, w, len, c);
+    check_launch("dots_multi");
+}
+void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st) {
+    if (m <= 0) return;
+    hipLaunchKernelGGL(sub_vc_kernel, dim3(flat_grid(len)), dim3(256), 0, st, w, V, ldv, c, m, len);
+    check_launch("sub_vc");
+}
+void launch_gemv_n(double *y, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st) {
+    hipLaunchKernelGGL(gemv_n_kernel, dim3(flat_grid(len)), dim3(256), 0, st, y, V, ldv, c, m, len);
+    check_launch("gemv_n");
+}
+void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hipStream_t st) {
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(flat_grid(len)), dim3(256), 0, st, dst, src, a, len);
+    check_launch("scale_copy");
+}
+
+}  // namespace xm

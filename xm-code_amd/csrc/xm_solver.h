@@ -1,0 +1,125 @@
+// xm_solver.h — host-side driver of the MI355X-native XM solve (C++; mirrors XM_main.cu / trustregion.h / checkeig.h).
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/xm_amd.h"
+#include "xm_common.h"
+
+namespace xm {
+
+// ---- communicator (row partition over the GPUs of one node; RCCL loaded at run time) -----------------------------
+struct Comm {
+    int rank = 0, world = 1;
+    bool active() const { return world > 1; }
+    // in-place all-gather on `stream`: every rank contributes `count` doubles located at buf + rank*count
+    void allgather(double *buf, size_t count, hipStream_t st);
+};
+Comm &global_comm();
+void comm_unique_id(unsigned char id[128]);
+void comm_init(int rank, int world, int device, const unsigned char id[128], const char *lib_path);
+void comm_finalize();
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    void alloc(size_t n, bool zero = true) {
+        release();
+        count = n;
+        XM_HIP_CHECK(hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)));
+        if (zero) XM_HIP_CHECK(hipMemset(p, 0, (n ? n : 1) * sizeof(T)));
+    }
+};
+
+struct PointState {  // everything the gradient epilogue writes for one point (R, s)
+    DevBuf<double> G, egs, S0, rgR, rgs;
+};
+
+struct TrResult {
+    double primal = 0;
+    int outer_iters = 0;
+    int stop_reason = 0;
+    bool ls_failed = false;
+};
+
+struct CertResult {
+    bool accepted = false;
+    double min_eig = 0, dual = 0, gap = 0;
+    int lanczos_iters = 0;
+};
+
+class Context {
+public:
+    explicit Context(const xm_problem_t &prob);
+    ~Context();
+    void solve(const xm_options_t &opt, xm_result_t &res);
+
+private:
+    // ---- problem ------------------------------------------------------------------------------------------------
+    int64_t n_ = 0;        // true cameras
+    int nloc_ = 0;         // cameras owned by this GPU (padded so that every rank owns the same number)
+    int cam0_ = 0;         // global index of the first local camera
+    int64_t ntot_ = 0;     // padded total = world * nloc
+    int64_t ld_ = 0;       // rows of every product input W (>= 3*ntot, multiple of 128)
+    int storage_ = XM_STORAGE_DENSE;
+    double *dQ_ = nullptr; // dense: 3*nloc rows x ld, row-major
+    bool ownQ_ = false;
+    DevBuf<int64_t> rowptr_;
+    DevBuf<int32_t> colidx_;
+    DevBuf<double> blocks_;
+    int64_t nb_loc_ = 0;
+    hipStream_t st_ = nullptr;
+    Comm *comm_ = nullptr;
+
+    // ---- per-rank workspace -------------------------------------------------------------------------------------
+    int o_ = 0, OP_ = 0;
+    DevBuf<double> R_, s_, Rc_, sc_, W_, D_;
+    PointState ps_[2];
+    int cur_ = 0;
+    DevBuf<double> rR_, rs_, pR_, psA_, psB_, vR_, vs_, HvR_, Hvs_, HpR_, Hps_;
+    DevBuf<double> partsA_, partsB_, partsM_;
+    DevBuf<TcgScal> scal_;
+    unsigned long long *hstat_ = nullptr;      // host-mapped progress word (iter << 8 | status)
+    unsigned long long *hstat_dev_ = nullptr;
+    double *hpin_ = nullptr;                   // pinned host scratch for partial sums
+    size_t hpin_count_ = 0;
+    int nA_ = 0, nB_ = 0;                      // partial counts (whole job)
+
+    // ---- options / statistics of the running solve -------------------------------------------------------------------
+    const xm_options_t *opt_ = nullptr;
+    xm_result_t *res_ = nullptr;
+    bool verbose_ = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
+    size_t ev_used_ = 0;
+    int64_t hess_launches_ = 0;
+
+    void setup_rank(int o);
+    void upload_point(const std::vector<double> &R_cm, int o, const std::vector<double> &s_ex);
+    void download_point(std::vector<double> &R_cm, std::vector<double> &s_ex);
+    CamArgs cam_args(int state) const;
+    void product(int epi, int o, double alpha, const CamArgs &a);
+    void gather_W();
+    void eval_point(int state, const double *Rp, const double *sp, double &f, double &rr);
+    double sum_parts(const double *dparts, int count);
+    int run_tcg(double rr, double delta, TcgScal &fin);
+    void drain_events();
+    TrResult trust_region(int o, double &gradtol, double linesearch_step, const std::vector<double> &v_dir, double max_time);
+    CertResult certificate(int o, double primal, std::vector<double> &v_out);
+    int lanczos_min(std::vector<double> &x_out, double &theta, int &iters);
+    void log(const char *fmt, ...) const;
+};
+
+}  // namespace xm

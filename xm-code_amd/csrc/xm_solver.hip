@@ -1,0 +1,753 @@
+// xm_solver.hip — host driver: Riemannian staircase (XM_main.cu:180-310), RTR-tCG (trustregion.h:77-724) and the
+// dual certificate (checkeig.h:42-368) on top of the kernels in xm_kernels.hip.
+//
+// Design notes (MI355X-first, not a translation of the reference's call sequence):
+//  * one Q pass per tCG iteration and ONE per outer iteration (the reference spends three: cost, gradient and a
+//    redundant 2*C*sR, trustregion.h:422/467/553): cost, gradient, projection and <g,g> all come out of the
+//    gradient epilogue of the candidate point, which becomes the next iterate's state when the step is accepted.
+//  * the inner loop never synchronises: alpha/beta/tau and the exit tests live in a device-resident scalar block;
+//    the host enqueues iterations a few ahead and watches a host-mapped progress word.
+//  * all per-camera state is row-major with an odd pitch (xm_common.h) so no transposes exist (the reference does 4
+//    per inner iteration, Dense/transpose.h:7-22).
+#include "xm_solver.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <thread>
+
+namespace xm {
+
+using clk = std::chrono::steady_clock;
+static double secs_since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+void Context::log(const char *fmt, ...) const {
+    if (!verbose_ || (comm_ && comm_->rank != 0)) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vprintf(fmt, ap);
+    va_end(ap);
+    fflush(stdout);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// construction: lay Q out on the device
+// ------------------------------------------------------------------------------------------------------------------
+Context::Context(const xm_problem_t &prob) {
+    comm_ = &global_comm();
+    const int world = comm_->world, rank = comm_->rank;
+    if (prob.n < 1) throw Error(XM_ERR_ARG, "n must be >= 1");
+    if (3 * prob.n > 2000000000LL) throw Error(XM_ERR_ARG, "n too large");
+    n_ = prob.n;
+    nloc_ = (int)((n_ + world - 1) / world);
+    cam0_ = rank * nloc_;
+    ntot_ = (int64_t)nloc_ * world;
+    ld_ = dense_ld(ntot_);
+    storage_ = prob.storage;
+    XM_HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    const int64_t true_loc = std::max<int64_t>(0, std::min<int64_t>(n_ - cam0_, nloc_));  // real cameras on this rank
+
+    if (storage_ == XM_STORAGE_DENSE) {
+        if (prob.q_on_device) {
+            dQ_ = const_cast<double *>(prob.q);
+            ownQ_ = false;
+        } else {
+            if (!prob.q || prob.ldq < 3 * n_) throw Error(XM_ERR_ARG, "dense Q needs q and ldq >= 3n");
+            const size_t rows = (size_t)3 * nloc_;
+            XM_HIP_CHECK(hipMalloc((void **)&dQ_, rows * (size_t)ld_ * sizeof(double)));
+            ownQ_ = true;
+            XM_HIP_CHECK(hipMemsetAsync(dQ_, 0, rows * (size_t)ld_ * sizeof(double), st_));
+            if (true_loc > 0) {
+                // rows [3 cam0, 3 cam0 + 3 true_loc) of the column-major host matrix, all 3n columns -> device slab
+                // (column-major, leading dim = local rows), then an LDS-tiled transpose into the padded row-major layout.
+                const int64_t lr = 3 * true_loc, cols = 3 * n_;
+                DevBuf<double> slab;
+                slab.alloc((size_t)lr * cols, false);
+                XM_HIP_CHECK(hipMemcpy2D(slab.p, (size_t)lr * sizeof(double), prob.q + 3 * (int64_t)cam0_, (size_t)prob.ldq * sizeof(double),
+                                         (size_t)lr * sizeof(double), (size_t)cols, hipMemcpyHostToDevice));
+                launch_transpose_pad(slab.p, lr, lr, cols, dQ_, ld_, st_);
+                XM_HIP_CHECK(hipStreamSynchronize(st_));
+            }
+        }
+    } else if (storage_ == XM_STORAGE_BSR3) {
+        if (!prob.rowptr || !prob.colidx || !prob.blocks) throw Error(XM_ERR_ARG, "BSR3 needs rowptr/colidx/blocks");
+        std::vector<int64_t> rp((size_t)nloc_ + 1, 0);
+        const int64_t b0 = (true_loc > 0) ? prob.rowptr[cam0_] : 0;
+        for (int64_t i = 0; i <= nloc_; ++i) {
+            const int64_t g = std::min<int64_t>(cam0_ + i, n_);
+            rp[(size_t)i] = ((true_loc > 0) ? prob.rowptr[std::max<int64_t>(g, cam0_)] : 0) - b0;
+        }
+        nb_loc_ = rp[(size_t)nloc_];
+        rowptr_.alloc((size_t)nloc_ + 1);
+        colidx_.alloc((size_t)std::max<int64_t>(nb_loc_, 1));
+        blocks_.alloc((size_t)std::max<int64_t>(nb_loc_, 1) * 9);
+        XM_HIP_CHECK(hipMemcpy(rowptr_.p, rp.data(), rp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (nb_loc_ > 0) {
+            XM_HIP_CHECK(hipMemcpy(colidx_.p, prob.colidx + b0, (size_t)nb_loc_ * sizeof(int32_t), hipMemcpyHostToDevice));
+            XM_HIP_CHECK(hipMemcpy(blocks_.p, prob.blocks + b0 * 9, (size_t)nb_loc_ * 9 * sizeof(double), hipMemcpyHostToDevice));
+        }
+    } else {
+        throw Error(XM_ERR_ARG, "unknown storage");
+    }
+    XM_HIP_CHECK(hipHostMalloc((void **)&hstat_, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(hstat_, 0, 64);
+    XM_HIP_CHECK(hipHostGetDevicePointer((void **)&hstat_dev_, hstat_, 0));
+}
+
+Context::~Context() {
+    for (auto &e : ev_pool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (ownQ_ && dQ_) (void)hipFree(dQ_);
+    if (hstat_) (void)hipHostFree(hstat_);
+    if (hpin_) (void)hipHostFree(hpin_);
+    if (st_) (void)hipStreamDestroy(st_);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-rank workspace
+// ------------------------------------------------------------------------------------------------------------------
+void Context::setup_rank(int o) {
+    o_ = o;
+    OP_ = pitch_of(o);
+    const size_t mat = (size_t)nloc_ * 3 * OP_, vec = (size_t)nloc_;
+    const int world = comm_->world;
+    for (DevBuf<double> *b : {&R_, &Rc_, &D_, &rR_, &pR_, &vR_, &HvR_, &HpR_}) b->alloc(mat);
+    for (DevBuf<double> *b : {&s_, &sc_, &rs_, &psA_, &psB_, &vs_, &Hvs_, &Hps_}) b->alloc(vec);
+    for (int k = 0; k < 2; ++k) {
+        ps_[k].G.alloc(mat); ps_[k].rgR.alloc(mat); ps_[k].egs.alloc(vec); ps_[k].rgs.alloc(vec); ps_[k].S0.alloc(vec * 9);
+    }
+    cur_ = 0;
+    W_.alloc((size_t)ld_ * OP_ + 2);
+    const int nA_loc = qw_grid(nloc_), nB_loc = flat_grid((int64_t)mat);
+    nA_ = nA_loc * world;
+    nB_ = nB_loc * world;
+    partsA_.alloc((size_t)2 * nA_);
+    partsB_.alloc((size_t)nB_);
+    partsM_.alloc((size_t)std::max(nB_, 2 * ((nloc_ + 255) / 256) * world));
+    scal_.alloc(2);
+    const size_t need = std::max<size_t>({(size_t)2 * nA_, (size_t)nB_, partsM_.count, (size_t)64});
+    if (need > hpin_count_) {
+        if (hpin_) (void)hipHostFree(hpin_);
+        XM_HIP_CHECK(hipHostMalloc((void **)&hpin_, need * sizeof(double), hipHostMallocDefault));
+        hpin_count_ = need;
+    }
+}
+
+// host column-major (true n) -> device row-major (pitch OP) rows of the local cameras; padding cameras get [I 0]
+void Context::upload_point(const std::vector<double> &R_cm, int o, const std::vector<double> &s_ex) {
+    const size_t m = (size_t)3 * n_;
+    std::vector<double> Rr((size_t)nloc_ * 3 * OP_, 0.0), sl((size_t)nloc_, 1.0);
+    for (int c = 0; c < nloc_; ++c) {
+        const int64_t g = (int64_t)cam0_ + c;
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < o; ++k)
+                Rr[((size_t)c * 3 + a) * OP_ + k] = (g < n_) ? R_cm[(size_t)(3 * g + a) + (size_t)k * m] : (a == k ? 1.0 : 0.0);
+        if (g < n_) sl[(size_t)c] = s_ex[(size_t)g];
+    }
+    if (cam0_ == 0) sl[0] = 1.0;  // the anchor's scale is 1 inside the solver (trustregion.h:125-127)
+    XM_HIP_CHECK(hipMemcpyAsync(R_.p, Rr.data(), Rr.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+    XM_HIP_CHECK(hipMemcpyAsync(s_.p, sl.data(), sl.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+// device -> host column-major for ALL cameras (gathers across ranks through the W buffer)
+void Context::download_point(std::vector<double> &R_cm, std::vector<double> &s_ex) {
+    const size_t m = (size_t)3 * n_, mat = (size_t)nloc_ * 3 * OP_;
+    std::vector<double> full((size_t)ntot_ * 3 * OP_), sf((size_t)ntot_);
+    XM_HIP_CHECK(hipMemcpyAsync(W_.p + (size_t)comm_->rank * mat, R_.p, mat * sizeof(double), hipMemcpyDeviceToDevice, st_));
+    if (comm_->active()) comm_->allgather(W_.p, mat, st_);
+    XM_HIP_CHECK(hipMemcpyAsync(full.data(), W_.p, full.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+    XM_HIP_CHECK(hipMemcpyAsync(W_.p + (size_t)comm_->rank * nloc_, s_.p, (size_t)nloc_ * sizeof(double), hipMemcpyDeviceToDevice, st_));
+    if (comm_->active()) comm_->allgather(W_.p, (size_t)nloc_, st_);
+    XM_HIP_CHECK(hipMemcpyAsync(sf.data(), W_.p, sf.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+    XM_HIP_CHECK(hipMemsetAsync(W_.p, 0, W_.count * sizeof(double), st_));
+    R_cm.assign(m * (size_t)o_, 0.0);
+    s_ex.assign((size_t)n_, 1.0);
+    for (int64_t g = 0; g < n_; ++g) {
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < o_; ++k) R_cm[(size_t)(3 * g + a) + (size_t)k * m] = full[((size_t)g * 3 + a) * OP_ + k];
+        s_ex[(size_t)g] = sf[(size_t)g];
+    }
+}
+
+CamArgs Context::cam_args(int state) const {
+    CamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.nloc = nloc_;
+    a.cam0 = cam0_;
+    a.lam = opt_ ? opt_->lam : 0.0;
+    a.R = R_.p;
+    a.s = s_.p;
+    const PointState &p = ps_[state];
+    a.G = p.G.p; a.egs = p.egs.p; a.S0 = p.S0.p; a.rgR = p.rgR.p; a.rgs = p.rgs.p;
+    a.pR = pR_.p; a.ps = psA_.p; a.HpR = HpR_.p; a.Hps = Hps_.p;
+    a.Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
+    a.out = HpR_.p;
+    a.partials = partsA_.p;
+    a.scal = scal_.p;
+    return a;
+}
+
+void Context::product(int epi, int o, double alpha, const CamArgs &a) {
+    if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
+    else launch_qw_bsr3(o, epi, rowptr_.p, colidx_.p, blocks_.p, W_.p, alpha, a, st_);
+    if (res_) res_->qw_products++;
+}
+
+void Context::gather_W() {
+    if (comm_->active()) comm_->allgather(W_.p, (size_t)nloc_ * 3 * OP_, st_);
+}
+
+double Context::sum_parts(const double *dparts, int count) {
+    XM_HIP_CHECK(hipMemcpyAsync(hpin_, dparts, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st_));
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+    double t = 0.0;
+    for (int i = 0; i < count; ++i) t += hpin_[i];
+    return t;
+}
+
+// Gradient epilogue on the point (Rp, sp) with the product input currently in W (already gathered).
+// Fills ps_[state]; returns f and <rg,rg>_metric.   trustregion.h:162-170 + 186-194 + 307-317 + 483-484
+void Context::eval_point(int state, const double *Rp, const double *sp, double &f, double &rr) {
+    const int nA_loc = qw_grid(nloc_);
+    CamArgs a = cam_args(state);
+    a.R = Rp;
+    a.s = sp;
+    a.partials = partsA_.p + (size_t)comm_->rank * 2 * nA_loc;
+    product(EPI_GRAD, o_, 2.0, a);
+    if (comm_->active()) comm_->allgather(partsA_.p, (size_t)2 * nA_loc, st_);
+    XM_HIP_CHECK(hipMemcpyAsync(hpin_, partsA_.p, (size_t)2 * nA_ * sizeof(double), hipMemcpyDeviceToHost, st_));
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+    f = 0.0; rr = 0.0;
+    for (int r = 0; r < comm_->world; ++r) {
+        const double *p = hpin_ + (size_t)r * 2 * nA_loc;
+        for (int i = 0; i < nA_loc; ++i) f += p[i];
+        for (int i = 0; i < nA_loc; ++i) rr += p[nA_loc + i];
+    }
+}
+
+void Context::drain_events() {
+    for (size_t i = 0; i < ev_used_; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev_pool_[i].first, ev_pool_[i].second) == hipSuccess) {
+            res_->qw_ms_sum += ms;
+            res_->qw_ms_count++;
+        }
+    }
+    ev_used_ = 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// truncated CG (trustregion.h:559-664): enqueue-ahead with a host-mapped progress word, no host sync per iteration
+// ------------------------------------------------------------------------------------------------------------------
+int Context::run_tcg(double rr, double delta, TcgScal &fin) {
+    const bool stepped = (opt_->flags & XM_FLAG_HOST_STEPPED) != 0;
+    const bool profile = (opt_->flags & XM_FLAG_PROFILE_QW) != 0;
+    const int nA_loc = qw_grid(nloc_), nB_loc = flat_grid((int64_t)nloc_ * 3 * OP_);
+    const int rank = comm_->rank;
+    double *Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
+    const PointState &P = ps_[cur_];
+    *hstat_ = ~0ull;
+    launch_tcg_init(o_, nloc_, P.rgR.p, P.rgs.p, R_.p, s_.p, rR_.p, rs_.p, pR_.p, psA_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, Wloc,
+                    scal_.p, rr, delta, hstat_dev_, st_);
+    gather_W();
+    const int run_ahead = comm_->active() ? 3 : 6;
+    int it = 0;  // iterations enqueued
+    auto enqueue = [&](int i) {
+        const int par = i & 1;
+        CamArgs a = cam_args(cur_);
+        a.scal = scal_.p + par;
+        a.ps = par ? psB_.p : psA_.p;
+        a.partials = partsA_.p + (size_t)rank * nA_loc;
+        const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
+        if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
+        product(EPI_HESS, o_, 2.0, a);
+        if (timed) { XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].second, st_)); ev_used_++; }
+        hess_launches_++;
+        if (comm_->active()) comm_->allgather(partsA_.p, (size_t)nA_loc, st_);
+        launch_cg_update(o_, nloc_, scal_.p + par, partsA_.p, nA_, pR_.p, a.ps, HpR_.p, Hps_.p, s_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p,
+                         rR_.p, rs_.p, partsB_.p + (size_t)rank * nB_loc, st_);
+        if (comm_->active()) comm_->allgather(partsB_.p, (size_t)nB_loc, st_);
+        launch_p_update(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), partsA_.p, nA_, partsB_.p, nB_, rR_.p, rs_.p, R_.p, s_.p, pR_.p,
+                        par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, Wloc, hstat_dev_, st_);
+        gather_W();
+    };
+    auto read_scal = [&](int par) {
+        TcgScal sc;
+        XM_HIP_CHECK(hipMemcpyAsync(&sc, scal_.p + par, sizeof(TcgScal), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        return sc;
+    };
+    if (stepped) {
+        for (;;) {
+            TcgScal sc = read_scal(it & 1);
+            if (sc.status != 0 || it >= kMaxInner) break;
+            enqueue(it++);
+        }
+    } else {
+        volatile unsigned long long *hs = hstat_;
+        auto last_progress = clk::now();
+        unsigned long long seen = ~0ull;
+        for (;;) {
+            const unsigned long long v = *hs;
+            if (v != seen) { seen = v; last_progress = clk::now(); }
+            const bool valid = (v != ~0ull);
+            const int status = valid ? (int)(v & 0xff) : 0;
+            const int done = valid ? (int)(v >> 8) : 0;
+            if (status != 0) break;
+            if (it < kMaxInner && it - done < run_ahead) { enqueue(it++); continue; }
+            if (secs_since(last_progress) > 200e-6) {
+                // Nothing new for a while: if the stream has drained the progress word is stale (or this platform does not
+                // make device writes to mapped host memory visible promptly) -> read the truth from the device.
+                if (hipStreamQuery(st_) == hipSuccess) {
+                    TcgScal sc = read_scal(it & 1);
+                    if (sc.status != 0) break;
+                    if (it >= kMaxInner) break;
+                    *hstat_ = ((unsigned long long)(unsigned)sc.iter << 8);
+                    if (it - sc.iter >= run_ahead) enqueue(it++);  // cannot happen, but never stall
+                }
+                last_progress = clk::now();
+            }
+        }
+    }
+    fin = read_scal(it & 1);
+    if (fin.status == 0) fin.status = 6;  // ran out of iterations
+    return it;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Riemannian trust region (trustregion.h:77-724).  On entry R_/s_ hold the initial point.
+// ------------------------------------------------------------------------------------------------------------------
+TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, const std::vector<double> &v_dir, double max_time) {
+    TrResult out;
+    const double lam = opt_->lam;
+    (void)lam;
+    const double dim = (double)n_ * (3.0 * o - 6.0) + (double)n_ - 1.0;  // trustregion.h:104
+    const double delta_bar = std::sqrt(dim);
+    double delta = delta_bar / 8.0;
+    double *Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
+    double f = 0, rr = 0;
+
+    log("start linesearch\n");
+    if (linesearch_step != 0) {  // trustregion.h:360-408
+        launch_scale_rows(o, nloc_, R_.p, s_.p, Wloc, st_);
+        gather_W();
+        double f0, tmp;
+        eval_point(cur_ ^ 1, R_.p, s_.p, f0, tmp);
+        double alpha = linesearch_step;
+        // direction: v in the new last column only
+        std::vector<double> D((size_t)nloc_ * 3 * OP_, 0.0);
+        for (int c = 0; c < nloc_; ++c) {
+            const int64_t g = (int64_t)cam0_ + c;
+            if (g < n_) for (int a = 0; a < 3; ++a) D[((size_t)c * 3 + a) * OP_ + (o - 1)] = v_dir[(size_t)(3 * g + a)];
+        }
+        XM_HIP_CHECK(hipMemcpyAsync(D_.p, D.data(), D.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+        double fn;
+        for (;;) {
+            launch_retract(o, nloc_, cam0_, R_.p, s_.p, D_.p, nullptr, -alpha, Rc_.p, nullptr, Wloc, st_);
+            gather_W();
+            eval_point(cur_ ^ 1, Rc_.p, s_.p, fn, tmp);
+            if (!(fn > f0)) break;
+            alpha *= 0.5;
+            if (alpha < 1e-20) { log("linesearch failed! BM stopped! \n"); out.primal = -1; out.ls_failed = true; out.stop_reason = -1; return out; }
+        }
+        if (f0 - fn > 0) {
+            log("linesearch decrease %1.3e\n", f0 - fn);
+            if (opt_->flags & XM_FLAG_FIX_STALE_SR) {
+                std::swap(R_.p, Rc_.p);
+                launch_scale_rows(o, nloc_, R_.p, s_.p, Wloc, st_);
+            } else {
+                // the reference keeps sR of the point BEFORE the line search for the first cost/gradient
+                // (trustregion.h:394-422: R is replaced, sR is not)
+                launch_scale_rows(o, nloc_, R_.p, s_.p, Wloc, st_);
+                std::swap(R_.p, Rc_.p);
+            }
+            gather_W();
+        } else {
+            log("linesearch failed! BM stopped! \n");
+            out.primal = -1; out.ls_failed = true; out.stop_reason = -1;
+            return out;
+        }
+    } else {
+        launch_scale_rows(o, nloc_, R_.p, s_.p, Wloc, st_);
+        gather_W();
+    }
+    eval_point(cur_, R_.p, s_.p, f, rr);  // loss[0] and the gradient state of the first outer iteration
+    double loss = f;
+
+    int endreason = 6, trstatus = 4, shrink_count = 0, inner_print = 1, k = 0;
+    long long totalite = 0;
+    int stop_reason = 14;
+    const auto start = clk::now();
+    for (k = 0; k < kMaxOuter; ++k) {
+        const double gradnorm = std::sqrt(rr);
+        if (verbose_) {
+            static const char *trn[] = {"", "TR- ", "TR+ ", "REJ ", "TR "};
+            if (k > 0) log("%s", trn[trstatus]);
+            log("%d   %d   %1.3e   %1.3e", k, inner_print, loss, gradnorm);
+            if (k > 0) {
+                const char *er = endreason == 1 ? "nagative curvature" : endreason == 2 ? "exceed trust region"
+                               : endreason == 3 ? "reached norm tolerance" : endreason == 5 ? "numerical issue" : "max iteration";
+                log("   %s\n", er);
+            } else log("\n");
+        }
+        if (opt_->trace && res_->trace_len < opt_->trace_cap) {
+            double *tr = opt_->trace + (size_t)res_->trace_len * 6;
+            tr[0] = loss; tr[1] = gradnorm; tr[2] = inner_print; tr[3] = endreason; tr[4] = trstatus; tr[5] = delta;
+            res_->trace_len++;
+        }
+        if (endreason == 5) { stop_reason = 5; log("Terminate because of rdotr touched machine precise\n"); break; }
+        if (gradnorm < gradtol) { log("Terminate because of small gradient norm\n"); gradtol /= 10; stop_reason = 10; break; }
+        if ((double)(long long)secs_since(start) > max_time) { log("Terminate because of time limit\n"); stop_reason = 11; break; }
+        endreason = 6; trstatus = 4;
+
+        TcgScal fin;
+        run_tcg(rr, delta, fin);
+        endreason = fin.status;
+        inner_print = fin.iter + 1;
+        totalite += fin.iter + 1;
+
+        // model decrease, retraction and the candidate's cost/gradient in one go (trustregion.h:667-678)
+        const int nB_loc = flat_grid((int64_t)nloc_ * 3 * OP_);
+        const PointState &P = ps_[cur_];
+        launch_model_value(o, nloc_, vR_.p, vs_.p, HvR_.p, Hvs_.p, P.rgR.p, P.rgs.p, s_.p, partsM_.p + (size_t)comm_->rank * nB_loc, st_);
+        if (comm_->active()) comm_->allgather(partsM_.p, (size_t)nB_loc, st_);
+        launch_retract(o, nloc_, cam0_, R_.p, s_.p, vR_.p, vs_.p, 1.0, Rc_.p, sc_.p, Wloc, st_);
+        gather_W();
+        double f_new, rr_new;
+        eval_point(cur_ ^ 1, Rc_.p, sc_.p, f_new, rr_new);
+        const double loss_qu = sum_parts(partsM_.p, nB_);
+        if (opt_->flags & XM_FLAG_PROFILE_QW) drain_events();
+        if (loss_qu >= 0) { log("error! loss_qu is larger than 0\n"); stop_reason = 12; break; }
+        const double rou = (f_new - loss) / loss_qu;  // trustregion.h:680-701
+        if (rou < 0.25) { delta *= 0.25; trstatus = 1; shrink_count++; }
+        else if (rou > 0.75 && endreason <= 2) { delta = std::min(delta * 2, delta_bar); trstatus = 2; shrink_count = 0; }
+        else shrink_count = 0;
+        bool stop_delta = false;
+        if (shrink_count > 3) {
+            delta *= 1e-3; shrink_count = 0;
+            log("delta shrinked to %1.3e\n", delta);
+            if (delta < 1e-20) { log("delta is too small, BM stopped!\n"); stop_delta = true; }
+        }
+        const bool reject = (f_new > loss || rou < 0.1);  // trustregion.h:702
+        if (stop_delta || !reject) {
+            std::swap(R_.p, Rc_.p);
+            std::swap(s_.p, sc_.p);
+            cur_ ^= 1;
+            if (stop_delta) { stop_reason = 13; break; }  // the reference leaves the new point in place but reports loss[k]
+            loss = f_new;
+            rr = rr_new;
+        } else {
+            trstatus = 3;  // keep point, state, loss and rr
+        }
+    }
+    log("\nTotal iteration:     %lld\n", totalite);
+    const double secs = secs_since(start);
+    log("Time taken by function1: %lld ms\n", (long long)(secs * 1e3));
+    res_->tcg_iters += totalite;
+    res_->outer_iters += k;
+    res_->tr_seconds += secs;
+    res_->last_stop_reason = stop_reason;
+    out.primal = loss;
+    out.outer_iters = k;
+    out.stop_reason = stop_reason;
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// smallest eigenpair of a symmetric tridiagonal matrix: Sturm bisection + inverse iteration
+// ------------------------------------------------------------------------------------------------------------------
+static int sturm_count(const std::vector<double> &a, const std::vector<double> &b, int m, double x) {
+    int cnt = 0;
+    double d = a[0] - x;
+    if (d < 0) cnt++;
+    for (int i = 1; i < m; ++i) {
+        if (d == 0) d = 1e-300;
+        d = (a[(size_t)i] - x) - b[(size_t)i - 1] * b[(size_t)i - 1] / d;
+        if (d < 0) cnt++;
+    }
+    return cnt;
+}
+static void tridiag_min(const std::vector<double> &a, const std::vector<double> &b, int m, double &theta, std::vector<double> &y,
+                        double &tmax) {
+    double lo = a[0], hi = a[0];
+    for (int i = 0; i < m; ++i) {
+        const double r = (i > 0 ? std::fabs(b[(size_t)i - 1]) : 0.0) + (i < m - 1 ? std::fabs(b[(size_t)i]) : 0.0);
+        lo = std::min(lo, a[(size_t)i] - r);
+        hi = std::max(hi, a[(size_t)i] + r);
+    }
+    tmax = std::max(std::fabs(lo), std::fabs(hi));
+    double l = lo, h = hi;
+    for (int it = 0; it < 200 && h - l > 4e-16 * std::max(1.0, tmax); ++it) {
+        const double mid = 0.5 * (l + h);
+        if (sturm_count(a, b, m, mid) >= 1) h = mid; else l = mid;
+    }
+    theta = 0.5 * (l + h);
+    // inverse iteration: (T - theta I) y = rhs, tridiagonal LU with partial pivoting
+    y.assign((size_t)m, 1.0 / std::sqrt((double)m));
+    if (m == 1) { y[0] = 1.0; return; }
+    const double shift = theta - 1e-14 * std::max(1.0, tmax);
+    std::vector<double> dl((size_t)m), dd((size_t)m), du((size_t)m), du2((size_t)m), rhs((size_t)m);
+    for (int rep = 0; rep < 3; ++rep) {
+        for (int i = 0; i < m; ++i) {
+            dd[(size_t)i] = a[(size_t)i] - shift;
+            du[(size_t)i] = (i < m - 1) ? b[(size_t)i] : 0.0;
+            dl[(size_t)i] = (i < m - 1) ? b[(size_t)i] : 0.0;  // dl[i] = T(i+1,i)
+            du2[(size_t)i] = 0.0;
+            rhs[(size_t)i] = y[(size_t)i];
+        }
+        for (int i = 0; i < m - 1; ++i) {
+            if (std::fabs(dd[(size_t)i]) >= std::fabs(dl[(size_t)i])) {
+                if (dd[(size_t)i] == 0) dd[(size_t)i] = 1e-300;
+                const double f = dl[(size_t)i] / dd[(size_t)i];
+                dd[(size_t)i + 1] -= f * du[(size_t)i];
+                rhs[(size_t)i + 1] -= f * rhs[(size_t)i];
+            } else {  // swap rows i and i+1
+                const double f = dd[(size_t)i] / dl[(size_t)i];
+                const double t_dd = dd[(size_t)i + 1], t_du = du[(size_t)i + 1];
+                dd[(size_t)i] = dl[(size_t)i];
+                const double old_du = du[(size_t)i];
+                du[(size_t)i] = t_dd;
+                du2[(size_t)i] = (i < m - 2) ? t_du : 0.0;
+                dd[(size_t)i + 1] = old_du - f * t_dd;
+                if (i < m - 2) du[(size_t)i + 1] = -f * t_du;
+                const double tr = rhs[(size_t)i];
+                rhs[(size_t)i] = rhs[(size_t)i + 1];
+                rhs[(size_t)i + 1] = tr - f * rhs[(size_t)i + 1];
+            }
+        }
+        if (dd[(size_t)m - 1] == 0) dd[(size_t)m - 1] = 1e-300;
+        y[(size_t)m - 1] = rhs[(size_t)m - 1] / dd[(size_t)m - 1];
+        y[(size_t)m - 2] = (rhs[(size_t)m - 2] - du[(size_t)m - 2] * y[(size_t)m - 1]) / dd[(size_t)m - 2];
+        for (int i = m - 3; i >= 0; --i)
+            y[(size_t)i] = (rhs[(size_t)i] - du[(size_t)i] * y[(size_t)i + 1] - du2[(size_t)i] * y[(size_t)i + 2]) / dd[(size_t)i];
+        double nrm = 0;
+        for (int i = 0; i < m; ++i) nrm += y[(size_t)i] * y[(size_t)i];
+        nrm = std::sqrt(nrm);
+        if (!(nrm > 0) || !std::isfinite(nrm)) { y.assign((size_t)m, 0.0); y[0] = 1.0; break; }
+        for (int i = 0; i < m; ++i) y[(size_t)i] /= nrm;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// lambda_min and its eigenvector of S = Q + diag(dz) - blockdiag(Lam) by Lanczos with full re-orthogonalisation.
+// Replaces cusolverDnXsyevd on the 3n x 3n certificate matrix (checkeig.h:303-318, Dense/eig.h:35-73), O((3n)^3),
+// by products with the same Q*W kernel (rank-1 input).  Lam_/dz live in ps_[cur^1].S0 / .egs (free at this point).
+// ------------------------------------------------------------------------------------------------------------------
+int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &iters_out) {
+    const int64_t len = ld_;           // vectors are replicated, full length, zero beyond 3n
+    const int64_t m3 = 3 * n_;
+    const int mmax = (int)std::min<int64_t>(m3, 400);
+    DevBuf<double> V, c, w;
+    V.alloc((size_t)len * (mmax + 1));
+    c.alloc((size_t)mmax + 2);
+    w.alloc((size_t)len);
+    DevBuf<double> Wsave;  // the o-pitch W buffer is reused as the rank-1 product input
+    std::vector<double> x((size_t)len, 0.0);
+    unsigned long long lcg = 0x9E3779B97F4A7C15ull;
+    double nrm = 0;
+    for (int64_t i = 0; i < m3; ++i) {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        x[(size_t)i] = ((double)(lcg >> 11) / 9007199254740992.0) - 0.5;
+        nrm += x[(size_t)i] * x[(size_t)i];
+    }
+    nrm = std::sqrt(nrm);
+    for (int64_t i = 0; i < m3; ++i) x[(size_t)i] /= nrm;
+
+    CamArgs a = cam_args(cur_);
+    a.Lam = ps_[cur_ ^ 1].S0.p;
+    a.dz = ps_[cur_ ^ 1].egs.p;
+    double theta = 0, resid = 1e300, tmax = 1;
+    std::vector<double> al, be, y;
+    int total = 0;
+    std::vector<double> hc((size_t)mmax + 2);
+    for (int restart = 0; restart < 6; ++restart) {
+        XM_HIP_CHECK(hipMemcpyAsync(V.p, x.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, st_));
+        al.clear(); be.clear();
+        int j = 0;
+        bool done = false;
+        for (j = 0; j < mmax; ++j) {
+            const double *vj = V.p + (size_t)j * len;
+            // w = S v_j : product input is v_j itself (pitch 1); output rows land in w at this rank's offset
+            a.Wloc = vj + (size_t)cam0_ * 3;
+            a.out = w.p + (size_t)cam0_ * 3;
+            if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
+            else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_);
+            res_->qw_products++;
+            if (comm_->active()) comm_->allgather(w.p, (size_t)nloc_ * 3, st_);
+            // classical Gram-Schmidt twice against V(:,0..j)
+            launch_dots_multi(V.p, len, j + 1, w.p, len, c.p, st_);
+            launch_sub_vc(w.p, V.p, len, c.p, j + 1, len, st_);
+            XM_HIP_CHECK(hipMemcpyAsync(hc.data(), c.p + j, sizeof(double), hipMemcpyDeviceToHost, st_));
+            launch_dots_multi(V.p, len, j + 1, w.p, len, c.p, st_);
+            launch_sub_vc(w.p, V.p, len, c.p, j + 1, len, st_);
+            XM_HIP_CHECK(hipMemcpyAsync(hc.data() + 1, c.p + j, sizeof(double), hipMemcpyDeviceToHost, st_));
+            launch_dots_multi(w.p, len, 1, w.p, len, c.p + mmax + 1, st_);
+            XM_HIP_CHECK(hipMemcpyAsync(hc.data() + 2, c.p + mmax + 1, sizeof(double), hipMemcpyDeviceToHost, st_));
+            XM_HIP_CHECK(hipStreamSynchronize(st_));
+            total++;
+            al.push_back(hc[0] + hc[1]);
+            const double beta = std::sqrt(std::max(hc[2], 0.0));
+            const int m = j + 1;
+            const bool check = (m <= 8) || (m % 4 == 0) || m == mmax || beta < 1e-13 * std::max(1.0, tmax);
+            if (check) {
+                tridiag_min(al, be, m, theta, y, tmax);
+                resid = std::fabs(beta * y[(size_t)m - 1]);
+                if (resid <= 1e-9 * std::max(1.0, tmax) || beta < 1e-13 * std::max(1.0, tmax) || m == (int)m3) { done = true; j = m; break; }
+            }
+            if (m == mmax) { j = m; break; }
+            be.push_back(beta);
+            launch_scale_copy(V.p + (size_t)m * len, w.p, 1.0 / beta, len, st_);
+        }
+        // Ritz vector x = V(:,0..j-1) y
+        const int m = (int)al.size();
+        XM_HIP_CHECK(hipMemcpyAsync(c.p, y.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, st_));
+        launch_gemv_n(w.p, V.p, len, c.p, m, len, st_);
+        XM_HIP_CHECK(hipMemcpyAsync(x.data(), w.p, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        double nn = 0;
+        for (int64_t i = 0; i < len; ++i) nn += x[(size_t)i] * x[(size_t)i];
+        nn = std::sqrt(nn);
+        if (nn > 0) for (int64_t i = 0; i < len; ++i) x[(size_t)i] /= nn;
+        if (done) break;
+    }
+    x_out.assign(x.begin(), x.begin() + m3);
+    theta_out = theta;
+    iters_out = total;
+    return (resid <= 1e-6 * std::max(1.0, tmax)) ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dual certificate (checkeig.h:42-368)
+// ------------------------------------------------------------------------------------------------------------------
+CertResult Context::certificate(int o, double primal, std::vector<double> &v_out) {
+    CertResult cr;
+    const auto t0 = clk::now();
+    double *Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
+    // Right-hand side pieces: C * sR  (checkeig.h:182 with the diagonal term folded into cert_prepare)
+    launch_scale_rows(o, nloc_, R_.p, s_.p, Wloc, st_);
+    gather_W();
+    CamArgs a = cam_args(cur_);
+    a.out = HpR_.p;
+    product(EPI_PLAIN, o, 1.0, a);
+    const int g = (nloc_ + 255) / 256;
+    double *Lam = ps_[cur_ ^ 1].S0.p, *dz = ps_[cur_ ^ 1].egs.p;
+    launch_cert_prepare(o, nloc_, cam0_, opt_->lam, HpR_.p, R_.p, s_.p, Lam, dz, partsM_.p + (size_t)comm_->rank * 2 * g, st_);
+    if (comm_->active()) comm_->allgather(partsM_.p, (size_t)2 * g, st_);
+    const double dual = sum_parts(partsM_.p, 2 * g * comm_->world);   // y0+y3+y5 + lam*sum(1 - xii^2)  (checkeig.h:322-332)
+    // lambda_min(S) and its eigenvector
+    XM_HIP_CHECK(hipMemsetAsync(W_.p, 0, W_.count * sizeof(double), st_));
+    double theta = 0;
+    int its = 0;
+    lanczos_min(v_out, theta, its);
+    res_->lanczos_iters += its;
+    log("The min eig is: %1.3e \n", theta);
+    log("Primal value: %g\nnew dual%g\n", primal, dual);
+    const double K = 3.0 * (double)n_;
+    const double gap = primal - dual - K * std::min(0.0, theta);   // checkeig.h:334-336
+    log("Optimility gap: %g\n", gap);
+    double bound = 1e-4;                                           // checkeig.h:349-358 (later branches unreachable)
+    if (n_ > 2000) bound = 1e-3;
+    cr.accepted = (gap / primal < 1e-3 || theta > -bound);
+    cr.min_eig = theta; cr.dual = dual; cr.gap = gap; cr.lanczos_iters = its;
+    if (cr.accepted) log("BM finished with rank %d\n", o); else log("BM order plus one\n");
+    res_->cert_seconds += secs_since(t0);
+    return cr;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// staircase drivers (XM_main.cu:180-310 solve, :312-401 solve_rank3, :35-178 solve_rebuttle)
+// ------------------------------------------------------------------------------------------------------------------
+void Context::solve(const xm_options_t &opt, xm_result_t &res) {
+    opt_ = &opt;
+    res_ = &res;
+    verbose_ = (opt.flags & XM_FLAG_VERBOSE) != 0;
+    double *Rout = res.R, *sout = res.s;
+    std::memset(&res, 0, sizeof(res));
+    res.R = Rout; res.s = sout;
+    if (!Rout || !sout) throw Error(XM_ERR_ARG, "result buffers missing");
+    if (opt.max_rank > (unsigned)kMaxRank) throw Error(XM_ERR_ARG, "max_rank > 10 is not instantiated");
+    if ((opt.flags & XM_FLAG_PROFILE_QW) && ev_pool_.empty()) {
+        ev_pool_.resize(256);
+        for (auto &e : ev_pool_) { XM_HIP_CHECK(hipEventCreate(&e.first)); XM_HIP_CHECK(hipEventCreate(&e.second)); }
+    }
+    ev_used_ = 0;
+    hess_launches_ = 0;
+    const auto t0 = clk::now();
+    const size_t m = (size_t)3 * n_;
+    log("+++++++++++++++++++++++++++++++++\nBegin XM\n+++++++++++++++++++++++++++++++++\n");
+    unsigned o = 3;
+    std::vector<double> v(m, 0.0), R0(m * 3, 0.0), Rk, s0((size_t)n_, 1.0), sk;
+    if (opt.mode == XM_MODE_REBUTTLE && opt.s_ini) for (int64_t i = 0; i < n_; ++i) s0[(size_t)i] = opt.s_ini[i];
+    const double s_anchor = s0[0];
+    double gradtol = opt.tol, primal = 0;
+    int status = XM_STATUS_NONE;
+    auto identity_stack = [&]() {
+        R0.assign(m * 3, 0.0);
+        for (size_t i = 0; i < (size_t)n_; ++i) { R0[3 * i] = 1.0; R0[3 * i + m + 1] = 1.0; R0[3 * i + 2 * m + 2] = 1.0; }
+    };
+    int out_rank = 3;
+    if (opt.mode == XM_MODE_RANK3) {
+        log("+++++++++++++++++++++++++++++++++\nSolve TR with Rank   3\n+++++++++++++++++++++++++++++++++\n");
+        identity_stack();
+        setup_rank(3);
+        upload_point(R0, 3, s0);
+        TrResult tr = trust_region(3, gradtol, 0.0, v, opt.max_time);
+        primal = tr.primal;
+        download_point(R0, s0);
+        out_rank = 3;
+    } else {
+        while (o <= opt.max_rank) {  // XM_main.cu:223
+            log("+++++++++++++++++++++++++++++++++\nSolve TR with Rank   %u\n+++++++++++++++++++++++++++++++++\n", o);
+            TrResult tr;
+            setup_rank((int)o);
+            if (o == 3) {
+                identity_stack();
+                upload_point(R0, 3, s0);
+                tr = trust_region(3, gradtol, 0.0, v, opt.max_time);
+            } else {
+                upload_point(R0, (int)o, s0);
+                tr = trust_region((int)o, gradtol, 1.0, v, opt.max_time);
+            }
+            primal = tr.primal;
+            if (primal < 0) { status = XM_STATUS_LS_FAILED; o += 1; break; }  // XM_main.cu:244-247 (R0 keeps [R | 0])
+            log("+++++++++++++++++++++++++++++++++\nCheck Eigen value\n+++++++++++++++++++++++++++++++++\n");
+            CertResult ce = certificate((int)o, primal, v);
+            res.dual = ce.dual; res.min_eig = ce.min_eig; res.gap = ce.gap;
+            download_point(Rk, sk);
+            if (ce.accepted) {
+                R0 = Rk; s0 = sk; o += 1; status = XM_STATUS_CERTIFIED;
+                break;
+            } else if (o < opt.max_rank) {  // XM_main.cu:265-271
+                R0.assign(m * (o + 1), 0.0);
+                std::copy(Rk.begin(), Rk.end(), R0.begin());
+                s0 = sk;
+                for (size_t i = 0; i < (size_t)n_; ++i) { v[3 * i] /= sk[i]; v[3 * i + 1] /= sk[i]; v[3 * i + 2] /= sk[i]; }  // XM_main.cu:8-16
+            } else {
+                R0 = Rk; s0 = sk; status = XM_STATUS_MAX_RANK;
+            }
+            o += 1;
+        }
+        if (o > opt.max_rank) log("BM stoped because max rank\n");
+        out_rank = (int)o - 1;
+    }
+    res.rank = out_rank;
+    if (out_rank >= 3 && R0.size() >= m * (size_t)out_rank) std::memcpy(Rout, R0.data(), m * (size_t)out_rank * sizeof(double));
+    for (int64_t i = 0; i < n_; ++i) sout[i] = s0[(size_t)i];
+    sout[0] = s_anchor;  // the callers' s_ex[0] is never touched by the reference (XM_main.cu:203-219)
+    res.status = status;
+    res.primal = primal;
+    if (opt.flags & XM_FLAG_PROFILE_QW) drain_events();
+    // algorithmic bytes of one tCG product at the final rank
+    const int of = std::max(3, std::min(out_rank, (int)opt.max_rank));
+    if (storage_ == XM_STORAGE_DENSE) res.qw_bytes = 8LL * (3 * n_) * (3 * n_) + 2LL * 8 * 3 * n_ * of;
+    else res.qw_bytes = 76LL * nb_loc_ + 4LL * (n_ + 1) + 2LL * 8 * 3 * n_ * of;
+    res.seconds = secs_since(t0);
+    opt_ = nullptr;
+    res_ = nullptr;
+}
+
+}  // namespace xm

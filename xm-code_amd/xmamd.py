@@ -1,0 +1,290 @@
+"""ctypes binding of the C ABI in include/xm_amd.h (libxm_amd.so) — the host-side mirror used by the tests,
+bench.py and __graft_entry__.  The product path is the HIP library; this file only marshals numpy arrays.
+
+There is NO CPU fallback: every compute entry point raises XmError when the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libxm_amd.so")
+MODULE_DIR = os.path.join(_HERE, "build")      # holds XM.cpython-*.so (the reference's module name)
+
+STORAGE_DENSE, STORAGE_BSR3 = 0, 1
+MODE_SOLVE, MODE_RANK3, MODE_REBUTTLE = 0, 1, 2
+FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
+
+EXPORTS = [
+    "xm_last_error", "xm_version", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
+    "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
+    "xm_dev_sync", "xm_dense_upload", "xm_qw_dense", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time",
+    "xm_comm_unique_id", "xm_comm_init", "xm_comm_finalize", "xm_partition",
+]
+
+
+class XmError(RuntimeError):
+    pass
+
+
+class Problem(C.Structure):
+    _fields_ = [("n", C.c_int64), ("storage", C.c_int32), ("q_on_device", C.c_int32), ("q", C.c_void_p),
+                ("ldq", C.c_int64), ("nb", C.c_int64), ("rowptr", C.c_void_p), ("colidx", C.c_void_p),
+                ("blocks", C.c_void_p)]
+
+
+class Options(C.Structure):
+    _fields_ = [("max_rank", C.c_uint32), ("tol", C.c_double), ("lam", C.c_double), ("max_time", C.c_double),
+                ("mode", C.c_int32), ("flags", C.c_uint32), ("s_ini", C.c_void_p), ("trace_cap", C.c_int32),
+                ("trace", C.c_void_p)]
+
+
+class Result(C.Structure):
+    _fields_ = [("R", C.c_void_p), ("s", C.c_void_p), ("rank", C.c_int32), ("status", C.c_int32),
+                ("primal", C.c_double), ("dual", C.c_double), ("min_eig", C.c_double), ("gap", C.c_double),
+                ("tcg_iters", C.c_int64), ("outer_iters", C.c_int64), ("qw_products", C.c_int64),
+                ("lanczos_iters", C.c_int64), ("seconds", C.c_double), ("tr_seconds", C.c_double),
+                ("cert_seconds", C.c_double), ("qw_ms_sum", C.c_double), ("qw_ms_count", C.c_int64),
+                ("qw_bytes", C.c_int64), ("trace_len", C.c_int32), ("last_stop_reason", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libxm_amd.so (built by `make -C xm-code_amd` / __graft_entry__.build()).  Fails loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise XmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.xm_last_error.restype = C.c_char_p
+        L.xm_version.restype = C.c_char_p
+        L.xm_dense_ld.restype = C.c_int64
+        L.xm_dense_ld.argtypes = [C.c_int64]
+        for name in ("xm_solve", "xm_solve_rank3"):
+            getattr(L, name).argtypes = [C.c_char_p, C.c_uint, C.c_double, C.c_double, C.c_double]
+        L.xm_solve_rebuttle.argtypes = [C.c_char_p, C.c_uint, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int)]
+        L.xm_ctx_create.argtypes = [C.POINTER(Problem), C.POINTER(C.c_void_p)]
+        L.xm_ctx_solve.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Result)]
+        L.xm_ctx_destroy.argtypes = [C.c_void_p]
+        L.xm_ctx_destroy.restype = None
+        L.xm_dev_count.argtypes = [C.POINTER(C.c_int)]
+        L.xm_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        L.xm_dev_free.argtypes = [C.c_void_p]
+        L.xm_dev_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.xm_dev_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.xm_dense_upload.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]
+        L.xm_qw_dense.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.xm_qw_bsr3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_double, C.c_void_p]
+        L.xm_retract.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        L.xm_qw_dense_time.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.POINTER(C.c_double)]
+        L.xm_comm_unique_id.argtypes = [C.c_char_p]
+        L.xm_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+        L.xm_partition.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise XmError(f"xm_amd error {rc}: {lib().xm_last_error().decode()}")
+
+
+def device_count():
+    c = C.c_int(0)
+    lib().xm_dev_count(C.byref(c))
+    return c.value
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise XmError("no HIP device visible: the XM solver has no CPU fallback")
+
+
+def pitch_of(o):
+    return o | 1
+
+
+def dense_ld(n):
+    return int(lib().xm_dense_ld(n))
+
+
+# ------------------------------------------------------------------------------------------------ device buffers
+class DevArray:
+    """A float64 / int device buffer owned through the C ABI (no torch needed)."""
+
+    def __init__(self, host=None, nbytes=None):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(host.nbytes if host is not None else nbytes)
+        _chk(lib().xm_dev_alloc(C.byref(self.ptr), self.nbytes))
+        if host is not None:
+            host = np.ascontiguousarray(host)
+            _chk(lib().xm_dev_h2d(self.ptr, host.ctypes.data_as(C.c_void_p), self.nbytes))
+
+    def get(self, dtype=np.float64, shape=None):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _chk(lib().xm_dev_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out if shape is None else out.reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            lib().xm_dev_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def to_rm(M, o=None, rows=None):
+    """host (m x o) matrix -> the device layout: row-major, pitch OP = o|1, `rows` rows (zero padded)."""
+    M = np.asarray(M, dtype=np.float64)
+    m, o = M.shape
+    out = np.zeros((rows or m, pitch_of(o)))
+    out[:m, :o] = M
+    return out
+
+
+def from_rm(buf, m, o):
+    return np.asarray(buf).reshape(-1, pitch_of(o))[:m, :o].copy()
+
+
+# ------------------------------------------------------------------------------------------------ kernel-level calls
+def dense_upload(Q):
+    Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
+    n = Q.shape[0] // 3
+    p = C.c_void_p()
+    _chk(lib().xm_dense_upload(Q.ctypes.data_as(C.c_void_p), Q.shape[0], n, C.byref(p)))
+    d = DevArray.__new__(DevArray)
+    d.ptr, d.nbytes = p, 3 * n * dense_ld(n) * 8
+    return d
+
+
+def qw_dense(Q, W, alpha=1.0, dq=None):
+    """alpha * Q @ W on the GPU through xm_qw_dense (Q: 3n x 3n, W: 3n x o)."""
+    require_gpu()
+    W = np.asarray(W, dtype=np.float64)
+    n, o = W.shape[0] // 3, W.shape[1]
+    own = dq is None
+    dq = dq or dense_upload(Q)
+    dW = DevArray(to_rm(W, rows=dense_ld(n)))
+    dO = DevArray(nbytes=3 * n * pitch_of(o) * 8)
+    _chk(lib().xm_qw_dense(dq.ptr, n, o, dW.ptr, dO.ptr, alpha, None))
+    _chk(lib().xm_dev_sync())
+    out = from_rm(dO.get(), 3 * n, o)
+    for b in (dW, dO) + ((dq,) if own else ()):
+        b.free()
+    return out
+
+
+def qw_bsr3(rowptr, colidx, blocks, W, alpha=1.0):
+    require_gpu()
+    W = np.asarray(W, dtype=np.float64)
+    n, o = W.shape[0] // 3, W.shape[1]
+    drp = DevArray(np.asarray(rowptr, dtype=np.int64)); dci = DevArray(np.asarray(colidx, dtype=np.int32))
+    dbl = DevArray(np.asarray(blocks, dtype=np.float64).reshape(-1))
+    dW = DevArray(to_rm(W)); dO = DevArray(nbytes=3 * n * pitch_of(o) * 8)
+    _chk(lib().xm_qw_bsr3(drp.ptr, dci.ptr, dbl.ptr, n, o, dW.ptr, dO.ptr, alpha, None))
+    _chk(lib().xm_dev_sync())
+    out = from_rm(dO.get(), 3 * n, o)
+    for b in (drp, dci, dbl, dW, dO):
+        b.free()
+    return out
+
+
+def retract(R, s, D, ds, t):
+    """(MGS_rows(R + t D), s*exp(t ds/s)) through xm_retract."""
+    require_gpu()
+    R = np.asarray(R, dtype=np.float64)
+    n, o = R.shape[0] // 3, R.shape[1]
+    dR = DevArray(to_rm(R)); dD = DevArray(to_rm(D)); dsv = DevArray(np.asarray(s, dtype=np.float64))
+    dds = DevArray(np.asarray(ds, dtype=np.float64))
+    dRo = DevArray(nbytes=dR.nbytes); dso = DevArray(nbytes=dsv.nbytes)
+    _chk(lib().xm_retract(n, o, dR.ptr, dsv.ptr, dD.ptr, dds.ptr, t, dRo.ptr, dso.ptr, None))
+    _chk(lib().xm_dev_sync())
+    out = from_rm(dRo.get(), 3 * n, o), dso.get()
+    for b in (dR, dD, dsv, dds, dRo, dso):
+        b.free()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ context API
+class Context:
+    """Q resident in HBM; solve() == the reference's staircase (XM_main.cu:180 / :312 / :35)."""
+
+    def __init__(self, Q=None, bsr=None, n=None):
+        require_gpu()
+        self._keep = []
+        p = Problem()
+        if Q is not None:
+            Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
+            self.n = Q.shape[0] // 3
+            p.n, p.storage, p.q, p.ldq = self.n, STORAGE_DENSE, Q.ctypes.data_as(C.c_void_p), Q.shape[0]
+            self._keep.append(Q)
+        else:
+            rowptr, colidx, blocks = bsr
+            rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+            blocks = np.ascontiguousarray(blocks, dtype=np.float64)
+            self.n = rowptr.size - 1
+            p.n, p.storage, p.nb = self.n, STORAGE_BSR3, colidx.size
+            p.rowptr, p.colidx, p.blocks = (a.ctypes.data_as(C.c_void_p) for a in (rowptr, colidx, blocks))
+            self._keep += [rowptr, colidx, blocks]
+        self.h = C.c_void_p()
+        _chk(lib().xm_ctx_create(C.byref(p), C.byref(self.h)))
+        self._keep = []   # Q has been copied to the device
+
+    def solve(self, max_rank, tol, lam, max_time=1000.0, mode=MODE_SOLVE, flags=0, s_ini=None, trace=0):
+        n = self.n
+        rmax = max(int(max_rank), 3)
+        R = np.zeros((3 * n, rmax + 1), order="F"); s = np.zeros(n)
+        opt = Options(); res = Result()
+        opt.max_rank, opt.tol, opt.lam, opt.max_time, opt.mode, opt.flags = int(max_rank), tol, lam, max_time, mode, flags
+        si = None
+        if s_ini is not None:
+            si = np.ascontiguousarray(s_ini, dtype=np.float64).reshape(-1)
+            opt.s_ini = si.ctypes.data_as(C.c_void_p)
+        tr = None
+        if trace:
+            tr = np.zeros((trace, 6)); opt.trace_cap = trace; opt.trace = tr.ctypes.data_as(C.c_void_p)
+        res.R = R.ctypes.data_as(C.c_void_p); res.s = s.ctypes.data_as(C.c_void_p)
+        _chk(lib().xm_ctx_solve(self.h, C.byref(opt), C.byref(res)))
+        info = {k: getattr(res, k) for k, _ in Result._fields_ if k not in ("R", "s")}
+        if tr is not None:
+            info["trace"] = tr[: res.trace_len].copy()
+        return np.ascontiguousarray(R[:, : res.rank]), s, info
+
+    def close(self):
+        if self.h:
+            lib().xm_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve_dense(Q, max_rank, tol, lam, **kw):
+    ctx = Context(Q=Q)
+    try:
+        return ctx.solve(max_rank, tol, lam, **kw)
+    finally:
+        ctx.close()
+
+
+def import_XM():
+    """import the reference-named extension module `XM` (xm-code_amd/build/XM*.so)"""
+    import importlib
+    import sys
+    if MODULE_DIR not in sys.path:
+        sys.path.insert(0, MODULE_DIR)
+    return importlib.import_module("XM")
