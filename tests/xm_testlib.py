@@ -59,7 +59,11 @@ def so3_exp(w):
 
 
 def gen_dense(n, seed=None, eps=1e-3):
-    """G_dense(n, seed): fully dense 'Schur-complement-like' PSD Q with planted optimum U* (SURVEY §8d C2-C4).
+    """G_dense(n, seed): fully dense 'Schur-complement-like' PSD Q with planted optimum U* (SURVEY §8d C2-C4):
+    Q = P M P + eps-noise, M = B B^T + diag(d) (B Gaussian / sqrt(3n), d ~ U[0.5, 1.5]), P = projector onto the
+    complement of U* (the stacked planted rotations), noise = PSD (diagonal + rank-8) scaled to eps * |PMP|_F.
+    The noise is kept PSD on purpose: a real XM Q is a sum of squares, and the staircase driver (like the reference,
+    XM_main.cu:244) treats a negative optimum value as its line-search-failure sentinel.
     eps = 0 gives the known-answer variant (f* = 0, R* = U*)."""
     seed = n if seed is None else seed
     rng = np.random.default_rng(seed)
@@ -73,9 +77,11 @@ def gen_dense(n, seed=None, eps=1e-3):
     MU = M @ Uo
     Qm = M - Uo @ MU.T - MU @ Uo.T + Uo @ (Uo.T @ MU) @ Uo.T
     if eps:
-        E = rng.standard_normal((m, m))
-        E = (E + E.T) * 0.5
-        Qm += (eps * np.linalg.norm(Qm) / np.linalg.norm(E)) * E
+        F = rng.standard_normal((m, 8)) / np.sqrt(8.0)
+        u = rng.uniform(0.0, 1.0, m)
+        scale = eps * np.linalg.norm(Qm) / np.sqrt(np.sum(u * u) + np.linalg.norm(F.T @ F) ** 2 + 2 * np.sum(u * np.sum(F * F, axis=1)))
+        Qm += scale * (F @ F.T)
+        Qm[np.diag_indices(m)] += scale * u
     Qm = (Qm + Qm.T) * 0.5
     return dict(Q=Qm, R_star=Rs, n=n)
 
