@@ -28,7 +28,7 @@ struct Error : std::runtime_error {
 __host__ __device__ constexpr int pitch_of(int o) { return o | 1; }
 
 constexpr int kQwWaves = 4;       // cameras (wavefronts) per workgroup in the Q*W kernels
-constexpr int kQwTileCols = 512;  // columns of Q per LDS-staged W tile
+constexpr int kQwNsub = 2;        // 128-column sub-chunks per LDS-staged W tile (tile = 256 columns)
 constexpr int kColPad = 128;      // dense leading dimension is a multiple of this (64 lanes x double2)
 constexpr int kMaxRank = 10;      // template instantiations cover o = 1 and 3..10
 constexpr int kMaxInner = 1000;   // trustregion.h:416

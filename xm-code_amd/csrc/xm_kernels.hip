@@ -15,6 +15,8 @@
 //
 // No MFMA on this path (no dense contraction with reuse); everything is float64 like the reference
 // (Optimization/optimization.h:9).
+#include <cstdlib>
+
 #include "xm_common.h"
 
 namespace xm {
@@ -206,20 +208,25 @@ __device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool acti
 // ----------------------------------------------------------------------------------------------------------------
 // dense Q*W
 // ----------------------------------------------------------------------------------------------------------------
-template <int O, int EPI>
+// Software-pipelined: while a wavefront multiplies tile t (Q fragment in registers, W tile in LDS buffer t&1) the loads
+// of tile t+1 (its 3 rows of Q and the workgroup's share of the next W tile) are already in flight; one barrier per tile.
+template <int O, int EPI, int NSUB>
 __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict__ Q, int64_t ld,
                                                         const double *__restrict__ W, double alpha, CamArgs a) {
     constexpr int OP = pitch_of(O);
-    constexpr int NSUB = kQwTileCols / 128;
+    constexpr int TILE = NSUB * 128;                 // columns per tile
+    constexpr int TILE2 = TILE * OP / 2;             // double2 elements of one W tile
+    constexpr int NST = (TILE2 + 255) / 256;         // staging registers (double2) per thread
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;  // tCG already terminated: enqueued-ahead launch becomes a no-op
     }
-    __shared__ __attribute__((aligned(16))) double wt[kQwTileCols * OP];
+    __shared__ __attribute__((aligned(16))) double wt[2][TILE * OP];
     __shared__ double red[kQwWaves][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cam = blockIdx.x * kQwWaves + wave;
     const bool active = cam < a.nloc;
     const double *q0 = Q + (size_t)(active ? cam : 0) * 3 * (size_t)ld + 2 * lane;
+    const int ntiles = (int)((ld + TILE - 1) / TILE);
 
     double acc[3][O];
 #pragma unroll
@@ -227,46 +234,75 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
 
-    for (int64_t c0 = 0; c0 < ld; c0 += kQwTileCols) {
-        // (1) issue this tile's Q loads first: 3 rows x NSUB x 16 B per lane, fully coalesced (1 KiB per wave-instruction)
-        double2 q[NSUB][3];
+    double2 qn[NSUB][3];   // Q fragment of the NEXT tile
+    double2 ws[NST];       // this thread's share of the NEXT W tile
+    auto load_q = [&](int t) {
+        const int64_t c0 = (int64_t)t * TILE;
 #pragma unroll
         for (int u = 0; u < NSUB; ++u) {
             const int64_t c = c0 + u * 128;
             if (active && c < ld) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) q[u][r] = *reinterpret_cast<const double2 *>(q0 + (size_t)r * ld + c);
+                for (int r = 0; r < 3; ++r) qn[u][r] = *reinterpret_cast<const double2 *>(q0 + (size_t)r * ld + c);
             } else {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) q[u][r] = make_double2(0.0, 0.0);
+                for (int r = 0; r < 3; ++r) qn[u][r] = make_double2(0.0, 0.0);
             }
         }
-        // (2) stage the W tile (rows c0..c0+511, pitch OP) in LDS: flat 16-byte copy, shared by the 4 wavefronts
-        const int64_t tile_cols = (ld - c0 < kQwTileCols) ? (ld - c0) : kQwTileCols;
-        const int n2 = (int)(tile_cols * OP / 2);
-        const double2 *wsrc = reinterpret_cast<const double2 *>(W + (size_t)c0 * OP);
-        double2 *wdst = reinterpret_cast<double2 *>(wt);
-        __syncthreads();
-        for (int j = threadIdx.x; j < n2; j += 256) wdst[j] = wsrc[j];
-        __syncthreads();
-        // (3) fp64 FMAs: per lane 2 columns x 3 rows x O
+    };
+    auto load_w = [&](int t) {
+        const int64_t c0 = (int64_t)t * TILE;
+        const int64_t cols = (ld - c0 < TILE) ? (ld - c0) : TILE;
+        const int n2 = (int)(cols * OP / 2);
+        const double2 *src = reinterpret_cast<const double2 *>(W + (size_t)c0 * OP);
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            ws[j] = (idx < n2) ? src[idx] : make_double2(0.0, 0.0);
+        }
+    };
+    auto store_w = [&](int buf) {
+        double2 *dst = reinterpret_cast<double2 *>(wt[buf]);
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            if (idx < TILE2) dst[idx] = ws[j];
+        }
+    };
+
+    load_q(0);
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        double2 q[NSUB][3];
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) q[u][r] = qn[u][r];
+        const bool more = (t + 1 < ntiles);
+        if (more) {  // uniform
+            load_q(t + 1);
+            load_w(t + 1);
+        }
+        const double2 *wbase = reinterpret_cast<const double2 *>(wt[t & 1]);
 #pragma unroll
         for (int u = 0; u < NSUB; ++u) {
-            if (c0 + u * 128 < ld) {
-                const double2 *wp = reinterpret_cast<const double2 *>(wt) + (size_t)(u * 64 + lane) * OP;
-                double wv[2 * OP];
+            const double2 *wp = wbase + (size_t)(u * 64 + lane) * OP;
+            double wv[2 * OP];
 #pragma unroll
-                for (int j = 0; j < OP; ++j) {
-                    const double2 t = wp[j];
-                    wv[2 * j] = t.x;
-                    wv[2 * j + 1] = t.y;
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int k = 0; k < O; ++k) acc[r][k] += q[u][r].x * wv[k] + q[u][r].y * wv[OP + k];
+            for (int j = 0; j < OP; ++j) {
+                const double2 tt = wp[j];
+                wv[2 * j] = tt.x;
+                wv[2 * j + 1] = tt.y;
             }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc[r][k] += q[u][r].x * wv[k] + q[u][r].y * wv[OP + k];
         }
+        if (more) store_w((t + 1) & 1);
+        __syncthreads();
     }
     qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, red);
 }
@@ -351,7 +387,7 @@ __device__ __forceinline__ unsigned long long pack_stat(int iter, int status) {
     return ((unsigned long long)(unsigned)iter << 8) | (unsigned long long)(unsigned)(status & 0xff);
 }
 __device__ __forceinline__ void publish_host(unsigned long long *hstat, unsigned long long v) {
-    if (hstat) __hip_atomic_store(hstat, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (hstat) __hip_atomic_store(hstat, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the word is its own payload
 }
 
 struct StepDecision {
@@ -409,6 +445,8 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
 }
 
 // v += step p, Hv += step Hp, (CG step only) r += step Hp and the partial of <r,r>_metric   (trustregion.h:577-626)
+// Latency-trimmed: the vector operands of the thread's first element are requested before the scalar block and the
+// partial sums are read, so the three dependent memory round trips overlap.
 template <int O>
 __global__ __launch_bounds__(256) void cg_update_kernel(int nloc, const TcgScal *__restrict__ scal, const double *__restrict__ partsA,
                                                          int nA, const double *__restrict__ pR, const double *__restrict__ ps,
@@ -417,24 +455,43 @@ __global__ __launch_bounds__(256) void cg_update_kernel(int nloc, const TcgScal 
                                                          double *Hvs, double *rR, double *rs, double *partsB) {
     constexpr int OP = pitch_of(O);
     __shared__ double sh[4];
+    const int64_t total = (int64_t)nloc * 3 * OP;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // prefetch the first element's operands
+    double hp = 0, pv = 0, vv = 0, hv = 0, rv = 0, hs = 0, psv = 0, vsv = 0, hvs = 0, rsv = 0, sv = 1;
+    const bool in0 = i < total;
+    const bool own0 = in0 && (i % (3 * OP) == 0);
+    const int cam0 = (int)(i / (3 * OP));
+    if (in0) { hp = HpR[i]; pv = pR[i]; vv = vR[i]; hv = HvR[i]; rv = rR[i]; }
+    if (own0) { hs = Hps[cam0]; psv = ps[cam0]; vsv = vs[cam0]; hvs = Hvs[cam0]; rsv = rs[cam0]; sv = s[cam0]; }
     const TcgScal sc = *scal;
     if (sc.status != 0) return;
     const double pHp = sum_partials256(partsA, nA, sh);
     const StepDecision d = tcg_decide(sc, pHp);
     if (d.mode == 5) return;
-    const int64_t total = (int64_t)nloc * 3 * OP;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const double hp = HpR[i];
+    if (in0) {
+        vR[i] = vv + d.step * pv;
+        HvR[i] = hv + d.step * hp;
+        if (d.mode == 0) { const double r = rv + d.step * hp; rR[i] = r; acc += r * r; }
+        if (own0) {
+            vs[cam0] = vsv + d.step * psv;
+            Hvs[cam0] = hvs + d.step * hs;
+            if (d.mode == 0) { const double r = rsv + d.step * hs; rs[cam0] = r; const double q = r / sv; acc += q * q; }
+        }
+    }
+    for (i += stride; i < total; i += stride) {
+        const double hpi = HpR[i];
         vR[i] += d.step * pR[i];
-        HvR[i] += d.step * hp;
-        if (d.mode == 0) { const double r = rR[i] + d.step * hp; rR[i] = r; acc += r * r; }
+        HvR[i] += d.step * hpi;
+        if (d.mode == 0) { const double r = rR[i] + d.step * hpi; rR[i] = r; acc += r * r; }
         if (i % (3 * OP) == 0) {
             const int cam = (int)(i / (3 * OP));
-            const double hs = Hps[cam];
+            const double hsi = Hps[cam];
             vs[cam] += d.step * ps[cam];
-            Hvs[cam] += d.step * hs;
-            if (d.mode == 0) { const double r = rs[cam] + d.step * hs; rs[cam] = r; const double q = r / s[cam]; acc += q * q; }
+            Hvs[cam] += d.step * hsi;
+            if (d.mode == 0) { const double r = rs[cam] + d.step * hsi; rs[cam] = r; const double q = r / s[cam]; acc += q * q; }
         }
     }
     if (d.mode == 0) {
@@ -455,6 +512,13 @@ __global__ __launch_bounds__(256) void p_update_kernel(int nloc, const TcgScal *
                                                         unsigned long long *hstat) {
     constexpr int OP = pitch_of(O);
     __shared__ double sh[4];
+    const int64_t total = (int64_t)nloc * 3 * OP;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in0 = i < total;
+    const int camf = (int)(i / (3 * OP));
+    double p0 = 0, r0 = 0, R0 = 0, ps0 = 0, rs0 = 0, s0 = 1;   // prefetch: overlaps with the scalar block / partial sums
+    if (in0) { p0 = pR[i]; r0 = rR[i]; R0 = R[i]; ps0 = ps_cur[camf]; rs0 = rs[camf]; s0 = s[camf]; }
     const TcgScal sc = *scal_cur;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (sc.status != 0) {
@@ -482,8 +546,14 @@ __global__ __launch_bounds__(256) void p_update_kernel(int nloc, const TcgScal *
         return;
     }
     const double beta = rr2 / sc.rr;
-    const int64_t total = (int64_t)nloc * 3 * OP;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    if (in0) {
+        const double pn = beta * p0 - r0;
+        const double psn = beta * ps0 - rs0;
+        pR[i] = pn;
+        Wloc[i] = s0 * pn + psn * R0;
+        if (i % (3 * OP) == 0) ps_next[camf] = psn;
+    }
+    for (i += stride; i < total; i += stride) {
         const int cam = (int)(i / (3 * OP));
         const double pn = beta * pR[i] - rR[i];
         const double psn = beta * ps_cur[cam] - rs[cam];
@@ -760,13 +830,21 @@ static void check_launch(const char *what) {
     if (e != hipSuccess) throw Error(-3, std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
 }
 
-template <int O>
+static int qw_nsub() {  // tuning knob: XM_QW_NSUB=2|4 (tile = 256 / 512 columns)
+    static int v = [] {
+        const char *e = std::getenv("XM_QW_NSUB");
+        const int x = e ? std::atoi(e) : kQwNsub;
+        return (x == 4) ? 4 : 2;
+    }();
+    return v;
+}
+template <int O, int NSUB>
 static void qw_dense_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
     const dim3 g(qw_grid(a.nloc)), b(256);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN>), g, b, 0, st, Q, ld, W, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD>), g, b, 0, st, Q, ld, W, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_HESS>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_HESS, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
         default: throw Error(-2, "bad epilogue");
     }
 }
@@ -774,9 +852,11 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
     if (a.nloc <= 0) return;
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
-        hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
+        hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
+    } else if (qw_nsub() == 4) {
+        XM_DISPATCH_O(o, (qw_dense_epi<O_, 4>(epi, Q, ld, W, alpha, a, st)));
     } else {
-        XM_DISPATCH_O(o, (qw_dense_epi<O_>(epi, Q, ld, W, alpha, a, st)));
+        XM_DISPATCH_O(o, (qw_dense_epi<O_, 2>(epi, Q, ld, W, alpha, a, st)));
     }
     check_launch("qw_dense");
 }

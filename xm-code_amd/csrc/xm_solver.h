@@ -105,6 +105,7 @@ private:
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
     size_t ev_used_ = 0;
     int64_t hess_launches_ = 0;
+    std::vector<float> qw_samples_;
 
     void setup_rank(int o);
     void upload_point(const std::vector<double> &R_cm, int o, const std::vector<double> &s_ex);
@@ -116,6 +117,7 @@ private:
     double sum_parts(const double *dparts, int count);
     int run_tcg(double rr, double delta, TcgScal &fin);
     void drain_events();
+    void finish_profile();
     TrResult trust_region(int o, double &gradtol, double linesearch_step, const std::vector<double> &v_dir, double max_time);
     CertResult certificate(int o, double primal, std::vector<double> &v_out);
     int lanczos_min(std::vector<double> &x_out, double &theta, int &iters);

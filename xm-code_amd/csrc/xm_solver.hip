@@ -126,7 +126,7 @@ void Context::setup_rank(int o) {
     partsB_.alloc((size_t)nB_);
     partsM_.alloc((size_t)std::max(nB_, 2 * ((nloc_ + 255) / 256) * world));
     scal_.alloc(2);
-    const size_t need = std::max<size_t>({(size_t)2 * nA_, (size_t)nB_, partsM_.count, (size_t)64});
+    const size_t need = (size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64;
     if (need > hpin_count_) {
         if (hpin_) (void)hipHostFree(hpin_);
         XM_HIP_CHECK(hipHostMalloc((void **)&hpin_, need * sizeof(double), hipHostMallocDefault));
@@ -232,12 +232,22 @@ void Context::eval_point(int state, const double *Rp, const double *sp, double &
 void Context::drain_events() {
     for (size_t i = 0; i < ev_used_; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev_pool_[i].first, ev_pool_[i].second) == hipSuccess) {
-            res_->qw_ms_sum += ms;
-            res_->qw_ms_count++;
-        }
+        if (hipEventElapsedTime(&ms, ev_pool_[i].first, ev_pool_[i].second) == hipSuccess) qw_samples_.push_back(ms);
     }
     ev_used_ = 0;
+}
+
+// Sampled launches that turned out to be enqueued-ahead no-ops (a few microseconds) are not Q*W passes: keep the samples
+// within a factor 2 of the upper quartile.
+void Context::finish_profile() {
+    drain_events();
+    if (qw_samples_.empty()) return;
+    std::vector<float> v = qw_samples_;
+    std::sort(v.begin(), v.end());
+    const float ref = v[(v.size() * 3) / 4];
+    for (float x : v)
+        if (x >= 0.5f * ref) { res_->qw_ms_sum += x; res_->qw_ms_count++; }
+    qw_samples_.clear();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -254,7 +264,7 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     launch_tcg_init(o_, nloc_, P.rgR.p, P.rgs.p, R_.p, s_.p, rR_.p, rs_.p, pR_.p, psA_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, Wloc,
                     scal_.p, rr, delta, hstat_dev_, st_);
     gather_W();
-    const int run_ahead = comm_->active() ? 3 : 6;
+    const int run_ahead = 3;   // iterations in flight ahead of the last one seen finished; the excess become no-op launches
     int it = 0;  // iterations enqueued
     auto enqueue = [&](int i) {
         const int par = i & 1;
@@ -313,9 +323,8 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
             }
         }
     }
-    fin = read_scal(it & 1);
-    if (fin.status == 0) fin.status = 6;  // ran out of iterations
-    return it;
+    (void)fin;
+    return it;  // the final scalar block is scal_[it & 1]; the caller fetches it together with the other results
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -405,21 +414,43 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         endreason = 6; trstatus = 4;
 
         TcgScal fin;
-        run_tcg(rr, delta, fin);
-        endreason = fin.status;
-        inner_print = fin.iter + 1;
-        totalite += fin.iter + 1;
+        const int enq = run_tcg(rr, delta, fin);
 
-        // model decrease, retraction and the candidate's cost/gradient in one go (trustregion.h:667-678)
+        // model decrease, retraction and the candidate's cost/gradient are enqueued right behind the tCG and fetched with
+        // ONE synchronisation (trustregion.h:667-678 needs four blocking reads + a sync here)
         const int nB_loc = flat_grid((int64_t)nloc_ * 3 * OP_);
+        const int nA_loc = qw_grid(nloc_);
         const PointState &P = ps_[cur_];
         launch_model_value(o, nloc_, vR_.p, vs_.p, HvR_.p, Hvs_.p, P.rgR.p, P.rgs.p, s_.p, partsM_.p + (size_t)comm_->rank * nB_loc, st_);
         if (comm_->active()) comm_->allgather(partsM_.p, (size_t)nB_loc, st_);
         launch_retract(o, nloc_, cam0_, R_.p, s_.p, vR_.p, vs_.p, 1.0, Rc_.p, sc_.p, Wloc, st_);
         gather_W();
-        double f_new, rr_new;
-        eval_point(cur_ ^ 1, Rc_.p, sc_.p, f_new, rr_new);
-        const double loss_qu = sum_parts(partsM_.p, nB_);
+        {
+            CamArgs a = cam_args(cur_ ^ 1);
+            a.R = Rc_.p;
+            a.s = sc_.p;
+            a.partials = partsA_.p + (size_t)comm_->rank * 2 * nA_loc;
+            product(EPI_GRAD, o_, 2.0, a);
+            if (comm_->active()) comm_->allgather(partsA_.p, (size_t)2 * nA_loc, st_);
+        }
+        double *hA = hpin_, *hM = hpin_ + (size_t)2 * nA_;
+        TcgScal *hS = reinterpret_cast<TcgScal *>(hpin_ + (size_t)2 * nA_ + nB_);
+        XM_HIP_CHECK(hipMemcpyAsync(hA, partsA_.p, (size_t)2 * nA_ * sizeof(double), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipMemcpyAsync(hM, partsM_.p, (size_t)nB_ * sizeof(double), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipMemcpyAsync(hS, scal_.p + (enq & 1), sizeof(TcgScal), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        fin = *hS;
+        if (fin.status == 0) fin.status = 6;  // ran out of iterations
+        endreason = fin.status;
+        inner_print = fin.iter + 1;
+        totalite += fin.iter + 1;
+        double f_new = 0.0, rr_new = 0.0, loss_qu = 0.0;
+        for (int r = 0; r < comm_->world; ++r) {
+            const double *p = hA + (size_t)r * 2 * nA_loc;
+            for (int i = 0; i < nA_loc; ++i) f_new += p[i];
+            for (int i = 0; i < nA_loc; ++i) rr_new += p[nA_loc + i];
+        }
+        for (int i = 0; i < nB_; ++i) loss_qu += hM[i];
         if (opt_->flags & XM_FLAG_PROFILE_QW) drain_events();
         if (loss_qu >= 0) { log("error! loss_qu is larger than 0\n"); stop_reason = 12; break; }
         const double rou = (f_new - loss) / loss_qu;  // trustregion.h:680-701
@@ -676,6 +707,7 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     }
     ev_used_ = 0;
     hess_launches_ = 0;
+    qw_samples_.clear();
     const auto t0 = clk::now();
     const size_t m = (size_t)3 * n_;
     log("+++++++++++++++++++++++++++++++++\nBegin XM\n+++++++++++++++++++++++++++++++++\n");
@@ -740,7 +772,7 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     sout[0] = s_anchor;  // the callers' s_ex[0] is never touched by the reference (XM_main.cu:203-219)
     res.status = status;
     res.primal = primal;
-    if (opt.flags & XM_FLAG_PROFILE_QW) drain_events();
+    if (opt.flags & XM_FLAG_PROFILE_QW) finish_profile();
     // algorithmic bytes of one tCG product at the final rank
     const int of = std::max(3, std::min(out_rank, (int)opt.max_rank));
     if (storage_ == XM_STORAGE_DENSE) res.qw_bytes = 8LL * (3 * n_) * (3 * n_) + 2LL * 8 * 3 * n_ * of;
