@@ -1,0 +1,141 @@
+"""Row-partitioned numpy model of the multi-GPU trust region (xm-code_amd/csrc/xm_solver.hip).
+
+Test infrastructure: mirrors, rank for rank, what each GPU process does — local camera rows of Q, replicated product
+input W obtained by an all-gather, per-rank partial sums that are *gathered* (not all-reduced) and added in a fixed order
+so that every rank takes bit-identical branch decisions, inert padding cameras on the last rank.  The collectives are
+injected (`allgather(vec) -> concatenated vec`) so the same code runs single-process (world 1) or under
+torch.distributed/gloo (tests/test_distributed_cpu.py).  Formulas follow trustregion.h exactly like the kernels do.
+"""
+import numpy as np
+
+
+def _sym(M):
+    return 0.5 * (M + np.transpose(M, (0, 2, 1)))
+
+
+class RankModel:
+    def __init__(self, Q, o, lam, rank, world, allgather):
+        n = Q.shape[0] // 3
+        self.n, self.o, self.lam, self.rank, self.world, self.ag = n, o, lam, rank, world, allgather
+        self.nloc = -(-n // world)
+        self.cam0 = rank * self.nloc
+        self.ntot = self.nloc * world
+        Qp = np.zeros((3 * self.ntot, 3 * self.ntot))
+        Qp[:3 * n, :3 * n] = Q
+        self.Qloc = Qp[3 * self.cam0:3 * (self.cam0 + self.nloc)]          # this rank's rows only
+        self.anchor = np.zeros(self.nloc, dtype=bool)
+        if self.cam0 == 0:
+            self.anchor[0] = True
+
+    # ---- collectives -------------------------------------------------------------------------------------------
+    def gather_rows(self, Xloc):                       # (nloc,3,o) -> (ntot*3, o) replicated product input
+        return self.ag(Xloc.reshape(-1)).reshape(3 * self.ntot, self.o)
+
+    def gsum(self, partial):                           # fixed-order sum of the gathered per-rank partials
+        parts = self.ag(np.atleast_1d(np.asarray(partial, dtype=np.float64)))
+        t = 0.0
+        for p in parts:
+            t += p
+        return t
+
+    # ---- epilogues (xm_kernels.hip: epi_grad / epi_hess) -------------------------------------------------------------
+    def eval_point(self, R, s):
+        W = self.gather_rows(s[:, None, None] * R)
+        G = 2.0 * (self.Qloc @ W).reshape(self.nloc, 3, self.o)
+        Wl = W.reshape(self.ntot, 3, self.o)[self.cam0:self.cam0 + self.nloc]
+        q = s * s - 1.0
+        f = self.gsum(np.sum(0.5 * np.sum(G * Wl, axis=(1, 2)) + np.where(self.anchor, 0.0, self.lam * q * q)))
+        egs = np.where(self.anchor, 0.0, np.sum(G * R, axis=(1, 2)) + 4 * self.lam * q * s)
+        eg = G * s[:, None, None]
+        S0 = _sym(R @ np.transpose(eg, (0, 2, 1)))
+        rgR = eg - S0 @ R
+        rgs = egs * s * s
+        rr = self.gsum(np.sum(rgR * rgR) + np.sum((rgs / s) ** 2))
+        return dict(G=G, egs=egs, S0=S0, rgR=rgR, rgs=rgs, f=f, rr=rr)
+
+    def hess(self, st, R, s, pR, ps):
+        W = self.gather_rows(s[:, None, None] * pR + ps[:, None, None] * R)
+        H = 2.0 * (self.Qloc @ W).reshape(self.nloc, 3, self.o)
+        hs = np.where(self.anchor, 0.0, np.sum(H * R, axis=(1, 2)) + np.sum(st["G"] * pR, axis=(1, 2))
+                      + 4 * self.lam * (3 * s * s - 1) * ps)
+        rh = H * s[:, None, None] + st["G"] * ps[:, None, None]
+        rh = rh - st["S0"] @ pR
+        rh = rh - _sym(R @ np.transpose(rh, (0, 2, 1))) @ R
+        rhs = np.where(self.anchor, 0.0, hs * s * s + ps * s * st["egs"])
+        pHp = self.gsum(np.sum(pR * rh) + np.sum(ps * rhs / (s * s)))
+        return rh, rhs, pHp
+
+    @staticmethod
+    def retract(R, s, vR, vs, anchor):
+        A = R + vR
+        q = A.copy()
+        for i in range(3):
+            q[:, i] /= np.linalg.norm(q[:, i], axis=1)[:, None]
+            for j in range(i + 1, 3):
+                q[:, j] -= np.sum(q[:, i] * q[:, j], axis=1)[:, None] * q[:, i]
+        sn = np.where(anchor, s, s * np.exp(vs / s))
+        return q, sn
+
+    # ---- trust region at fixed rank (trustregion.h:452-710 as restructured in Context::trust_region) -----------------
+    def trust_region(self, R0, s0, gradtol, max_outer=1000):
+        n, o = self.n, self.o
+        R = np.zeros((self.nloc, 3, o)); R[:, :, :3] = np.eye(3)
+        s = np.ones(self.nloc)
+        real = max(0, min(n - self.cam0, self.nloc))
+        R[:real] = R0.reshape(n, 3, o)[self.cam0:self.cam0 + real]
+        s[:real] = s0[self.cam0:self.cam0 + real]
+        delta_bar = np.sqrt(n * (3 * o - 6) + n - 1)
+        delta = delta_bar / 8
+        st = self.eval_point(R, s)
+        loss, rr = st["f"], st["rr"]
+        endreason, shrink, trace, total = 6, 0, [], 0
+        for k in range(max_outer):
+            gn = np.sqrt(rr)
+            trace.append((loss, gn, endreason))
+            if endreason == 5 or gn < gradtol:
+                break
+            # ---- tCG
+            rR, rs = st["rgR"].copy(), st["rgs"].copy()
+            pR, ps = -rR, -rs
+            vR, vs = np.zeros_like(rR), np.zeros_like(rs)
+            HvR, Hvs = np.zeros_like(rR), np.zeros_like(rs)
+            vv = vp = 0.0; pp = rr; rcur = rr; endreason = 6
+            for i in range(1000):
+                HpR, Hps, pHp = self.hess(st, R, s, pR, ps)
+                alpha = rcur / pHp
+                if rcur < 1e-15:
+                    endreason = 5; break
+                if alpha <= 0 or vv + 2 * alpha * vp + alpha * alpha * pp > delta * delta:
+                    tau = (-vp + np.sqrt(vp * vp + pp * (delta * delta - vv))) / pp
+                    vR += tau * pR; vs += tau * ps; HvR += tau * HpR; Hvs += tau * Hps
+                    endreason = 1 if alpha <= 0 else 2; break
+                vR += alpha * pR; vs += alpha * ps; rR += alpha * HpR; rs += alpha * Hps
+                HvR += alpha * HpR; Hvs += alpha * Hps
+                rnew = self.gsum(np.sum(rR * rR) + np.sum((rs / s) ** 2))
+                if np.sqrt(rnew) < gn * min(gn, 0.1):
+                    endreason = 3; break
+                beta = rnew / rcur
+                pR = beta * pR - rR; ps = beta * ps - rs
+                vv, vp, pp = vv + 2 * alpha * vp + alpha * alpha * pp, beta * (vp + alpha * pp), beta * beta * pp + rnew
+                rcur = rnew
+            total += i + 1
+            m = self.gsum(np.sum(vR * (0.5 * HvR + st["rgR"])) + np.sum(vs / (s * s) * (0.5 * Hvs + st["rgs"])))
+            if m >= 0:
+                break
+            Rc, sc = self.retract(R, s, vR, vs, self.anchor)
+            stc = self.eval_point(Rc, sc)
+            rou = (stc["f"] - loss) / m
+            if rou < 0.25:
+                delta *= 0.25; shrink += 1
+            elif rou > 0.75 and endreason <= 2:
+                delta = min(2 * delta, delta_bar); shrink = 0
+            else:
+                shrink = 0
+            if shrink > 3:
+                delta *= 1e-3; shrink = 0
+            if not (stc["f"] > loss or rou < 0.1):
+                R, s, st, loss, rr = Rc, sc, stc, stc["f"], stc["rr"]
+        # assemble the full solution on every rank
+        Rfull = self.ag(R.reshape(-1)).reshape(self.ntot * 3, o)[:3 * n]
+        sfull = self.ag(s)[:n]
+        return Rfull, sfull, dict(primal=loss, tcg_iters=total, outer=len(trace) - 1, trace=np.array(trace))
