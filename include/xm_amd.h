@@ -129,6 +129,9 @@ int xm_dev_sync(void);
 
 /* lay a host column-major symmetric Q out as the device row-major padded matrix (allocates *dq) */
 int xm_dense_upload(const double *q_host, int64_t ldq, int64_t n, double **dq);
+/* build the same device layout from a 3x3-block CSR description on the host (zero elsewhere) without ever forming
+ * the dense matrix on the host — used to store a >= 10k-camera view-graph Q densely (13.5 GB at n = 13682) */
+int xm_dense_from_bsr3(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, double **dq);
 /* out = alpha * Q * W.  dq from xm_dense_upload; dW, dOut: device, row-major 3n x o (o in 1,3..10).
  * Replaces cublasDgemm via DnMatDnMat (Dense/matmul.h:42-87). stream: hipStream_t or NULL. */
 int xm_qw_dense(const double *dq, int64_t n, int o, const double *dW, double *dOut, double alpha, void *stream);

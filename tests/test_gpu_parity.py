@@ -189,3 +189,44 @@ def test_full_size_properties(xmamd, n):
     assert tl.rel_fro(lhs, rhs) < 1e-13
     assert tl.rel_fro(xmamd.qw_dense(None, A, dq=dq), P["Q"] @ A) < 1e-13
     dq.free()
+
+
+def test_dense_from_bsr3_equals_upload(xmamd):
+    P = tl.gen_vg(200, deg=9, sigma=0.2, seed=9)
+    W = np.random.default_rng(1).standard_normal((600, 4))
+    dq = xmamd.dense_from_bsr3(P["rowptr"], P["colidx"], P["blocks"])
+    got = xmamd.qw_dense(None, W, dq=dq)
+    assert np.array_equal(got, xmamd.qw_dense(P["Q"], W))
+    ctx = xmamd.Context(dq=dq, n=200)
+    R, s, info = ctx.solve(4, 1e-8, 9.0)
+    ctx.close(); dq.free()
+    R2, s2, i2 = xmamd.solve_dense(P["Q"], 4, 1e-8, 9.0)
+    assert np.array_equal(R, R2) and np.array_equal(s, s2)
+
+
+def test_rccl_path_single_rank(xmamd, tmp_path):
+    """XM_FORCE_COMM=1 issues every all-gather of the multi-GPU path on a 1-rank RCCL communicator: the result must be
+    bit-identical to the plain single-GPU run (exercises dlopen(RCCL), ncclCommInitRank and in-place ncclAllGather)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys, os, ctypes as C
+        sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'xm-code_amd')!r})
+        sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import numpy as np, xmamd, xm_testlib as tl
+        Q = tl.load_bin(os.path.join(tl.GOLDEN, 'simple2', 'Q.bin'))
+        if os.environ.get('XM_FORCE_COMM') == '1':
+            buf = (C.c_char * 128)()
+            xmamd._chk(xmamd.lib().xm_comm_unique_id(buf))
+            xmamd._chk(xmamd.lib().xm_comm_init(0, 1, 0, buf.raw, None))
+        R, s, info = xmamd.solve_dense(Q, 3, 1e-16, 0.0)
+        np.savez(sys.argv[1], R=R, s=s, primal=info['primal'], tcg=info['tcg_iters'])
+        xmamd.lib().xm_comm_finalize()
+    """)
+    outs = []
+    for force in ("0", "1"):
+        out = str(tmp_path / f"r{force}.npz")
+        env = dict(os.environ, XM_FORCE_COMM=force)
+        subprocess.check_call([sys.executable, "-c", code, out], env=env, timeout=600)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["R"], outs[1]["R"]) and np.array_equal(outs[0]["s"], outs[1]["s"])
+    assert int(outs[0]["tcg"]) == int(outs[1]["tcg"])

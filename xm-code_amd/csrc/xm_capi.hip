@@ -161,6 +161,26 @@ int xm_dense_upload(const double *q_host, int64_t ldq, int64_t n, double **dq) {
     XM_CATCH
 }
 
+int xm_dense_from_bsr3(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, double **dq) {
+    XM_TRY
+    require_device();
+    if (!rowptr || !colidx || !blocks || !dq || n < 1) throw xm::Error(XM_ERR_ARG, "bad argument");
+    const int64_t ld = xm::dense_ld(n), nb = rowptr[n];
+    xm::DevBuf<int64_t> rp; xm::DevBuf<int32_t> ci; xm::DevBuf<double> bl;
+    rp.alloc((size_t)n + 1, false); ci.alloc((size_t)nb, false); bl.alloc((size_t)nb * 9, false);
+    XM_HIP_CHECK(hipMemcpy(rp.p, rowptr, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    XM_HIP_CHECK(hipMemcpy(ci.p, colidx, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice));
+    XM_HIP_CHECK(hipMemcpy(bl.p, blocks, (size_t)nb * 9 * sizeof(double), hipMemcpyHostToDevice));
+    double *out = nullptr;
+    XM_HIP_CHECK(hipMalloc((void **)&out, (size_t)3 * n * ld * sizeof(double)));
+    XM_HIP_CHECK(hipMemset(out, 0, (size_t)3 * n * ld * sizeof(double)));
+    xm::launch_dense_from_bsr(rp.p, ci.p, bl.p, n, 0, out, ld, nullptr);
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    *dq = out;
+    return XM_OK;
+    XM_CATCH
+}
+
 static xm::CamArgs plain_args(int64_t n, double *out) {
     xm::CamArgs a;
     std::memset(&a, 0, sizeof(a));

@@ -8,6 +8,7 @@
 // loaded is reused, otherwise /opt/rocm/lib/librccl.so).  No link-time dependency, no collective unless world > 1.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "xm_solver.h"
@@ -78,16 +79,19 @@ void comm_init(int rank, int world, int device, const unsigned char id[128], con
     }
     g_comm.rank = rank;
     g_comm.world = world;
+    const char *f = std::getenv("XM_FORCE_COMM");
+    g_comm.forced = (f && *f == '1' && g_rccl.comm != nullptr);
 }
 
 void comm_finalize() {
     if (g_rccl.comm) { g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
     g_comm.rank = 0;
     g_comm.world = 1;
+    g_comm.forced = false;
 }
 
 void Comm::allgather(double *buf, size_t count, hipStream_t st) {
-    if (world <= 1 && !g_rccl.comm) return;
+    if (!g_rccl.comm) return;
     check(g_rccl.AllGather(buf + (size_t)rank * count, buf, count, kNcclFloat64, g_rccl.comm, st), "ncclAllGather");
 }
 

@@ -14,7 +14,8 @@ namespace xm {
 // ---- communicator (row partition over the GPUs of one node; RCCL loaded at run time) -----------------------------
 struct Comm {
     int rank = 0, world = 1;
-    bool active() const { return world > 1; }
+    bool forced = false;   // XM_FORCE_COMM=1: issue the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
+    bool active() const { return world > 1 || forced; }
     // in-place all-gather on `stream`: every rank contributes `count` doubles located at buf + rank*count
     void allgather(double *buf, size_t count, hipStream_t st);
 };

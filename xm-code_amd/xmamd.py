@@ -19,7 +19,7 @@ FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 EXPORTS = [
     "xm_last_error", "xm_version", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
-    "xm_dev_sync", "xm_dense_upload", "xm_qw_dense", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time",
+    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_finalize", "xm_partition",
 ]
 
@@ -77,6 +77,7 @@ def lib():
         L.xm_dev_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.xm_dev_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.xm_dense_upload.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]
+        L.xm_dense_from_bsr3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
         L.xm_qw_dense.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
         L.xm_qw_bsr3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_double, C.c_void_p]
@@ -168,6 +169,20 @@ def dense_upload(Q):
     return d
 
 
+def dense_from_bsr3(rowptr, colidx, blocks):
+    """device-side densification of a 3x3-block CSR matrix into the solver's padded row-major layout"""
+    require_gpu()
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    blocks = np.ascontiguousarray(blocks, dtype=np.float64)
+    n = rowptr.size - 1
+    p = C.c_void_p()
+    _chk(lib().xm_dense_from_bsr3(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p),
+                                  blocks.ctypes.data_as(C.c_void_p), n, C.byref(p)))
+    d = DevArray.__new__(DevArray)
+    d.ptr, d.nbytes = p, 3 * n * dense_ld(n) * 8
+    return d
+
+
 def qw_dense(Q, W, alpha=1.0, dq=None):
     """alpha * Q @ W on the GPU through xm_qw_dense (Q: 3n x 3n, W: 3n x o)."""
     require_gpu()
@@ -220,11 +235,15 @@ def retract(R, s, D, ds, t):
 class Context:
     """Q resident in HBM; solve() == the reference's staircase (XM_main.cu:180 / :312 / :35)."""
 
-    def __init__(self, Q=None, bsr=None, n=None):
+    def __init__(self, Q=None, bsr=None, dq=None, n=None):
         require_gpu()
         self._keep = []
         p = Problem()
-        if Q is not None:
+        if dq is not None:                      # dense Q already on the device in the solver's layout (borrowed)
+            self.n = int(n)
+            p.n, p.storage, p.q_on_device, p.q, p.ldq = self.n, STORAGE_DENSE, 1, dq.ptr, dense_ld(self.n)
+            self._dq = dq
+        elif Q is not None:
             Q = np.asfortranarray(np.asarray(Q, dtype=np.float64))
             self.n = Q.shape[0] // 3
             p.n, p.storage, p.q, p.ldq = self.n, STORAGE_DENSE, Q.ctypes.data_as(C.c_void_p), Q.shape[0]
