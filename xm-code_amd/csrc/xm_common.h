@@ -109,6 +109,8 @@ void launch_p_update(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_nex
                      hipStream_t st);
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs,
                         const double *rgR, const double *rgs, const double *s, double *parts, hipStream_t st);
+void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,
+                           unsigned long long seq, hipStream_t st);
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
                     double *Rout, double *sout, double *Wloc, hipStream_t st);
 void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *QsR, const double *R, const double *s,

@@ -24,10 +24,26 @@ namespace xm {
 // ----------------------------------------------------------------------------------------------------------------
 // wave / block reductions (deterministic: fixed shuffle tree, fixed block size 256)
 // ----------------------------------------------------------------------------------------------------------------
+// 64-lane sum with DPP (data-parallel primitives: cross-lane operands inside the VALU, ~10 cycles per step) instead of
+// ds_bpermute (LDS crossbar, ~100 cycles per dependent step): butterfly inside each row of 16 lanes (quad_perm, row_ror),
+// then row_bcast:15 / row_bcast:31 accumulate the rows into row 3 and lane 63 is broadcast through a scalar register.
+// Fixed tree => bit-reproducible; the result is uniform across the wave.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
+    v += dpp_mov<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
+    v += dpp_mov<0x124, 0xf>(v);   // row_ror:4
+    v += dpp_mov<0x128, 0xf>(v);   // row_ror:8   -> every lane holds its row's sum
+    v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> row 3 holds the wave total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 // sum over the 256 threads of a block; result valid in every thread.  `sh` must hold >= 4 doubles.
@@ -92,14 +108,41 @@ __device__ __forceinline__ void sub_s_times(Col3 &X, const double (&S)[3][3], co
     for (int a = 0; a < 3; ++a) X.v[a] -= S[a][0] * Y.v[0] + S[a][1] * Y.v[1] + S[a][2] * Y.v[2];
 }
 
+// Operands of the epilogues, fetched while the last tile is still being multiplied (they were written by the previous
+// launches, so the loads miss the L2 of this XCD; issuing them early hides ~1 us at the end of every wavefront).
+struct EpiOps {
+    Col3 R, P, G, Wl;
+    double s, ps, egs;
+    double S0[9];
+};
+template <int O, int EPI>
+__device__ __forceinline__ void epi_prefetch(EpiOps &e, int cam, int lane, bool active, const CamArgs &a) {
+    if (!active) return;
+    if (EPI == EPI_GRAD) {
+        e.s = a.s[cam];
+        e.R = load_col<O>(a.R, cam, lane);
+        e.Wl = load_col<O>(a.Wloc, cam, lane);
+    } else if (EPI == EPI_HESS) {
+        e.s = a.s[cam];
+        e.ps = a.ps[cam];
+        e.egs = a.egs[cam];
+        e.R = load_col<O>(a.R, cam, lane);
+        e.P = load_col<O>(a.pR, cam, lane);
+        e.G = load_col<O>(a.G, cam, lane);
+        const double *sp = a.S0 + (size_t)cam * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) e.S0[j] = sp[j];
+    }
+}
+
 // Gradient / point-state epilogue: trustregion.h:186-194 (grad), :307-317 (projection), :162-170 (objc) fused.
 // h = 2*C*sR rows.  Produces G, egs, S0, rg and this camera's share of {f, <rg,rg>_metric} (uniform on return).
 template <int O>
-__device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const CamArgs &a, double &p0, double &p1) {
+__device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const EpiOps &e, const CamArgs &a, double &p0, double &p1) {
     const bool anchor = (a.cam0 + cam) == 0;
-    const double s = a.s[cam];
-    const Col3 R = load_col<O>(a.R, cam, lane);
-    const Col3 Wl = load_col<O>(a.Wloc, cam, lane);
+    const double s = e.s;
+    const Col3 &R = e.R;
+    const Col3 &Wl = e.Wl;
     store_col<O>(h, a.G, cam, lane);
     // f = <C sR, sR> + lam * sum_{i>=1} (s_i^2-1)^2 ;  <C sR, sR> = 0.5 * <G, sR>
     const double q = s * s - 1.0;
@@ -131,13 +174,13 @@ __device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const
 // Hessian epilogue: trustregion.h:227-255 (ehess) + :277-295 (ehess2rhess) fused.  h = 2*C*(s.*Ru + su.*R) rows.
 // Produces Hp = (rhr, rhs) and this camera's share of <p, Hp>_metric.
 template <int O>
-__device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const CamArgs &a, double &p0) {
+__device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const EpiOps &e, const CamArgs &a, double &p0) {
     const bool anchor = (a.cam0 + cam) == 0;
-    const double s = a.s[cam];
-    const double ps = anchor ? 0.0 : a.ps[cam];
-    const Col3 R = load_col<O>(a.R, cam, lane);
-    const Col3 P = load_col<O>(a.pR, cam, lane);
-    const Col3 G = load_col<O>(a.G, cam, lane);
+    const double s = e.s;
+    const double ps = anchor ? 0.0 : e.ps;
+    const Col3 &R = e.R;
+    const Col3 &P = e.P;
+    const Col3 &G = e.G;
     // hs = sum(CsRu.*R) + sum(CsR.*Ru) + 4 lam (3 s^2 - 1) su
     const double hRGP = wave_sum(dot3(h, R)) + wave_sum(dot3(G, P));
     const double hs = anchor ? 0.0 : hRGP + 4.0 * a.lam * ((3.0 * s * s - 1.0) * ps);
@@ -146,15 +189,14 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
 #pragma unroll
     for (int r = 0; r < 3; ++r) rh.v[r] = h.v[r] * s + G.v[r] * ps;
     double S0[3][3], S1[3][3];
-    const double *sp = a.S0 + (size_t)cam * 9;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) S0[r][c] = sp[r * 3 + c];
+        for (int c = 0; c < 3; ++c) S0[r][c] = e.S0[r * 3 + c];
     sub_s_times(rh, S0, P);   // rhr = ehessR - Ru * sym(R' egradR)
     sym_abt(R, rh, S1);
     sub_s_times(rh, S1, R);   // rhr -= R * sym(R' rhr)
-    const double rhs = anchor ? 0.0 : hs * (s * s) + (ps * s) * a.egs[cam];
+    const double rhs = anchor ? 0.0 : hs * (s * s) + (ps * s) * e.egs;
     store_col<O>(rh, a.HpR, cam, lane);
     if (lane == 0) a.Hps[cam] = rhs;
     p0 = wave_sum(dot3(P, rh)) + ps * (rhs / (s * s));
@@ -165,7 +207,7 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
 // ----------------------------------------------------------------------------------------------------------------
 template <int O, int EPI>
 __device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool active, double (&acc)[3][O], double alpha,
-                                          const CamArgs &a, double (*red)[2]) {
+                                          const CamArgs &a, const EpiOps &e, double (*red)[2]) {
     constexpr int OP = pitch_of(O);
     Col3 h;
     h.v[0] = h.v[1] = h.v[2] = 0.0;
@@ -181,9 +223,9 @@ __device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool acti
         if (EPI == EPI_PLAIN) {
             store_col<O>(h, a.out, cam, lane);
         } else if (EPI == EPI_GRAD) {
-            epi_grad<O>(cam, lane, h, a, p0, p1);
+            epi_grad<O>(cam, lane, h, e, a, p0, p1);
         } else if (EPI == EPI_HESS) {
-            epi_hess<O>(cam, lane, h, a, p0);
+            epi_hess<O>(cam, lane, h, e, a, p0);
         } else if (EPI == EPI_CERT) {
             // y_i = (Q x)_i + dz_i * x[3i] e_0 - Lam_i x_i      (O == 1, lane 0 owns the column)
             const double *x = a.Wloc + (size_t)cam * 3 * OP;
@@ -222,8 +264,8 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
     }
     __shared__ __attribute__((aligned(16))) double wt[2][TILE * OP];
     __shared__ double red[kQwWaves][2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cam = blockIdx.x * kQwWaves + wave;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cam = blockIdx.x * kQwWaves + wave;   // wave-uniform (scalar): per-camera scalars load through the scalar cache
     const bool active = cam < a.nloc;
     const double *q0 = Q + (size_t)(active ? cam : 0) * 3 * (size_t)ld + 2 * lane;
     const int ntiles = (int)((ld + TILE - 1) / TILE);
@@ -234,6 +276,7 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
 
+    EpiOps eops;
     double2 qn[NSUB][3];   // Q fragment of the NEXT tile
     double2 ws[NST];       // this thread's share of the NEXT W tile
     auto load_q = [&](int t) {
@@ -284,6 +327,8 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
         if (more) {  // uniform
             load_q(t + 1);
             load_w(t + 1);
+        } else {
+            epi_prefetch<O, EPI>(eops, cam, lane, active, a);
         }
         const double2 *wbase = reinterpret_cast<const double2 *>(wt[t & 1]);
 #pragma unroll
@@ -304,7 +349,7 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
         if (more) store_w((t + 1) & 1);
         __syncthreads();
     }
-    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, red);
+    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -319,9 +364,11 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
         if (a.scal->status != 0) return;
     }
     __shared__ double red[kQwWaves][2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cam = blockIdx.x * kQwWaves + wave;
     const bool active = cam < a.nloc;
+    EpiOps eops;
+    epi_prefetch<O, EPI>(eops, cam, lane, active, a);
     double part[O];
 #pragma unroll
     for (int k = 0; k < O; ++k) part[k] = 0.0;
@@ -344,7 +391,7 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = mine ? part[k] : 0.0;
     }
-    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, red);
+    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -595,6 +642,32 @@ __global__ __launch_bounds__(256) void model_value_kernel(int nloc, const double
     }
     const double tot = block_sum256(acc, sh);
     if (threadIdx.x == 0) parts[blockIdx.x] = tot;
+}
+
+// End of an outer iteration: one 256-thread block adds the gathered partial sums in their fixed order and hands
+// {f_new, <g,g>_new, model value, tCG exit status, inner iterations} to the host through mapped memory; the sequence word
+// is written last.  Replaces three device-to-host copies and a stream synchronisation per outer iteration.
+__global__ __launch_bounds__(256) void outer_finalize_kernel(const double *__restrict__ partsA, int nA_loc, int world,
+                                                              const double *__restrict__ partsM, int nM,
+                                                              const TcgScal *__restrict__ scal, double *hres, unsigned long long seq) {
+    __shared__ double sh[4];
+    double f = 0.0, rr = 0.0;
+    for (int r = 0; r < world; ++r) {   // same grouping as the host-side summation it replaces: rank by rank
+        f += sum_partials256(partsA + (size_t)r * 2 * nA_loc, nA_loc, sh);
+        rr += sum_partials256(partsA + (size_t)r * 2 * nA_loc + nA_loc, nA_loc, sh);
+    }
+    const double m = sum_partials256(partsM, nM, sh);
+    if (threadIdx.x == 0) {
+        const TcgScal sc = *scal;
+        __hip_atomic_store(hres + 0, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hres + 1, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hres + 2, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hres + 3, (double)sc.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hres + 4, (double)sc.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(hres + 5), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -927,6 +1000,11 @@ void launch_model_value(int o, int nloc, const double *vR, const double *vs, con
     XM_DISPATCH_O(o, hipLaunchKernelGGL((model_value_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
                                         nloc, vR, vs, HvR, Hvs, rgR, rgs, s, parts));
     check_launch("model_value");
+}
+void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,
+                           unsigned long long seq, hipStream_t st) {
+    hipLaunchKernelGGL(outer_finalize_kernel, dim3(1), dim3(256), 0, st, partsA, nA_loc, world, partsM, nM, scal, hres, seq);
+    check_launch("outer_finalize");
 }
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
                     double *Rout, double *sout, double *Wloc, hipStream_t st) {

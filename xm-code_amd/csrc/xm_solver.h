@@ -98,6 +98,7 @@ private:
     double *hpin_ = nullptr;                   // pinned host scratch for partial sums
     size_t hpin_count_ = 0;
     int nA_ = 0, nB_ = 0;                      // partial counts (whole job)
+    unsigned long long outer_seq_ = 0;         // sequence number of the host-mapped outer-iteration result block
 
     // ---- options / statistics of the running solve -------------------------------------------------------------------
     const xm_options_t *opt_ = nullptr;
@@ -117,6 +118,7 @@ private:
     void eval_point(int state, const double *Rp, const double *sp, double &f, double &rr);
     double sum_parts(const double *dparts, int count);
     int run_tcg(double rr, double delta, TcgScal &fin);
+    volatile double *wait_outer_result();
     void drain_events();
     void finish_profile();
     TrResult trust_region(int o, double &gradtol, double linesearch_step, const std::vector<double> &v_dir, double max_time);

@@ -91,8 +91,8 @@ Context::Context(const xm_problem_t &prob) {
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
     }
-    XM_HIP_CHECK(hipHostMalloc((void **)&hstat_, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(hstat_, 0, 64);
+    XM_HIP_CHECK(hipHostMalloc((void **)&hstat_, 256, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(hstat_, 0, 256);
     XM_HIP_CHECK(hipHostGetDevicePointer((void **)&hstat_dev_, hstat_, 0));
 }
 
@@ -219,14 +219,25 @@ void Context::eval_point(int state, const double *Rp, const double *sp, double &
     a.partials = partsA_.p + (size_t)comm_->rank * 2 * nA_loc;
     product(EPI_GRAD, o_, 2.0, a);
     if (comm_->active()) comm_->allgather(partsA_.p, (size_t)2 * nA_loc, st_);
-    XM_HIP_CHECK(hipMemcpyAsync(hpin_, partsA_.p, (size_t)2 * nA_ * sizeof(double), hipMemcpyDeviceToHost, st_));
-    XM_HIP_CHECK(hipStreamSynchronize(st_));
-    f = 0.0; rr = 0.0;
-    for (int r = 0; r < comm_->world; ++r) {
-        const double *p = hpin_ + (size_t)r * 2 * nA_loc;
-        for (int i = 0; i < nA_loc; ++i) f += p[i];
-        for (int i = 0; i < nA_loc; ++i) rr += p[nA_loc + i];
+    launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, 0, scal_.p, reinterpret_cast<double *>(hstat_dev_) + 8,
+                          ++outer_seq_, st_);
+    volatile double *hres = wait_outer_result();
+    f = hres[0];
+    rr = hres[1];
+}
+
+// spin on the sequence word of the host-mapped result block (written last by outer_finalize_kernel)
+volatile double *Context::wait_outer_result() {
+    volatile unsigned long long *hseq = reinterpret_cast<volatile unsigned long long *>(hstat_) + 8 + 5;
+    const unsigned long long seq = outer_seq_;
+    auto t_wait = clk::now();
+    while (*hseq != seq) {
+        if (secs_since(t_wait) > 500e-6 && hipStreamQuery(st_) == hipSuccess) {
+            XM_HIP_CHECK(hipStreamSynchronize(st_));
+            if (*hseq != seq) throw Error(XM_ERR_HIP, "outer-iteration results did not reach host-mapped memory");
+        }
     }
+    return reinterpret_cast<volatile double *>(hstat_) + 8;
 }
 
 void Context::drain_events() {
@@ -433,24 +444,16 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
             product(EPI_GRAD, o_, 2.0, a);
             if (comm_->active()) comm_->allgather(partsA_.p, (size_t)2 * nA_loc, st_);
         }
-        double *hA = hpin_, *hM = hpin_ + (size_t)2 * nA_;
-        TcgScal *hS = reinterpret_cast<TcgScal *>(hpin_ + (size_t)2 * nA_ + nB_);
-        XM_HIP_CHECK(hipMemcpyAsync(hA, partsA_.p, (size_t)2 * nA_ * sizeof(double), hipMemcpyDeviceToHost, st_));
-        XM_HIP_CHECK(hipMemcpyAsync(hM, partsM_.p, (size_t)nB_ * sizeof(double), hipMemcpyDeviceToHost, st_));
-        XM_HIP_CHECK(hipMemcpyAsync(hS, scal_.p + (enq & 1), sizeof(TcgScal), hipMemcpyDeviceToHost, st_));
-        XM_HIP_CHECK(hipStreamSynchronize(st_));
-        fin = *hS;
+        launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, nB_, scal_.p + (enq & 1),
+                              reinterpret_cast<double *>(hstat_dev_) + 8, ++outer_seq_, st_);
+        volatile double *hres = wait_outer_result();
+        double f_new = hres[0], rr_new = hres[1], loss_qu = hres[2];
+        fin.status = (int)hres[3];
+        fin.iter = (int)hres[4];
         if (fin.status == 0) fin.status = 6;  // ran out of iterations
         endreason = fin.status;
         inner_print = fin.iter + 1;
         totalite += fin.iter + 1;
-        double f_new = 0.0, rr_new = 0.0, loss_qu = 0.0;
-        for (int r = 0; r < comm_->world; ++r) {
-            const double *p = hA + (size_t)r * 2 * nA_loc;
-            for (int i = 0; i < nA_loc; ++i) f_new += p[i];
-            for (int i = 0; i < nA_loc; ++i) rr_new += p[nA_loc + i];
-        }
-        for (int i = 0; i < nB_; ++i) loss_qu += hM[i];
         if (opt_->flags & XM_FLAG_PROFILE_QW) drain_events();
         if (loss_qu >= 0) { log("error! loss_qu is larger than 0\n"); stop_reason = 12; break; }
         const double rou = (f_new - loss) / loss_qu;  // trustregion.h:680-701
