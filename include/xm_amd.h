@@ -144,6 +144,8 @@ int xm_retract(int64_t n, int o, const double *dR, const double *ds, const doubl
                double *dRout, double *dsout, void *stream);
 /* timing helper for bench.py: average milliseconds of `reps` back-to-back xm_qw_dense launches (HIP events) */
 int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
+int xm_qw_bsr3_time(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o, const double *dW,
+                    double *dOut, int reps, double *ms_avg);
 
 /* ================================================================== 4. multi-GPU row partition (one process per GPU) */
 /* 128-byte unique id of the RCCL communicator: rank 0 calls xm_comm_unique_id and broadcasts the bytes

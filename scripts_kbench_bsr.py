@@ -1,0 +1,18 @@
+"""micro-benchmark of the BSR3 Q*W kernel: python scripts_kbench_bsr.py n deg o [o ...]"""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "xm-code_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, xmamd, xm_testlib as tl
+n = int(sys.argv[1]); deg = int(sys.argv[2]); os_ = [int(x) for x in sys.argv[3:]] or [3]
+P = tl.gen_vg(n, deg=deg, sigma=0.05, seed=n, dense=False)
+nb = P["colidx"].size
+L = xmamd.lib()
+drp = xmamd.DevArray(P["rowptr"]); dci = xmamd.DevArray(P["colidx"]); dbl = xmamd.DevArray(P["blocks"].reshape(-1))
+rng = np.random.default_rng(0)
+for o in os_:
+    OP = o | 1
+    dW = xmamd.DevArray(rng.standard_normal((3 * n, OP))); dO = xmamd.DevArray(nbytes=3 * n * OP * 8)
+    ms = C.c_double()
+    xmamd._chk(L.xm_qw_bsr3_time(drp.ptr, dci.ptr, dbl.ptr, n, o, dW.ptr, dO.ptr, 100, C.byref(ms)))
+    by = 76.0 * nb + 4 * (n + 1) + 2 * 8 * 3 * n * o
+    print(f"BSR n={n} deg={deg} nb={nb} o={o}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s algorithmic ({by/1e6:.1f} MB)")

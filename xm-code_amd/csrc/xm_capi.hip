@@ -227,6 +227,25 @@ int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, doubl
     XM_CATCH
 }
 
+int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int64_t n, int o, const double *dW, double *dOut, int reps,
+                    double *ms_avg) {
+    XM_TRY
+    hipEvent_t e0, e1;
+    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+    const xm::CamArgs a = plain_args(n, dOut);
+    for (int i = 0; i < 3; ++i) xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+    XM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_avg) *ms_avg = (double)ms / reps;
+    return XM_OK;
+    XM_CATCH
+}
+
 int xm_comm_unique_id(unsigned char id[128]) { XM_TRY xm::comm_unique_id(id); return XM_OK; XM_CATCH }
 int xm_comm_init(int rank, int world, int device, const unsigned char id[128], const char *rccl_path) {
     XM_TRY require_device(); xm::comm_init(rank, world, device, id, rccl_path); return XM_OK; XM_CATCH

@@ -111,8 +111,8 @@ __device__ __forceinline__ void sub_s_times(Col3 &X, const double (&S)[3][3], co
 // Operands of the epilogues, fetched while the last tile is still being multiplied (they were written by the previous
 // launches, so the loads miss the L2 of this XCD; issuing them early hides ~1 us at the end of every wavefront).
 struct EpiOps {
-    Col3 R, P, G, Wl;
-    double s, ps, egs;
+    Col3 R, P, G, Wl, Rr;
+    double s, ps, egs, rs;
     double S0[9];
 };
 template <int O, int EPI>
@@ -129,6 +129,8 @@ __device__ __forceinline__ void epi_prefetch(EpiOps &e, int cam, int lane, bool 
         e.R = load_col<O>(a.R, cam, lane);
         e.P = load_col<O>(a.pR, cam, lane);
         e.G = load_col<O>(a.G, cam, lane);
+        e.Rr = load_col<O>(a.rR, cam, lane);
+        e.rs = a.rs[cam];
         const double *sp = a.S0 + (size_t)cam * 9;
 #pragma unroll
         for (int j = 0; j < 9; ++j) e.S0[j] = sp[j];
@@ -172,9 +174,10 @@ __device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const
 }
 
 // Hessian epilogue: trustregion.h:227-255 (ehess) + :277-295 (ehess2rhess) fused.  h = 2*C*(s.*Ru + su.*R) rows.
-// Produces Hp = (rhr, rhs) and this camera's share of <p, Hp>_metric.
+// Produces Hp = (rhr, rhs) and this camera's shares of <p,Hp>, <r,Hp>, <Hp,Hp> (product metric).
 template <int O>
-__device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const EpiOps &e, const CamArgs &a, double &p0) {
+__device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const EpiOps &e, const CamArgs &a, double &p0, double &p1,
+                                         double &p2) {
     const bool anchor = (a.cam0 + cam) == 0;
     const double s = e.s;
     const double ps = anchor ? 0.0 : e.ps;
@@ -200,6 +203,12 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
     store_col<O>(rh, a.HpR, cam, lane);
     if (lane == 0) a.Hps[cam] = rhs;
     p0 = wave_sum(dot3(P, rh)) + ps * (rhs / (s * s));
+    // <r,Hp> and <Hp,Hp> in the same metric: with them the residual norm after the CG step follows without a second
+    // global reduction, |r + alpha Hp|^2 = <r,r> + 2 alpha <r,Hp> + alpha^2 <Hp,Hp>   (one flat kernel per iteration)
+    const double rsv = anchor ? 0.0 : e.rs;
+    p1 = wave_sum(dot3(e.Rr, rh)) + rsv * (rhs / (s * s));
+    const double hq = rhs / s;
+    p2 = wave_sum(dot3(rh, rh)) + hq * hq;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -207,7 +216,7 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
 // ----------------------------------------------------------------------------------------------------------------
 template <int O, int EPI>
 __device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool active, double (&acc)[3][O], double alpha,
-                                          const CamArgs &a, const EpiOps &e, double (*red)[2]) {
+                                          const CamArgs &a, const EpiOps &e, double (*red)[3]) {
     constexpr int OP = pitch_of(O);
     Col3 h;
     h.v[0] = h.v[1] = h.v[2] = 0.0;
@@ -218,14 +227,14 @@ __device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool acti
             const double t = alpha * wave_sum(acc[r][k]);
             if (lane == k) h.v[r] = t;
         }
-    double p0 = 0.0, p1 = 0.0;
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
     if (active) {  // wave-uniform
         if (EPI == EPI_PLAIN) {
             store_col<O>(h, a.out, cam, lane);
         } else if (EPI == EPI_GRAD) {
             epi_grad<O>(cam, lane, h, e, a, p0, p1);
         } else if (EPI == EPI_HESS) {
-            epi_hess<O>(cam, lane, h, e, a, p0);
+            epi_hess<O>(cam, lane, h, e, a, p0, p1, p2);
         } else if (EPI == EPI_CERT) {
             // y_i = (Q x)_i + dz_i * x[3i] e_0 - Lam_i x_i      (O == 1, lane 0 owns the column)
             const double *x = a.Wloc + (size_t)cam * 3 * OP;
@@ -238,11 +247,12 @@ __device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool acti
         }
     }
     if (EPI == EPI_GRAD || EPI == EPI_HESS) {
-        if (lane == 0) { red[wave][0] = p0; red[wave][1] = p1; }
+        if (lane == 0) { red[wave][0] = p0; red[wave][1] = p1; red[wave][2] = p2; }
         __syncthreads();
         if (threadIdx.x == 0) {
             a.partials[blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-            if (EPI == EPI_GRAD) a.partials[gridDim.x + blockIdx.x] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+            a.partials[gridDim.x + blockIdx.x] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+            if (EPI == EPI_HESS) a.partials[2 * gridDim.x + blockIdx.x] = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
         }
     }
 }
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
         if (a.scal->status != 0) return;  // tCG already terminated: enqueued-ahead launch becomes a no-op
     }
     __shared__ __attribute__((aligned(16))) double wt[2][TILE * OP];
-    __shared__ double red[kQwWaves][2];
+    __shared__ double red[kQwWaves][3];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cam = blockIdx.x * kQwWaves + wave;   // wave-uniform (scalar): per-camera scalars load through the scalar cache
     const bool active = cam < a.nloc;
@@ -353,9 +363,12 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// 3x3-block CSR Q*W: one wavefront per camera row; 63 lanes cover 7 blocks x 9 entries per step.
+// 3x3-block CSR Q*W: one wavefront per camera row, ONE LANE PER STORED BLOCK.  A lane fetches its column index, then
+// (independently, all in flight together) its 72-byte block and the 3 x O rows of W it multiplies, and does the 9*O FMAs
+// itself; a row of up to 64 blocks is a single pass with two dependent memory round trips (a lane-per-element mapping
+// needs ten).  Blocks of one row are contiguous, so the 64 lanes sweep one contiguous 4.6 KB window of the block array.
 // ----------------------------------------------------------------------------------------------------------------
-template <int O, int EPI>
+template <int O, int EPI, int VAR>
 __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                                        const double *__restrict__ blocks, const double *__restrict__ W,
                                                        double alpha, CamArgs a) {
@@ -363,33 +376,61 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
-    __shared__ double red[kQwWaves][2];
+    __shared__ double red[kQwWaves][3];
+    __shared__ double stage[(VAR == 1) ? kQwWaves * 64 * 9 : 1];   // VAR 1: blocks pass through LDS (perfectly coalesced loads)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cam = blockIdx.x * kQwWaves + wave;
     const bool active = cam < a.nloc;
     EpiOps eops;
     epi_prefetch<O, EPI>(eops, cam, lane, active, a);
-    double part[O];
-#pragma unroll
-    for (int k = 0; k < O; ++k) part[k] = 0.0;
-    const int slot = lane / 9, e = lane - slot * 9;  // e = 3*row + col inside the block
-    const int ecol = e % 3;
-    if (active && lane < 63) {
-        const int64_t b0 = rowptr[cam], b1 = rowptr[cam + 1];
-        for (int64_t b = b0 + slot; b < b1; b += 7) {
-            const double qv = blocks[b * 9 + e];
-            const double *w = W + ((size_t)colidx[b] * 3 + ecol) * OP;
-#pragma unroll
-            for (int k = 0; k < O; ++k) part[k] += qv * w[k];
-        }
-    }
-    // reduce the 21 lanes (7 slots x 3 cols) that share a block row; every lane ends with the full 3 x O result
     double acc[3][O];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const bool mine = (lane < 63) && (e / 3 == r);
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int k = 0; k < O; ++k) acc[r][k] = mine ? part[k] : 0.0;
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+    if (active) {
+        const int64_t b0 = rowptr[cam], b1 = rowptr[cam + 1];
+        for (int64_t base = b0; base < b1; base += 64) {
+            const int64_t b = base + lane;
+            if (VAR == 1) {
+                double *st = stage + wave * 64 * 9;
+                const int64_t nd = ((b1 - base < 64) ? (b1 - base) : 64) * 9;   // doubles of this window
+                const double *src = blocks + base * 9;
+                double t[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) t[i] = (lane + 64 * i < nd) ? src[lane + 64 * i] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) st[lane + 64 * i] = t[i];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (b < b1) {
+                const int j = colidx[b];
+                const double *qb = blocks + b * 9;
+                const double *wj = W + (size_t)j * 3 * OP;
+                double q[9], w[3][O];
+                if (VAR == 1) {
+                    const double *st = stage + wave * 64 * 9 + lane * 9;
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) q[e] = st[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) q[e] = qb[e];
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int k = 0; k < O; ++k) w[c][k] = wj[c * OP + k];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < O; ++k) acc[r][k] += q[3 * r] * w[0][k] + q[3 * r + 1] * w[1][k] + q[3 * r + 2] * w[2][k];
+            }
+            if (VAR == 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
     qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }
@@ -491,132 +532,128 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
     }
 }
 
-// v += step p, Hv += step Hp, (CG step only) r += step Hp and the partial of <r,r>_metric   (trustregion.h:577-626)
-// Latency-trimmed: the vector operands of the thread's first element are requested before the scalar block and the
-// partial sums are read, so the three dependent memory round trips overlap.
+// One flat kernel per tCG iteration (trustregion.h:565-644): alpha (or tau) from the gathered partial sums and the
+// device-resident scalar block, the branch logic of :572-600, v/r/Hv updates, the :627 exit test, beta, the new direction p
+// and the next product input W = s.*p_R + p_s.*R.  The residual norm after the step is obtained from the three inner products
+// the Hessian epilogue already delivered, <r,r> + 2 alpha <r,Hp> + alpha^2 <Hp,Hp>, so beta needs no second grid-wide
+// reduction; the directly summed |r|^2 (partsB_out) replaces that estimate as <r,r> of the NEXT iteration, so no error
+// accumulates.  Block 0 owns the scalar state (other parity buffer) and the host-mapped progress word.  The scale parts of
+// p and r are ping-ponged (cur -> next): every element thread of a camera reads them while one thread rewrites them.
 template <int O>
-__global__ __launch_bounds__(256) void cg_update_kernel(int nloc, const TcgScal *__restrict__ scal, const double *__restrict__ partsA,
-                                                         int nA, const double *__restrict__ pR, const double *__restrict__ ps,
-                                                         const double *__restrict__ HpR, const double *__restrict__ Hps,
-                                                         const double *__restrict__ s, double *vR, double *vs, double *HvR,
-                                                         double *Hvs, double *rR, double *rs, double *partsB) {
+__global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *__restrict__ scal_cur, TcgScal *scal_next,
+                                                       const double *__restrict__ partsA, int nA_loc, int world,
+                                                       const double *__restrict__ partsB_prev, int nB, const double *__restrict__ HpR,
+                                                       const double *__restrict__ Hps, const double *__restrict__ R,
+                                                       const double *__restrict__ s, double *pR, const double *__restrict__ ps_cur,
+                                                       double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR,
+                                                       const double *__restrict__ rs_cur, double *rs_next, double *Wloc,
+                                                       double *partsB_out, unsigned long long *hstat) {
     constexpr int OP = pitch_of(O);
     __shared__ double sh[4];
     const int64_t total = (int64_t)nloc * 3 * OP;
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    // prefetch the first element's operands
-    double hp = 0, pv = 0, vv = 0, hv = 0, rv = 0, hs = 0, psv = 0, vsv = 0, hvs = 0, rsv = 0, sv = 1;
-    const bool in0 = i < total;
-    const bool own0 = in0 && (i % (3 * OP) == 0);
-    const int cam0 = (int)(i / (3 * OP));
-    if (in0) { hp = HpR[i]; pv = pR[i]; vv = vR[i]; hv = HvR[i]; rv = rR[i]; }
-    if (own0) { hs = Hps[cam0]; psv = ps[cam0]; vsv = vs[cam0]; hvs = Hvs[cam0]; rsv = rs[cam0]; sv = s[cam0]; }
-    const TcgScal sc = *scal;
-    if (sc.status != 0) return;
-    const double pHp = sum_partials256(partsA, nA, sh);
-    const StepDecision d = tcg_decide(sc, pHp);
-    if (d.mode == 5) return;
-    double acc = 0.0;
-    if (in0) {
-        vR[i] = vv + d.step * pv;
-        HvR[i] = hv + d.step * hp;
-        if (d.mode == 0) { const double r = rv + d.step * hp; rR[i] = r; acc += r * r; }
-        if (own0) {
-            vs[cam0] = vsv + d.step * psv;
-            Hvs[cam0] = hvs + d.step * hs;
-            if (d.mode == 0) { const double r = rsv + d.step * hs; rs[cam0] = r; const double q = r / sv; acc += q * q; }
-        }
-    }
-    for (i += stride; i < total; i += stride) {
-        const double hpi = HpR[i];
-        vR[i] += d.step * pR[i];
-        HvR[i] += d.step * hpi;
-        if (d.mode == 0) { const double r = rR[i] + d.step * hpi; rR[i] = r; acc += r * r; }
-        if (i % (3 * OP) == 0) {
-            const int cam = (int)(i / (3 * OP));
-            const double hsi = Hps[cam];
-            vs[cam] += d.step * ps[cam];
-            Hvs[cam] += d.step * hsi;
-            if (d.mode == 0) { const double r = rs[cam] + d.step * hsi; rs[cam] = r; const double q = r / s[cam]; acc += q * q; }
-        }
-    }
-    if (d.mode == 0) {
-        const double tot = block_sum256(acc, sh);
-        if (threadIdx.x == 0) partsB[blockIdx.x] = tot;
-    }
-}
-
-// beta, p = -r + beta p, W = s.*p + ps.*R for the next product, scalar recurrences, termination tests
-// (trustregion.h:625-644).  Block 0 owns the scalar state (written to the OTHER parity buffer).  The scale part of p
-// is ping-ponged too (ps_cur -> ps_next): every element thread of a camera reads it while one thread rewrites it.
-template <int O>
-__global__ __launch_bounds__(256) void p_update_kernel(int nloc, const TcgScal *__restrict__ scal_cur, TcgScal *scal_next,
-                                                        const double *__restrict__ partsA, int nA, const double *__restrict__ partsB,
-                                                        int nB, const double *__restrict__ rR, const double *__restrict__ rs,
-                                                        const double *__restrict__ R, const double *__restrict__ s, double *pR,
-                                                        const double *__restrict__ ps_cur, double *ps_next, double *Wloc,
-                                                        unsigned long long *hstat) {
-    constexpr int OP = pitch_of(O);
-    __shared__ double sh[4];
-    const int64_t total = (int64_t)nloc * 3 * OP;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // operands of the thread's first element are requested before the scalar block / partial sums are read
     const bool in0 = i < total;
     const int camf = (int)(i / (3 * OP));
-    double p0 = 0, r0 = 0, R0 = 0, ps0 = 0, rs0 = 0, s0 = 1;   // prefetch: overlaps with the scalar block / partial sums
-    if (in0) { p0 = pR[i]; r0 = rR[i]; R0 = R[i]; ps0 = ps_cur[camf]; rs0 = rs[camf]; s0 = s[camf]; }
-    const TcgScal sc = *scal_cur;
+    const bool own0 = in0 && (i % (3 * OP) == 0);
+    double hp = 0, pv = 0, vv0 = 0, hv = 0, rv = 0, Rv = 0, hs = 0, psv = 0, rsv = 0, sv = 1, vsv = 0, hvs = 0;
+    if (in0) { hp = HpR[i]; pv = pR[i]; vv0 = vR[i]; hv = HvR[i]; rv = rR[i]; Rv = R[i]; hs = Hps[camf]; psv = ps_cur[camf]; rsv = rs_cur[camf]; sv = s[camf]; }
+    if (own0) { vsv = vs[camf]; hvs = Hvs[camf]; }
+    const TcgScal sc0 = *scal_cur;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
-    if (sc.status != 0) {
-        if (lead) *scal_next = sc;
+    if (sc0.status != 0) {
+        if (lead) *scal_next = sc0;
         return;
     }
-    const double pHp = sum_partials256(partsA, nA, sh);
+    double pHp = 0.0, rHp = 0.0, HpHp = 0.0;
+    for (int r = 0; r < world; ++r) {
+        const double *pa = partsA + (size_t)r * 3 * nA_loc;
+        pHp += sum_partials256(pa, nA_loc, sh);
+        rHp += sum_partials256(pa + nA_loc, nA_loc, sh);
+        HpHp += sum_partials256(pa + 2 * nA_loc, nA_loc, sh);
+    }
+    TcgScal sc = sc0;
+    if (sc0.iter > 0) sc.rr = sum_partials256(partsB_prev, nB, sh);   // exact |r|^2 summed by the previous iteration
     const StepDecision d = tcg_decide(sc, pHp);
-    if (d.mode != 0) {
+    if (d.mode == 5) {
         if (lead) {
-            TcgScal nx = sc; nx.status = d.mode; nx.last_step = d.step;
+            TcgScal nx = sc; nx.status = 5; nx.last_step = 0.0;
             *scal_next = nx;
             publish_host(hstat, pack_stat(nx.iter, nx.status));
         }
         return;
     }
-    const double rr2 = sum_partials256(partsB, nB, sh);
-    const double alpha = d.step;
-    if (sqrt(rr2) < sc.gradnorm * fmin(sc.gradnorm, 0.1)) {  // trustregion.h:627
-        if (lead) {
-            TcgScal nx = sc; nx.rr = rr2; nx.status = 3; nx.last_step = alpha;
-            *scal_next = nx;
-            publish_host(hstat, pack_stat(nx.iter, nx.status));
-        }
-        return;
-    }
-    const double beta = rr2 / sc.rr;
+    const double step = d.step;
+    const bool cg = (d.mode == 0);
+    double rr_est = sc.rr + 2.0 * step * rHp + step * step * HpHp;
+    if (rr_est < 0.0) rr_est = 0.0;
+    const bool conv = cg && (sqrt(rr_est) < sc.gradnorm * fmin(sc.gradnorm, 0.1));   // trustregion.h:627
+    const double beta = rr_est / sc.rr;
+    const bool newdir = cg && !conv;
+    double acc = 0.0;
     if (in0) {
-        const double pn = beta * p0 - r0;
-        const double psn = beta * ps0 - rs0;
-        pR[i] = pn;
-        Wloc[i] = s0 * pn + psn * R0;
-        if (i % (3 * OP) == 0) ps_next[camf] = psn;
+        vR[i] = vv0 + step * pv;
+        HvR[i] = hv + step * hp;
+        if (cg) {
+            const double rn = rv + step * hp;
+            const double rsn = rsv + step * hs;
+            rR[i] = rn;
+            acc += rn * rn;
+            if (newdir) {
+                const double pn = beta * pv - rn;
+                const double psn = beta * psv - rsn;
+                pR[i] = pn;
+                Wloc[i] = sv * pn + psn * Rv;
+                if (own0) ps_next[camf] = psn;
+            }
+            if (own0) { rs_next[camf] = rsn; const double q = rsn / sv; acc += q * q; }
+        }
+        if (own0) { vs[camf] = vsv + step * psv; Hvs[camf] = hvs + step * hs; }
     }
     for (i += stride; i < total; i += stride) {
         const int cam = (int)(i / (3 * OP));
-        const double pn = beta * pR[i] - rR[i];
-        const double psn = beta * ps_cur[cam] - rs[cam];
-        pR[i] = pn;
-        Wloc[i] = s[cam] * pn + psn * R[i];
-        if (i % (3 * OP) == 0) ps_next[cam] = psn;
+        const bool own = (i % (3 * OP) == 0);
+        const double hpi = HpR[i], pi = pR[i], hsi = Hps[cam], psi = ps_cur[cam];
+        vR[i] += step * pi;
+        HvR[i] += step * hpi;
+        if (cg) {
+            const double rn = rR[i] + step * hpi;
+            const double rsn = rs_cur[cam] + step * hsi;
+            rR[i] = rn;
+            acc += rn * rn;
+            if (newdir) {
+                const double pn = beta * pi - rn;
+                const double psn = beta * psi - rsn;
+                pR[i] = pn;
+                Wloc[i] = s[cam] * pn + psn * R[i];
+                if (own) ps_next[cam] = psn;
+            }
+            if (own) { rs_next[cam] = rsn; const double q = rsn / s[cam]; acc += q * q; }
+        }
+        if (own) { vs[cam] += step * psi; Hvs[cam] += step * hsi; }
+    }
+    if (cg) {
+        const double tot = block_sum256(acc, sh);
+        if (threadIdx.x == 0) partsB_out[blockIdx.x] = tot;
     }
     if (lead) {
         TcgScal nx = sc;
-        nx.rr = rr2;
-        nx.vv = sc.vv + 2.0 * alpha * sc.vp + alpha * alpha * sc.pp;  // trustregion.h:642-644
-        nx.vp = beta * (sc.vp + alpha * sc.pp);
-        nx.pp = beta * beta * sc.pp + rr2;
-        nx.last_step = alpha;
-        nx.iter = sc.iter + 1;
-        nx.status = (nx.iter >= kMaxInner) ? 6 : 0;
+        nx.last_step = step;
+        if (!cg) {
+            nx.status = d.mode;
+        } else {
+            nx.rr = rr_est;
+            nx.vv = sc.vv + 2.0 * step * sc.vp + step * step * sc.pp;  // trustregion.h:642-644
+            nx.vp = beta * (sc.vp + step * sc.pp);
+            nx.pp = beta * beta * sc.pp + rr_est;
+            if (conv) {
+                nx.status = 3;
+            } else {
+                nx.iter = sc.iter + 1;
+                nx.status = (nx.iter >= kMaxInner) ? 6 : 0;
+            }
+        }
         *scal_next = nx;
         publish_host(hstat, pack_stat(nx.iter, nx.status));
     }
@@ -934,14 +971,18 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
     check_launch("qw_dense");
 }
 
-template <int O>
+static int bsr_variant() {  // XM_BSR_VARIANT=1 (default: blocks staged through LDS, 137 vs 183 us at 100k cameras) | 0 (direct block loads)
+    static int v = [] { const char *e = std::getenv("XM_BSR_VARIANT"); return (e && *e == '0') ? 0 : 1; }();
+    return v;
+}
+template <int O, int VAR>
 static void qw_bsr3_epi(int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, double alpha,
                         const CamArgs &a, hipStream_t st) {
     const dim3 g(qw_grid(a.nloc)), b(256);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_PLAIN>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_HESS>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_PLAIN, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_HESS, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
         default: throw Error(-2, "bad epilogue");
     }
 }
@@ -950,9 +991,11 @@ void launch_qw_bsr3(int o, int epi, const int64_t *rp, const int32_t *ci, const 
     if (a.nloc <= 0) return;
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
-        hipLaunchKernelGGL((qw_bsr3_kernel<1, EPI_CERT>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, rp, ci, bl, W, alpha, a);
+        hipLaunchKernelGGL((qw_bsr3_kernel<1, EPI_CERT, 0>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, rp, ci, bl, W, alpha, a);
+    } else if (bsr_variant() == 1) {
+        XM_DISPATCH_O(o, (qw_bsr3_epi<O_, 1>(epi, rp, ci, bl, W, alpha, a, st)));
     } else {
-        XM_DISPATCH_O(o, (qw_bsr3_epi<O_>(epi, rp, ci, bl, W, alpha, a, st)));
+        XM_DISPATCH_O(o, (qw_bsr3_epi<O_, 0>(epi, rp, ci, bl, W, alpha, a, st)));
     }
     check_launch("qw_bsr3");
 }
@@ -980,20 +1023,14 @@ void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, cons
                                         nloc, rgR, rgs, R, s, rR, rs, pR, ps, vR, vs, HvR, Hvs, Wloc, scal0, rr, delta, hstat));
     check_launch("tcg_init");
 }
-void launch_cg_update(int o, int nloc, const TcgScal *scal, const double *partsA, int nA, const double *pR, const double *ps,
-                      const double *HpR, const double *Hps, const double *s, double *vR, double *vs, double *HvR, double *Hvs,
-                      double *rR, double *rs, double *partsB, hipStream_t st) {
-    XM_DISPATCH_O(o, hipLaunchKernelGGL((cg_update_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
-                                        nloc, scal, partsA, nA, pR, ps, HpR, Hps, s, vR, vs, HvR, Hvs, rR, rs, partsB));
-    check_launch("cg_update");
-}
-void launch_p_update(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *partsA, int nA, const double *partsB,
-                     int nB, const double *rR, const double *rs, const double *R, const double *s, double *pR, const double *ps_cur,
-                     double *ps_next, double *Wloc, unsigned long long *hstat, hipStream_t st) {
-    XM_DISPATCH_O(o, hipLaunchKernelGGL((p_update_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
-                                        nloc, scal_cur, scal_next, partsA, nA, partsB, nB, rR, rs, R, s, pR, ps_cur, ps_next, Wloc,
-                                        hstat));
-    check_launch("p_update");
+void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *partsA, int nA_loc, int world,
+                    const double *partsB_prev, int nB, const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
+                    const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
+                    double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, hipStream_t st) {
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((cg_step_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st, nloc,
+                                        scal_cur, scal_next, partsA, nA_loc, world, partsB_prev, nB, HpR, Hps, R, s, pR, ps_cur, ps_next, vR,
+                                        vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat));
+    check_launch("cg_step");
 }
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs, const double *rgR,
                         const double *rgs, const double *s, double *parts, hipStream_t st) {

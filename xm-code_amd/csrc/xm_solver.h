@@ -90,7 +90,7 @@ private:
     DevBuf<double> R_, s_, Rc_, sc_, W_, D_;
     PointState ps_[2];
     int cur_ = 0;
-    DevBuf<double> rR_, rs_, pR_, psA_, psB_, vR_, vs_, HvR_, Hvs_, HpR_, Hps_;
+    DevBuf<double> rR_, rs_, rsB_, pR_, psA_, psB_, vR_, vs_, HvR_, Hvs_, HpR_, Hps_;
     DevBuf<double> partsA_, partsB_, partsM_;
     DevBuf<TcgScal> scal_;
     unsigned long long *hstat_ = nullptr;      // host-mapped progress word (iter << 8 | status)
@@ -119,6 +119,7 @@ private:
     double sum_parts(const double *dparts, int count);
     int run_tcg(double rr, double delta, TcgScal &fin);
     volatile double *wait_outer_result();
+    bool agree_any(bool local);
     void drain_events();
     void finish_profile();
     TrResult trust_region(int o, double &gradtol, double linesearch_step, const std::vector<double> &v_dir, double max_time);

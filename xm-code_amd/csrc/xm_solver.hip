@@ -113,7 +113,7 @@ void Context::setup_rank(int o) {
     const size_t mat = (size_t)nloc_ * 3 * OP_, vec = (size_t)nloc_;
     const int world = comm_->world;
     for (DevBuf<double> *b : {&R_, &Rc_, &D_, &rR_, &pR_, &vR_, &HvR_, &HpR_}) b->alloc(mat);
-    for (DevBuf<double> *b : {&s_, &sc_, &rs_, &psA_, &psB_, &vs_, &Hvs_, &Hps_}) b->alloc(vec);
+    for (DevBuf<double> *b : {&s_, &sc_, &rs_, &rsB_, &psA_, &psB_, &vs_, &Hvs_, &Hps_}) b->alloc(vec);
     for (int k = 0; k < 2; ++k) {
         ps_[k].G.alloc(mat); ps_[k].rgR.alloc(mat); ps_[k].egs.alloc(vec); ps_[k].rgs.alloc(vec); ps_[k].S0.alloc(vec * 9);
     }
@@ -122,8 +122,8 @@ void Context::setup_rank(int o) {
     const int nA_loc = qw_grid(nloc_), nB_loc = flat_grid((int64_t)mat);
     nA_ = nA_loc * world;
     nB_ = nB_loc * world;
-    partsA_.alloc((size_t)2 * nA_);
-    partsB_.alloc((size_t)nB_);
+    partsA_.alloc((size_t)3 * nA_);
+    partsB_.alloc((size_t)2 * nB_);   // two parity buffers
     partsM_.alloc((size_t)std::max(nB_, 2 * ((nloc_ + 255) / 256) * world));
     scal_.alloc(2);
     const size_t need = (size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64;
@@ -183,7 +183,7 @@ CamArgs Context::cam_args(int state) const {
     a.s = s_.p;
     const PointState &p = ps_[state];
     a.G = p.G.p; a.egs = p.egs.p; a.S0 = p.S0.p; a.rgR = p.rgR.p; a.rgs = p.rgs.p;
-    a.pR = pR_.p; a.ps = psA_.p; a.HpR = HpR_.p; a.Hps = Hps_.p;
+    a.pR = pR_.p; a.ps = psA_.p; a.rR = rR_.p; a.rs = rs_.p; a.HpR = HpR_.p; a.Hps = Hps_.p;
     a.Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
     a.out = HpR_.p;
     a.partials = partsA_.p;
@@ -224,6 +224,21 @@ void Context::eval_point(int state, const double *Rp, const double *sp, double &
     volatile double *hres = wait_outer_result();
     f = hres[0];
     rr = hres[1];
+}
+
+// Wall-clock decisions must be identical on every rank (a rank that stops alone would leave the others inside a
+// collective): the local flags are all-gathered and OR-ed.  Single rank: returns the flag.
+bool Context::agree_any(bool local) {
+    if (!comm_->active()) return local;
+    const int world = comm_->world;
+    double v = local ? 1.0 : 0.0;
+    XM_HIP_CHECK(hipMemcpyAsync(partsM_.p + comm_->rank, &v, sizeof(double), hipMemcpyHostToDevice, st_));
+    comm_->allgather(partsM_.p, 1, st_);
+    XM_HIP_CHECK(hipMemcpyAsync(hpin_, partsM_.p, (size_t)world * sizeof(double), hipMemcpyDeviceToHost, st_));
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+    bool any = false;
+    for (int r = 0; r < world; ++r) any = any || (hpin_[r] != 0.0);
+    return any;
 }
 
 // spin on the sequence word of the host-mapped result block (written last by outer_finalize_kernel)
@@ -275,25 +290,29 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     launch_tcg_init(o_, nloc_, P.rgR.p, P.rgs.p, R_.p, s_.p, rR_.p, rs_.p, pR_.p, psA_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, Wloc,
                     scal_.p, rr, delta, hstat_dev_, st_);
     gather_W();
-    const int run_ahead = 3;   // iterations in flight ahead of the last one seen finished; the excess become no-op launches
+    // Iterations in flight ahead of the last one seen finished; the excess become no-op launches.  With a communicator the
+    // loop must issue the SAME number of collectives on every rank, and ranks poll at different moments, so each iteration is
+    // confirmed before the next is enqueued (identical scalar state on all ranks => identical iteration counts).
+    const int run_ahead = comm_->active() ? 1 : 3;
     int it = 0;  // iterations enqueued
     auto enqueue = [&](int i) {
         const int par = i & 1;
         CamArgs a = cam_args(cur_);
         a.scal = scal_.p + par;
         a.ps = par ? psB_.p : psA_.p;
-        a.partials = partsA_.p + (size_t)rank * nA_loc;
+        a.rs = par ? rsB_.p : rs_.p;
+        a.partials = partsA_.p + (size_t)rank * 3 * nA_loc;
         const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
         if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
         product(EPI_HESS, o_, 2.0, a);
         if (timed) { XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].second, st_)); ev_used_++; }
         hess_launches_++;
-        if (comm_->active()) comm_->allgather(partsA_.p, (size_t)nA_loc, st_);
-        launch_cg_update(o_, nloc_, scal_.p + par, partsA_.p, nA_, pR_.p, a.ps, HpR_.p, Hps_.p, s_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p,
-                         rR_.p, rs_.p, partsB_.p + (size_t)rank * nB_loc, st_);
-        if (comm_->active()) comm_->allgather(partsB_.p, (size_t)nB_loc, st_);
-        launch_p_update(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), partsA_.p, nA_, partsB_.p, nB_, rR_.p, rs_.p, R_.p, s_.p, pR_.p,
-                        par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, Wloc, hstat_dev_, st_);
+        if (comm_->active()) comm_->allgather(partsA_.p, (size_t)3 * nA_loc, st_);
+        double *pB_out = partsB_.p + (size_t)par * nB_, *pB_prev = partsB_.p + (size_t)(par ^ 1) * nB_;
+        launch_cg_step(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), partsA_.p, nA_loc, comm_->world, pB_prev, nB_, HpR_.p, Hps_.p, R_.p,
+                       s_.p, pR_.p, par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, rR_.p,
+                       par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pB_out + (size_t)rank * nB_loc, hstat_dev_, st_);
+        if (comm_->active()) comm_->allgather(pB_out, (size_t)nB_loc, st_);
         gather_W();
     };
     auto read_scal = [&](int par) {
@@ -421,7 +440,7 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         }
         if (endreason == 5) { stop_reason = 5; log("Terminate because of rdotr touched machine precise\n"); break; }
         if (gradnorm < gradtol) { log("Terminate because of small gradient norm\n"); gradtol /= 10; stop_reason = 10; break; }
-        if ((double)(long long)secs_since(start) > max_time) { log("Terminate because of time limit\n"); stop_reason = 11; break; }
+        if (agree_any((double)(long long)secs_since(start) > max_time)) { log("Terminate because of time limit\n"); stop_reason = 11; break; }
         endreason = 6; trstatus = 4;
 
         TcgScal fin;
