@@ -230,3 +230,32 @@ def test_rccl_path_single_rank(xmamd, tmp_path):
         outs.append(np.load(out))
     assert np.array_equal(outs[0]["R"], outs[1]["R"]) and np.array_equal(outs[0]["s"], outs[1]["s"])
     assert int(outs[0]["tcg"]) == int(outs[1]["tcg"])
+
+
+def test_dubrovnik356_full_solve_matches_oracle(xmamd, oracle):
+    """BASELINE config 'Dubrovnik-356 on one MI355X': the complete staircase solve (trust region + certificate) against the
+    CPU oracle on the same dense Q: optimum value, certificate and anchored rotations (<= 1e-6, north_star)."""
+    P = tl.gen_dense(356, seed=356)
+    R, s, info = xmamd.solve_dense(P["Q"], 5, 1e-9, 0.0, trace=2000)
+    Ro, so, io = oracle.solve(P["Q"], 5, 1e-9, 0.0, 1000.0, trace=2000)
+    assert info["rank"] == io["rank"] == 3 and info["status"] == io["status"] == 1
+    assert info["primal"] == pytest.approx(io["trace"][-1, 0], rel=1e-10)
+    assert info["min_eig"] == pytest.approx(io["cert"]["min_eig"], abs=1e-7)
+    assert tl.rotation_parity(R, s, Ro, so) < 1e-6
+    assert tl.rel_fro(tl.gram(R, s), tl.gram(Ro, so)) < 1e-6
+    k = 8
+    assert np.allclose(info["trace"][:k, 0], io["trace"][:k, 0], rtol=1e-9)
+    assert np.array_equal(info["trace"][:k, 2:4], io["trace"][:k, 2:4])
+
+
+@pytest.mark.skipif(os.environ.get("XM_SLOW") != "1", reason="oracle certificate is O(n^3) single-threaded: ~4 min; set XM_SLOW=1")
+def test_mid700_staircase_matches_oracle(xmamd, oracle):
+    """700-camera dense instance whose rank-3 critical point is NOT optimal: both solvers escalate to rank 4 (saddle
+    escape along the certificate's eigenvector) and certify there; value, certificate and gauge-invariant solution agree."""
+    P = tl.gen_dense(700, seed=700)
+    R, s, info = xmamd.solve_dense(P["Q"], 5, 1e-9, 0.0)
+    Ro, so, io = oracle.solve(P["Q"], 5, 1e-9, 0.0, 1000.0, trace=4000)
+    assert info["rank"] == io["rank"] == 4 and info["status"] == io["status"] == 1
+    assert info["primal"] == pytest.approx(io["trace"][-1, 0], rel=1e-9)
+    assert tl.rel_fro(tl.gram(R, s), tl.gram(Ro, so)) < 1e-6
+    assert tl.rotation_parity(R, s, Ro, so) < 1e-6

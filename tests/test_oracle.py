@@ -64,7 +64,7 @@ def test_planted_known_answer(oracle):
     (Driven through xmo_trustregion: with f* == 0 round-off can make the final loss slightly negative, which the
     staircase driver — like the reference, XM_main.cu:244 — mistakes for its line-search-failure sentinel.)"""
     n = 30
-    P = tl.gen_dense(n, seed=7, eps=0.0)
+    P = tl.gen_dense(n, seed=7, noise=0.0)
     R, s, primal, _, st = oracle.trustregion(P["Q"], np.tile(np.eye(3), (n, 1)), np.ones(n), gradtol=1e-10)
     assert abs(primal) < 1e-10
     rot, sc = tl.recover_rotations(R, s)

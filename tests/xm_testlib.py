@@ -58,13 +58,15 @@ def so3_exp(w):
     return np.eye(3)[None] + a[:, None, None] * K + b[:, None, None] * (K @ K)
 
 
-def gen_dense(n, seed=None, eps=1e-3):
+def gen_dense(n, seed=None, noise=0.3):
     """G_dense(n, seed): fully dense 'Schur-complement-like' PSD Q with planted optimum U* (SURVEY §8d C2-C4):
-    Q = P M P + eps-noise, M = B B^T + diag(d) (B Gaussian / sqrt(3n), d ~ U[0.5, 1.5]), P = projector onto the
-    complement of U* (the stacked planted rotations), noise = PSD (diagonal + rank-8) scaled to eps * |PMP|_F.
-    The noise is kept PSD on purpose: a real XM Q is a sum of squares, and the staircase driver (like the reference,
+    Q = P M P + N, M = B B^T + diag(d) (B Gaussian / sqrt(3n), d ~ U[0.5, 1.5]), P = projector onto the complement of
+    U* (the stacked planted rotations), N = PSD noise (diagonal + rank-8) scaled so that the planted point costs
+    f(U*) = tr(U*^T Q U*) = `noise` whatever n.  Keeping f(U*) far below tr(Q_00) ~ 6 (the cost of letting every free scale
+    collapse to 0) makes the instance well posed like a real XM Q: scales stay ~1 and the relaxation is tight at rank 3.
+    The noise is PSD on purpose: a real XM Q is a sum of squares and the staircase driver (like the reference,
     XM_main.cu:244) treats a negative optimum value as its line-search-failure sentinel.
-    eps = 0 gives the known-answer variant (f* = 0, R* = U*)."""
+    noise = 0 gives the known-answer variant (f* = 0, R* = U*)."""
     seed = n if seed is None else seed
     rng = np.random.default_rng(seed)
     Rs = haar_so3(rng, n)
@@ -76,10 +78,10 @@ def gen_dense(n, seed=None, eps=1e-3):
     Uo, _ = np.linalg.qr(U)                       # P = I - Uo Uo^T
     MU = M @ Uo
     Qm = M - Uo @ MU.T - MU @ Uo.T + Uo @ (Uo.T @ MU) @ Uo.T
-    if eps:
+    if noise:
         F = rng.standard_normal((m, 8)) / np.sqrt(8.0)
         u = rng.uniform(0.0, 1.0, m)
-        scale = eps * np.linalg.norm(Qm) / np.sqrt(np.sum(u * u) + np.linalg.norm(F.T @ F) ** 2 + 2 * np.sum(u * np.sum(F * F, axis=1)))
+        scale = noise / (np.sum(u) + np.linalg.norm(F.T @ U) ** 2)    # rows of U* have unit norm
         Qm += scale * (F @ F.T)
         Qm[np.diag_indices(m)] += scale * u
     Qm = (Qm + Qm.T) * 0.5
