@@ -147,6 +147,12 @@ int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, doubl
 int xm_qw_bsr3_time(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o, const double *dW,
                     double *dOut, int reps, double *ms_avg);
 
+/* Solution recovery, the step right after the solve (replaces the rotation/scale part of
+ * utils/recoversolution.py:recover_XM, lines 12-86): R (3n x r column-major) and s (n) as written to R.bin / s.bin ->
+ * rot: 3 x 3n column-major, block i = the anchored orthogonal 3x3 of camera i (block 0 = identity), scale: n.
+ * n_negative_det (optional) = cameras whose block had negative determinant before the majority sign flip. */
+int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, double *rot, double *scale, int *n_negative_det);
+
 /* ================================================================== 4. multi-GPU row partition (one process per GPU) */
 /* 128-byte unique id of the RCCL communicator: rank 0 calls xm_comm_unique_id and broadcasts the bytes
  * (bench.py does that with torch.distributed); every rank then calls xm_comm_init before xm_ctx_create. */

@@ -259,3 +259,19 @@ def test_mid700_staircase_matches_oracle(xmamd, oracle):
     assert info["primal"] == pytest.approx(io["trace"][-1, 0], rel=1e-9)
     assert tl.rel_fro(tl.gram(R, s), tl.gram(Ro, so)) < 1e-6
     assert tl.rotation_parity(R, s, Ro, so) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["simple1", "simple2", "synth/dense49", "synth/vg40_stair"])
+def test_recover_rotations_matches_reference_recover_XM(xmamd, oracle, name):
+    """xm_recover_rotations against the golden output of the REFERENCE's own utils/recoversolution.py
+    (rot_anchor.npy was produced by recover_XM on the oracle's solution; vg40_stair has rank 6 -> rank-3 projection)."""
+    Q, exp, d = _case(name)
+    Ro, so, io = oracle.solve(Q, exp["max_rank"], exp["tol"], exp["lam"], 1000.0)
+    rot, sc, neg = xmamd.recover_rotations(Ro, so)
+    gold = np.load(os.path.join(d, "rot_anchor.npy"))
+    assert tl.rel_fro(rot, gold) < 1e-9
+    rot2, sc2 = tl.recover_rotations(Ro, so)
+    assert np.allclose(sc, sc2, rtol=1e-12)
+    blocks = rot.T.reshape(-1, 3, 3)                    # block i transposed
+    assert np.abs(blocks @ np.transpose(blocks, (0, 2, 1)) - np.eye(3)).max() < 1e-13
+    assert np.allclose(np.abs(rot[:, :3]), np.eye(3), atol=1e-13)     # +-I (the reference flips the global sign on a negative-det majority)

@@ -1,4 +1,6 @@
 // xm_capi.hip — extern "C" boundary (include/xm_amd.h).  No exceptions cross it.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <mutex>
@@ -242,6 +244,81 @@ int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int6
     XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (ms_avg) *ms_avg = (double)ms / reps;
+    return XM_OK;
+    XM_CATCH
+}
+
+// symmetric r x r eigen-decomposition (cyclic Jacobi), ascending; V columns = eigenvectors (col-major)
+static void jacobi_eig(int r, std::vector<double> &A, std::vector<double> &V, std::vector<double> &w) {
+    V.assign((size_t)r * r, 0.0);
+    for (int i = 0; i < r; ++i) V[i + (size_t)i * r] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < r; ++p) for (int q = p + 1; q < r; ++q) off += A[p + (size_t)q * r] * A[p + (size_t)q * r];
+        if (off < 1e-300) break;
+        for (int p = 0; p < r; ++p)
+            for (int q = p + 1; q < r; ++q) {
+                const double apq = A[p + (size_t)q * r];
+                if (apq == 0.0) continue;
+                const double theta = (A[q + (size_t)q * r] - A[p + (size_t)p * r]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < r; ++k) {
+                    const double akp = A[k + (size_t)p * r], akq = A[k + (size_t)q * r];
+                    A[k + (size_t)p * r] = c * akp - sn * akq; A[k + (size_t)q * r] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < r; ++k) {
+                    const double apk = A[p + (size_t)k * r], aqk = A[q + (size_t)k * r];
+                    A[p + (size_t)k * r] = c * apk - sn * aqk; A[q + (size_t)k * r] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < r; ++k) {
+                    const double vkp = V[k + (size_t)p * r], vkq = V[k + (size_t)q * r];
+                    V[k + (size_t)p * r] = c * vkp - sn * vkq; V[k + (size_t)q * r] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    w.resize((size_t)r);
+    for (int i = 0; i < r; ++i) w[(size_t)i] = A[i + (size_t)i * r];
+}
+
+int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, double *rot, double *scale, int *n_negative_det) {
+    XM_TRY
+    require_device();
+    if (n < 1 || r < 3 || r > 16 || !R || !s || !rot || !scale) throw xm::Error(XM_ERR_ARG, "bad argument");
+    const int64_t m = 3 * n;
+    xm::DevBuf<double> dR, ds, dV, drot, dscale, dparts;
+    xm::DevBuf<int> dneg;
+    dR.alloc((size_t)m * r, false); ds.alloc((size_t)n, false); dV.alloc((size_t)r * 3); drot.alloc((size_t)9 * n, false);
+    dscale.alloc((size_t)n, false); dneg.alloc(1);
+    XM_HIP_CHECK(hipMemcpy(dR.p, R, (size_t)m * r * sizeof(double), hipMemcpyHostToDevice));
+    XM_HIP_CHECK(hipMemcpy(ds.p, s, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> V((size_t)r * 3, 0.0);
+    if (r == 3) {
+        V[0] = V[4] = V[8] = 1.0;
+    } else {
+        // top-3 eigenvectors of the r x r Gram matrix sR^T sR == top-3 right singular vectors of sR; sR*V spans the same
+        // rank-3 factor as the reference's eigh of the 3n x 3n matrix sR sR^T (recoversolution.py:12-24) up to a 3x3 orthogonal
+        // gauge, which the anchoring removes.
+        const int grid = xm::flat_grid(m);
+        dparts.alloc((size_t)grid * r * r);
+        xm::launch_recover_gram(n, r, dR.p, ds.p, dparts.p, grid, nullptr);
+        std::vector<double> parts((size_t)grid * r * r), G((size_t)r * r, 0.0), Ev, w;
+        XM_HIP_CHECK(hipMemcpy(parts.data(), dparts.p, parts.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < grid; ++b) for (int e = 0; e < r * r; ++e) G[(size_t)e] += parts[(size_t)b * r * r + e];
+        jacobi_eig(r, G, Ev, w);
+        std::vector<int> idx((size_t)r);
+        for (int i = 0; i < r; ++i) idx[(size_t)i] = i;
+        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return w[(size_t)a] > w[(size_t)b]; });
+        for (int c = 0; c < 3; ++c) for (int k = 0; k < r; ++k) V[k + (size_t)c * r] = Ev[k + (size_t)idx[(size_t)c] * r];
+    }
+    XM_HIP_CHECK(hipMemcpy(dV.p, V.data(), V.size() * sizeof(double), hipMemcpyHostToDevice));
+    xm::launch_recover_project(n, r, dR.p, ds.p, dV.p, drot.p, dscale.p, dneg.p, nullptr);
+    int neg = 0;
+    XM_HIP_CHECK(hipMemcpy(&neg, dneg.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (2 * (int64_t)neg > n) xm::launch_negate(drot.p, 9 * n, nullptr);   // recoversolution.py:60-62 (polar(-M) = -polar(M))
+    XM_HIP_CHECK(hipMemcpy(rot, drot.p, (size_t)9 * n * sizeof(double), hipMemcpyDeviceToHost));
+    XM_HIP_CHECK(hipMemcpy(scale, dscale.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_negative_det) *n_negative_det = neg;
     return XM_OK;
     XM_CATCH
 }

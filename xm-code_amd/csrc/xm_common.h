@@ -114,6 +114,11 @@ void launch_retract(int o, int nloc, int cam0, const double *R, const double *s,
                     double *Rout, double *sout, double *Wloc, hipStream_t st);
 void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *QsR, const double *R, const double *s,
                          double *Lam, double *dz, double *parts, hipStream_t st);
+// solution recovery
+void launch_recover_gram(int64_t n, int r, const double *R, const double *s, double *parts, int grid, hipStream_t st);
+void launch_recover_project(int64_t n, int r, const double *R, const double *s, const double *V, double *rot, double *scale, int *negcount,
+                            hipStream_t st);
+void launch_negate(double *x, int64_t len, hipStream_t st);
 // small vector kernels used by Lanczos
 void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, hipStream_t st);
 void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);

@@ -911,6 +911,94 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(double *dst, const doub
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// Solution recovery (reference utils/recoversolution.py:22-86): rank-r -> 3 projection, per-camera scale,
+// anchoring to camera 0 and projection of every 3x3 block onto O(3) (the polar factor U V^T of its SVD).
+// One thread per camera: the whole per-camera problem is 9 doubles, so a 64-lane wavefront per camera would idle 55 lanes;
+// the polar factor is computed by the scaled Newton iteration X <- (g X + X^{-T}/g)/2 (quadratically convergent; the blocks
+// are already within round-off of a rotation times a scale, so 3-4 steps reach 1e-16), which equals U V^T of the SVD.
+// ----------------------------------------------------------------------------------------------------------------
+// partial Gram matrix G = sR^T sR (r x r, r <= 10): block partial sums, summed on the host
+__global__ __launch_bounds__(256) void recover_gram_kernel(int64_t n, int r, const double *__restrict__ R /* 3n x r col-major */,
+                                                            const double *__restrict__ s, double *parts /* grid x r*r */) {
+    __shared__ double sh[4];
+    const int64_t m = 3 * n;
+    for (int a = 0; a < r; ++a)
+        for (int b = a; b < r; ++b) {
+            double acc = 0.0;
+            for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < m; row += (int64_t)gridDim.x * 256) {
+                const double sc = s[row / 3];
+                acc += (sc * R[row + a * m]) * (sc * R[row + b * m]);
+            }
+            const double t = block_sum256(acc, sh);
+            if (threadIdx.x == 0) { parts[(size_t)blockIdx.x * r * r + a * r + b] = t; parts[(size_t)blockIdx.x * r * r + b * r + a] = t; }
+        }
+}
+
+__device__ __forceinline__ double det3(const double (&M)[3][3]) {
+    return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+           M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+}
+__device__ __forceinline__ void polar3(double (&X)[3][3]) {
+    for (int it = 0; it < 30; ++it) {
+        const double d = det3(X);
+        if (d == 0.0) return;
+        double C[3][3];   // cofactor matrix: X^{-T} = C / det
+        C[0][0] = X[1][1] * X[2][2] - X[1][2] * X[2][1]; C[0][1] = X[1][2] * X[2][0] - X[1][0] * X[2][2]; C[0][2] = X[1][0] * X[2][1] - X[1][1] * X[2][0];
+        C[1][0] = X[0][2] * X[2][1] - X[0][1] * X[2][2]; C[1][1] = X[0][0] * X[2][2] - X[0][2] * X[2][0]; C[1][2] = X[0][1] * X[2][0] - X[0][0] * X[2][1];
+        C[2][0] = X[0][1] * X[1][2] - X[0][2] * X[1][1]; C[2][1] = X[0][2] * X[1][0] - X[0][0] * X[1][2]; C[2][2] = X[0][0] * X[1][1] - X[0][1] * X[1][0];
+        double nx = 0.0, nc = 0.0;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { nx += X[a][b] * X[a][b]; nc += C[a][b] * C[a][b]; }
+        const double g = sqrt(sqrt(nc) / fabs(d) / sqrt(nx));   // Frobenius scaling: g = (|X^{-1}|_F / |X|_F)^(1/2)
+        double delta = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                const double y = 0.5 * (g * X[a][b] + C[a][b] / (d * g));
+                delta += (y - X[a][b]) * (y - X[a][b]);
+                X[a][b] = y;
+            }
+        if (delta < 1e-31) return;
+    }
+}
+
+// V: r x 3 (col-major) basis of the top-3 eigenspace of sR^T sR (identity when r == 3).  Outputs: rot (3 x 3n col-major,
+// block i = columns 3i..3i+2, like the reference's R_real), scale (n), negdet partial counts.
+__global__ __launch_bounds__(256) void recover_project_kernel(int64_t n, int r, const double *__restrict__ R, const double *__restrict__ s,
+                                                               const double *__restrict__ V, double *rot, double *scale, int *negcount) {
+    const int64_t m = 3 * n;
+    const int64_t cam = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // anchor block (camera 0): A = Rt_0^T with Rt_0 = B_0^T / s_0  ->  A = B_0 / s_0
+    double B0[3][3], n0 = 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) {
+            double t = 0.0;
+            for (int k = 0; k < r; ++k) t += s[0] * R[a + (int64_t)k * m] * V[k + c * r];
+            B0[a][c] = t; n0 += t * t;
+        }
+    const double s0 = sqrt(n0) / sqrt(3.0);
+    if (cam >= n) return;
+    double B[3][3], nb = 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) {
+            double t = 0.0;
+            for (int k = 0; k < r; ++k) t += s[cam] * R[3 * cam + a + (int64_t)k * m] * V[k + c * r];
+            B[a][c] = t; nb += t * t;
+        }
+    const double sc = sqrt(nb) / sqrt(3.0);           // recoversolution.py:40
+    double X[3][3];                                     // X = (B_0/s_0) * (B_i^T / s_i)   (recoversolution.py:41-47)
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) X[a][b] = (B0[a][0] * B[b][0] + B0[a][1] * B[b][1] + B0[a][2] * B[b][2]) / (s0 * sc);
+    polar3(X);
+    const bool neg = det3(X) < 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) rot[a + 3 * (3 * cam + b)] = X[a][b];
+    scale[cam] = sc;
+    if (neg) atomicAdd(negcount, 1);
+}
+__global__ __launch_bounds__(256) void negate_kernel(double *x, int64_t len) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) x[i] = -x[i];
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // launchers (dispatch on the rank o)
 // ----------------------------------------------------------------------------------------------------------------
 int qw_grid(int nloc) { return (nloc + kQwWaves - 1) / kQwWaves; }
@@ -1054,6 +1142,19 @@ void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *Qs
     XM_DISPATCH_O(o, hipLaunchKernelGGL((cert_prepare_kernel<O_>), dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, lam, QsR, R,
                                         s, Lam, dz, parts));
     check_launch("cert_prepare");
+}
+void launch_recover_gram(int64_t n, int r, const double *R, const double *s, double *parts, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(recover_gram_kernel, dim3(grid), dim3(256), 0, st, n, r, R, s, parts);
+    check_launch("recover_gram");
+}
+void launch_recover_project(int64_t n, int r, const double *R, const double *s, const double *V, double *rot, double *scale, int *negcount,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(recover_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, r, R, s, V, rot, scale, negcount);
+    check_launch("recover_project");
+}
+void launch_negate(double *x, int64_t len, hipStream_t st) {
+    hipLaunchKernelGGL(negate_kernel, dim3(flat_grid(len)), dim3(256), 0, st, x, len);
+    check_launch("negate");
 }
 void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, hipStream_t st) {
     if (m <= 0) return;

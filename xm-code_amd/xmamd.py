@@ -19,7 +19,7 @@ FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 EXPORTS = [
     "xm_last_error", "xm_version", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
-    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time",
+    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_finalize", "xm_partition",
 ]
 
@@ -87,6 +87,7 @@ def lib():
                                        C.POINTER(C.c_double)]
         L.xm_qw_bsr3_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                       C.POINTER(C.c_double)]
+        L.xm_recover_rotations.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.xm_comm_unique_id.argtypes = [C.c_char_p]
         L.xm_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.xm_partition.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -231,6 +232,17 @@ def retract(R, s, D, ds, t):
     for b in (dR, dD, dsv, dds, dRo, dso):
         b.free()
     return out
+
+
+def recover_rotations(R, s):
+    """anchored O(3) rotations (3 x 3n) and scales of a solution (R: 3n x r, s: n) through xm_recover_rotations"""
+    require_gpu()
+    R = np.asfortranarray(np.asarray(R, dtype=np.float64)); s = np.ascontiguousarray(np.asarray(s, dtype=np.float64).reshape(-1))
+    n, r = s.size, R.shape[1]
+    rot = np.zeros((3, 3 * n), order="F"); sc = np.zeros(n); neg = C.c_int(0)
+    _chk(lib().xm_recover_rotations(n, r, R.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
+                                    rot.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), C.byref(neg)))
+    return np.ascontiguousarray(rot), sc, neg.value
 
 
 # ------------------------------------------------------------------------------------------------ context API
