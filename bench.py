@@ -154,6 +154,15 @@ def main():
         alg_bytes = (76.0 * nb + 4 * (n + 1)) / world + 2 * 8 * 3 * n * o_fin
         kname = "qw_bsr3_kernel<o, EPI_HESS>"
     achieved = alg_bytes / (qw_ms * 1e-3) / 1e9 if qw_ms > 0 else 0.0
+    # HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE (own pass, kernel-trace only), corrected as
+    # MI355X_MICROARCH.md prescribes (KB -> bytes, x2 for the gfx950 wide-load half count); see profiles/r01_pmc_*.json
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_qw_dense.json")))
+        if wl["kind"] == "dense" and str(n) in pmc and world == 1:
+            traffic = pmc[str(n)]["hbm_read_bytes_per_launch"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
         "value": iters / elapsed, "unit": "tCG iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,7 +176,7 @@ def main():
                   "qw_products": last["qw_products"], "lanczos_iters": last["lanczos_iters"],
                   "tr_seconds": last["tr_seconds"], "cert_seconds": last["cert_seconds"], "setup_gen_s": gen_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": kname, "avg_launch_ms": qw_ms,
+                     "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r01_pmc_fetch_qw_dense.json (rocprofv3 --pmc FETCH_SIZE pass of the same kernel on the same matrix size, x1024 x2)", "kernel": kname, "avg_launch_ms": qw_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); "
                              "per-rank Q is %.0f MB: below ~256 MB it sits in the Infinity Cache, so the figure is cache-assisted, "

@@ -123,6 +123,8 @@ void launch_negate(double *x, int64_t len, hipStream_t st);
 void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, hipStream_t st);
 void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);
 void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hipStream_t st);
+void launch_lz_alpha(const double *c1j, const double *c2j, double *alpha_j, hipStream_t st);
+void launch_lz_next(double *dst, const double *w, const double *ww, double *beta_j, int64_t len, hipStream_t st);
 void launch_gemv_n(double *y, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);  // y = V c
 
 }  // namespace xm

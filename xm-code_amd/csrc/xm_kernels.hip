@@ -906,6 +906,18 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(double *y, const double *__
         y[i] = acc;
     }
 }
+// Lanczos bookkeeping on the device (no host round trip per step): alpha_j = c1[j] + c2[j];  beta_j = sqrt(<w,w>);
+// v_{j+1} = w / beta_j
+__global__ void lz_alpha_kernel(const double *__restrict__ c1j, const double *__restrict__ c2j, double *alpha_j) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *alpha_j = *c1j + *c2j;
+}
+__global__ __launch_bounds__(256) void lz_next_kernel(double *dst, const double *__restrict__ w, const double *__restrict__ ww, double *beta_j,
+                                                       int64_t len) {
+    const double beta = sqrt(fmax(*ww, 0.0));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *beta_j = beta;
+    const double inv = (beta > 0.0) ? 1.0 / beta : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) dst[i] = w[i] * inv;
+}
 __global__ __launch_bounds__(256) void scale_copy_kernel(double *dst, const double *__restrict__ src, double a, int64_t len) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) dst[i] = a * src[i];
 }
@@ -1169,6 +1181,14 @@ void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int
 void launch_gemv_n(double *y, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st) {
     hipLaunchKernelGGL(gemv_n_kernel, dim3(flat_grid(len)), dim3(256), 0, st, y, V, ldv, c, m, len);
     check_launch("gemv_n");
+}
+void launch_lz_alpha(const double *c1j, const double *c2j, double *alpha_j, hipStream_t st) {
+    hipLaunchKernelGGL(lz_alpha_kernel, dim3(1), dim3(64), 0, st, c1j, c2j, alpha_j);
+    check_launch("lz_alpha");
+}
+void launch_lz_next(double *dst, const double *w, const double *ww, double *beta_j, int64_t len, hipStream_t st) {
+    hipLaunchKernelGGL(lz_next_kernel, dim3(flat_grid(len)), dim3(256), 0, st, dst, w, ww, beta_j, len);
+    check_launch("lz_next");
 }
 void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hipStream_t st) {
     hipLaunchKernelGGL(scale_copy_kernel, dim3(flat_grid(len)), dim3(256), 0, st, dst, src, a, len);

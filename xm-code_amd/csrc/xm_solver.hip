@@ -616,49 +616,55 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
     double theta = 0, resid = 1e300, tmax = 1;
     std::vector<double> al, be, y;
     int total = 0;
-    std::vector<double> hc((size_t)mmax + 2);
+    // device-side bookkeeping: c1 / c2 = Gram-Schmidt coefficients of the two passes, ab = [alpha_0.. | beta_0..]
+    DevBuf<double> c2, ab;
+    c2.alloc((size_t)mmax + 2);
+    ab.alloc((size_t)2 * (mmax + 1));
+    std::vector<double> hab((size_t)2 * (mmax + 1));
+    const int batch = 8;   // Lanczos steps enqueued between two host checks
     for (int restart = 0; restart < 6; ++restart) {
         XM_HIP_CHECK(hipMemcpyAsync(V.p, x.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, st_));
         al.clear(); be.clear();
-        int j = 0;
         bool done = false;
-        for (j = 0; j < mmax; ++j) {
-            const double *vj = V.p + (size_t)j * len;
-            // w = S v_j : product input is v_j itself (pitch 1); output rows land in w at this rank's offset
-            a.Wloc = vj + (size_t)cam0_ * 3;
-            a.out = w.p + (size_t)cam0_ * 3;
-            if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
-            else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_);
-            res_->qw_products++;
-            if (comm_->active()) comm_->allgather(w.p, (size_t)nloc_ * 3, st_);
-            // classical Gram-Schmidt twice against V(:,0..j)
-            launch_dots_multi(V.p, len, j + 1, w.p, len, c.p, st_);
-            launch_sub_vc(w.p, V.p, len, c.p, j + 1, len, st_);
-            XM_HIP_CHECK(hipMemcpyAsync(hc.data(), c.p + j, sizeof(double), hipMemcpyDeviceToHost, st_));
-            launch_dots_multi(V.p, len, j + 1, w.p, len, c.p, st_);
-            launch_sub_vc(w.p, V.p, len, c.p, j + 1, len, st_);
-            XM_HIP_CHECK(hipMemcpyAsync(hc.data() + 1, c.p + j, sizeof(double), hipMemcpyDeviceToHost, st_));
-            launch_dots_multi(w.p, len, 1, w.p, len, c.p + mmax + 1, st_);
-            XM_HIP_CHECK(hipMemcpyAsync(hc.data() + 2, c.p + mmax + 1, sizeof(double), hipMemcpyDeviceToHost, st_));
+        int m_use = 0;
+        for (int j0 = 0; j0 < mmax && !done; j0 += batch) {
+            const int j1 = std::min(mmax, j0 + batch);
+            for (int j = j0; j < j1; ++j) {
+                const double *vj = V.p + (size_t)j * len;
+                // w = S v_j : the product input is v_j itself (pitch 1); output rows land in w at this rank's offset
+                a.Wloc = vj + (size_t)cam0_ * 3;
+                a.out = w.p + (size_t)cam0_ * 3;
+                if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
+                else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_);
+                res_->qw_products++;
+                if (comm_->active()) comm_->allgather(w.p, (size_t)nloc_ * 3, st_);
+                // classical Gram-Schmidt twice against V(:,0..j); alpha_j = c1[j] + c2[j]; beta_j = |w|; v_{j+1} = w / beta_j
+                launch_dots_multi(V.p, len, j + 1, w.p, len, c.p, st_);
+                launch_sub_vc(w.p, V.p, len, c.p, j + 1, len, st_);
+                launch_dots_multi(V.p, len, j + 1, w.p, len, c2.p, st_);
+                launch_sub_vc(w.p, V.p, len, c2.p, j + 1, len, st_);
+                launch_lz_alpha(c.p + j, c2.p + j, ab.p + j, st_);
+                launch_dots_multi(w.p, len, 1, w.p, len, c.p + mmax + 1, st_);
+                launch_lz_next(V.p + (size_t)(j + 1) * len, w.p, c.p + mmax + 1, ab.p + (mmax + 1) + j, len, st_);
+                total++;
+            }
+            XM_HIP_CHECK(hipMemcpyAsync(hab.data(), ab.p, hab.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
             XM_HIP_CHECK(hipStreamSynchronize(st_));
-            total++;
-            al.push_back(hc[0] + hc[1]);
-            const double beta = std::sqrt(std::max(hc[2], 0.0));
-            const int m = j + 1;
-            const bool check = (m <= 8) || (m % 4 == 0) || m == mmax || beta < 1e-13 * std::max(1.0, tmax);
-            if (check) {
+            for (int j = j0; j < j1; ++j) {
+                al.push_back(hab[(size_t)j]);
+                const double beta = hab[(size_t)(mmax + 1) + j];
+                const int m = j + 1;
                 tridiag_min(al, be, m, theta, y, tmax);
                 resid = std::fabs(beta * y[(size_t)m - 1]);
-                if (resid <= 1e-9 * std::max(1.0, tmax) || beta < 1e-13 * std::max(1.0, tmax) || m == (int)m3) { done = true; j = m; break; }
+                m_use = m;
+                if (resid <= 1e-9 * std::max(1.0, tmax) || beta < 1e-13 * std::max(1.0, tmax) || m == (int)m3 || !std::isfinite(beta)) { done = true; break; }
+                be.push_back(beta);
             }
-            if (m == mmax) { j = m; break; }
-            be.push_back(beta);
-            launch_scale_copy(V.p + (size_t)m * len, w.p, 1.0 / beta, len, st_);
         }
-        // Ritz vector x = V(:,0..j-1) y
-        const int m = (int)al.size();
-        XM_HIP_CHECK(hipMemcpyAsync(c.p, y.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, st_));
-        launch_gemv_n(w.p, V.p, len, c.p, m, len, st_);
+        // Ritz vector x = V(:,0..m_use-1) y
+        if ((int)y.size() != m_use) tridiag_min(al, be, m_use, theta, y, tmax);
+        XM_HIP_CHECK(hipMemcpyAsync(c.p, y.data(), (size_t)m_use * sizeof(double), hipMemcpyHostToDevice, st_));
+        launch_gemv_n(w.p, V.p, len, c.p, m_use, len, st_);
         XM_HIP_CHECK(hipMemcpyAsync(x.data(), w.p, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, st_));
         XM_HIP_CHECK(hipStreamSynchronize(st_));
         double nn = 0;
