@@ -102,8 +102,8 @@ void launch_scale_rows(int o, int nloc, const double *R, const double *s, double
 void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, const double *R, const double *s, double *rR,
                      double *rs, double *pR, double *ps, double *vR, double *vs, double *HvR, double *Hvs, double *Wloc,
                      TcgScal *scal0, double rr, double delta, unsigned long long *hstat, hipStream_t st);
-void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *partsA, int nA_loc, int world,
-                    const double *partsB_prev, int nB, const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
+void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *parts, int nA_loc, int nB_loc, int world,
+                    const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
                     double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, hipStream_t st);
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs,

@@ -541,8 +541,8 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
 // p and r are ping-ponged (cur -> next): every element thread of a camera reads them while one thread rewrites them.
 template <int O>
 __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *__restrict__ scal_cur, TcgScal *scal_next,
-                                                       const double *__restrict__ partsA, int nA_loc, int world,
-                                                       const double *__restrict__ partsB_prev, int nB, const double *__restrict__ HpR,
+                                                       const double *__restrict__ parts, int nA_loc, int nB_loc, int world,
+                                                       const double *__restrict__ HpR,
                                                        const double *__restrict__ Hps, const double *__restrict__ R,
                                                        const double *__restrict__ s, double *pR, const double *__restrict__ ps_cur,
                                                        double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR,
@@ -566,15 +566,19 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
         if (lead) *scal_next = sc0;
         return;
     }
-    double pHp = 0.0, rHp = 0.0, HpHp = 0.0;
+    // `parts` = the gathered per-rank chunks [ <p,Hp> | <r,Hp> | <Hp,Hp> (nA_loc each, from this iteration's Hessian epilogue)
+    //                                          | |r|^2 partials of the PREVIOUS iteration's cg_step (nB_loc) ]
+    const int chunk = 3 * nA_loc + nB_loc;
+    double pHp = 0.0, rHp = 0.0, HpHp = 0.0, rr_prev = 0.0;
     for (int r = 0; r < world; ++r) {
-        const double *pa = partsA + (size_t)r * 3 * nA_loc;
+        const double *pa = parts + (size_t)r * chunk;
         pHp += sum_partials256(pa, nA_loc, sh);
         rHp += sum_partials256(pa + nA_loc, nA_loc, sh);
         HpHp += sum_partials256(pa + 2 * nA_loc, nA_loc, sh);
+        if (sc0.iter > 0) rr_prev += sum_partials256(pa + 3 * nA_loc, nB_loc, sh);
     }
     TcgScal sc = sc0;
-    if (sc0.iter > 0) sc.rr = sum_partials256(partsB_prev, nB, sh);   // exact |r|^2 summed by the previous iteration
+    if (sc0.iter > 0) sc.rr = rr_prev;   // exact |r|^2 summed by the previous iteration
     const StepDecision d = tcg_decide(sc, pHp);
     if (d.mode == 5) {
         if (lead) {
@@ -1123,12 +1127,12 @@ void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, cons
                                         nloc, rgR, rgs, R, s, rR, rs, pR, ps, vR, vs, HvR, Hvs, Wloc, scal0, rr, delta, hstat));
     check_launch("tcg_init");
 }
-void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *partsA, int nA_loc, int world,
-                    const double *partsB_prev, int nB, const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
+void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *parts, int nA_loc, int nB_loc, int world,
+                    const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
                     double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, hipStream_t st) {
     XM_DISPATCH_O(o, hipLaunchKernelGGL((cg_step_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st, nloc,
-                                        scal_cur, scal_next, partsA, nA_loc, world, partsB_prev, nB, HpR, Hps, R, s, pR, ps_cur, ps_next, vR,
+                                        scal_cur, scal_next, parts, nA_loc, nB_loc, world, HpR, Hps, R, s, pR, ps_cur, ps_next, vR,
                                         vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat));
     check_launch("cg_step");
 }

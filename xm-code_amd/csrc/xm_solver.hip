@@ -123,7 +123,7 @@ void Context::setup_rank(int o) {
     nA_ = nA_loc * world;
     nB_ = nB_loc * world;
     partsA_.alloc((size_t)3 * nA_);
-    partsB_.alloc((size_t)2 * nB_);   // two parity buffers
+    partsB_.alloc((size_t)2 * (3 * nA_ + nB_));   // tCG partial sums: two parity buffers of world chunks [3*nA_loc | nB_loc]
     partsM_.alloc((size_t)std::max(nB_, 2 * ((nloc_ + 255) / 256) * world));
     scal_.alloc(2);
     const size_t need = (size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64;
@@ -301,18 +301,20 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
         a.scal = scal_.p + par;
         a.ps = par ? psB_.p : psA_.p;
         a.rs = par ? rsB_.p : rs_.p;
-        a.partials = partsA_.p + (size_t)rank * 3 * nA_loc;
+        // tCG partial sums travel in ONE all-gather per iteration: chunk = [Hessian-epilogue partials of this iteration |
+        // |r|^2 partials the previous cg_step left in this parity's buffer]
+        const size_t chunk = (size_t)3 * nA_loc + nB_loc;
+        double *pcur = partsB_.p + (size_t)par * chunk * comm_->world, *pnext = partsB_.p + (size_t)(par ^ 1) * chunk * comm_->world;
+        a.partials = pcur + (size_t)rank * chunk;
         const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
         if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
         product(EPI_HESS, o_, 2.0, a);
         if (timed) { XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].second, st_)); ev_used_++; }
         hess_launches_++;
-        if (comm_->active()) comm_->allgather(partsA_.p, (size_t)3 * nA_loc, st_);
-        double *pB_out = partsB_.p + (size_t)par * nB_, *pB_prev = partsB_.p + (size_t)(par ^ 1) * nB_;
-        launch_cg_step(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), partsA_.p, nA_loc, comm_->world, pB_prev, nB_, HpR_.p, Hps_.p, R_.p,
+        if (comm_->active()) comm_->allgather(pcur, chunk, st_);
+        launch_cg_step(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), pcur, nA_loc, nB_loc, comm_->world, HpR_.p, Hps_.p, R_.p,
                        s_.p, pR_.p, par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, rR_.p,
-                       par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pB_out + (size_t)rank * nB_loc, hstat_dev_, st_);
-        if (comm_->active()) comm_->allgather(pB_out, (size_t)nB_loc, st_);
+                       par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pnext + (size_t)rank * chunk + 3 * nA_loc, hstat_dev_, st_);
         gather_W();
     };
     auto read_scal = [&](int par) {
