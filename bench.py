@@ -176,7 +176,7 @@ def main():
                   "qw_products": last["qw_products"], "lanczos_iters": last["lanczos_iters"],
                   "tr_seconds": last["tr_seconds"], "cert_seconds": last["cert_seconds"], "setup_gen_s": gen_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r01_pmc_fetch_qw_dense.json (rocprofv3 --pmc FETCH_SIZE pass of the same kernel on the same matrix size, x1024 x2)", "kernel": kname, "avg_launch_ms": qw_ms,
+                     "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r01_pmc_fetch_qw_dense.json (rocprofv3 --pmc FETCH_SIZE pass of the same kernel on the same matrix size, x1024 x2)", "kernel": kname + (" via the half-traffic symmetric path (qw_sym_kernel + sym_reduce_kernel; bytes counted at FULL storage, SURVEY 8d)" if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); "
                              "per-rank Q is %.0f MB: below ~256 MB it sits in the Infinity Cache, so the figure is cache-assisted, "

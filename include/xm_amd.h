@@ -111,6 +111,8 @@ typedef struct {
     int64_t qw_bytes;          /* algorithmic bytes of ONE tCG Q*W launch at the final rank */
     int32_t trace_len;
     int32_t last_stop_reason;
+    int32_t sym_product;       /* 1 when the half-traffic symmetric product was used (dense, single GPU, Q symmetric to round-off) */
+    int32_t reserved;
 } xm_result_t;
 
 int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out);          /* uploads / lays out Q on device 0 (or the rank's device) */
@@ -136,6 +138,9 @@ int xm_dense_from_bsr3(const int64_t *rowptr, const int32_t *colidx, const doubl
  * Replaces cublasDgemm via DnMatDnMat (Dense/matmul.h:42-87). stream: hipStream_t or NULL. */
 int xm_qw_dense(const double *dq, int64_t n, int o, const double *dW, double *dOut, double alpha, void *stream);
 /* same product from 3x3-block CSR (device arrays; blocks row-major 9 doubles) */
+/* the same product reading only the upper block triangle of a SYMMETRIC Q (o in 3..5; allocates its scratch per call) */
+int xm_qw_dense_sym(const double *dq, int64_t n, int o, const double *dW, double *dOut, double alpha, void *stream);
+int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
 int xm_qw_bsr3(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o,
                const double *dW, double *dOut, double alpha, void *stream);
 /* per-camera kernels (device, row-major 3n x o; s: n):

@@ -275,3 +275,39 @@ def test_recover_rotations_matches_reference_recover_XM(xmamd, oracle, name):
     blocks = rot.T.reshape(-1, 3, 3)                    # block i transposed
     assert np.abs(blocks @ np.transpose(blocks, (0, 2, 1)) - np.eye(3)).max() < 1e-13
     assert np.allclose(np.abs(rot[:, :3]), np.eye(3), atol=1e-13)     # +-I (the reference flips the global sign on a negative-det majority)
+
+
+@pytest.mark.parametrize("n,o", [(1, 3), (7, 3), (8, 4), (9, 5), (43, 3), (149, 4), (171, 5), (700, 3), (1031, 5)])
+def test_qw_dense_symmetric_kernel_matches_oracle(xmamd, oracle, n, o):
+    """half-traffic product (reads only the upper block triangle) on a symmetric Q == the full product"""
+    rng = np.random.default_rng(7 * n + o)
+    A = rng.standard_normal((3 * n, 3 * n)); Q = A + A.T
+    W = rng.standard_normal((3 * n, o))
+    ref = oracle.qw(Q, W, 2.0)
+    got = xmamd.qw_dense(Q, W, 2.0, sym=True)
+    assert tl.rel_fro(got, ref) < 1e-13
+    assert tl.rel_fro(xmamd.qw_dense(Q, W, 2.0), ref) < 1e-13
+
+
+def test_symmetric_path_equals_general_path(xmamd, tmp_path):
+    """the solver picks the symmetric product when Q is symmetric to round-off; XM_SYM=0 forces the general kernel.
+    Both must land on the same certified optimum (trajectories differ only by summation order)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys, os
+        sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'xm-code_amd')!r})
+        sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import numpy as np, xmamd, xm_testlib as tl
+        Q = tl.gen_dense(356, seed=356)["Q"]
+        R, s, info = xmamd.solve_dense(Q, 5, 1e-9, 0.0)
+        np.savez(sys.argv[1], R=R, s=s, primal=info['primal'], sym=info['sym_product'], rank=info['rank'])
+    """)
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"s{flag}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, XM_SYM=flag), timeout=600)
+        outs.append(np.load(out))
+    assert int(outs[0]["sym"]) == 1 and int(outs[1]["sym"]) == 0
+    assert int(outs[0]["rank"]) == int(outs[1]["rank"]) == 3
+    assert float(outs[0]["primal"]) == pytest.approx(float(outs[1]["primal"]), rel=1e-11)
+    assert tl.rotation_parity(outs[0]["R"], outs[0]["s"], outs[1]["R"], outs[1]["s"]) < 1e-7

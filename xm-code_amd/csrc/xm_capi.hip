@@ -196,6 +196,38 @@ int xm_qw_dense(const double *dq, int64_t n, int o, const double *dW, double *dO
     return XM_OK;
     XM_CATCH
 }
+int xm_qw_dense_sym(const double *dq, int64_t n, int o, const double *dW, double *dOut, double alpha, void *stream) {
+    XM_TRY
+    const int64_t ld = xm::dense_ld(n);
+    xm::DevBuf<double> prow, pcol;
+    prow.alloc(xm::sym_prow_count((int)n, ld, o));
+    pcol.alloc((size_t)xm::sym_groups((int)n) * (size_t)ld * o, false);
+    xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, alpha, plain_args(n, dOut), prow.p, pcol.p, (hipStream_t)stream);
+    XM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return XM_OK;
+    XM_CATCH
+}
+int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
+    XM_TRY
+    const int64_t ld = xm::dense_ld(n);
+    xm::DevBuf<double> prow, pcol;
+    prow.alloc(xm::sym_prow_count((int)n, ld, o));
+    pcol.alloc((size_t)xm::sym_groups((int)n) * (size_t)ld * o, false);
+    hipEvent_t e0, e1;
+    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+    const xm::CamArgs a = plain_args(n, dOut);
+    for (int i = 0; i < 3; ++i) xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, prow.p, pcol.p, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, prow.p, pcol.p, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+    XM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_avg) *ms_avg = (double)ms / reps;
+    return XM_OK;
+    XM_CATCH
+}
 int xm_qw_bsr3(const int64_t *rp, const int32_t *ci, const double *bl, int64_t n, int o, const double *dW, double *dOut, double alpha,
                void *stream) {
     XM_TRY

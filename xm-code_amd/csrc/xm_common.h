@@ -89,6 +89,11 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
 void launch_qw_bsr3(int o, int epi, const int64_t *rowptr, const int32_t *colidx, const double *blocks, const double *W,
                     double alpha, const CamArgs &a, hipStream_t st);
 int qw_grid(int nloc);
+int sym_groups(int nloc);
+size_t sym_prow_count(int nloc, int64_t ld, int o);
+void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,
+                   double *Pcol, hipStream_t st);
+void launch_asym(const double *Q, int64_t ld, int64_t m, double *out, int grid, hipStream_t st);
 
 // layout helpers
 void launch_transpose_pad(const double *src_colmajor, int64_t lds, int64_t rows, int64_t cols, double *dst, int64_t ldd,

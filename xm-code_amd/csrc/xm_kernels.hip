@@ -363,6 +363,195 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// Half-traffic product for SYMMETRIC dense Q (single GPU, o <= 5).  Only the upper block triangle is read: a workgroup of 8
+// wavefronts owns 8 consecutive cameras (24 rows) and sweeps the column tiles from its diagonal block to the right.  Every Q
+// fragment is used twice: y_rows += Q_tile * w_cols (accumulated in registers over the sweep, as in the full kernel) and
+// y_cols += Q_tile^T * w_rows (per-lane column sums need no cross-lane step; the 8 wavefronts' sums are added in LDS in a
+// fixed order and written as one partial per (workgroup, column)).  sym_reduce_kernel then adds, per camera, the row result
+// and the column partials of the workgroups above it — in a fixed order, no atomics — and runs the same fused epilogue.
+// Traffic: half of Q + o/24 of it written and read back as partials (12.5 % at o = 3).  Workgroups are dispatched heaviest
+// first (block 0 sweeps every tile), which balances the triangular work over the CUs.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int kSymWaves = 8;
+constexpr int kSymTile = 128;
+constexpr int kSymChunk = 6;   // column tiles per workgroup: the triangular sweep is cut into equal pieces for load balance
+
+template <int O>
+__global__ __launch_bounds__(512) void qw_sym_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc,
+                                                      const TcgScal *__restrict__ scal, double *__restrict__ Prow,
+                                                      double *__restrict__ Pcol) {
+    constexpr int OP = pitch_of(O);
+    constexpr int TILE = kSymTile;
+    constexpr int TILE2 = TILE * OP / 2;   // double2 elements of one W tile (<= 320 < 512 threads)
+    if (scal != nullptr) {
+        if (scal->status != 0) return;
+    }
+    const int b = blockIdx.y, cx = blockIdx.x;
+    const int64_t col_lo = (int64_t)24 * b, col_hi = col_lo + 24;   // the group's diagonal block spans [col_lo, col_hi)
+    const int ntiles = (int)((ld + TILE - 1) / TILE);
+    const int t0 = (int)(col_lo / TILE);
+    const int tb = (cx * kSymChunk > t0) ? cx * kSymChunk : t0;
+    const int te = ((cx + 1) * kSymChunk < ntiles) ? (cx + 1) * kSymChunk : ntiles;
+    if (tb >= te) return;   // chunk entirely left of the diagonal (uniform exit, before any barrier)
+    __shared__ __attribute__((aligned(16))) double wt[2][TILE * OP];
+    __shared__ __attribute__((aligned(16))) double cs[2][kSymWaves][TILE * O];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cam = b * kSymWaves + wave;
+    const bool active = cam < nloc;
+    const double *q0p = Q + (size_t)(active ? cam : 0) * 3 * (size_t)ld + 2 * lane;
+    // this camera's rows of W (wave-uniform): operand of the transposed product
+    double wr[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) wr[r][k] = active ? W[((size_t)cam * 3 + r) * OP + k] : 0.0;
+
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+
+    double2 q1[3], q2[3];   // Q fragments of tiles t+1 and t+2 (two tiles in flight per wavefront)
+    double2 ws;
+    auto load_q = [&](double2 (&dst)[3], int t) {
+        const int64_t c = (int64_t)t * TILE;
+        if (active && t < te) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dst[r] = *reinterpret_cast<const double2 *>(q0p + (size_t)r * ld + c);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dst[r] = make_double2(0.0, 0.0);
+        }
+    };
+    auto load_w = [&](int t) {
+        const double2 *src = reinterpret_cast<const double2 *>(W + (size_t)t * TILE * OP);
+        ws = ((int)threadIdx.x < TILE2) ? src[threadIdx.x] : make_double2(0.0, 0.0);
+    };
+    auto store_w = [&](int buf) {
+        if ((int)threadIdx.x < TILE2) reinterpret_cast<double2 *>(wt[buf])[threadIdx.x] = ws;
+    };
+
+    load_q(q1, tb);
+    load_q(q2, tb + 1);
+    load_w(tb);
+    store_w(tb & 1);
+    __syncthreads();
+    for (int t = tb; t < te; ++t) {
+        double2 q[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { q[r] = q1[r]; q1[r] = q2[r]; }
+        load_q(q2, t + 2);
+        const bool more = (t + 1 < te);
+        if (more) load_w(t + 1);
+        const int64_t c = (int64_t)t * TILE + 2 * lane;            // this lane's two columns: c, c+1 (same class: bounds are even)
+        const double mrow = (c >= col_lo) ? 1.0 : 0.0;             // left of the diagonal block: belongs to a workgroup above
+        const double mcol = (c >= col_hi) ? 1.0 : 0.0;             // inside the diagonal block: used one way only
+        const double2 *wp = reinterpret_cast<const double2 *>(wt[t & 1]) + (size_t)lane * OP;
+        double wv[2 * OP];
+#pragma unroll
+        for (int j = 0; j < OP; ++j) {
+            const double2 tt = wp[j];
+            wv[2 * j] = tt.x;
+            wv[2 * j + 1] = tt.y;
+        }
+        double cxs[O], cys[O];
+#pragma unroll
+        for (int k = 0; k < O; ++k) { cxs[k] = 0.0; cys[k] = 0.0; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double qx = q[r].x * mrow, qy = q[r].y * mrow;
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                acc[r][k] += qx * wv[k] + qy * wv[OP + k];
+                cxs[k] += qx * wr[r][k];
+                cys[k] += qy * wr[r][k];
+            }
+        }
+        double *cw = cs[t & 1][wave] + (size_t)(2 * lane) * O;
+#pragma unroll
+        for (int k = 0; k < O; ++k) { cw[k] = cxs[k] * mcol; cw[O + k] = cys[k] * mcol; }
+        if (more) store_w((t + 1) & 1);
+        __syncthreads();
+        // fixed-order sum over the 8 wavefronts -> one partial per (workgroup row group, column, k)
+        for (int i = threadIdx.x; i < TILE * O; i += 512) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < kSymWaves; ++w8) sum += cs[t & 1][w8][i];
+            Pcol[((size_t)b * (size_t)ld + (size_t)t * TILE) * O + i] = sum;
+        }
+    }
+    // row results of this chunk: wave reduction, lane k keeps column k, raw sums (alpha is applied by the reducer)
+    double *pr = Prow + (((size_t)b * gridDim.x + cx) * kSymWaves + wave) * 3 * O;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            const double tsum = wave_sum(acc[r][k]);
+            if (lane == k) pr[r * O + k] = tsum;
+        }
+}
+
+// second half of the symmetric product: y_j = sum_chunks Prow[group(j)][chunk][j] + sum_{b < group(j)} Pcol[b][rows of j]
+// (fixed order, no atomics), then the fused epilogue
+template <int O, int EPI>
+__global__ __launch_bounds__(256) void sym_reduce_kernel(const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t ld,
+                                                          int nchunks, double alpha, CamArgs a) {
+    if (EPI == EPI_HESS) {
+        if (a.scal->status != 0) return;
+    }
+    __shared__ double red[kQwWaves][3];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cam = blockIdx.x * kQwWaves + wave;
+    const bool active = cam < a.nloc;
+    EpiOps eops;
+    epi_prefetch<O, EPI>(eops, cam, lane, active, a);
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+    if (active) {
+        const int g = cam / kSymWaves, w = cam - g * kSymWaves;
+        for (int bb = lane; bb < g; bb += 64) {
+            const double *p = Pcol + ((size_t)bb * (size_t)ld + (size_t)cam * 3) * O;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
+        }
+        const int c0 = (int)(((int64_t)24 * g / kSymTile) / kSymChunk);   // first chunk that holds tiles of this row group
+        for (int cx = c0 + lane; cx < nchunks; cx += 64) {
+            const double *p = Prow + (((size_t)g * nchunks + cx) * kSymWaves + w) * 3 * O;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
+        }
+    }
+    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, eops, red);
+}
+
+// max |Q[r][c] - Q[c][r]| and max |Q| over the device layout (decides whether the symmetric path may be used)
+__global__ __launch_bounds__(256) void asym_kernel(const double *__restrict__ Q, int64_t ld, int64_t m, double *out /* [2*grid] */) {
+    __shared__ double sh[2][4];
+    double da = 0.0, mx = 0.0;
+    for (int64_t r = blockIdx.x; r < m; r += gridDim.x)
+        for (int64_t c = threadIdx.x; c < m; c += 256) {
+            const double v = Q[r * ld + c];
+            da = fmax(da, fabs(v - Q[c * ld + r]));
+            mx = fmax(mx, fabs(v));
+        }
+    for (int off = 32; off >= 1; off >>= 1) { da = fmax(da, __shfl_xor(da, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = da; sh[1][threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = fmax(fmax(sh[0][0], sh[0][1]), fmax(sh[0][2], sh[0][3]));
+        out[gridDim.x + blockIdx.x] = fmax(fmax(sh[1][0], sh[1][1]), fmax(sh[1][2], sh[1][3]));
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // 3x3-block CSR Q*W: one wavefront per camera row, ONE LANE PER STORED BLOCK.  A lane fetches its column index, then
 // (independently, all in flight together) its 72-byte block and the 3 x O rows of W it multiplies, and does the 9*O FMAs
 // itself; a row of up to 64 blocks is a single pass with two dependent memory round trips (a lane-per-element mapping
@@ -1079,6 +1268,41 @@ static int bsr_variant() {  // XM_BSR_VARIANT=1 (default: blocks staged through 
     static int v = [] { const char *e = std::getenv("XM_BSR_VARIANT"); return (e && *e == '0') ? 0 : 1; }();
     return v;
 }
+int sym_groups(int nloc) { return (nloc + kSymWaves - 1) / kSymWaves; }
+int sym_chunks(int64_t ld) { const int nt = (int)((ld + kSymTile - 1) / kSymTile); return (nt + kSymChunk - 1) / kSymChunk; }
+size_t sym_prow_count(int nloc, int64_t ld, int o) { return (size_t)sym_groups(nloc) * sym_chunks(ld) * kSymWaves * 3 * o; }
+
+template <int O>
+static void qw_sym_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
+                       hipStream_t st) {
+    const int nch = sym_chunks(ld);
+    hipLaunchKernelGGL((qw_sym_kernel<O>), dim3(nch, sym_groups(a.nloc)), dim3(512), 0, st, Q, ld, W, a.nloc,
+                       (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr, Prow, Pcol);
+    const dim3 g(qw_grid(a.nloc)), b(256);
+    switch (epi) {
+        case EPI_PLAIN: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nch, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nch, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nch, alpha, a); break;
+        default: throw Error(-2, "bad epilogue");
+    }
+}
+// symmetric half-traffic product (o in 3..5); Prow: sym_prow_count() doubles, Pcol: sym_groups(nloc) * ld * o doubles
+void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,
+                   double *Pcol, hipStream_t st) {
+    if (a.nloc <= 0) return;
+    switch (o) {
+        case 3: qw_sym_epi<3>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+        case 4: qw_sym_epi<4>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+        case 5: qw_sym_epi<5>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+        default: throw Error(-2, "symmetric product is instantiated for o = 3..5");
+    }
+    check_launch("qw_sym");
+}
+void launch_asym(const double *Q, int64_t ld, int64_t m, double *out, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(asym_kernel, dim3(grid), dim3(256), 0, st, Q, ld, m, out);
+    check_launch("asym");
+}
+
 template <int O, int VAR>
 static void qw_bsr3_epi(int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, double alpha,
                         const CamArgs &a, hipStream_t st) {

@@ -92,6 +92,10 @@ private:
     int cur_ = 0;
     DevBuf<double> rR_, rs_, rsB_, pR_, psA_, psB_, vR_, vs_, HvR_, Hvs_, HpR_, Hps_;
     DevBuf<double> partsA_, partsB_, partsM_;
+    DevBuf<double> Prow_, Pcol_;               // symmetric product: row results and per-workgroup column partials
+    bool sym_ok_ = false;
+    int sym_max_o_ = 4;
+    double q_asym_ = 0, q_max_ = 0;
     DevBuf<TcgScal> scal_;
     unsigned long long *hstat_ = nullptr;      // host-mapped progress word (iter << 8 | status)
     unsigned long long *hstat_dev_ = nullptr;

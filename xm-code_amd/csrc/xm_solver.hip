@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -91,6 +92,30 @@ Context::Context(const xm_problem_t &prob) {
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
     }
+    // Symmetric half-traffic product: single GPU, dense, Q symmetric to round-off.  It pays when the product is truly HBM
+    // bound (measured: 13682 cameras 2215 -> 1667 us at o = 3) and not at Venice size, where the per-tile column-sum exchange
+    // costs what the halved traffic saves (34.1 vs 33.8 us).  Default: on for 3n >= 12288 and o <= 4; XM_SYM=1 forces it for
+    // every size (o <= 5), XM_SYM=0 disables it.
+    sym_ok_ = false;
+    sym_max_o_ = 4;
+    {
+        const char *e = std::getenv("XM_SYM");
+        const bool force = (e && *e == '1'), off = (e && *e == '0');
+        if (force) sym_max_o_ = 5;
+        if (storage_ == XM_STORAGE_DENSE && world == 1 && !off && (force || 3 * n_ >= 12288)) {
+            const int grid = 512;
+            DevBuf<double> d;
+            d.alloc((size_t)2 * grid);
+            launch_asym(dQ_, ld_, 3 * n_, d.p, grid, st_);
+            std::vector<double> h((size_t)2 * grid);
+            XM_HIP_CHECK(hipMemcpyAsync(h.data(), d.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+            XM_HIP_CHECK(hipStreamSynchronize(st_));
+            double da = 0, mx = 0;
+            for (int i = 0; i < grid; ++i) { da = std::max(da, h[(size_t)i]); mx = std::max(mx, h[(size_t)grid + i]); }
+            q_asym_ = da; q_max_ = mx;
+            sym_ok_ = (da <= 1e-9 * mx);
+        }
+    }
     XM_HIP_CHECK(hipHostMalloc((void **)&hstat_, 256, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(hstat_, 0, 256);
     XM_HIP_CHECK(hipHostGetDevicePointer((void **)&hstat_dev_, hstat_, 0));
@@ -125,6 +150,12 @@ void Context::setup_rank(int o) {
     partsA_.alloc((size_t)3 * nA_);
     partsB_.alloc((size_t)2 * (3 * nA_ + nB_));   // tCG partial sums: two parity buffers of world chunks [3*nA_loc | nB_loc]
     partsM_.alloc((size_t)std::max(nB_, 2 * ((nloc_ + 255) / 256) * world));
+    if (sym_ok_ && o >= 3 && o <= sym_max_o_) {
+        Prow_.alloc(sym_prow_count(nloc_, ld_, o));
+        Pcol_.alloc((size_t)sym_groups(nloc_) * (size_t)ld_ * o, false);
+    } else {
+        Prow_.release(); Pcol_.release();
+    }
     scal_.alloc(2);
     const size_t need = (size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64;
     if (need > hpin_count_) {
@@ -192,8 +223,12 @@ CamArgs Context::cam_args(int state) const {
 }
 
 void Context::product(int epi, int o, double alpha, const CamArgs &a) {
-    if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
-    else launch_qw_bsr3(o, epi, rowptr_.p, colidx_.p, blocks_.p, W_.p, alpha, a, st_);
+    if (storage_ == XM_STORAGE_DENSE) {
+        if (sym_ok_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT && Pcol_.p) launch_qw_sym(o, epi, dQ_, ld_, W_.p, alpha, a, Prow_.p, Pcol_.p, st_);
+        else launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
+    } else {
+        launch_qw_bsr3(o, epi, rowptr_.p, colidx_.p, blocks_.p, W_.p, alpha, a, st_);
+    }
     if (res_) res_->qw_products++;
 }
 
@@ -805,6 +840,7 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     if (opt.flags & XM_FLAG_PROFILE_QW) finish_profile();
     // algorithmic bytes of one tCG product at the final rank
     const int of = std::max(3, std::min(out_rank, (int)opt.max_rank));
+    res.sym_product = (sym_ok_ && storage_ == XM_STORAGE_DENSE) ? 1 : 0;
     if (storage_ == XM_STORAGE_DENSE) res.qw_bytes = 8LL * (3 * n_) * (3 * n_) + 2LL * 8 * 3 * n_ * of;
     else res.qw_bytes = 76LL * nb_loc_ + 4LL * (n_ + 1) + 2LL * 8 * 3 * n_ * of;
     res.seconds = secs_since(t0);

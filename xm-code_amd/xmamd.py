@@ -19,7 +19,7 @@ FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 EXPORTS = [
     "xm_last_error", "xm_version", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
-    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
+    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_finalize", "xm_partition",
 ]
 
@@ -46,7 +46,8 @@ class Result(C.Structure):
                 ("tcg_iters", C.c_int64), ("outer_iters", C.c_int64), ("qw_products", C.c_int64),
                 ("lanczos_iters", C.c_int64), ("seconds", C.c_double), ("tr_seconds", C.c_double),
                 ("cert_seconds", C.c_double), ("qw_ms_sum", C.c_double), ("qw_ms_count", C.c_int64),
-                ("qw_bytes", C.c_int64), ("trace_len", C.c_int32), ("last_stop_reason", C.c_int32)]
+                ("qw_bytes", C.c_int64), ("trace_len", C.c_int32), ("last_stop_reason", C.c_int32),
+                ("sym_product", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None
@@ -79,6 +80,8 @@ def lib():
         L.xm_dense_upload.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]
         L.xm_dense_from_bsr3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
         L.xm_qw_dense.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.xm_qw_dense_sym.argtypes = L.xm_qw_dense.argtypes
+        L.xm_qw_dense_sym_time.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.xm_qw_bsr3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_double, C.c_void_p]
         L.xm_retract.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
@@ -186,8 +189,8 @@ def dense_from_bsr3(rowptr, colidx, blocks):
     return d
 
 
-def qw_dense(Q, W, alpha=1.0, dq=None):
-    """alpha * Q @ W on the GPU through xm_qw_dense (Q: 3n x 3n, W: 3n x o)."""
+def qw_dense(Q, W, alpha=1.0, dq=None, sym=False):
+    """alpha * Q @ W on the GPU through xm_qw_dense (Q: 3n x 3n, W: 3n x o); sym=True: the half-traffic symmetric kernel."""
     require_gpu()
     W = np.asarray(W, dtype=np.float64)
     n, o = W.shape[0] // 3, W.shape[1]
@@ -195,7 +198,7 @@ def qw_dense(Q, W, alpha=1.0, dq=None):
     dq = dq or dense_upload(Q)
     dW = DevArray(to_rm(W, rows=dense_ld(n)))
     dO = DevArray(nbytes=3 * n * pitch_of(o) * 8)
-    _chk(lib().xm_qw_dense(dq.ptr, n, o, dW.ptr, dO.ptr, alpha, None))
+    _chk((lib().xm_qw_dense_sym if sym else lib().xm_qw_dense)(dq.ptr, n, o, dW.ptr, dO.ptr, alpha, None))
     _chk(lib().xm_dev_sync())
     out = from_rm(dO.get(), 3 * n, o)
     for b in (dW, dO) + ((dq,) if own else ()):
