@@ -1,6 +1,6 @@
-"""micro-benchmark of the BSR3 Q*W kernel: python scripts_kbench_bsr.py n deg o [o ...]"""
+"""micro-benchmark of the BSR3 Q*W kernel: python scripts/kbench_bsr.py n deg o [o ...]"""
 import sys, os, ctypes as C
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "xm-code_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, xmamd, xm_testlib as tl
 n = int(sys.argv[1]); deg = int(sys.argv[2]); os_ = [int(x) for x in sys.argv[3:]] or [3]

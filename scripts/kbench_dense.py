@@ -1,6 +1,7 @@
-"""micro-benchmark of the dense Q*W kernel (plain epilogue) through the C ABI: python scripts_kbench.py n o [o ...]"""
+"""micro-benchmark of the dense Q*W kernel (plain epilogue) through the C ABI: python scripts/kbench_dense.py n o [o ...]"""
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "xm-code_amd"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "xm-code_amd"))
 import numpy as np, xmamd
 n = int(sys.argv[1]); os_ = [int(x) for x in sys.argv[2:]] or [3]
 L = xmamd.lib(); ld = xmamd.dense_ld(n)
