@@ -570,8 +570,6 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cam = blockIdx.x * kQwWaves + wave;
     const bool active = cam < a.nloc;
-    EpiOps eops;
-    epi_prefetch<O, EPI>(eops, cam, lane, active, a);
     double acc[3][O];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -621,6 +619,10 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
             }
         }
     }
+    // epilogue operands are fetched only now: this kernel is bound by the dependent rowptr -> colidx -> W chain, i.e. by the
+    // number of rows in flight, and holding ~40 more VGPRs through the gather phase would cost a wave per SIMD
+    EpiOps eops;
+    epi_prefetch<O, EPI>(eops, cam, lane, active, a);
     qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }
 
