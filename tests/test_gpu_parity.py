@@ -311,3 +311,21 @@ def test_symmetric_path_equals_general_path(xmamd, tmp_path):
     assert int(outs[0]["rank"]) == int(outs[1]["rank"]) == 3
     assert float(outs[0]["primal"]) == pytest.approx(float(outs[1]["primal"]), rel=1e-11)
     assert tl.rotation_parity(outs[0]["R"], outs[0]["s"], outs[1]["R"], outs[1]["s"]) < 1e-7
+
+
+def test_high_rank_staircase(xmamd, oracle):
+    """noisy view graphs that need ranks up to 9 / run out at max_rank 10: exercises every rank instantiation (o = 3..10) of
+    the kernels inside whole solves, status 1 (certified) and status 2 (max rank) exits (XM_main.cu:260-276)"""
+    P = tl.gen_vg(80, deg=5, sigma=3.0, seed=5)
+    R, s, info = xmamd.solve_dense(P["Q"], 10, 1e-9, 3.0)
+    Ro, so, io = oracle.solve(P["Q"], 10, 1e-9, 3.0, 1000.0, trace=20000)
+    assert info["rank"] == io["rank"] == 9 and info["status"] == io["status"] == 1
+    assert info["primal"] == pytest.approx(io["trace"][-1, 0], rel=1e-8)
+    assert tl.rel_fro(tl.gram(R, s), tl.gram(Ro, so)) < 1e-6          # certified optimum is unique
+    assert tl.stiefel_defect(R) < 1e-12
+    P = tl.gen_vg(100, deg=6, sigma=3.0, seed=6)
+    R, s, info = xmamd.solve_dense(P["Q"], 10, 1e-9, 5.0)
+    Ro, so, io = oracle.solve(P["Q"], 10, 1e-9, 5.0, 1000.0, trace=20000)
+    assert info["rank"] == io["rank"] == 10 and info["status"] == io["status"] == 2
+    assert R.shape == (300, 10) and info["min_eig"] < -1e-4
+    assert info["primal"] == pytest.approx(io["trace"][-1, 0], rel=1e-3)
