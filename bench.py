@@ -22,6 +22,7 @@ for p in (ROOT, os.path.join(ROOT, "xm-code_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")              # control-plane rendezvous on loopback (hostname may not resolve)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (multi-process runs)
 
 import numpy as np  # noqa: E402
