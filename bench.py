@@ -22,6 +22,8 @@ for p in (ROOT, os.path.join(ROOT, "xm-code_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:   # torchrun pins OMP_NUM_THREADS=1; give each rank its share of the host cores
+    os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // int(os.environ["WORLD_SIZE"])))
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")              # control-plane rendezvous on loopback (hostname may not resolve)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (multi-process runs)
 
@@ -83,6 +85,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("XM_BENCH_SINGLE_DEVICE") == "1":      # debugging aid: put every rank on device 0 of a 1-GPU box
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     xmamd.require_gpu()
