@@ -163,6 +163,9 @@ int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, dou
  * (bench.py does that with torch.distributed); every rank then calls xm_comm_init before xm_ctx_create. */
 int xm_comm_unique_id(unsigned char id[128]);
 int xm_comm_init(int rank, int world, int device, const unsigned char id[128], const char *rccl_path /* NULL = default search */);
+/* TEST transport: the same collectives through a POSIX shared-memory segment, so several ranks can share one GPU on a
+ * 1-GPU box (tests/test_gpu_parity.py::test_two_ranks_one_gpu); `bytes` = capacity of the exchange area */
+int xm_comm_init_shm(int rank, int world, int device, const char *name, size_t bytes);
 int xm_comm_finalize(void);
 /* contiguous camera range [*c0, *c1) owned by `rank` (balanced by rows for dense, by stored blocks for BSR3) */
 int xm_partition(int64_t n, int world, int rank, int64_t *c0, int64_t *c1);

@@ -329,3 +329,53 @@ def test_high_rank_staircase(xmamd, oracle):
     assert info["rank"] == io["rank"] == 10 and info["status"] == io["status"] == 2
     assert R.shape == (300, 10) and info["min_eig"] < -1e-4
     assert info["primal"] == pytest.approx(io["trace"][-1, 0], rel=1e-3)
+
+
+def _two_rank_worker_code():
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return textwrap.dedent(f"""
+        import sys, os
+        sys.path.insert(0, {os.path.join(root, 'xm-code_amd')!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        import numpy as np, xmamd, xm_testlib as tl
+        rank, world, name, out, case = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+        if world > 1:
+            xmamd._chk(xmamd.lib().xm_comm_init_shm(rank, world, 0, name.encode(), 64 << 20))
+        if case == "dense":
+            P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)         # odd camera count (padding camera), needs rank escalation
+            ctx = xmamd.Context(Q=P["Q"]); args = (6, 1e-9, 3.0)
+        else:
+            P = tl.gen_vg(301, deg=10, sigma=0.1, seed=5)
+            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"])); args = (5, 1e-10, 10.0)
+        R, s, info = ctx.solve(*args, trace=4000)
+        ctx.close()
+        np.savez(out, R=R, s=s, primal=info["primal"], rank=info["rank"], status=info["status"], tcg=info["tcg_iters"],
+                 min_eig=info["min_eig"], trace=info["trace"])
+        xmamd.lib().xm_comm_finalize()
+    """)
+
+
+@pytest.mark.parametrize("case", ["dense", "bsr"])
+def test_two_ranks_one_gpu(xmamd, tmp_path, case):
+    """The whole row-partitioned solver with TWO ranks (processes) sharing the one GPU of the test box through the
+    shared-memory test transport: camera partition 21+20 (+1 inert padding camera), replicated product input, gathered
+    partial sums, staircase with rank escalation, Lanczos certificate.  Both ranks must return bit-identical results and
+    agree with the single-rank run (same optimum; trajectories differ only by summation grouping)."""
+    import subprocess, sys, uuid
+    code = _two_rank_worker_code()
+    name = "/xm_test_" + uuid.uuid4().hex[:12]
+    procs, outs = [], []
+    for r in range(2):
+        out = str(tmp_path / f"w2_r{r}.npz"); outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, "-c", code, str(r), "2", name, out, case]))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    single = str(tmp_path / "w1.npz")
+    subprocess.check_call([sys.executable, "-c", code, "0", "1", name, single, case], timeout=600)
+    a, b, c = np.load(outs[0]), np.load(outs[1]), np.load(single)
+    assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["s"], b["s"]) and np.array_equal(a["trace"], b["trace"])
+    assert int(a["rank"]) == int(c["rank"]) and int(a["status"]) == int(c["status"]) == 1
+    assert float(a["primal"]) == pytest.approx(float(c["primal"]), rel=1e-9)
+    assert tl.rel_fro(tl.gram(a["R"], a["s"]), tl.gram(c["R"], c["s"])) < 1e-6
+    k = 5
+    assert np.allclose(a["trace"][:k, :2], c["trace"][:k, :2], rtol=1e-9)

@@ -359,6 +359,9 @@ int xm_comm_unique_id(unsigned char id[128]) { XM_TRY xm::comm_unique_id(id); re
 int xm_comm_init(int rank, int world, int device, const unsigned char id[128], const char *rccl_path) {
     XM_TRY require_device(); xm::comm_init(rank, world, device, id, rccl_path); return XM_OK; XM_CATCH
 }
+int xm_comm_init_shm(int rank, int world, int device, const char *name, size_t bytes) {
+    XM_TRY require_device(); xm::comm_init_shm(rank, world, device, name, bytes); return XM_OK; XM_CATCH
+}
 int xm_comm_finalize(void) { XM_TRY xm::comm_finalize(); return XM_OK; XM_CATCH }
 int xm_partition(int64_t n, int world, int rank, int64_t *c0, int64_t *c1) {
     if (n < 0 || world < 1 || rank < 0 || rank >= world || !c0 || !c1) { g_err = "bad argument"; return XM_ERR_ARG; }

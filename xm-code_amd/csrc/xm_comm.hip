@@ -7,6 +7,13 @@
 // RCCL is dlopen()ed at run time (torch bundles its own librccl.so with the same soname; whichever the process already
 // loaded is reused, otherwise /opt/rocm/lib/librccl.so).  No link-time dependency, no collective unless world > 1.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <vector>
 
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +39,34 @@ struct Rccl {
 };
 Rccl g_rccl;
 Comm g_comm;
+
+// Test transport: the same collectives through a POSIX shared-memory segment (device -> host -> shm -> host -> device), so
+// that several ranks can share ONE GPU on a 1-GPU box and the whole row-partitioned solver (partition, padding cameras,
+// identical collective counts on every rank) can be exercised there.  Never used when RCCL is initialised.
+struct ShmHeader {
+    std::atomic<unsigned long long> arrive;   // monotonically increasing barrier counter
+};
+struct Shm {
+    void *base = nullptr;
+    size_t bytes = 0;
+    unsigned long long barriers = 0;           // barriers completed by this rank
+    std::string name;
+    std::vector<double> host;
+    bool active() const { return base != nullptr; }
+};
+Shm g_shm;
+
+void shm_barrier(int world) {
+    ShmHeader *h = static_cast<ShmHeader *>(g_shm.base);
+    h->arrive.fetch_add(1, std::memory_order_acq_rel);
+    g_shm.barriers++;
+    const unsigned long long target = g_shm.barriers * (unsigned long long)world;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (h->arrive.load(std::memory_order_acquire) < target) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
+            throw Error(XM_ERR_COMM, "shared-memory communicator: peer did not arrive within 120 s (ranks issued different collectives?)");
+    }
+}
 
 void load_rccl(const char *path) {
     if (g_rccl.handle) return;
@@ -83,7 +118,28 @@ void comm_init(int rank, int world, int device, const unsigned char id[128], con
     g_comm.forced = (f && *f == '1' && g_rccl.comm != nullptr);
 }
 
+void comm_init_shm(int rank, int world, int device, const char *name, size_t bytes) {
+    if (world < 1 || rank < 0 || rank >= world || !name) throw Error(XM_ERR_ARG, "bad rank/world/name");
+    XM_HIP_CHECK(hipSetDevice(device));
+    comm_finalize();
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) throw Error(XM_ERR_COMM, "shm_open failed");
+    const size_t total = sizeof(ShmHeader) + 64 + bytes;
+    if (ftruncate(fd, (off_t)total) != 0) { close(fd); throw Error(XM_ERR_COMM, "ftruncate failed"); }
+    void *p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) throw Error(XM_ERR_COMM, "mmap failed");
+    g_shm.base = p; g_shm.bytes = total; g_shm.barriers = 0; g_shm.name = name;
+    g_comm.rank = rank; g_comm.world = world; g_comm.forced = true;
+    shm_barrier(world);   // everybody has the segment mapped (a fresh segment is zero-filled)
+}
+
 void comm_finalize() {
+    if (g_shm.base) {
+        munmap(g_shm.base, g_shm.bytes);
+        if (g_comm.rank == 0) shm_unlink(g_shm.name.c_str());
+        g_shm = Shm();
+    }
     if (g_rccl.comm) { g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
     g_comm.rank = 0;
     g_comm.world = 1;
@@ -91,6 +147,18 @@ void comm_finalize() {
 }
 
 void Comm::allgather(double *buf, size_t count, hipStream_t st) {
+    if (g_shm.active()) {
+        const size_t cap = (g_shm.bytes - sizeof(ShmHeader) - 64) / sizeof(double);
+        if (count * (size_t)world > cap) throw Error(XM_ERR_COMM, "shared-memory communicator: message too large");
+        double *data = reinterpret_cast<double *>(static_cast<char *>(g_shm.base) + sizeof(ShmHeader) + 64);
+        XM_HIP_CHECK(hipMemcpyAsync(data + (size_t)rank * count, buf + (size_t)rank * count, count * sizeof(double), hipMemcpyDeviceToHost, st));
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        shm_barrier(world);                       // every chunk is in the segment
+        XM_HIP_CHECK(hipMemcpyAsync(buf, data, count * (size_t)world * sizeof(double), hipMemcpyHostToDevice, st));
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        shm_barrier(world);                       // everybody has read it; the segment may be overwritten
+        return;
+    }
     if (!g_rccl.comm) return;
     check(g_rccl.AllGather(buf + (size_t)rank * count, buf, count, kNcclFloat64, g_rccl.comm, st), "ncclAllGather");
 }

@@ -22,6 +22,7 @@ struct Comm {
 Comm &global_comm();
 void comm_unique_id(unsigned char id[128]);
 void comm_init(int rank, int world, int device, const unsigned char id[128], const char *lib_path);
+void comm_init_shm(int rank, int world, int device, const char *name, size_t bytes);
 void comm_finalize();
 
 template <class T>

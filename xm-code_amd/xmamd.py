@@ -20,7 +20,7 @@ EXPORTS = [
     "xm_last_error", "xm_version", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
-    "xm_comm_unique_id", "xm_comm_init", "xm_comm_finalize", "xm_partition",
+    "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition",
 ]
 
 
@@ -93,6 +93,7 @@ def lib():
         L.xm_recover_rotations.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.xm_comm_unique_id.argtypes = [C.c_char_p]
         L.xm_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+        L.xm_comm_init_shm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
         L.xm_partition.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
