@@ -326,9 +326,12 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
                     scal_.p, rr, delta, hstat_dev_, st_);
     gather_W();
     // Iterations in flight ahead of the last one seen finished; the excess become no-op launches.  With a communicator the
-    // loop must issue the SAME number of collectives on every rank, and ranks poll at different moments, so each iteration is
-    // confirmed before the next is enqueued (identical scalar state on all ranks => identical iteration counts).
-    const int run_ahead = comm_->active() ? 1 : 3;
+    // loop must issue the SAME number of collectives on every rank although ranks poll at different moments: iteration j is
+    // enqueued only once iteration j-2 is confirmed (so nobody can be past T+1 when the tCG ends in iteration T) and every
+    // rank tops its queue up to exactly T+2 iterations after it has seen the end (identical scalar state on all ranks =>
+    // identical T).  One iteration is always queued behind the running one, so the host round trip is hidden.
+    const int run_ahead = comm_->active() ? 2 : 3;
+    int fin_status = 0, fin_iter = 0;
     int it = 0;  // iterations enqueued
     auto enqueue = [&](int i) {
         const int par = i & 1;
@@ -374,21 +377,25 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
             const bool valid = (v != ~0ull);
             const int status = valid ? (int)(v & 0xff) : 0;
             const int done = valid ? (int)(v >> 8) : 0;
-            if (status != 0) break;
+            if (status != 0) { fin_status = status; fin_iter = done; break; }
             if (it < kMaxInner && it - done < run_ahead) { enqueue(it++); continue; }
             if (secs_since(last_progress) > 200e-6) {
                 // Nothing new for a while: if the stream has drained the progress word is stale (or this platform does not
                 // make device writes to mapped host memory visible promptly) -> read the truth from the device.
                 if (hipStreamQuery(st_) == hipSuccess) {
                     TcgScal sc = read_scal(it & 1);
-                    if (sc.status != 0) break;
-                    if (it >= kMaxInner) break;
+                    if (sc.status != 0) { fin_status = sc.status; fin_iter = sc.iter; break; }
+                    if (it >= kMaxInner) { fin_status = 6; fin_iter = kMaxInner; break; }
                     *hstat_ = ((unsigned long long)(unsigned)sc.iter << 8);
                     if (it - sc.iter >= run_ahead) enqueue(it++);  // cannot happen, but never stall
                 }
                 last_progress = clk::now();
             }
         }
+    }
+    if (comm_->active() && !stepped) {
+        const int T = (fin_status == 6) ? fin_iter - 1 : fin_iter;   // iteration in which the tCG ended
+        while (it < std::min(kMaxInner, T + 2)) enqueue(it++);      // no-ops, but the same collectives on every rank
     }
     (void)fin;
     return it;  // the final scalar block is scal_[it & 1]; the caller fetches it together with the other results
