@@ -406,8 +406,6 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
 // ------------------------------------------------------------------------------------------------------------------
 TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, const std::vector<double> &v_dir, double max_time) {
     TrResult out;
-    const double lam = opt_->lam;
-    (void)lam;
     const double dim = (double)n_ * (3.0 * o - 6.0) + (double)n_ - 1.0;  // trustregion.h:104
     const double delta_bar = std::sqrt(dim);
     double delta = delta_bar / 8.0;
@@ -642,7 +640,6 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
     V.alloc((size_t)len * (mmax + 1));
     c.alloc((size_t)mmax + 2);
     w.alloc((size_t)len);
-    DevBuf<double> Wsave;  // the o-pitch W buffer is reused as the rank-1 product input
     std::vector<double> x((size_t)len, 0.0);
     unsigned long long lcg = 0x9E3779B97F4A7C15ull;
     double nrm = 0;
