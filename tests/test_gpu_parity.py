@@ -379,3 +379,24 @@ def test_two_ranks_one_gpu(xmamd, tmp_path, case):
     assert tl.rel_fro(tl.gram(a["R"], a["s"]), tl.gram(c["R"], c["s"])) < 1e-6
     k = 5
     assert np.allclose(a["trace"][:k, :2], c["trace"][:k, :2], rtol=1e-9)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_tiny_problems(xmamd, oracle, n):
+    """degenerate sizes: a single camera (no free scale, zero gradient at the start), two and three cameras"""
+    Q = np.diag([2.0, 3.0, 4.0]) if n == 1 else tl.gen_vg(n, deg=2, sigma=0.3, seed=n)["Q"]
+    R, s, info = xmamd.solve_dense(Q, 4, 1e-9, 1.0)
+    Ro, so, io = oracle.solve(Q, 4, 1e-9, 1.0, 100.0, trace=100)
+    assert info["rank"] == io["rank"] and info["status"] == io["status"] == 1
+    assert info["primal"] == pytest.approx(io["trace"][-1, 0], rel=1e-9, abs=1e-12)
+    assert np.allclose(tl.gram(R, s), tl.gram(Ro, so), atol=1e-7)
+    assert R.shape == (3 * n, 3) and s[0] == 1.0
+
+
+def test_loose_tolerance_and_small_max_rank(xmamd, oracle):
+    Q, exp, d = _case("synth/dense49")
+    R, s, info = xmamd.solve_dense(Q, 3, 1e6, 0.0)        # gradient norm already below tol: identity start is returned
+    Ro, so, io = oracle.solve(Q, 3, 1e6, 0.0, 100.0)
+    assert np.array_equal(R, Ro) and info["tcg_iters"] == io["tcg_iters"] == 0 and info["status"] == io["status"]
+    R2, s2, i2 = xmamd.solve_dense(Q, 2, 1e-6, 0.0)       # max_rank < 3: the staircase loop never runs (XM_main.cu:223)
+    assert i2["rank"] == 2 and i2["status"] == 0 and i2["tcg_iters"] == 0
