@@ -262,7 +262,7 @@ __device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool acti
 // ----------------------------------------------------------------------------------------------------------------
 // Software-pipelined: while a wavefront multiplies tile t (Q fragment in registers, W tile in LDS buffer t&1) the loads
 // of tile t+1 (its 3 rows of Q and the workgroup's share of the next W tile) are already in flight; one barrier per tile.
-template <int O, int EPI, int NSUB>
+template <int O, int EPI, int NSUB, bool NT>
 __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict__ Q, int64_t ld,
                                                         const double *__restrict__ W, double alpha, CamArgs a) {
     constexpr int OP = pitch_of(O);
@@ -296,7 +296,13 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
             const int64_t c = c0 + u * 128;
             if (active && c < ld) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) qn[u][r] = *reinterpret_cast<const double2 *>(q0 + (size_t)r * ld + c);
+                for (int r = 0; r < 3; ++r) {
+                    const double2 *qp = reinterpret_cast<const double2 *>(q0 + (size_t)r * ld + c);
+                    // a Q larger than the 256 MB Infinity Cache is a pure stream: non-temporal loads keep it from thrashing the
+                    // cache (measured at 349 MB: 78.9 us default policy); a Q that fits stays cacheable across iterations
+                    if (NT) qn[u][r] = make_double2(__builtin_nontemporal_load(&qp->x), __builtin_nontemporal_load(&qp->y));
+                    else qn[u][r] = *qp;
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) qn[u][r] = make_double2(0.0, 0.0);
@@ -376,7 +382,7 @@ constexpr int kSymWaves = 8;
 constexpr int kSymTile = 128;
 constexpr int kSymChunk = 6;   // column tiles per workgroup: the triangular sweep is cut into equal pieces for load balance
 
-template <int O>
+template <int O, bool NT>
 __global__ __launch_bounds__(512) void qw_sym_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc,
                                                       const TcgScal *__restrict__ scal, double *__restrict__ Prow,
                                                       double *__restrict__ Pcol) {
@@ -418,7 +424,11 @@ __global__ __launch_bounds__(512) void qw_sym_kernel(const double *__restrict__ 
         const int64_t c = (int64_t)t * TILE;
         if (active && t < te) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) dst[r] = *reinterpret_cast<const double2 *>(q0p + (size_t)r * ld + c);
+            for (int r = 0; r < 3; ++r) {
+                const double2 *qp = reinterpret_cast<const double2 *>(q0p + (size_t)r * ld + c);
+                if (NT) dst[r] = make_double2(__builtin_nontemporal_load(&qp->x), __builtin_nontemporal_load(&qp->y));
+                else dst[r] = *qp;
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 3; ++r) dst[r] = make_double2(0.0, 0.0);
@@ -1235,6 +1245,11 @@ static void check_launch(const char *what) {
     if (e != hipSuccess) throw Error(-3, std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
 }
 
+static bool qw_stream_nt(int nloc, int64_t ld) {   // per-GPU Q beyond the Infinity Cache -> non-temporal stream (XM_QW_NT=0|1 overrides)
+    static const int force = [] { const char *e = std::getenv("XM_QW_NT"); return e ? std::atoi(e) : -1; }();
+    if (force >= 0) return force != 0;
+    return (size_t)nloc * 3 * (size_t)ld * sizeof(double) > (size_t)240 << 20;
+}
 static int qw_nsub() {  // tuning knob: XM_QW_NSUB=2|4 (tile = 256 / 512 columns)
     static int v = [] {
         const char *e = std::getenv("XM_QW_NSUB");
@@ -1243,21 +1258,27 @@ static int qw_nsub() {  // tuning knob: XM_QW_NSUB=2|4 (tile = 256 / 512 columns
     }();
     return v;
 }
-template <int O, int NSUB>
-static void qw_dense_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+template <int O, int NSUB, bool NT>
+static void qw_dense_epi2(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
     const dim3 g(qw_grid(a.nloc)), b(256);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_HESS, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, NSUB, NT>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, NSUB, NT>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_HESS, NSUB, NT>), g, b, 0, st, Q, ld, W, alpha, a); break;
         default: throw Error(-2, "bad epilogue");
     }
+}
+template <int O, int NSUB>
+static void qw_dense_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+    if (qw_stream_nt(a.nloc, ld)) qw_dense_epi2<O, NSUB, true>(epi, Q, ld, W, alpha, a, st);
+    else qw_dense_epi2<O, NSUB, false>(epi, Q, ld, W, alpha, a, st);
 }
 void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
     if (a.nloc <= 0) return;
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
-        hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
+        if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2, true>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
+        else hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2, false>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
     } else if (qw_nsub() == 4) {
         XM_DISPATCH_O(o, (qw_dense_epi<O_, 4>(epi, Q, ld, W, alpha, a, st)));
     } else {
@@ -1278,8 +1299,9 @@ template <int O>
 static void qw_sym_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
                        hipStream_t st) {
     const int nch = sym_chunks(ld);
-    hipLaunchKernelGGL((qw_sym_kernel<O>), dim3(nch, sym_groups(a.nloc)), dim3(512), 0, st, Q, ld, W, a.nloc,
-                       (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr, Prow, Pcol);
+    const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
+    if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_sym_kernel<O, true>), dim3(nch, sym_groups(a.nloc)), dim3(512), 0, st, Q, ld, W, a.nloc, sc, Prow, Pcol);
+    else hipLaunchKernelGGL((qw_sym_kernel<O, false>), dim3(nch, sym_groups(a.nloc)), dim3(512), 0, st, Q, ld, W, a.nloc, sc, Prow, Pcol);
     const dim3 g(qw_grid(a.nloc)), b(256);
     switch (epi) {
         case EPI_PLAIN: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nch, alpha, a); break;
