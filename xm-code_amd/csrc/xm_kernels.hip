@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
                 const double *src = blocks + base * 9;
                 double t[9];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) t[i] = (lane + 64 * i < nd) ? src[lane + 64 * i] : 0.0;
+                for (int i = 0; i < 9; ++i) t[i] = (lane + 64 * i < nd) ? __builtin_nontemporal_load(src + lane + 64 * i) : 0.0;   // pure stream
 #pragma unroll
                 for (int i = 0; i < 9; ++i) st[lane + 64 * i] = t[i];
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
