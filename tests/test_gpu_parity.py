@@ -365,11 +365,21 @@ def test_two_ranks_one_gpu(xmamd, tmp_path, case):
     code = _two_rank_worker_code()
     name = "/xm_test_" + uuid.uuid4().hex[:12]
     procs, outs = [], []
+    logs = []
     for r in range(2):
         out = str(tmp_path / f"w2_r{r}.npz"); outs.append(out)
-        procs.append(subprocess.Popen([sys.executable, "-c", code, str(r), "2", name, out, case]))
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+        logs.append(open(tmp_path / f"w2_r{r}.log", "w+"))
+        procs.append(subprocess.Popen([sys.executable, "-c", code, str(r), "2", name, out, case], stdout=logs[-1], stderr=subprocess.STDOUT))
+    rcs = [p.wait(timeout=600) for p in procs]
+    if any(rcs) and os.environ.get("XM_COMM_TRACE"):
+        a_, b_ = (open(os.environ["XM_COMM_TRACE"] + f".{r}").read().splitlines() for r in range(2))
+        k = next((i for i, (x, y) in enumerate(zip(a_, b_)) if x != y), min(len(a_), len(b_)))
+        print(f"first divergence at line {k} of {len(a_)}/{len(b_)}:\n rank0: {a_[max(0,k-4):k+4]}\n rank1: {b_[max(0,k-4):k+4]}")
+    if any(rcs):
+        for r, lg in enumerate(logs):
+            lg.seek(0)
+            print(f"---- rank {r} (rc {rcs[r]}) ----\n" + lg.read()[-1500:])
+    assert rcs == [0, 0]
     single = str(tmp_path / "w1.npz")
     subprocess.check_call([sys.executable, "-c", code, "0", "1", name, single, case], timeout=600)
     a, b, c = np.load(outs[0]), np.load(outs[1]), np.load(single)

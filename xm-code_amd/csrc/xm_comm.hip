@@ -63,8 +63,11 @@ void shm_barrier(int world) {
     const unsigned long long target = g_shm.barriers * (unsigned long long)world;
     const auto t0 = std::chrono::steady_clock::now();
     while (h->arrive.load(std::memory_order_acquire) < target) {
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
-            throw Error(XM_ERR_COMM, "shared-memory communicator: peer did not arrive within 120 s (ranks issued different collectives?)");
+        static const double limit = [] { const char *e = std::getenv("XM_SHM_TIMEOUT"); return e ? std::atof(e) : 120.0; }();
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+            throw Error(XM_ERR_COMM, "shared-memory communicator: rank " + std::to_string(g_comm.rank) + " waited too long in barrier #" +
+                                         std::to_string(g_shm.barriers) + " (arrived " + std::to_string(h->arrive.load()) +
+                                         "): ranks issued different collectives?");
     }
 }
 
@@ -94,6 +97,20 @@ void check(ncclResult_t r, const char *what) {
 }  // namespace
 
 Comm &global_comm() { return g_comm; }
+
+// XM_COMM_TRACE=<prefix>: every collective / marker is appended to <prefix>.<rank> (debugging aid for rank divergence)
+static FILE *g_trace = nullptr;
+static void trace_open() {
+    static bool tried = false;
+    if (tried) return;
+    tried = true;
+    const char *e = std::getenv("XM_COMM_TRACE");
+    if (e && *e) g_trace = std::fopen((std::string(e) + "." + std::to_string(g_comm.rank)).c_str(), "w");
+}
+void Comm::note(const char *what, double a, double b) {
+    trace_open();
+    if (g_trace) { std::fprintf(g_trace, "%s %.17g %.17g\n", what, a, b); std::fflush(g_trace); }
+}
 
 void comm_unique_id(unsigned char id[128]) {
     load_rccl(nullptr);
@@ -147,6 +164,7 @@ void comm_finalize() {
 }
 
 void Comm::allgather(double *buf, size_t count, hipStream_t st) {
+    note("allgather", (double)count, 0.0);
     if (g_shm.active()) {
         const size_t cap = (g_shm.bytes - sizeof(ShmHeader) - 64) / sizeof(double);
         if (count * (size_t)world > cap) throw Error(XM_ERR_COMM, "shared-memory communicator: message too large");

@@ -18,6 +18,7 @@ struct Comm {
     bool active() const { return world > 1 || forced; }
     // in-place all-gather on `stream`: every rank contributes `count` doubles located at buf + rank*count
     void allgather(double *buf, size_t count, hipStream_t st);
+    void note(const char *what, double a, double b);   // XM_COMM_TRACE debugging aid
 };
 Comm &global_comm();
 void comm_unique_id(unsigned char id[128]);
@@ -42,7 +43,13 @@ struct DevBuf {
         release();
         count = n;
         XM_HIP_CHECK(hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)));
-        if (zero) XM_HIP_CHECK(hipMemset(p, 0, (n ? n : 1) * sizeof(T)));
+        if (zero) {
+            // hipMemset runs on the NULL stream and may return before it has executed; the solver works on its own NON-BLOCKING
+            // stream, which is not ordered against the NULL stream -> wait here, or a late memset could wipe data that kernels on
+            // the solver stream have already written (seen with two processes time-slicing one GPU).
+            XM_HIP_CHECK(hipMemset(p, 0, (n ? n : 1) * sizeof(T)));
+            XM_HIP_CHECK(hipStreamSynchronize(nullptr));
+        }
     }
 };
 

@@ -321,6 +321,7 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     const int rank = comm_->rank;
     double *Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
     const PointState &P = ps_[cur_];
+    if (comm_->active()) comm_->note("tcg_start", rr, delta);
     *hstat_ = ~0ull;
     launch_tcg_init(o_, nloc_, P.rgR.p, P.rgs.p, R_.p, s_.p, rR_.p, rs_.p, pR_.p, psA_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, Wloc,
                     scal_.p, rr, delta, hstat_dev_, st_);
@@ -393,6 +394,7 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
             }
         }
     }
+    if (comm_->active()) comm_->note("tcg_end_before_topup", (double)it, (double)(fin_iter * 16 + fin_status));
     if (comm_->active() && !stepped) {
         const int T = (fin_status == 6) ? fin_iter - 1 : fin_iter;   // iteration in which the tCG ended
         while (it < std::min(kMaxInner, T + 2)) enqueue(it++);      // no-ops, but the same collectives on every rank
