@@ -89,6 +89,7 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
 void launch_qw_bsr3(int o, int epi, const int64_t *rowptr, const int32_t *colidx, const double *blocks, const double *W,
                     double alpha, const CamArgs &a, hipStream_t st);
 int qw_grid(int nloc);
+int bsr_grid(int nloc);   // workgroups (= partial sums per epilogue slot) of the BSR3 kernels
 int sym_groups(int nloc);
 size_t sym_prow_count(int nloc, int64_t ld, int o);
 void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,

@@ -46,6 +46,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// sum over a lane group: GW = 64 the whole wavefront, GW = 16 one DPP row (the four butterfly steps alone leave every lane of
+// a row with its row's sum); the result is uniform across the group
+template <int GW>
+__device__ __forceinline__ double group_sum(double v) {
+    if (GW == 64) return wave_sum(v);
+    v += dpp_mov<0xb1, 0xf>(v);
+    v += dpp_mov<0x4e, 0xf>(v);
+    v += dpp_mov<0x124, 0xf>(v);
+    v += dpp_mov<0x128, 0xf>(v);
+    return v;
+}
+
 // sum over the 256 threads of a block; result valid in every thread.  `sh` must hold >= 4 doubles.
 __device__ __forceinline__ double block_sum256(double v, double *sh) {
     v = wave_sum(v);
@@ -91,12 +103,13 @@ __device__ __forceinline__ void store_col(const Col3 &c, double *base, int cam, 
 __device__ __forceinline__ double dot3(const Col3 &x, const Col3 &y) { return x.v[0] * y.v[0] + x.v[1] * y.v[1] + x.v[2] * y.v[2]; }
 
 // S = sym(A B^T) with A, B 3 x O blocks held column-per-lane: 9 wave reductions, result uniform across the wave
+template <int GW>
 __device__ __forceinline__ void sym_abt(const Col3 &A, const Col3 &B, double (&S)[3][3]) {
     double M[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) M[a][b] = wave_sum(A.v[a] * B.v[b]);
+        for (int b = 0; b < 3; ++b) M[a][b] = group_sum<GW>(A.v[a] * B.v[b]);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -139,7 +152,7 @@ __device__ __forceinline__ void epi_prefetch(EpiOps &e, int cam, int lane, bool 
 
 // Gradient / point-state epilogue: trustregion.h:186-194 (grad), :307-317 (projection), :162-170 (objc) fused.
 // h = 2*C*sR rows.  Produces G, egs, S0, rg and this camera's share of {f, <rg,rg>_metric} (uniform on return).
-template <int O>
+template <int O, int GW>
 __device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const EpiOps &e, const CamArgs &a, double &p0, double &p1) {
     const bool anchor = (a.cam0 + cam) == 0;
     const double s = e.s;
@@ -148,15 +161,15 @@ __device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const
     store_col<O>(h, a.G, cam, lane);
     // f = <C sR, sR> + lam * sum_{i>=1} (s_i^2-1)^2 ;  <C sR, sR> = 0.5 * <G, sR>
     const double q = s * s - 1.0;
-    const double hW = wave_sum(dot3(h, Wl));
-    const double hR = wave_sum(dot3(h, R));
+    const double hW = group_sum<GW>(dot3(h, Wl));
+    const double hR = group_sum<GW>(dot3(h, R));
     p0 = 0.5 * hW + (anchor ? 0.0 : a.lam * q * q);
     const double egs = anchor ? 0.0 : hR + 4.0 * a.lam * (q * s);
     Col3 eg;
 #pragma unroll
     for (int r = 0; r < 3; ++r) eg.v[r] = h.v[r] * s;
     double S0[3][3];
-    sym_abt(R, eg, S0);
+    sym_abt<GW>(R, eg, S0);
     sub_s_times(eg, S0, R);  // eg is now the Riemannian gradient column
     const double rgs = egs * (s * s);
     store_col<O>(eg, a.rgR, cam, lane);
@@ -170,12 +183,12 @@ __device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const
         a.rgs[cam] = rgs;
     }
     const double rsds = rgs / s;
-    p1 = wave_sum(dot3(eg, eg)) + rsds * rsds;
+    p1 = group_sum<GW>(dot3(eg, eg)) + rsds * rsds;
 }
 
 // Hessian epilogue: trustregion.h:227-255 (ehess) + :277-295 (ehess2rhess) fused.  h = 2*C*(s.*Ru + su.*R) rows.
 // Produces Hp = (rhr, rhs) and this camera's shares of <p,Hp>, <r,Hp>, <Hp,Hp> (product metric).
-template <int O>
+template <int O, int GW>
 __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const EpiOps &e, const CamArgs &a, double &p0, double &p1,
                                          double &p2) {
     const bool anchor = (a.cam0 + cam) == 0;
@@ -185,7 +198,7 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
     const Col3 &P = e.P;
     const Col3 &G = e.G;
     // hs = sum(CsRu.*R) + sum(CsR.*Ru) + 4 lam (3 s^2 - 1) su
-    const double hRGP = wave_sum(dot3(h, R)) + wave_sum(dot3(G, P));
+    const double hRGP = group_sum<GW>(dot3(h, R)) + group_sum<GW>(dot3(G, P));
     const double hs = anchor ? 0.0 : hRGP + 4.0 * a.lam * ((3.0 * s * s - 1.0) * ps);
     // hr = CsRu.*s + CsR.*su
     Col3 rh;
@@ -197,26 +210,27 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
 #pragma unroll
         for (int c = 0; c < 3; ++c) S0[r][c] = e.S0[r * 3 + c];
     sub_s_times(rh, S0, P);   // rhr = ehessR - Ru * sym(R' egradR)
-    sym_abt(R, rh, S1);
+    sym_abt<GW>(R, rh, S1);
     sub_s_times(rh, S1, R);   // rhr -= R * sym(R' rhr)
     const double rhs = anchor ? 0.0 : hs * (s * s) + (ps * s) * e.egs;
     store_col<O>(rh, a.HpR, cam, lane);
     if (lane == 0) a.Hps[cam] = rhs;
-    p0 = wave_sum(dot3(P, rh)) + ps * (rhs / (s * s));
+    p0 = group_sum<GW>(dot3(P, rh)) + ps * (rhs / (s * s));
     // <r,Hp> and <Hp,Hp> in the same metric: with them the residual norm after the CG step follows without a second
     // global reduction, |r + alpha Hp|^2 = <r,r> + 2 alpha <r,Hp> + alpha^2 <Hp,Hp>   (one flat kernel per iteration)
     const double rsv = anchor ? 0.0 : e.rs;
-    p1 = wave_sum(dot3(e.Rr, rh)) + rsv * (rhs / (s * s));
+    p1 = group_sum<GW>(dot3(e.Rr, rh)) + rsv * (rhs / (s * s));
     const double hq = rhs / s;
-    p2 = wave_sum(dot3(rh, rh)) + hq * hq;
+    p2 = group_sum<GW>(dot3(rh, rh)) + hq * hq;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
 // common tail of the Q*W kernels: wave reduction of the 3 x O accumulators, epilogue, per-workgroup partial sums
 // ----------------------------------------------------------------------------------------------------------------
-template <int O, int EPI>
-__device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool active, double (&acc)[3][O], double alpha,
+template <int O, int EPI, int GW, int NSLOT>
+__device__ __forceinline__ void qw_finish(int cam, int lane, int slot, bool active, double (&acc)[3][O], double alpha,
                                           const CamArgs &a, const EpiOps &e, double (*red)[3]) {
+    // `lane` = position inside the camera's lane group (0..GW-1), `slot` = index of that group inside the workgroup
     constexpr int OP = pitch_of(O);
     Col3 h;
     h.v[0] = h.v[1] = h.v[2] = 0.0;
@@ -224,17 +238,17 @@ __device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool acti
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < O; ++k) {
-            const double t = alpha * wave_sum(acc[r][k]);
+            const double t = alpha * group_sum<GW>(acc[r][k]);
             if (lane == k) h.v[r] = t;
         }
     double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-    if (active) {  // wave-uniform
+    if (active) {  // uniform across the group
         if (EPI == EPI_PLAIN) {
             store_col<O>(h, a.out, cam, lane);
         } else if (EPI == EPI_GRAD) {
-            epi_grad<O>(cam, lane, h, e, a, p0, p1);
+            epi_grad<O, GW>(cam, lane, h, e, a, p0, p1);
         } else if (EPI == EPI_HESS) {
-            epi_hess<O>(cam, lane, h, e, a, p0, p1, p2);
+            epi_hess<O, GW>(cam, lane, h, e, a, p0, p1, p2);
         } else if (EPI == EPI_CERT) {
             // y_i = (Q x)_i + dz_i * x[3i] e_0 - Lam_i x_i      (O == 1, lane 0 owns the column)
             const double *x = a.Wloc + (size_t)cam * 3 * OP;
@@ -247,12 +261,15 @@ __device__ __forceinline__ void qw_finish(int cam, int lane, int wave, bool acti
         }
     }
     if (EPI == EPI_GRAD || EPI == EPI_HESS) {
-        if (lane == 0) { red[wave][0] = p0; red[wave][1] = p1; red[wave][2] = p2; }
+        if (lane == 0) { red[slot][0] = p0; red[slot][1] = p1; red[slot][2] = p2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            a.partials[blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-            a.partials[gridDim.x + blockIdx.x] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
-            if (EPI == EPI_HESS) a.partials[2 * gridDim.x + blockIdx.x] = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) { t0 += red[q][0]; t1 += red[q][1]; t2 += red[q][2]; }
+            a.partials[blockIdx.x] = t0;
+            a.partials[gridDim.x + blockIdx.x] = t1;
+            if (EPI == EPI_HESS) a.partials[2 * gridDim.x + blockIdx.x] = t2;
         }
     }
 }
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
         if (more) store_w((t + 1) & 1);
         __syncthreads();
     }
-    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, eops, red);
+    qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -539,7 +556,7 @@ __global__ __launch_bounds__(256) void sym_reduce_kernel(const double *__restric
                 for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
         }
     }
-    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, eops, red);
+    qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }
 
 // max |Q[r][c] - Q[c][r]| and max |Q| over the device layout (decides whether the symmetric path may be used)
@@ -562,11 +579,15 @@ __global__ __launch_bounds__(256) void asym_kernel(const double *__restrict__ Q,
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// 3x3-block CSR Q*W: one wavefront per camera row, ONE LANE PER STORED BLOCK.  A lane fetches its column index, then
-// (independently, all in flight together) its 72-byte block and the 3 x O rows of W it multiplies, and does the 9*O FMAs
-// itself; a row of up to 64 blocks is a single pass with two dependent memory round trips (a lane-per-element mapping
-// needs ten).  Blocks of one row are contiguous, so the 64 lanes sweep one contiguous 4.6 KB window of the block array.
+// 3x3-block CSR Q*W: ONE 16-LANE GROUP (a DPP row) PER CAMERA ROW, ONE LANE PER STORED BLOCK.  The kernel is bound by the
+// dependent chain rowptr -> colidx -> gathered W rows, i.e. by how many camera rows are in flight, so a wavefront carries four
+// rows (16 per workgroup) instead of one; a lane fetches its column index, then (independently, all in flight together) its
+// 72-byte block and the 3 x O rows of W it multiplies and does the 9*O FMAs itself.  The blocks of a row are contiguous and
+// pass through LDS so that the global loads are perfectly coalesced (VAR 1; direct 72-byte-strided loads are 1.3x slower).
+// The row sums and the whole fused epilogue run inside the 16-lane row with four DPP steps per reduction.
 // ----------------------------------------------------------------------------------------------------------------
+constexpr int kBsrRows = 16;   // camera rows per workgroup (4 wavefronts x 4 groups)
+
 template <int O, int EPI, int VAR>
 __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                                        const double *__restrict__ blocks, const double *__restrict__ W,
@@ -575,65 +596,70 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
-    __shared__ double red[kQwWaves][3];
-    __shared__ double stage[(VAR == 1) ? kQwWaves * 64 * 9 : 1];   // VAR 1: blocks pass through LDS (perfectly coalesced loads)
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cam = blockIdx.x * kQwWaves + wave;
+    __shared__ double red[kBsrRows][3];
+    __shared__ double stage[(VAR == 1) ? kBsrRows * 16 * 9 : 1];   // VAR 1: blocks pass through LDS (coalesced loads)
+    const int gl = threadIdx.x & 15;          // lane inside the group
+    const int slot = threadIdx.x >> 4;        // group inside the workgroup (0..15)
+    const int cam = blockIdx.x * kBsrRows + slot;
     const bool active = cam < a.nloc;
     double acc[3][O];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
-    if (active) {
-        const int64_t b0 = rowptr[cam], b1 = rowptr[cam + 1];
-        for (int64_t base = b0; base < b1; base += 64) {
-            const int64_t b = base + lane;
+    int64_t b0 = 0, b1 = 0;
+    if (active) { b0 = rowptr[cam]; b1 = rowptr[cam + 1]; }
+    // the four groups of a wavefront loop together (wave-level trip count = the longest of their rows)
+    int64_t span = b1 - b0;
+    span = max(span, (int64_t)__shfl_xor((long long)span, 16, 64));
+    span = max(span, (int64_t)__shfl_xor((long long)span, 32, 64));
+    for (int64_t off = 0; off < span; off += 16) {
+        const int64_t base = b0 + off;
+        const int64_t b = base + gl;
+        if (VAR == 1) {
+            double *st = stage + slot * 16 * 9;
+            const int64_t left = b1 - base;
+            const int64_t nd = ((left < 16) ? ((left > 0) ? left : 0) : 16) * 9;   // doubles of this group's window
+            const double *src = blocks + base * 9;
+            double t[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) t[i] = (gl + 16 * i < nd) ? __builtin_nontemporal_load(src + gl + 16 * i) : 0.0;   // pure stream
+#pragma unroll
+            for (int i = 0; i < 9; ++i) st[gl + 16 * i] = t[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (b < b1) {
+            const int j = colidx[b];
+            const double *qb = blocks + b * 9;
+            const double *wj = W + (size_t)j * 3 * OP;
+            double q[9], w[3][O];
             if (VAR == 1) {
-                double *st = stage + wave * 64 * 9;
-                const int64_t nd = ((b1 - base < 64) ? (b1 - base) : 64) * 9;   // doubles of this window
-                const double *src = blocks + base * 9;
-                double t[9];
+                const double *st = stage + slot * 16 * 9 + gl * 9;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) t[i] = (lane + 64 * i < nd) ? __builtin_nontemporal_load(src + lane + 64 * i) : 0.0;   // pure stream
+                for (int e = 0; e < 9; ++e) q[e] = st[e];
+            } else {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) st[lane + 64 * i] = t[i];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                for (int e = 0; e < 9; ++e) q[e] = qb[e];
             }
-            if (b < b1) {
-                const int j = colidx[b];
-                const double *qb = blocks + b * 9;
-                const double *wj = W + (size_t)j * 3 * OP;
-                double q[9], w[3][O];
-                if (VAR == 1) {
-                    const double *st = stage + wave * 64 * 9 + lane * 9;
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) q[e] = st[e];
-                } else {
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) q[e] = qb[e];
-                }
+                for (int k = 0; k < O; ++k) w[c][k] = wj[c * OP + k];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int k = 0; k < O; ++k) w[c][k] = wj[c * OP + k];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int k = 0; k < O; ++k) acc[r][k] += q[3 * r] * w[0][k] + q[3 * r + 1] * w[1][k] + q[3 * r + 2] * w[2][k];
-            }
-            if (VAR == 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+                for (int k = 0; k < O; ++k) acc[r][k] += q[3 * r] * w[0][k] + q[3 * r + 1] * w[1][k] + q[3 * r + 2] * w[2][k];
+        }
+        if (VAR == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    // epilogue operands are fetched only now: this kernel is bound by the dependent rowptr -> colidx -> W chain, i.e. by the
-    // number of rows in flight, and holding ~40 more VGPRs through the gather phase would cost a wave per SIMD
+    // epilogue operands are fetched only now: holding ~40 more VGPRs through the gather phase would cost rows in flight
     EpiOps eops;
-    epi_prefetch<O, EPI>(eops, cam, lane, active, a);
-    qw_finish<O, EPI>(cam, lane, wave, active, acc, alpha, a, eops, red);
+    epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
+    qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1219,6 +1245,7 @@ __global__ __launch_bounds__(256) void negate_kernel(double *x, int64_t len) {
 // launchers (dispatch on the rank o)
 // ----------------------------------------------------------------------------------------------------------------
 int qw_grid(int nloc) { return (nloc + kQwWaves - 1) / kQwWaves; }
+int bsr_grid(int nloc) { return (nloc + kBsrRows - 1) / kBsrRows; }
 int flat_grid(int64_t elems) {
     int64_t g = (elems + 255) / 256;
     if (g < 1) g = 1;
@@ -1330,7 +1357,7 @@ void launch_asym(const double *Q, int64_t ld, int64_t m, double *out, int grid, 
 template <int O, int VAR>
 static void qw_bsr3_epi(int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, double alpha,
                         const CamArgs &a, hipStream_t st) {
-    const dim3 g(qw_grid(a.nloc)), b(256);
+    const dim3 g((a.nloc + kBsrRows - 1) / kBsrRows), b(256);
     switch (epi) {
         case EPI_PLAIN: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_PLAIN, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
         case EPI_GRAD: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
@@ -1343,7 +1370,7 @@ void launch_qw_bsr3(int o, int epi, const int64_t *rp, const int32_t *ci, const 
     if (a.nloc <= 0) return;
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
-        hipLaunchKernelGGL((qw_bsr3_kernel<1, EPI_CERT, 0>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, rp, ci, bl, W, alpha, a);
+        hipLaunchKernelGGL((qw_bsr3_kernel<1, EPI_CERT, 0>), dim3((a.nloc + kBsrRows - 1) / kBsrRows), dim3(256), 0, st, rp, ci, bl, W, alpha, a);
     } else if (bsr_variant() == 1) {
         XM_DISPATCH_O(o, (qw_bsr3_epi<O_, 1>(epi, rp, ci, bl, W, alpha, a, st)));
     } else {

@@ -125,6 +125,7 @@ private:
     void upload_point(const std::vector<double> &R_cm, int o, const std::vector<double> &s_ex);
     void download_point(std::vector<double> &R_cm, std::vector<double> &s_ex);
     CamArgs cam_args(int state) const;
+    int prod_grid() const;
     void product(int epi, int o, double alpha, const CamArgs &a);
     void gather_W();
     void eval_point(int state, const double *Rp, const double *sp, double &f, double &rr);

@@ -144,7 +144,7 @@ void Context::setup_rank(int o) {
     }
     cur_ = 0;
     W_.alloc((size_t)ld_ * OP_ + 2);
-    const int nA_loc = qw_grid(nloc_), nB_loc = flat_grid((int64_t)mat);
+    const int nA_loc = prod_grid(), nB_loc = flat_grid((int64_t)mat);
     nA_ = nA_loc * world;
     nB_ = nB_loc * world;
     partsA_.alloc((size_t)3 * nA_);
@@ -204,6 +204,9 @@ void Context::download_point(std::vector<double> &R_cm, std::vector<double> &s_e
     }
 }
 
+// workgroups of the product kernels == number of per-workgroup partial sums per epilogue slot
+int Context::prod_grid() const { return storage_ == XM_STORAGE_BSR3 ? bsr_grid(nloc_) : qw_grid(nloc_); }
+
 CamArgs Context::cam_args(int state) const {
     CamArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -247,7 +250,7 @@ double Context::sum_parts(const double *dparts, int count) {
 // Gradient epilogue on the point (Rp, sp) with the product input currently in W (already gathered).
 // Fills ps_[state]; returns f and <rg,rg>_metric.   trustregion.h:162-170 + 186-194 + 307-317 + 483-484
 void Context::eval_point(int state, const double *Rp, const double *sp, double &f, double &rr) {
-    const int nA_loc = qw_grid(nloc_);
+    const int nA_loc = prod_grid();
     CamArgs a = cam_args(state);
     a.R = Rp;
     a.s = sp;
@@ -317,7 +320,7 @@ void Context::finish_profile() {
 int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     const bool stepped = (opt_->flags & XM_FLAG_HOST_STEPPED) != 0;
     const bool profile = (opt_->flags & XM_FLAG_PROFILE_QW) != 0;
-    const int nA_loc = qw_grid(nloc_), nB_loc = flat_grid((int64_t)nloc_ * 3 * OP_);
+    const int nA_loc = prod_grid(), nB_loc = flat_grid((int64_t)nloc_ * 3 * OP_);
     const int rank = comm_->rank;
     double *Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
     const PointState &P = ps_[cur_];
@@ -493,7 +496,7 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         // model decrease, retraction and the candidate's cost/gradient are enqueued right behind the tCG and fetched with
         // ONE synchronisation (trustregion.h:667-678 needs four blocking reads + a sync here)
         const int nB_loc = flat_grid((int64_t)nloc_ * 3 * OP_);
-        const int nA_loc = qw_grid(nloc_);
+        const int nA_loc = prod_grid();
         const PointState &P = ps_[cur_];
         launch_model_value(o, nloc_, vR_.p, vs_.p, HvR_.p, Hvs_.p, P.rgR.p, P.rgs.p, s_.p, partsM_.p + (size_t)comm_->rank * nB_loc, st_);
         if (comm_->active()) comm_->allgather(partsM_.p, (size_t)nB_loc, st_);
