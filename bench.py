@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--storage", default="dense", choices=["dense", "bsr"], help="storage of view-graph workloads")
     ap.add_argument("--no-hbm-check", action="store_true", help="skip the 13.5 GB HBM-bound run of the same kernel")
+    ap.add_argument("--no-rome", action="store_true", help="skip the Rome-scale (13682-camera view-graph) leg")
     args = ap.parse_args()
 
     import torch
@@ -190,6 +191,33 @@ def main():
                              "see roofline_hbm for the HBM-bound run of the same kernel" % (alg_bytes / 1e6)},
     }
     ctx.close()
+    if not args.no_rome and args.workload == "venice1778":
+        # BASELINE.json north_star: "end-to-end solve of a Rome-scale (>= 10k-camera) Q reported as iters/s and wall-clock at
+        # 1, 2, 4 and 8 GPUs" — a secondary leg at every N (same rules: warmup, barrier-bracketed, max over ranks); the headline
+        # `value` above stays the Venice-1778 metric.
+        wr = workload("final13682")
+        Pr = tl.gen_vg(wr["n"], deg=wr["deg"], sigma=wr["sigma"], seed=wr["seed"], dense=False)
+        cr = xmamd.Context(bsr=(Pr["rowptr"], Pr["colidx"], Pr["blocks"]))
+        cr.solve(wr["max_rank"], wr["tol"], wr["lam"])
+        barrier()
+        t0 = time.perf_counter()
+        ri = [cr.solve(wr["max_rank"], wr["tol"], wr["lam"], flags=xmamd.FLAG_PROFILE_QW)[2] for _ in range(2)]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t[0])
+        cr.close()
+        nbr = int(Pr["colidx"].size)
+        rq = sum(i["qw_ms_sum"] for i in ri) / max(1, sum(i["qw_ms_count"] for i in ri))
+        rb = (76.0 * nbr + 4 * (wr["n"] + 1)) / world + 2 * 8 * 3 * wr["n"] * max(3, ri[-1]["rank"])
+        out["rome_scale"] = {"workload": wr["desc"] + ", 3x3-block CSR, %d blocks (%.1f MB)" % (nbr, 76.0 * nbr / 1e6), "n_gpus": world,
+                             "value": sum(i["tcg_iters"] for i in ri) / el, "unit": "tCG iters/s", "steps": 2, "warmup": 1,
+                             "ms_per_step": el / 2 * 1e3, "rank": ri[-1]["rank"], "status": ri[-1]["status"],
+                             "tcg_iters_per_solve": ri[-1]["tcg_iters"], "primal": ri[-1]["primal"],
+                             "hess_launch_ms": rq, "hess_algorithmic_GBs": rb / (rq * 1e-3) / 1e9 if rq > 0 else None}
     if rank == 0 and world == 1 and not args.no_hbm_check and wl["kind"] == "dense":
         # same kernel, matrix far beyond every cache: 13682 cameras = 13.5 GB of random f64 generated on the device
         nb_, o_ = 13682, 3

@@ -6,6 +6,8 @@ import numpy as np, xmamd, xm_testlib as tl
 n = int(sys.argv[1]); deg = int(sys.argv[2]); os_ = [int(x) for x in sys.argv[3:]] or [3]
 P = tl.gen_vg(n, deg=deg, sigma=0.05, seed=n, dense=False)
 nb = P["colidx"].size
+if os.environ.get("XM_KB_COLMOD"):   # timing experiment: shrink the gathered working set of W (result meaningless)
+    P["colidx"] = (P["colidx"] % int(os.environ["XM_KB_COLMOD"])).astype(np.int32)
 L = xmamd.lib()
 drp = xmamd.DevArray(P["rowptr"]); dci = xmamd.DevArray(P["colidx"]); dbl = xmamd.DevArray(P["blocks"].reshape(-1))
 rng = np.random.default_rng(0)

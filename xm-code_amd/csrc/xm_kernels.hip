@@ -16,6 +16,7 @@
 // No MFMA on this path (no dense contraction with reuse); everything is float64 like the reference
 // (Optimization/optimization.h:9).
 #include <cstdlib>
+#include <type_traits>
 
 #include "xm_common.h"
 
@@ -596,8 +597,10 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
+    constexpr int REC = 3 * OP;                                   // doubles of one camera's rows of W
+    constexpr int SW = (VAR == 2 && REC > 9) ? REC : 9;           // LDS doubles per lane (blocks and W share the window)
     __shared__ double red[kBsrRows][3];
-    __shared__ double stage[(VAR == 1) ? kBsrRows * 16 * 9 : 1];   // VAR 1: blocks pass through LDS (coalesced loads)
+    __shared__ double stage[(VAR >= 1) ? kBsrRows * 16 * SW : 1]; // VAR >= 1: blocks pass through LDS (coalesced loads)
     const int gl = threadIdx.x & 15;          // lane inside the group
     const int slot = threadIdx.x >> 4;        // group inside the workgroup (0..15)
     const int cam = blockIdx.x * kBsrRows + slot;
@@ -613,11 +616,106 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     int64_t span = b1 - b0;
     span = max(span, (int64_t)__shfl_xor((long long)span, 16, 64));
     span = max(span, (int64_t)__shfl_xor((long long)span, 32, 64));
+    double *st = stage + slot * 16 * SW;
+    if (VAR == 2) {
+        // Software pipeline, one window (16 blocks per group) deep: while the FMAs of window k run, the column indices and
+        // blocks of window k+1 are already in flight from HBM and its rows of W from L2, so a wavefront keeps two windows of
+        // loads outstanding instead of one dependent chain at a time (the kernel is latency-, not bandwidth-limited).
+        // The 16 records of W a group multiplies are fetched ELEMENT-per-lane: one load instruction of the group covers 128
+        // consecutive bytes of the concatenated records, so every cache line is touched by one or two instructions instead of by
+        // all 3*OP of a lane-per-record gather; LDS turns them back into lane-per-record.
+        // The load path (TA) is the limiter (TA_BUSY 85 % with 8-byte loads), so every global load is 16 bytes wide: a window
+        // of 16 blocks is 72 pairs of doubles (5 loads per lane instead of 9), a record of W is (REC+1)/2 pairs whose last one
+        // starts one double early when REC is odd (overlapping instead of over-reading).
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        constexpr int NP = (REC + 1) / 2;                  // pairs per record of W
+        int j = 0, jn = 0;
+        d2u t[5], tn[5], tw[NP];
+        int tpos[5], tposn[5];
+        // every load is UNCONDITIONAL (idle lanes re-read a valid neighbour, clamped addresses): predicated loads become
+        // exec-mask branches whose outstanding-load count the compiler cannot track, and it then drains the next window's loads
+        // (s_waitcnt vmcnt(0)) right after issuing them
+        auto load_window = [&](int64_t off, int &jj, d2u (&tt)[5], int (&pos)[5]) {
+            const int64_t base = b0 + off;
+            const int64_t left = b1 - base;
+            const int nd = (int)((left < 16) ? ((left > 0) ? left : 0) : 16) * 9;   // doubles of this group's window
+            const int64_t bj = (base + gl < b1) ? base + gl : ((b1 > 0) ? b1 - 1 : 0);
+            jj = colidx[bj];
+            const double *src = (nd > 0) ? blocks + base * 9 : blocks;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                pos[i] = max(min(2 * (gl + 16 * i), nd - 2), 0);
+                tt[i] = __builtin_nontemporal_load((const d2u *)(src + pos[i]));   // pure stream
+            }
+        };
+        auto load_w = [&](int jj) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int g = gl + 16 * i;
+                const int sl = g / NP;
+                const int start = min(2 * (g - sl * NP), REC - 2);
+                const int js = __shfl(jj, (threadIdx.x & 48) + sl, 64);
+                tw[i] = *(const d2u *)(W + (size_t)js * REC + start);
+            }
+        };
+        // one window: `prefetch` (compile time) issues the loads of the next one first.  No run-time branch may surround a
+        // load, or the compiler loses count of the outstanding ones and drains them all; hence the peeled last window.
+        auto window = [&](int64_t off, auto prefetch) {
+            if constexpr (decltype(prefetch)::value) load_window(off + 16, jn, tn, tposn);
+            double q[9], w[3][O];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { st[tpos[i]] = t[i].x; st[tpos[i] + 1] = t[i].y; }   // clamped lanes rewrite identical data
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 9; ++e) q[e] = st[gl * 9 + e];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int g = gl + 16 * i;
+                const int sl = g / NP;
+                const int start = min(2 * (g - sl * NP), REC - 2);
+                st[sl * REC + start] = tw[i].x;
+                st[sl * REC + start + 1] = tw[i].y;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int k = 0; k < O; ++k) w[c][k] = st[gl * REC + c * OP + k];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (decltype(prefetch)::value) load_w(jn);
+            const bool keep = b0 + off + gl < b1;   // idle lanes hold stale LDS contents: select, never multiply (NaN * 0)
+#pragma unroll
+            for (int e = 0; e < 9; ++e) q[e] = keep ? q[e] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc[r][k] += q[3 * r] * w[0][k] + q[3 * r + 1] * w[1][k] + q[3 * r + 2] * w[2][k];
+            if constexpr (decltype(prefetch)::value) {
+                j = jn;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { t[i] = tn[i]; tpos[i] = tposn[i]; }
+            }
+        };
+        if (span > 0) {
+            load_window(0, j, t, tpos);
+            load_w(j);
+            int64_t off = 0;
+            for (; off + 16 < span; off += 16) window(off, std::true_type{});
+            window(off, std::false_type{});
+        }
+    } else
     for (int64_t off = 0; off < span; off += 16) {
         const int64_t base = b0 + off;
         const int64_t b = base + gl;
-        if (VAR == 1) {
-            double *st = stage + slot * 16 * 9;
+        const bool has = b < b1;
+        const int j = has ? colidx[b] : 0;
+        double q[9], w[3][O];
+        if (VAR >= 1) {
             const int64_t left = b1 - base;
             const int64_t nd = ((left < 16) ? ((left > 0) ? left : 0) : 16) * 9;   // doubles of this group's window
             const double *src = blocks + base * 9;
@@ -628,30 +726,27 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
             for (int i = 0; i < 9; ++i) st[gl + 16 * i] = t[i];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 9; ++e) q[e] = st[gl * 9 + e];
+        } else {
+            const double *qb = blocks + (has ? b : 0) * 9;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) q[e] = qb[e];
         }
-        if (b < b1) {
-            const int j = colidx[b];
-            const double *qb = blocks + b * 9;
-            const double *wj = W + (size_t)j * 3 * OP;
-            double q[9], w[3][O];
-            if (VAR == 1) {
-                const double *st = stage + slot * 16 * 9 + gl * 9;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) q[e] = st[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 9; ++e) q[e] = qb[e];
-            }
+        {
+            const double *wj = W + (size_t)j * REC;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int k = 0; k < O; ++k) w[c][k] = wj[c * OP + k];
+        }
+        if (has) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int k = 0; k < O; ++k) acc[r][k] += q[3 * r] * w[0][k] + q[3 * r + 1] * w[1][k] + q[3 * r + 2] * w[2][k];
         }
-        if (VAR == 1) {
+        if (VAR >= 1) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -1314,9 +1409,10 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
     check_launch("qw_dense");
 }
 
-static int bsr_variant() {  // XM_BSR_VARIANT=1 (default: blocks staged through LDS, 137 vs 183 us at 100k cameras) | 0 (direct block loads)
-    static int v = [] { const char *e = std::getenv("XM_BSR_VARIANT"); return (e && *e == '0') ? 0 : 1; }();
-    return v;
+// XM_BSR_VARIANT = 2 (blocks AND the gathered rows of W staged through LDS; o <= 6) | 1 (blocks only) | 0 (direct loads)
+static int bsr_variant() {
+    const char *e = std::getenv("XM_BSR_VARIANT");
+    return (e && *e >= '0' && *e <= '2') ? (*e - '0') : 2;
 }
 int sym_groups(int nloc) { return (nloc + kSymWaves - 1) / kSymWaves; }
 int sym_chunks(int64_t ld) { const int nt = (int)((ld + kSymTile - 1) / kSymTile); return (nt + kSymChunk - 1) / kSymChunk; }
@@ -1371,7 +1467,15 @@ void launch_qw_bsr3(int o, int epi, const int64_t *rp, const int32_t *ci, const 
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
         hipLaunchKernelGGL((qw_bsr3_kernel<1, EPI_CERT, 0>), dim3((a.nloc + kBsrRows - 1) / kBsrRows), dim3(256), 0, st, rp, ci, bl, W, alpha, a);
-    } else if (bsr_variant() == 1) {
+    } else if (bsr_variant() == 2 && o <= 6) {
+        switch (o) {
+            case 3: qw_bsr3_epi<3, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
+            case 4: qw_bsr3_epi<4, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
+            case 5: qw_bsr3_epi<5, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
+            case 6: qw_bsr3_epi<6, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
+            default: XM_DISPATCH_O(o, (qw_bsr3_epi<O_, 1>(epi, rp, ci, bl, W, alpha, a, st)));
+        }
+    } else if (bsr_variant() >= 1) {
         XM_DISPATCH_O(o, (qw_bsr3_epi<O_, 1>(epi, rp, ci, bl, W, alpha, a, st)));
     } else {
         XM_DISPATCH_O(o, (qw_bsr3_epi<O_, 0>(epi, rp, ci, bl, W, alpha, a, st)));
