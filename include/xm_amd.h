@@ -47,7 +47,9 @@ const char *xm_last_error(void);
 const char *xm_version(void);
 
 /* ================================================================== 1. file-based surface == the reference's pybind functions */
-/* replaces XM_main.cu:180  solve(): reads <path>/Q.bin, writes <path>/R.bin and <path>/s.bin */
+/* replaces XM_main.cu:180  solve(): reads <path>/Q.bin, writes <path>/R.bin and <path>/s.bin
+ * (.bin = int32 rows, int32 cols, float64 column-major, XM_main.cu:18-33; Q.bin may instead carry the two 8-byte header
+ * fields of utils/io.py:24-26, recognised by the file size) */
 int xm_solve(const char *dataset_path, unsigned int max_rank, double tol, double lam, double max_time);
 /* replaces XM_main.cu:312  solve_rank3() */
 int xm_solve_rank3(const char *dataset_path, unsigned int max_rank, double tol, double lam, double max_time);

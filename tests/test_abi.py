@@ -63,6 +63,12 @@ def test_XM_module_surface(xmamd):
         XM.solve("x", -3, 1e-6, 0.0, 10.0)             # unsigned max_rank
     with pytest.raises(TypeError):
         XM.solve(dataset_path="x", max_rank=3, tol=1e-6, lam=0.0, max_time=1.0)
+    # additive in-memory surface: argument validation happens before any GPU work
+    assert callable(XM.solve_array) and callable(XM.solve_bsr)
+    with pytest.raises(ValueError):
+        XM.solve_array(np.zeros((4, 4)), 3, 1e-6, 0.0, 1.0)        # not 3n x 3n
+    with pytest.raises(ValueError):
+        XM.solve_bsr(np.array([0, 2]), np.array([0], dtype=np.int32), np.zeros((1, 3, 3)), 3, 1e-6, 0.0, 1.0)   # rowptr[n] != nb
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only behaviour")
@@ -75,6 +81,8 @@ def test_no_cpu_fallback(xmamd, tmp_path):
     with pytest.raises(RuntimeError, match="no HIP device"):
         XM.solve(str(tmp_path), 3, 1e-6, 0.0, 10.0)
     assert not (tmp_path / "R.bin").exists()
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        XM.solve_array(Q, 3, 1e-6, 0.0, 10.0)
     with pytest.raises(xmamd.XmError):
         xmamd.qw_dense(Q, np.ones((15, 3)))
     with pytest.raises(xmamd.XmError):

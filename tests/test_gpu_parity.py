@@ -165,6 +165,42 @@ def test_file_surface_XM_module(xmamd, tmp_path):
         XM.solve(str(tmp_path / "missing"), 3, 1e-6, 0.0, 10)
 
 
+def test_in_memory_XM_surface_and_bin_v2(xmamd, tmp_path):
+    """XM.solve_array / XM.solve_bsr return what the file surface writes (bit for bit), and Q.bin with the
+    8-byte header fields of utils/io.py:24-26 (`byte = 8`, which the reference's own C++ loader cannot read) is accepted"""
+    Q, exp, d = _case("simple2")
+    os.environ["XM_QUIET"] = "1"
+    XM = xmamd.import_XM()
+    R, s, info = XM.solve_array(Q, 3, 1e-12, 0.0, 1000.0)
+    assert R.shape == (3 * exp["n"], info["rank"]) and R.flags.f_contiguous and s.shape == (exp["n"],) and info["status"] == 1
+    tl.save_bin(tmp_path / "Q.bin", Q)
+    XM.solve(str(tmp_path), 3, 1e-12, 0.0, 1000.0)
+    R1 = tl.load_bin(tmp_path / "R.bin"); s1 = tl.load_bin(tmp_path / "s.bin")
+    assert np.array_equal(R, R1) and np.array_equal(s, s1[:, 0])
+    with open(tmp_path / "Q.bin", "wb") as f:                     # the same Q with int64 header fields
+        f.write(np.array(Q.shape, dtype="<i8").tobytes()); Q.T.tofile(f)
+    os.remove(tmp_path / "R.bin")
+    XM.solve(str(tmp_path), 3, 1e-12, 0.0, 1000.0)
+    assert np.array_equal(tl.load_bin(tmp_path / "R.bin"), R1)
+    tl.save_bin(tmp_path / "Q.bin", Q)
+    with open(tmp_path / "Q.bin", "ab") as f:                     # trailing bytes after an int32-header file
+        f.write(b"12345678")
+    XM.solve(str(tmp_path), 3, 1e-12, 0.0, 1000.0)               # the reference's reader ignores trailing bytes; so does v1 here
+    with open(tmp_path / "Q.bin", "wb") as f:
+        f.write(np.array(Q.shape, dtype="<i4").tobytes()); f.write(b"\0" * 100)
+    with pytest.raises(RuntimeError, match="short file"):
+        XM.solve(str(tmp_path), 3, 1e-12, 0.0, 1000.0)
+    # block-CSR in, warm-start mode with scales
+    P = tl.gen_vg(60, deg=6, sigma=0.3, seed=60)
+    Rb, sb, ib = XM.solve_bsr(P["rowptr"], P["colidx"], P["blocks"], 5, 1e-10, 2.0, 100.0)
+    ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+    Rc, sc, ic = ctx.solve(5, 1e-10, 2.0)
+    ctx.close()
+    assert np.array_equal(Rb, Rc) and np.array_equal(sb, sc) and ib["rank"] == ic["rank"]
+    Rw, sw, iw = XM.solve_array(P["Q"], 5, 1e-10, 2.0, 100.0, mode=2, s_ini=sb)
+    assert iw["status"] == ib["status"] and abs(iw["primal"] - ib["primal"]) <= 1e-8 * abs(ib["primal"])
+
+
 @pytest.mark.parametrize("n", [356, 1778])
 def test_full_size_properties(xmamd, n):
     """BASELINE configs at full size (Dubrovnik-356 / Venice-1778 camera counts, dense SBA-like Q): too big for the

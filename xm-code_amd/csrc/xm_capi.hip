@@ -31,14 +31,32 @@ void require_device() {
         throw xm::Error(XM_ERR_HIP, "no HIP device available: the XM solver has no CPU fallback (it needs an MI355X / gfx950 GPU)");
 }
 
-// .bin matrix: int32 rows, int32 cols, float64 column-major (XM_main.cu:18-33, utils/io.py:17-54)
+// .bin matrix: int32 rows, int32 cols, float64 column-major (XM_main.cu:18-33, utils/io.py:17-54).  The reference's Python I/O
+// also knows a variant with two 8-byte header fields (utils/io.py:24-26 `byte = 8`) that its C++ loader cannot read; it is
+// accepted here (told apart by the file size), which lifts the int32 limit on rows*cols for large Q.
 void read_bin(const std::string &fn, std::vector<double> &d, int64_t &rows, int64_t &cols) {
-    std::ifstream f(fn, std::ios::binary);
+    std::ifstream f(fn, std::ios::binary | std::ios::ate);
     if (!f) throw xm::Error(XM_ERR_IO, "cannot open file " + fn);
-    int32_t h[2];
-    f.read(reinterpret_cast<char *>(h), 8);
-    if (!f || h[0] < 0 || h[1] < 0) throw xm::Error(XM_ERR_IO, "bad header in " + fn);
-    rows = h[0]; cols = h[1];
+    const int64_t size = (int64_t)f.tellg();
+    f.seekg(0);
+    unsigned char raw[16] = {0};
+    f.read(reinterpret_cast<char *>(raw), std::min<int64_t>(16, size));
+    int32_t h4[2];
+    int64_t h8[2];
+    std::memcpy(h4, raw, 8);
+    std::memcpy(h8, raw, 16);
+    int64_t skip;
+    const bool v1 = size >= 8 && h4[0] >= 0 && h4[1] >= 0 && 8 + 8 * (int64_t)h4[0] * (int64_t)h4[1] == size;
+    const bool v2 = !v1 && size >= 16 && h8[0] >= 0 && h8[1] >= 0 && h8[0] < (1LL << 31) && h8[1] < (1LL << 31) &&
+                    16 + 8 * h8[0] * h8[1] == size;
+    if (v2) { rows = h8[0]; cols = h8[1]; skip = 16; }
+    else {
+        if (size < 8 || h4[0] < 0 || h4[1] < 0) throw xm::Error(XM_ERR_IO, "bad header in " + fn);
+        rows = h4[0]; cols = h4[1]; skip = 8;
+        if (8 + 8 * rows * cols > size) throw xm::Error(XM_ERR_IO, "short file " + fn);
+    }
+    f.clear();
+    f.seekg(skip);
     d.resize((size_t)rows * (size_t)cols);
     f.read(reinterpret_cast<char *>(d.data()), (std::streamsize)(d.size() * sizeof(double)));
     if ((size_t)f.gcount() != d.size() * sizeof(double)) throw xm::Error(XM_ERR_IO, "short file " + fn);
