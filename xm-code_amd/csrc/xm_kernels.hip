@@ -618,9 +618,7 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     span = max(span, (int64_t)__shfl_xor((long long)span, 32, 64));
     double *st = stage + slot * 16 * SW;
     if (VAR == 2) {
-        // Software pipeline, one window (16 blocks per group) deep: while the FMAs of window k run, the column indices and
-        // blocks of window k+1 are already in flight from HBM and its rows of W from L2, so a wavefront keeps two windows of
-        // loads outstanding instead of one dependent chain at a time (the kernel is latency-, not bandwidth-limited).
+        // Software pipeline over windows of 16 blocks per group (the kernel is latency-, not bandwidth-limited).
         // The 16 records of W a group multiplies are fetched ELEMENT-per-lane: one load instruction of the group covers 128
         // consecutive bytes of the concatenated records, so every cache line is touched by one or two instructions instead of by
         // all 3*OP of a lane-per-record gather; LDS turns them back into lane-per-record.
@@ -629,42 +627,52 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
         // starts one double early when REC is odd (overlapping instead of over-reading).
         typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
         constexpr int NP = (REC + 1) / 2;                  // pairs per record of W
-        int j = 0, jn = 0;
-        d2u t[5], tn[5], tw[NP];
-        int tpos[5], tposn[5];
         // every load is UNCONDITIONAL (idle lanes re-read a valid neighbour, clamped addresses): predicated loads become
         // exec-mask branches whose outstanding-load count the compiler cannot track, and it then drains the next window's loads
-        // (s_waitcnt vmcnt(0)) right after issuing them
-        auto load_window = [&](int64_t off, int &jj, d2u (&tt)[5], int (&pos)[5]) {
+        // (s_waitcnt vmcnt(0)) right after issuing them.
+        // Pipeline state at the top of window k: blocks(k) and W-records(k) in flight since window k-1, column indices of
+        // window k+1 in flight since window k-1.  Window k first issues cols(k+2), blocks(k+1) and - with the indices that have
+        // had a whole window to arrive - W-records(k+1), and only then consumes its own data: no load waits on a load issued
+        // in the same window, so a window costs one memory latency instead of the chained two (index, then gather).
+        int jn = 0, jnn = 0, nd = 0, ndn = 0;
+        d2u t[5], tn[5], tw[NP], twn[NP];
+        auto load_cols = [&](int64_t off, int &jj) {
+            const int64_t bj = (b0 + off + gl < b1) ? b0 + off + gl : ((b1 > 0) ? b1 - 1 : 0);
+            jj = colidx[bj];
+        };
+        auto load_blocks = [&](int64_t off, d2u (&tt)[5], int &ndd) {
             const int64_t base = b0 + off;
             const int64_t left = b1 - base;
-            const int nd = (int)((left < 16) ? ((left > 0) ? left : 0) : 16) * 9;   // doubles of this group's window
-            const int64_t bj = (base + gl < b1) ? base + gl : ((b1 > 0) ? b1 - 1 : 0);
-            jj = colidx[bj];
-            const double *src = (nd > 0) ? blocks + base * 9 : blocks;
+            ndd = (int)((left < 16) ? ((left > 0) ? left : 0) : 16) * 9;   // doubles of this group's window
+            const double *src = (ndd > 0) ? blocks + base * 9 : blocks;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                pos[i] = max(min(2 * (gl + 16 * i), nd - 2), 0);
-                tt[i] = __builtin_nontemporal_load((const d2u *)(src + pos[i]));   // pure stream
-            }
+            for (int i = 0; i < 5; ++i)
+                tt[i] = __builtin_nontemporal_load((const d2u *)(src + max(min(2 * (gl + 16 * i), ndd - 2), 0)));   // pure stream
         };
-        auto load_w = [&](int jj) {
+        auto load_w = [&](int jj, d2u (&ww)[NP]) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int g = gl + 16 * i;
                 const int sl = g / NP;
                 const int start = min(2 * (g - sl * NP), REC - 2);
                 const int js = __shfl(jj, (threadIdx.x & 48) + sl, 64);
-                tw[i] = *(const d2u *)(W + (size_t)js * REC + start);
+                ww[i] = *(const d2u *)(W + (size_t)js * REC + start);
             }
         };
-        // one window: `prefetch` (compile time) issues the loads of the next one first.  No run-time branch may surround a
-        // load, or the compiler loses count of the outstanding ones and drains them all; hence the peeled last window.
+        // `prefetch` is a compile-time flag: no run-time branch may surround a load, or the compiler loses count of the
+        // outstanding ones and drains them all; hence the peeled last window.
         auto window = [&](int64_t off, auto prefetch) {
-            if constexpr (decltype(prefetch)::value) load_window(off + 16, jn, tn, tposn);
+            if constexpr (decltype(prefetch)::value) {
+                load_cols(off + 32, jnn);
+                load_blocks(off + 16, tn, ndn);
+                load_w(jn, twn);
+            }
             double q[9], w[3][O];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { st[tpos[i]] = t[i].x; st[tpos[i] + 1] = t[i].y; }   // clamped lanes rewrite identical data
+            for (int i = 0; i < 5; ++i) {   // clamped lanes rewrite identical data
+                const int pos = max(min(2 * (gl + 16 * i), nd - 2), 0);
+                st[pos] = t[i].x; st[pos + 1] = t[i].y;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -687,7 +695,6 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
                 for (int k = 0; k < O; ++k) w[c][k] = st[gl * REC + c * OP + k];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if constexpr (decltype(prefetch)::value) load_w(jn);
             const bool keep = b0 + off + gl < b1;   // idle lanes hold stale LDS contents: select, never multiply (NaN * 0)
 #pragma unroll
             for (int e = 0; e < 9; ++e) q[e] = keep ? q[e] : 0.0;
@@ -696,14 +703,19 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
 #pragma unroll
                 for (int k = 0; k < O; ++k) acc[r][k] += q[3 * r] * w[0][k] + q[3 * r + 1] * w[1][k] + q[3 * r + 2] * w[2][k];
             if constexpr (decltype(prefetch)::value) {
-                j = jn;
+                jn = jnn; nd = ndn;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) { t[i] = tn[i]; tpos[i] = tposn[i]; }
+                for (int i = 0; i < 5; ++i) t[i] = tn[i];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) tw[i] = twn[i];
             }
         };
         if (span > 0) {
-            load_window(0, j, t, tpos);
-            load_w(j);
+            int j0;
+            load_cols(0, j0);
+            load_cols(16, jn);
+            load_blocks(0, t, nd);
+            load_w(j0, tw);
             int64_t off = 0;
             for (; off + 16 < span; off += 16) window(off, std::true_type{});
             window(off, std::false_type{});
