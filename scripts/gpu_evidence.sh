@@ -3,6 +3,8 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee gpurun_out/pytest_gpu.log
 timeout 600 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
+timeout 300 python bench.py --workload vg100k --storage bsr --steps 2 --warmup 1 --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/bench_vg100k.log
+rm -rf gpurun_out/prof_final
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_final -o run -- python $GRAFT_REPO_ROOT/bench.py --cpu-seconds 0 --no-hbm-check > $GRAFT_REPO_ROOT/gpurun_out/prof_final.log 2>&1
 cd $GRAFT_REPO_ROOT
-(python scripts/kbench_dense.py 1778 3 4 5 10; python scripts/kbench_dense.py 13682 3; python scripts/kbench_bsr.py 13682 30 3 5; python scripts/kbench_bsr.py 100000 50 3 5) 2>&1 | tee gpurun_out/kbench.log
+(python scripts/kbench_dense.py 1778 3 4 5 10; python scripts/kbench_dense.py 13682 3; python scripts/kbench_bsr.py 13682 30 3 5; python scripts/kbench_bsr.py 13682 58 3 5; python scripts/kbench_bsr.py 100000 50 3 5) 2>&1 | tee gpurun_out/kbench.log
