@@ -62,6 +62,8 @@ typedef struct xm_ctx xm_ctx_t;
 
 #define XM_STORAGE_DENSE 0     /* dense symmetric 3n x 3n, column-major (the reference format, XM_main.cu:18-33,191) */
 #define XM_STORAGE_BSR3  1     /* 3x3-block CSR over view-graph edges, both triangles stored */
+#define XM_STORAGE_BSR3_DENSE 2 /* described as BSR3 on the host (same fields), expanded to the dense layout on the device:
+                                  each rank builds only its own camera rows (a >= 10k-camera Q never exists on the host) */
 
 typedef struct {
     int64_t n;                 /* cameras */

@@ -238,6 +238,11 @@ def test_dense_from_bsr3_equals_upload(xmamd):
     ctx.close(); dq.free()
     R2, s2, i2 = xmamd.solve_dense(P["Q"], 4, 1e-8, 9.0)
     assert np.array_equal(R, R2) and np.array_equal(s, s2)
+    # XM_STORAGE_BSR3_DENSE: the context expands the block description itself (what bench.py uses at every N)
+    ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True)
+    R3, s3, i3 = ctx.solve(4, 1e-8, 9.0)
+    ctx.close()
+    assert np.array_equal(R3, R2) and np.array_equal(s3, s2)
 
 
 def test_rccl_path_single_rank(xmamd, tmp_path):
@@ -380,6 +385,9 @@ def _two_rank_worker_code():
         if case == "dense":
             P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)         # odd camera count (padding camera), needs rank escalation
             ctx = xmamd.Context(Q=P["Q"]); args = (6, 1e-9, 3.0)
+        elif case == "densify":                                    # block description expanded per rank on the device
+            P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
+            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True); args = (6, 1e-9, 3.0)
         else:
             P = tl.gen_vg(301, deg=10, sigma=0.1, seed=5)
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"])); args = (5, 1e-10, 10.0)
@@ -391,7 +399,7 @@ def _two_rank_worker_code():
     """)
 
 
-@pytest.mark.parametrize("case", ["dense", "bsr"])
+@pytest.mark.parametrize("case", ["dense", "bsr", "densify"])
 def test_two_ranks_one_gpu(xmamd, tmp_path, case):
     """The whole row-partitioned solver with TWO ranks (processes) sharing the one GPU of the test box through the
     shared-memory test transport: camera partition 21+20 (+1 inert padding camera), replicated product input, gathered

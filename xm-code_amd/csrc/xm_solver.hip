@@ -72,6 +72,29 @@ Context::Context(const xm_problem_t &prob) {
                 XM_HIP_CHECK(hipStreamSynchronize(st_));
             }
         }
+    } else if (storage_ == XM_STORAGE_BSR3_DENSE) {
+        // described as 3x3-block CSR on the host, stored dense (the reference's format) on the device: every rank expands
+        // only its own camera rows, so a 13.5 GB Q never exists on the host or on one GPU of a multi-GPU run
+        if (!prob.rowptr || !prob.colidx || !prob.blocks) throw Error(XM_ERR_ARG, "BSR3 needs rowptr/colidx/blocks");
+        const size_t rows = (size_t)3 * nloc_;
+        XM_HIP_CHECK(hipMalloc((void **)&dQ_, rows * (size_t)ld_ * sizeof(double)));
+        ownQ_ = true;
+        XM_HIP_CHECK(hipMemsetAsync(dQ_, 0, rows * (size_t)ld_ * sizeof(double), st_));
+        if (true_loc > 0) {
+            const int64_t b0 = prob.rowptr[cam0_], b1 = prob.rowptr[cam0_ + true_loc];
+            std::vector<int64_t> rp((size_t)true_loc + 1);
+            for (int64_t i = 0; i <= true_loc; ++i) rp[(size_t)i] = prob.rowptr[cam0_ + i] - b0;
+            DevBuf<int64_t> drp; DevBuf<int32_t> dci; DevBuf<double> dbl;
+            drp.alloc(rp.size(), false); dci.alloc((size_t)std::max<int64_t>(b1 - b0, 1), false); dbl.alloc((size_t)std::max<int64_t>(b1 - b0, 1) * 9, false);
+            XM_HIP_CHECK(hipMemcpy(drp.p, rp.data(), rp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+            if (b1 > b0) {
+                XM_HIP_CHECK(hipMemcpy(dci.p, prob.colidx + b0, (size_t)(b1 - b0) * sizeof(int32_t), hipMemcpyHostToDevice));
+                XM_HIP_CHECK(hipMemcpy(dbl.p, prob.blocks + b0 * 9, (size_t)(b1 - b0) * 9 * sizeof(double), hipMemcpyHostToDevice));
+            }
+            launch_dense_from_bsr(drp.p, dci.p, dbl.p, true_loc, 0, dQ_, ld_, st_);
+        }
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        storage_ = XM_STORAGE_DENSE;
     } else if (storage_ == XM_STORAGE_BSR3) {
         if (!prob.rowptr || !prob.colidx || !prob.blocks) throw Error(XM_ERR_ARG, "BSR3 needs rowptr/colidx/blocks");
         std::vector<int64_t> rp((size_t)nloc_ + 1, 0);

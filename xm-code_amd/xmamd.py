@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libxm_amd.so")
 MODULE_DIR = os.path.join(_HERE, "build")      # holds XM.cpython-*.so (the reference's module name)
 
 STORAGE_DENSE, STORAGE_BSR3 = 0, 1
+STORAGE_BSR3_DENSE = 2   # BSR3 on the host, expanded to the dense layout on the device (each rank: its own rows)
 MODE_SOLVE, MODE_RANK3, MODE_REBUTTLE = 0, 1, 2
 FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 
@@ -253,7 +254,7 @@ def recover_rotations(R, s):
 class Context:
     """Q resident in HBM; solve() == the reference's staircase (XM_main.cu:180 / :312 / :35)."""
 
-    def __init__(self, Q=None, bsr=None, dq=None, n=None):
+    def __init__(self, Q=None, bsr=None, dq=None, n=None, densify=False):
         require_gpu()
         self._keep = []
         p = Problem()
@@ -271,7 +272,7 @@ class Context:
             rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
             blocks = np.ascontiguousarray(blocks, dtype=np.float64)
             self.n = rowptr.size - 1
-            p.n, p.storage, p.nb = self.n, STORAGE_BSR3, colidx.size
+            p.n, p.storage, p.nb = self.n, (STORAGE_BSR3_DENSE if densify else STORAGE_BSR3), colidx.size
             p.rowptr, p.colidx, p.blocks = (a.ctypes.data_as(C.c_void_p) for a in (rowptr, colidx, blocks))
             self._keep += [rowptr, colidx, blocks]
         self.h = C.c_void_p()
