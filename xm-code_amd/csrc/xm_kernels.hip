@@ -306,9 +306,6 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
     constexpr int TILE = NSUB * 128;                 // columns per tile
     constexpr int TILE2 = TILE * OP / 2;             // double2 elements of one W tile
     constexpr int NST = (TILE2 + 255) / 256;         // staging registers (double2) per thread
-    if (EPI == EPI_HESS) {
-        if (a.scal->status != 0) return;  // tCG already terminated: enqueued-ahead launch becomes a no-op
-    }
     __shared__ __attribute__((aligned(16))) double wt[2][TILE * OP];
     __shared__ double red[kQwWaves][3];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -368,6 +365,11 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
 
     load_q(0);
     load_w(0);
+    if (EPI == EPI_HESS) {
+        // tCG already terminated: the enqueued-ahead launch becomes a no-op.  Checked only after the first tile's loads are
+        // in flight, so that a live launch does not start with an exposed dependent load (uniform over the grid).
+        if (a.scal->status != 0) return;
+    }
     store_w(0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
