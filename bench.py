@@ -100,13 +100,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only (id exchange, barrier, max)
         uid = bytearray(128)
-        if rank == 0:
+        if rank == 0 and os.environ.get("XM_BENCH_SHM") != "1":
             buf = (xmamd.C.c_char * 128)()
             xmamd._chk(xmamd.lib().xm_comm_unique_id(buf))
             uid = bytearray(buf.raw)
         box = [bytes(uid)]
         dist.broadcast_object_list(box, src=0)
-        xmamd._chk(xmamd.lib().xm_comm_init(rank, world, local, box[0], None))   # data plane: RCCL over xGMI inside the C++ solver
+        if os.environ.get("XM_BENCH_SHM") == "1":    # debugging aid: the library's shared-memory test transport instead of RCCL
+            xmamd._chk(xmamd.lib().xm_comm_init_shm(rank, world, local, b"/xm_bench_%d" % int(os.environ.get("MASTER_PORT", "0")), 256 << 20))
+        else:
+            xmamd._chk(xmamd.lib().xm_comm_init(rank, world, local, box[0], None))   # data plane: RCCL over xGMI inside the C++ solver
 
     wl = workload(args.workload)
     import xm_testlib as tl
@@ -262,6 +265,25 @@ def main():
         out["cpu_baseline"] = cpu_baseline(Q, wl, args.cpu_seconds)
     if world > 1:
         xmamd.lib().xm_comm_finalize()
+        # Replica throughput: what N GPUs deliver on N INDEPENDENT Venice-size scenes (no data-path communication; the row
+        # partition above is latency-bound at this size: 28 MB of Q per GPU at N = 8 against two collectives per iteration).
+        # Reported next to the partitioned headline, never instead of it.
+        cx = xmamd.Context(Q=Q) if Q is not None else None
+        if cx is not None:
+            cx.solve(wl["max_rank"], wl["tol"], wl["lam"])
+            barrier()
+            t0 = time.perf_counter()
+            ri = [cx.solve(wl["max_rank"], wl["tol"], wl["lam"])[2] for _ in range(max(1, args.steps))]
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            barrier()
+            t = torch.tensor([el, float(sum(i["tcg_iters"] for i in ri))], dtype=torch.float64)
+            tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+            cx.close()
+            out["replicas"] = {"what": "%d independent solves of the same workload, one per GPU, no communication" % world,
+                               "value": float(ts[1]) / float(tm[0]), "unit": "tCG iters/s", "scaling": "weak", "n_gpus": world,
+                               "steps": max(1, args.steps), "ms_per_step": float(tm[0]) / max(1, args.steps) * 1e3}
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))

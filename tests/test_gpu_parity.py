@@ -454,3 +454,27 @@ def test_loose_tolerance_and_small_max_rank(xmamd, oracle):
     assert np.array_equal(R, Ro) and info["tcg_iters"] == io["tcg_iters"] == 0 and info["status"] == io["status"]
     R2, s2, i2 = xmamd.solve_dense(Q, 2, 1e-6, 0.0)       # max_rank < 3: the staircase loop never runs (XM_main.cu:223)
     assert i2["rank"] == 2 and i2["status"] == 0 and i2["tcg_iters"] == 0
+
+
+def test_bench_two_ranks_flow(xmamd):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo control plane, per-rank on-device
+    expansion of the Rome-scale Q, replicas leg), with both ranks on the one GPU of the test box and the library's
+    shared-memory transport in place of RCCL: every leg must reach the certified optimum the single-GPU run reaches."""
+    import socket, subprocess, sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XM_BENCH_SHM="1", XM_BENCH_SINGLE_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1                                            # rank 0 prints ONE JSON line
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["solve"]["status"] == 1 and d["solve"]["primal"] == pytest.approx(0.2844696774, rel=1e-8)
+    for leg in ("rome_scale", "rome_scale_dense"):
+        assert d[leg]["n_gpus"] == 2 and d[leg]["status"] == 1 and d[leg]["rank"] == 3
+        assert d[leg]["primal"] == pytest.approx(2879.599460014564, rel=1e-10)
+    assert d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0
