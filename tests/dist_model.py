@@ -1,8 +1,10 @@
 """Row-partitioned numpy model of the multi-GPU trust region (xm-code_amd/csrc/xm_solver.hip).
 
 Test infrastructure: mirrors, rank for rank, what each GPU process does — local camera rows of Q, replicated product
-input W obtained by an all-gather, per-rank partial sums that are *gathered* (not all-reduced) and added in a fixed order
-so that every rank takes bit-identical branch decisions, inert padding cameras on the last rank.  The collectives are
+input W (one all-gather per outer-iteration product; inside the tCG ONE exchange per iteration carries the rows of the
+image of Hp together with the partial sums and W follows the recurrence W+ = beta W - A+), per-rank partial sums that are
+*gathered* (not all-reduced) and added in a fixed order so that every rank takes bit-identical branch decisions, inert
+padding cameras on the last rank.  The collectives are
 injected (`allgather(vec) -> concatenated vec`) so the same code runs single-process (world 1) or under
 torch.distributed/gloo (tests/test_distributed_cpu.py).  Formulas follow trustregion.h exactly like the kernels do.
 """
@@ -53,8 +55,9 @@ class RankModel:
         rr = self.gsum(np.sum(rgR * rgR) + np.sum((rgs / s) ** 2))
         return dict(G=G, egs=egs, S0=S0, rgR=rgR, rgs=rgs, f=f, rr=rr)
 
-    def hess(self, st, R, s, pR, ps):
-        W = self.gather_rows(s[:, None, None] * pR + ps[:, None, None] * R)
+    def hess(self, st, R, s, pR, ps, W=None):
+        if W is None:
+            W = self.gather_rows(s[:, None, None] * pR + ps[:, None, None] * R)
         H = 2.0 * (self.Qloc @ W).reshape(self.nloc, 3, self.o)
         hs = np.where(self.anchor, 0.0, np.sum(H * R, axis=(1, 2)) + np.sum(st["G"] * pR, axis=(1, 2))
                       + 4 * self.lam * (3 * s * s - 1) * ps)
@@ -64,6 +67,23 @@ class RankModel:
         rhs = np.where(self.anchor, 0.0, hs * s * s + ps * s * st["egs"])
         pHp = self.gsum(np.sum(pR * rh) + np.sum(ps * rhs / (s * s)))
         return rh, rhs, pHp
+
+    def hess_exchange(self, st, R, s, pR, ps, rR, rs, W):
+        """One tCG product of the multi-rank solver: the replicated product input W is NOT gathered; instead ONE all-gather
+        carries this rank's rows of B = s.*Hp_R + Hp_s.*R together with its partial sums <p,Hp>, <r,Hp>, <Hp,Hp> (what
+        epi_hess + the parity chunk of Context::run_tcg do)."""
+        rh, rhs, _ = self.hess(st, R, s, pR, ps, W=W)
+        B = s[:, None, None] * rh + rhs[:, None, None] * R
+        s2 = s * s
+        part = np.array([np.sum(pR * rh) + np.sum(ps * rhs / s2), np.sum(rR * rh) + np.sum(rs * rhs / s2),
+                         np.sum(rh * rh) + np.sum((rhs / s) ** 2)])
+        chunk = np.concatenate([B.reshape(-1), part])
+        allc = self.ag(chunk).reshape(self.world, -1)
+        Bfull = allc[:, :-3].reshape(3 * self.ntot, self.o)
+        sums = np.zeros(3)
+        for r in range(self.world):          # fixed order
+            sums += allc[r, -3:]
+        return rh, rhs, Bfull, sums
 
     @staticmethod
     def retract(R, s, vR, vs, anchor):
@@ -94,14 +114,16 @@ class RankModel:
             trace.append((loss, gn, endreason))
             if endreason == 5 or gn < gradtol:
                 break
-            # ---- tCG
+            # ---- tCG (Context::run_tcg + cg_step_kernel, multi-rank form: one exchange per iteration)
             rR, rs = st["rgR"].copy(), st["rgs"].copy()
             pR, ps = -rR, -rs
             vR, vs = np.zeros_like(rR), np.zeros_like(rs)
             HvR, Hvs = np.zeros_like(rR), np.zeros_like(rs)
             vv = vp = 0.0; pp = rr; rcur = rr; endreason = 6
+            W = self.gather_rows(s[:, None, None] * pR + ps[:, None, None] * R)   # the only gather of the product input
+            A = -W                                                                # image of r0 (p0 = -r0)
             for i in range(1000):
-                HpR, Hps, pHp = self.hess(st, R, s, pR, ps)
+                HpR, Hps, Bfull, (pHp, rHp, HpHp) = self.hess_exchange(st, R, s, pR, ps, rR, rs, W)
                 alpha = rcur / pHp
                 if rcur < 1e-15:
                     endreason = 5; break
@@ -111,13 +133,15 @@ class RankModel:
                     endreason = 1 if alpha <= 0 else 2; break
                 vR += alpha * pR; vs += alpha * ps; rR += alpha * HpR; rs += alpha * Hps
                 HvR += alpha * HpR; Hvs += alpha * Hps
-                rnew = self.gsum(np.sum(rR * rR) + np.sum((rs / s) ** 2))
+                rnew = max(rcur + 2 * alpha * rHp + alpha * alpha * HpHp, 0.0)       # no second reduction (epi_hess comment)
                 if np.sqrt(rnew) < gn * min(gn, 0.1):
                     endreason = 3; break
                 beta = rnew / rcur
                 pR = beta * pR - rR; ps = beta * ps - rs
+                A = A + alpha * Bfull                                              # replicated on every rank
+                W = beta * W - A                                                   # == gather(s.*p + ps.*R) up to rounding
                 vv, vp, pp = vv + 2 * alpha * vp + alpha * alpha * pp, beta * (vp + alpha * pp), beta * beta * pp + rnew
-                rcur = rnew
+                rcur = self.gsum(np.sum(rR * rR) + np.sum((rs / s) ** 2))           # exact |r|^2 (rides in the next chunk on the GPU)
             total += i + 1
             m = self.gsum(np.sum(vR * (0.5 * HvR + st["rgR"])) + np.sum(vs / (s * s) * (0.5 * Hvs + st["rgs"])))
             if m >= 0:

@@ -246,8 +246,9 @@ def test_dense_from_bsr3_equals_upload(xmamd):
 
 
 def test_rccl_path_single_rank(xmamd, tmp_path):
-    """XM_FORCE_COMM=1 issues every all-gather of the multi-GPU path on a 1-rank RCCL communicator: the result must be
-    bit-identical to the plain single-GPU run (exercises dlopen(RCCL), ncclCommInitRank and in-place ncclAllGather)."""
+    """XM_FORCE_COMM=1 runs the multi-GPU code path on a 1-rank RCCL communicator (exercises dlopen(RCCL), ncclCommInitRank,
+    the in-place ncclAllGather and the single-exchange tCG whose product input follows the recurrence W+ = beta W - A+
+    instead of being rebuilt from p): same optimum as the plain single-GPU run; the trajectories agree to rounding."""
     import subprocess, sys, textwrap
     code = textwrap.dedent(f"""
         import sys, os, ctypes as C
@@ -269,8 +270,9 @@ def test_rccl_path_single_rank(xmamd, tmp_path):
         env = dict(os.environ, XM_FORCE_COMM=force)
         subprocess.check_call([sys.executable, "-c", code, out], env=env, timeout=600)
         outs.append(np.load(out))
-    assert np.array_equal(outs[0]["R"], outs[1]["R"]) and np.array_equal(outs[0]["s"], outs[1]["s"])
-    assert int(outs[0]["tcg"]) == int(outs[1]["tcg"])
+    assert float(outs[0]["primal"]) == pytest.approx(float(outs[1]["primal"]), rel=1e-12)
+    assert tl.rotation_parity(outs[0]["R"], outs[0]["s"], outs[1]["R"], outs[1]["s"]) < 1e-8
+    assert abs(int(outs[0]["tcg"]) - int(outs[1]["tcg"])) <= 0.05 * int(outs[0]["tcg"])
 
 
 def test_dubrovnik356_full_solve_matches_oracle(xmamd, oracle):

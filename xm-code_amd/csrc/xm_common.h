@@ -78,6 +78,7 @@ struct CamArgs {
     const double *Lam;   // nloc*9 row-major symmetric
     const double *dz;    // nloc
     const TcgScal *scal; // tCG kernels return immediately when scal->status != 0
+    double *Bout;        // multi-rank tCG only: rows of  s.*Hp_R + Hp_s.*R  (the product-input image of Hp), else nullptr
 };
 
 enum Epilogue { EPI_PLAIN = 0, EPI_GRAD = 1, EPI_HESS = 2, EPI_CERT = 3 };
@@ -111,7 +112,8 @@ void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, cons
 void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *parts, int nA_loc, int nB_loc, int world,
                     const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
-                    double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, hipStream_t st);
+                    double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat, double *Afull,
+                    double *Wfull, hipStream_t st);
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs,
                         const double *rgR, const double *rgs, const double *s, double *parts, hipStream_t st);
 void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,

@@ -235,6 +235,12 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
     const double rhs = anchor ? 0.0 : hs * (s * s) + (ps * s) * e.egs;
     store_col<O>(rh, a.HpR, cam, lane);
     if (lane == 0) a.Hps[cam] = rhs;
+    if (a.Bout) {   // multi-rank tCG: the image of Hp under the map (xR, xs) -> s.*xR + xs.*R travels with the partial sums
+        Col3 b;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) b.v[r] = s * rh.v[r] + rhs * R.v[r];
+        store_col<O>(b, a.Bout, cam, lane);
+    }
     p0 = group_sum<GW>(dot3(P, rh)) + ps * (rhs / (s * s));
     // <r,Hp> and <Hp,Hp> in the same metric: with them the residual norm after the CG step follows without a second
     // global reduction, |r + alpha Hp|^2 = <r,r> + 2 alpha <r,Hp> + alpha^2 <Hp,Hp>   (one flat kernel per iteration)
@@ -904,7 +910,8 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
                                                        const double *__restrict__ s, double *pR, const double *__restrict__ ps_cur,
                                                        double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR,
                                                        const double *__restrict__ rs_cur, double *rs_next, double *Wloc,
-                                                       double *partsB_out, unsigned long long *hstat) {
+                                                       double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat,
+                                                       double *Afull, double *Wfull) {
     constexpr int OP = pitch_of(O);
     __shared__ double sh[4];
     __shared__ double sh16[16];
@@ -926,10 +933,11 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
     }
     // `parts` = the gathered per-rank chunks [ <p,Hp> | <r,Hp> | <Hp,Hp> (nA_loc each, from this iteration's Hessian epilogue)
     //                                          | |r|^2 partials of the PREVIOUS iteration's cg_step (nB_loc) ]
-    const int chunk = 3 * nA_loc + nB_loc;
+    // (multi-rank: each chunk starts with b_off doubles = that rank's rows of the image of Hp, see below)
+    const int chunk = b_off + 3 * nA_loc + nB_loc;
     double pHp = 0.0, rHp = 0.0, HpHp = 0.0, rr_prev = 0.0;
     for (int r = 0; r < world; ++r) {
-        const double *pa = parts + (size_t)r * chunk;
+        const double *pa = parts + (size_t)r * chunk + b_off;
         double t[4];
         sum_partials256_x4(pa, pa + nA_loc, pa + 2 * nA_loc, nA_loc, pa + 3 * nA_loc, (sc0.iter > 0) ? nB_loc : 0, sh16, t);
         pHp += t[0]; rHp += t[1]; HpHp += t[2];
@@ -966,7 +974,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
                 const double pn = beta * pv - rn;
                 const double psn = beta * psv - rsn;
                 pR[i] = pn;
-                Wloc[i] = sv * pn + psn * Rv;
+                if (!Afull) Wloc[i] = sv * pn + psn * Rv;
                 if (own0) ps_next[camf] = psn;
             }
             if (own0) { rs_next[camf] = rsn; const double q = rsn / sv; acc += q * q; }
@@ -988,12 +996,29 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
                 const double pn = beta * pi - rn;
                 const double psn = beta * psi - rsn;
                 pR[i] = pn;
-                Wloc[i] = s[cam] * pn + psn * R[i];
+                if (!Afull) Wloc[i] = s[cam] * pn + psn * R[i];
                 if (own) ps_next[cam] = psn;
             }
             if (own) { rs_next[cam] = rsn; const double q = rsn / s[cam]; acc += q * q; }
         }
         if (own) { vs[cam] += step * psi; Hvs[cam] += step * hsi; }
+    }
+    if (Afull && newdir) {
+        // Multi-rank tCG with ONE exchange per iteration.  The next product input is W+ = s.*p+ + ps+.*R with p+ = beta p - r+,
+        // r+ = r + alpha Hp, hence  W+ = beta W - A+,  A+ = A + alpha B  where A is the image of r and B the image of Hp under
+        // (xR, xs) -> s.*xR + xs.*R.  Every rank received every rank's rows of B in the same all-gather as the partial sums,
+        // keeps A and W replicated and advances both here for ALL cameras - identical arithmetic on identical data, so the
+        // replicas stay bit-identical and no second all-gather (of W) is needed.  A0 = -W0 because p0 = -r0.
+        const int64_t full = mat * world;
+        const bool first = (sc0.iter == 0);
+        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < full; j += stride) {
+            const int64_t r = j / mat;
+            const double b = parts[(size_t)r * chunk + (size_t)(j - r * mat)];
+            const double w = Wfull[j];
+            const double an = (first ? -w : Afull[j]) + step * b;
+            Afull[j] = an;
+            Wfull[j] = beta * w - an;
+        }
     }
     if (cg) {
         const double tot = block_sum256(acc, sh);
@@ -1545,10 +1570,11 @@ void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, cons
 void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *parts, int nA_loc, int nB_loc, int world,
                     const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
-                    double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, hipStream_t st) {
+                    double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat, double *Afull,
+                    double *Wfull, hipStream_t st) {
     XM_DISPATCH_O(o, hipLaunchKernelGGL((cg_step_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st, nloc,
                                         scal_cur, scal_next, parts, nA_loc, nB_loc, world, HpR, Hps, R, s, pR, ps_cur, ps_next, vR,
-                                        vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat));
+                                        vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat, b_off, mat, Afull, Wfull));
     check_launch("cg_step");
 }
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs, const double *rgR,

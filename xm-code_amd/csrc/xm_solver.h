@@ -86,6 +86,7 @@ private:
     int storage_ = XM_STORAGE_DENSE;
     double *dQ_ = nullptr; // dense: 3*nloc rows x ld, row-major
     bool ownQ_ = false;
+    DevBuf<double> Afull_;   // multi-rank tCG: replicated image of the residual (cg_step_kernel)
     DevBuf<int64_t> rowptr_;
     DevBuf<int32_t> colidx_;
     DevBuf<double> blocks_;

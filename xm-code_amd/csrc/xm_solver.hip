@@ -171,7 +171,10 @@ void Context::setup_rank(int o) {
     nA_ = nA_loc * world;
     nB_ = nB_loc * world;
     partsA_.alloc((size_t)3 * nA_);
-    partsB_.alloc((size_t)2 * (3 * nA_ + nB_));   // tCG partial sums: two parity buffers of world chunks [3*nA_loc | nB_loc]
+    // tCG exchange buffers: two parity buffers of world chunks [rows of the image of Hp (multi-rank only) | 3*nA_loc | nB_loc]
+    const size_t b_off = comm_->active() ? mat : 0;
+    partsB_.alloc((size_t)2 * (b_off * world + 3 * nA_ + nB_));
+    if (comm_->active()) Afull_.alloc(mat * world); else Afull_.release();
     partsM_.alloc((size_t)std::max(nB_, 2 * ((nloc_ + 255) / 256) * world));
     if (sym_ok_ && o >= 3 && o <= sym_max_o_) {
         Prow_.alloc(sym_prow_count(nloc_, ld_, o));
@@ -368,9 +371,14 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
         a.rs = par ? rsB_.p : rs_.p;
         // tCG partial sums travel in ONE all-gather per iteration: chunk = [Hessian-epilogue partials of this iteration |
         // |r|^2 partials the previous cg_step left in this parity's buffer]
-        const size_t chunk = (size_t)3 * nA_loc + nB_loc;
+        // and, with more than one rank, in front of them this rank's rows of the image of Hp (see cg_step_kernel): the product
+        // input of the next iteration then follows from replicated data and needs no all-gather of its own.
+        const size_t mat = (size_t)nloc_ * 3 * OP_;
+        const size_t b_off = comm_->active() ? mat : 0;
+        const size_t chunk = b_off + (size_t)3 * nA_loc + nB_loc;
         double *pcur = partsB_.p + (size_t)par * chunk * comm_->world, *pnext = partsB_.p + (size_t)(par ^ 1) * chunk * comm_->world;
-        a.partials = pcur + (size_t)rank * chunk;
+        a.partials = pcur + (size_t)rank * chunk + b_off;
+        a.Bout = comm_->active() ? pcur + (size_t)rank * chunk : nullptr;
         const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
         if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
         product(EPI_HESS, o_, 2.0, a);
@@ -379,8 +387,8 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
         if (comm_->active()) comm_->allgather(pcur, chunk, st_);
         launch_cg_step(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), pcur, nA_loc, nB_loc, comm_->world, HpR_.p, Hps_.p, R_.p,
                        s_.p, pR_.p, par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, rR_.p,
-                       par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pnext + (size_t)rank * chunk + 3 * nA_loc, hstat_dev_, st_);
-        gather_W();
+                       par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pnext + (size_t)rank * chunk + b_off + 3 * nA_loc, hstat_dev_,
+                       (int)b_off, (int64_t)mat, comm_->active() ? Afull_.p : nullptr, W_.p, st_);
     };
     auto read_scal = [&](int par) {
         TcgScal sc;
