@@ -169,10 +169,10 @@ def main():
     # HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE (own pass, kernel-trace only), corrected as
     # MI355X_MICROARCH.md prescribes (KB -> bytes, x2 for the gfx950 wide-load half count); see profiles/r01_pmc_*.json
     traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_qw_dense.json")))
-        if wl["kind"] == "dense" and str(n) in pmc and world == 1:
-            traffic = pmc[str(n)]["hbm_read_bytes_per_launch"]
+    try:   # the Hessian launches of THIS command under --pmc FETCH_SIZE (scripts/pmc_hess.sh), weighted over the ranks of the staircase
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_hess_bench.json")))
+        if args.workload == "venice1778" and world == 1:
+            traffic = pmc["hess_all_ranks_weighted"]["hbm_side_bytes_per_real_launch"]
     except Exception:
         traffic = None
     out = {
@@ -188,7 +188,7 @@ def main():
                   "qw_products": last["qw_products"], "lanczos_iters": last["lanczos_iters"],
                   "tr_seconds": last["tr_seconds"], "cert_seconds": last["cert_seconds"], "setup_gen_s": gen_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r01_pmc_fetch_qw_dense.json (rocprofv3 --pmc FETCH_SIZE pass of the same kernel on the same matrix size, x1024 x2)", "kernel": kname + (" via the half-traffic symmetric path (qw_sym_kernel + sym_reduce_kernel; bytes counted at FULL storage, SURVEY 8d)" if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
+                     "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r01_pmc_fetch_hess_bench.json (rocprofv3 --pmc FETCH_SIZE pass over this command's own Hessian launches, no-ops dropped; x1024 x2)", "kernel": kname + (" via the half-traffic symmetric path (qw_sym_kernel + sym_reduce_kernel; bytes counted at FULL storage, SURVEY 8d)" if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); "
                              "per-rank Q is %.0f MB: below ~256 MB it sits in the Infinity Cache, so the figure is cache-assisted, "
