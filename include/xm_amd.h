@@ -171,7 +171,8 @@ int xm_comm_init(int rank, int world, int device, const unsigned char id[128], c
  * 1-GPU box (tests/test_gpu_parity.py::test_two_ranks_one_gpu); `bytes` = capacity of the exchange area */
 int xm_comm_init_shm(int rank, int world, int device, const char *name, size_t bytes);
 int xm_comm_finalize(void);
-/* contiguous camera range [*c0, *c1) owned by `rank` (balanced by rows for dense, by stored blocks for BSR3) */
+/* contiguous camera range [*c0, *c1) owned by `rank`: equal ranges of ceil(n / world) cameras for every storage kind (the
+ * last rank is padded with inert cameras inside the solver) */
 int xm_partition(int64_t n, int world, int rank, int64_t *c0, int64_t *c1);
 
 #ifdef __cplusplus
