@@ -58,6 +58,24 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def test_partition_model_world3_gloo(tmp_path):
+    """61 cameras over 3 ranks: 21 + 21 + 19 (+2 padding cameras on the last rank); every rank ends bit-identical"""
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(3)]
+    assert [int(x["nloc"]) for x in r] == [21, 21, 21] and [int(x["cam0"]) for x in r] == [0, 21, 42]
+    for x in r[1:]:
+        assert np.array_equal(r[0]["R"], x["R"]) and np.array_equal(r[0]["s"], x["s"]) and np.array_equal(r[0]["trace"], x["trace"])
+    Q, lam = _problem()
+    n = Q.shape[0] // 3
+    R1, s1, i1 = RankModel(Q, 3, lam, 0, 1, lambda v: v).trust_region(np.tile(np.eye(3), (n, 1)), np.ones(n), 1e-9)
+    assert float(r[0]["primal"]) == pytest.approx(i1["primal"], rel=1e-11)
+    assert tl.rotation_parity(r[0]["R"], r[0]["s"], R1, s1) < 1e-8
+
+
 def test_partition_model_world2_gloo(oracle, tmp_path):
     import torch.multiprocessing as mp
     with socket.socket() as sk:
