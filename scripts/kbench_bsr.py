@@ -4,7 +4,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "xm-code_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, xmamd, xm_testlib as tl
 n = int(sys.argv[1]); deg = int(sys.argv[2]); os_ = [int(x) for x in sys.argv[3:]] or [3]
-P = tl.gen_vg(n, deg=deg, sigma=0.05, seed=n, dense=False)
+if os.environ.get("XM_KB_BAND") == "1":   # view graph WITH locality: camera i sees cameras i-deg/2 .. i+deg/2 (sequential capture)
+    h = deg // 2
+    lo = np.maximum(np.arange(n) - h, 0); hi = np.minimum(np.arange(n) + h, n - 1)
+    cnt = hi - lo + 1
+    rowptr = np.zeros(n + 1, dtype=np.int64); rowptr[1:] = np.cumsum(cnt)
+    colidx = (np.repeat(lo, cnt) + (np.arange(rowptr[-1]) - np.repeat(rowptr[:-1], cnt))).astype(np.int32)
+    P = dict(rowptr=rowptr, colidx=colidx, blocks=np.random.default_rng(n).standard_normal((rowptr[-1], 3, 3)))
+else:
+    P = tl.gen_vg(n, deg=deg, sigma=0.05, seed=n, dense=False)
 nb = P["colidx"].size
 if os.environ.get("XM_KB_COLMOD"):   # timing experiment: shrink the gathered working set of W (result meaningless)
     P["colidx"] = (P["colidx"] % int(os.environ["XM_KB_COLMOD"])).astype(np.int32)
