@@ -37,6 +37,27 @@ def test_qw_bsr3_matches_dense(xmamd, oracle, n, deg, o):
     assert tl.rel_fro(got, ref) < 1e-13
 
 
+def _banded(n, half, seed):
+    lo = np.maximum(np.arange(n) - half, 0); hi = np.minimum(np.arange(n) + half, n - 1)
+    cnt = hi - lo + 1
+    rowptr = np.zeros(n + 1, dtype=np.int64); rowptr[1:] = np.cumsum(cnt)
+    colidx = (np.repeat(lo, cnt) + (np.arange(rowptr[-1]) - np.repeat(rowptr[:-1], cnt))).astype(np.int32)
+    return rowptr, colidx, np.random.default_rng(seed).standard_normal((int(rowptr[-1]), 3, 3))
+
+
+@pytest.mark.parametrize("o", [3, 4, 5, 6])
+def test_qw_bsr3_banded(xmamd, monkeypatch, o):
+    """view graph with locality (camera i sees i-20 .. i+20): equal row lengths of 41 blocks = two full windows and a partial one"""
+    n = 1500
+    rowptr, colidx, blocks = _banded(n, 20, o)
+    W = np.random.default_rng(o).standard_normal((3 * n, o))
+    ref = tl.bsr_to_dense(n, rowptr, colidx, blocks) @ W
+    got = xmamd.qw_bsr3(rowptr, colidx, blocks, W, 1.0)
+    assert tl.rel_fro(got, ref) < 1e-13
+    monkeypatch.setenv("XM_BSR_VARIANT", "1")                       # and the same product without any window
+    assert tl.rel_fro(xmamd.qw_bsr3(rowptr, colidx, blocks, W, 1.0), ref) < 1e-13
+
+
 def test_qw_empty_rows_bsr(xmamd):
     # ragged: cameras without any stored block
     n = 9
