@@ -481,6 +481,22 @@ def test_loose_tolerance_and_small_max_rank(xmamd, oracle):
     assert i2["rank"] == 2 and i2["status"] == 0 and i2["tcg_iters"] == 0
 
 
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_medium_view_graph_vs_recorded_oracle(xmamd, case):
+    """600- and 2000-camera view-graph problems in the hard regime (small scale regulariser: hundreds of outer iterations, the
+    2000-camera one needs the staircase): rank, certificate and optimum recorded from the CPU oracle (hours of CPU), dense and
+    BSR3 storage on the GPU"""
+    c = json.load(open(os.path.join(G, "synth", "recorded_oracle_medium.json")))["cases"][case]
+    P = tl.gen_vg(c["n"], deg=c["deg"], sigma=0.05, seed=c["n"])
+    for ctx in (xmamd.Context(Q=P["Q"]), xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))):
+        R, s, i = ctx.solve(5, 1e-6, c["lam"])
+        ctx.close()
+        assert i["rank"] == c["rank"] and i["status"] == c["status"] == 1
+        assert i["primal"] == pytest.approx(c["f"], rel=1e-9)
+        assert abs(i["tcg_iters"] - c["tcg"]) <= 0.15 * c["tcg"]
+        assert i["min_eig"] > -1e-6
+
+
 def test_bench_two_ranks_flow(xmamd):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo control plane, per-rank on-device
     expansion of the Rome-scale Q, replicas leg), with both ranks on the one GPU of the test box and the library's
