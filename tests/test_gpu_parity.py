@@ -497,6 +497,23 @@ def test_medium_view_graph_vs_recorded_oracle(xmamd, case):
         assert i["min_eig"] > -1e-6
 
 
+def test_venice1778_vs_recorded_oracle(xmamd):
+    """The headline workload itself (BASELINE config 'Venice-1778 on one MI355X', bench.py's default): the complete staircase
+    3 -> 4 -> 5 against the CPU oracle's recorded run on the same Q (tests/golden/synth/venice1778_oracle.json + the oracle's
+    anchored rotations): same final rank and certificate, same optimum, rotations <= 1e-6 (north_star)."""
+    fj = os.path.join(G, "synth", "venice1778_oracle.json")
+    if not os.path.exists(fj):
+        pytest.skip("recorded oracle run not present")
+    c = json.load(open(fj))
+    P = tl.gen_dense(c["n"], seed=c["seed"])
+    R, s, i = xmamd.solve_dense(P["Q"], c["max_rank"], c["tol"], c["lam"])
+    assert i["rank"] == c["rank"] and i["status"] == c["status"] == 1
+    assert i["primal"] == pytest.approx(c["f"], rel=1e-8)
+    rot, _ = tl.recover_rotations(R, s)
+    assert tl.rel_fro(rot, np.load(os.path.join(G, "synth", "venice1778_oracle_rot.npy"))) < 1e-6
+    assert abs(i["tcg_iters"] - c["tcg"]) <= 0.35 * c["tcg"]       # the path through the two saddle points is rounding-sensitive
+
+
 def test_bench_two_ranks_flow(xmamd):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo control plane, per-rank on-device
     expansion of the Rome-scale Q, replicas leg), with both ranks on the one GPU of the test box and the library's
