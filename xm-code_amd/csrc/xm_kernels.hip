@@ -7,7 +7,13 @@
 //                     conflict-free ds_read_b128), fp64 FMA, wave-shuffle reduction, and the per-camera algebra that
 //                     the reference runs as ~40 extra launches (trustregion.h:227-295, 186-194, 307-317) is fused
 //                     into the epilogue.
-//   qw_bsr3_kernel    same product from 3x3-block CSR (coalesced reads of the block array, W gathered from L2).
+//   qw_bsr3_kernel    same product from 3x3-block CSR: a 16-lane DPP row per camera row, one lane per stored block; the block
+//                     stream and the gathered records of W pass through LDS with 16-byte loads, software-pipelined over
+//                     windows of 16 blocks; same fused epilogues.
+//   qw_sym_kernel     half-traffic product for symmetric dense Q (upper block triangle only) + sym_reduce_kernel.
+//   cg_step_kernel    one launch per tCG iteration next to the Hessian product: step decision from the epilogue's partial
+//                     sums, all vector updates; with several ranks also the replicated recurrence W+ = beta W - A+ that
+//                     replaces the second all-gather of a distributed CG iteration.
 //   flat kernels      the tCG vector updates (trustregion.h:605-644) with device-side alpha/beta/tau and branch
 //                     logic, so the host never reads a scalar inside the inner loop.
 //   per-camera        MGS-QR retraction (Dense/batchedQR.h:42-67), scale retraction (trustregion.h:19-24),
