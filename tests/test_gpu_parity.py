@@ -516,6 +516,25 @@ def test_venice1778_vs_recorded_oracle(xmamd):
     assert 0.5 * c["tcg"] <= i["tcg_iters"] <= 2.0 * c["tcg"]
 
 
+def test_rome13682_vs_recorded_oracle(xmamd):
+    """BASELINE config 'Final-13682' (bench.py's Rome-scale legs): the rank-3 trust region of the 13 682-camera view-graph Q on
+    the CPU oracle (dense 13.5 GB on the host, recorded once: tests/golden/synth/rome13682_oracle.json + anchored rotations)
+    against the GPU solve in BSR3 storage: same optimum, rotations <= 1e-6."""
+    fj = os.path.join(G, "synth", "rome13682_oracle.json")
+    if not os.path.exists(fj):
+        pytest.skip("recorded oracle run not present")
+    c = json.load(open(fj))
+    P = tl.gen_vg(c["n"], deg=c["deg"], sigma=c["sigma"], seed=c["n"], dense=False)
+    ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+    R, s, i = ctx.solve(5, c["tol"], c["lam"])
+    ctx.close()
+    assert i["rank"] == 3 and i["status"] == 1
+    assert i["primal"] == pytest.approx(c["f"], rel=1e-9)
+    rot, _ = tl.recover_rotations(R, s)
+    assert tl.rel_fro(rot, np.load(os.path.join(G, "synth", "rome13682_oracle_rot.npy"))) < 1e-6
+    assert abs(i["tcg_iters"] - c["tcg"]) <= 0.2 * c["tcg"]
+
+
 def test_bench_two_ranks_flow(xmamd):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo control plane, per-rank on-device
     expansion of the Rome-scale Q, replicas leg), with both ranks on the one GPU of the test box and the library's
