@@ -61,6 +61,8 @@ typedef struct {
 
 /* tr.h:77  XMtrustregion.  C: 3n x 3n col-major.  R0,R: 3n x o col-major.  s0_ex,s_ex: n (entry 0 == 1).
  * v: 3n (only read when linesearch_step != 0).  gradtol is in/out (tr.h:534).  Returns 0. */
+/* test-only extension: multiply from a 3x3-block CSR description instead of the dense C (NULL, NULL, NULL to unset) */
+void xmo_set_bsr(const int64_t *rowptr, const int32_t *colidx, const double *blocks);
 int xmo_trustregion(int n, int o, const double *C, const double *R0, const double *s0_ex,
                     double *R, double *s_ex, double lam, double *gradtol, double linesearch_step,
                     const double *v, double *primal, double maxtime, xmo_stats *st, unsigned flags);

@@ -112,6 +112,33 @@ def trustregion(Cm, R0, s0_ex, lam=0.0, gradtol=1e-6, linesearch_step=0.0, v=Non
     return R, s, pr.value, gt.value, _stats_dict(st, tr)
 
 
+def trustregion_bsr(rowptr, colidx, blocks, R0, s0_ex, lam=0.0, gradtol=1e-6, maxtime=1000.0, flags=0, trace=0):
+    """The same trust region with Q given as 3x3-block CSR (test-only extension of the oracle: the reference's Q is dense).
+    Returns what trustregion() returns."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    blocks = np.ascontiguousarray(blocks, dtype=np.float64)
+    R0 = _f(R0)
+    n = rowptr.size - 1
+    o = R0.shape[1]
+    s0 = np.ascontiguousarray(s0_ex, dtype=np.float64).reshape(-1).copy()
+    R = np.zeros_like(R0, order="F"); s = np.zeros(n)
+    vv = np.zeros(3 * n)
+    gt = C.c_double(gradtol); pr = C.c_double(0.0)
+    st = Stats()
+    tr = None
+    if trace:
+        tr = np.zeros((trace, TRACE_STRIDE)); st.trace_cap = trace; st.trace = _p(tr)
+    L = lib()
+    L.xmo_set_bsr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.xmo_set_bsr(rowptr.ctypes.data, colidx.ctypes.data, blocks.ctypes.data)
+    try:
+        L.xmo_trustregion(n, o, None, _p(R0), _p(s0), _p(R), _p(s), lam, C.byref(gt), 0.0, _p(vv), C.byref(pr), maxtime,
+                          C.byref(st), flags)
+    finally:
+        L.xmo_set_bsr(None, None, None)
+    return R, s, pr.value, gt.value, _stats_dict(st, tr)
+
+
 def checkeig(Cm, sR, lam, primal, flags=0):
     """ce.h:42.  Returns accepted(bool), v (3n), cert dict."""
     Cm = _f(Cm); sR = _f(sR)

@@ -535,6 +535,26 @@ def test_rome13682_vs_recorded_oracle(xmamd):
     assert abs(i["tcg_iters"] - c["tcg"]) <= 0.2 * c["tcg"]
 
 
+def test_vg100k_vs_recorded_oracle(xmamd):
+    """BASELINE config 'synthetic 100k-camera Erdos-Renyi view-graph Q': the rank-3 trust region on the CPU oracle multiplying
+    from the same 3x3-block CSR (oracle.trustregion_bsr, 100 s on 8 cores; recorded in tests/golden/synth/vg100k_oracle.json with
+    every 8th camera's anchored rotation) against the GPU solve: same optimum, rotations <= 1e-6."""
+    fj = os.path.join(G, "synth", "vg100k_oracle.json")
+    if not os.path.exists(fj):
+        pytest.skip("recorded oracle run not present")
+    c = json.load(open(fj))
+    P = tl.gen_vg(c["n"], deg=c["deg"], sigma=c["sigma"], seed=c["n"], dense=False)
+    ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+    R, s, i = ctx.solve(5, c["tol"], c["lam"])
+    ctx.close()
+    assert i["rank"] == 3 and i["status"] == 1
+    assert i["primal"] == pytest.approx(c["f"], rel=1e-9)
+    rot, _ = tl.recover_rotations(R, s)
+    sub = rot.reshape(3, c["n"], 3)[:, ::8, :]
+    assert tl.rel_fro(sub, np.load(os.path.join(G, "synth", "vg100k_oracle_rot_every8.npy"))) < 1e-6
+    assert abs(i["tcg_iters"] - c["tcg"]) <= 0.2 * c["tcg"]
+
+
 def test_bench_two_ranks_flow(xmamd):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo control plane, per-rank on-device
     expansion of the Rome-scale Q, replicas leg), with both ranks on the one GPU of the test box and the library's

@@ -174,3 +174,18 @@ def test_bin_roundtrip_and_solve_path(oracle, tmp_path):
     rot, _ = tl.recover_rotations(R, s)
     assert tl.rel_fro(rot, np.load(os.path.join(G, "synth/dense49/rot_anchor.npy"))) < 1e-8
     assert oracle.solve_path(str(tmp_path / "missing"), 5, 1e-6, 0.0, 10.0) < 0
+
+
+def test_bsr_product_of_the_oracle_equals_dense(oracle):
+    """test-only extension (oracle/xm_oracle.c:xmo_set_bsr): the trust region multiplied from 3x3-block CSR must walk the same
+    path as from the dense matrix it describes (used to anchor the GPU's BSR3 storage at sizes the dense oracle cannot hold)"""
+    P = tl.gen_vg(120, deg=8, sigma=0.2, seed=12)
+    n = 120
+    R0 = np.tile(np.eye(3), (n, 1)); s0 = np.ones(n)
+    Rd, sd, pd, _, std = oracle.trustregion(P["Q"], R0, s0, lam=5.0, gradtol=1e-9)
+    Rb, sb, pb, _, stb = oracle.trustregion_bsr(P["rowptr"], P["colidx"], P["blocks"], R0, s0, lam=5.0, gradtol=1e-9)
+    assert pb == pytest.approx(pd, rel=1e-12)
+    assert tl.rotation_parity(Rb, sb, Rd, sd) < 1e-8
+    assert abs(stb["tcg_iters"] - std["tcg_iters"]) <= 0.05 * std["tcg_iters"] + 5
+    W = np.random.default_rng(0).standard_normal((3 * n, 4))
+    assert np.allclose(oracle.qw(P["Q"], W, 1.0), tl.bsr_to_dense(n, P["rowptr"], P["colidx"], P["blocks"]) @ W, atol=1e-12)
