@@ -55,13 +55,16 @@ def workload(name):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(Q, wl, budget_s):
+def cpu_baseline(Q, wl, budget_s, bsr=None):
     """oracle (CPU restatement) on the SAME Q/options, bounded by the reference's own max_time mechanism."""
     from oracle import xm_oracle as xo
-    n = Q.shape[0] // 3
+    n = wl["n"]
     R0 = np.tile(np.eye(3), (n, 1))
     t0 = time.time()
-    _, _, primal, _, st = xo.trustregion(Q, R0, np.ones(n), lam=wl["lam"], gradtol=wl["tol"], maxtime=budget_s)
+    if bsr is not None:   # block-sparse workloads: the oracle's test-only BSR3 product (the dense matrix would not fit)
+        _, _, primal, _, st = xo.trustregion_bsr(bsr[0], bsr[1], bsr[2], R0, np.ones(n), lam=wl["lam"], gradtol=wl["tol"], maxtime=budget_s)
+    else:
+        _, _, primal, _, st = xo.trustregion(Q, R0, np.ones(n), lam=wl["lam"], gradtol=wl["tol"], maxtime=budget_s)
     el = time.time() - t0
     its = st["tcg_iters"]
     return dict(value=its / max(st["seconds"], 1e-9), unit="tCG iters/s", cores=xo.num_threads(), kind="port",
@@ -263,6 +266,8 @@ def main():
         del Qbig, Wbig, Obig
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and Q is not None:
         out["cpu_baseline"] = cpu_baseline(Q, wl, args.cpu_seconds)
+    elif rank == 0 and world == 1 and args.cpu_seconds > 0 and wl["kind"] == "vg" and args.storage == "bsr":
+        out["cpu_baseline"] = cpu_baseline(None, wl, args.cpu_seconds, bsr=(P["rowptr"], P["colidx"], P["blocks"]))
     if world > 1:
         xmamd.lib().xm_comm_finalize()
         # Replica throughput: what N GPUs deliver on N INDEPENDENT Venice-size scenes (no data-path communication; the row
