@@ -25,6 +25,7 @@ for p in (ROOT, os.path.join(ROOT, "xm-code_amd"), os.path.join(ROOT, "tests")):
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:   # torchrun pins OMP_NUM_THREADS=1; give each rank its share of the host cores
     os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // int(os.environ["WORLD_SIZE"])))
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")              # control-plane rendezvous on loopback (hostname may not resolve)
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")              # RCCL bootstrap of the single-node communicator likewise
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (multi-process runs)
 
 import numpy as np  # noqa: E402
