@@ -147,6 +147,19 @@ int xm_qw_dense_sym(const double *dq, int64_t n, int o, const double *dW, double
 int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
 int xm_qw_bsr3(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o,
                const double *dW, double *dOut, double alpha, void *stream);
+
+/* Large block-sparse Q: "sliced ELL over per-XCD column slabs" (xm-code_amd/csrc/xm_sell.h).  Same product as xm_qw_bsr3
+ * (the reference has no sparse product: Dense/matmul.h:42-87 on a dense Q); the matrix is described on the HOST as 3x3-block CSR
+ * (rows n, global columns in [0, ncols)) and re-laid on the device.  slabs in {1,2,4,8}; lmax = longest virtual row (hub
+ * cameras are cut); gather_mode 0 | 1 selects how the rows of W are fetched.  xm_sell_layout is host-only (CPU tests): with
+ * NULL arrays it fills sizes = {slices, steps, partial slots, virtual rows}. */
+int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t sizes[4],
+                   int64_t *slice_off, int32_t *slab_start, uint8_t *kind, int64_t *src, int32_t *pslot, int64_t *pptr);
+int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
+                   void **handle);
+void xm_sell_destroy(void *handle);
+int xm_qw_sell(void *handle, int o, const double *dW, double *dOut, double alpha, int gather_mode, void *stream);
+int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gather_mode, int reps, double *ms_avg);
 /* per-camera kernels (device, row-major 3n x o; s: n):
  * Rout = MGS_rows(R + t*D) (Dense/batchedQR.h:42-67), sout = s*exp(t*ds/s) (trustregion.h:19-24), s[0] stays 1 */
 int xm_retract(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t,

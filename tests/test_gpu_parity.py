@@ -83,6 +83,65 @@ def test_retraction_matches_oracle(xmamd, oracle, o):
     assert tl.stiefel_defect(Rn) < 1e-13
 
 
+# ---------------------------------------------------------------------------------------------- sliced-ELL product (xm_sell.hip)
+@pytest.mark.parametrize("n,deg,o,slabs,lmax", [(1, 2, 3, 4, 64), (7, 3, 3, 8, 64), (200, 8, 3, 4, 64), (300, 20, 5, 2, 64), (1000, 12, 4, 8, 5),
+                                                (150, 40, 3, 1, 64), (211, 9, 1, 4, 64), (4000, 30, 3, 4, 64)])
+@pytest.mark.parametrize("gather", [0, 1])
+def test_qw_sell_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather):
+    """same product as test_qw_bsr3_matches_dense through the large-n layout: every slab count, both gather modes, virtual rows
+    cut at lmax, odd and even slice widths (paired steps + unpaired last step)"""
+    if o == 1 and gather == 1:
+        pytest.skip("o = 1 has one gather mode")
+    P = tl.gen_vg(n, deg=deg, sigma=0.3, seed=n + o)
+    W = np.random.default_rng(n).standard_normal((3 * n, o))
+    ref = oracle.qw(P["Q"], W, 1.5)
+    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax)
+    got = M.qw(W, 1.5, gather=gather)
+    M.close()
+    assert tl.rel_fro(got, ref) < 1e-13
+
+
+def test_qw_sell_skewed_degrees_and_unsorted_rows(xmamd):
+    """hub cameras (rows of ~n/4 blocks among rows of ~20: cut into virtual rows of <= lmax blocks, partial results added per camera),
+    cameras without blocks, rows handed over in arbitrary column order; the block-CSR kernel runs the same skewed matrix"""
+    n = 6000
+    P = tl.gen_skewed(n, 20, seed=7)
+    rowptr, colidx, blocks = P["rowptr"], P["colidx"].copy(), P["blocks"].copy()
+    assert np.diff(rowptr).max() > 50 * np.median(np.diff(rowptr))
+    rng = np.random.default_rng(1)
+    for r in rng.choice(n, size=300, replace=False):            # shuffle the column order inside some rows
+        a, e = rowptr[r], rowptr[r + 1]
+        perm = rng.permutation(e - a)
+        colidx[a:e] = colidx[a:e][perm]; blocks[a:e] = blocks[a:e][perm]
+    W = rng.standard_normal((3 * n, 3))
+    ref = np.zeros((3 * n, 3))
+    Wc = W.reshape(n, 3, 3)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    np.add.at(ref.reshape(n, 3, 3), rows, blocks @ Wc[colidx])
+    for slabs, lmax in [(4, 64), (8, 16), (1, 1000)]:
+        M = xmamd.SellMatrix(rowptr, colidx, blocks, slabs=slabs, lmax=lmax)
+        assert tl.rel_fro(M.qw(W), ref) < 1e-13
+        M.close()
+    assert tl.rel_fro(xmamd.qw_bsr3(rowptr, colidx, blocks, W), ref) < 1e-13
+
+
+def test_solve_through_sell_equals_csr_path(xmamd, monkeypatch):
+    """the whole solver (gradient / Hessian / certificate epilogues, Lanczos with o = 1) on the sliced-ELL product reaches the
+    optimum of the block-CSR path: same rank, status, primal to 1e-12, rotations to 1e-8"""
+    P = tl.gen_vg(700, deg=10, sigma=0.3, seed=11, dense=False)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("XM_BSR_SELL", mode)
+        ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+        res[mode] = ctx.solve(5, 1e-9, 20.0)
+        ctx.close()
+    (R0, s0, i0), (R1, s1, i1) = res["0"], res["1"]
+    assert i0["rank"] == i1["rank"] and i0["status"] == i1["status"] == 1
+    assert i1["primal"] == pytest.approx(i0["primal"], rel=1e-12)
+    assert i1["min_eig"] == pytest.approx(i0["min_eig"], abs=1e-7)
+    assert tl.rotation_parity(R1, s1, R0, s0) < 1e-8
+
+
 # ---------------------------------------------------------------------------------------------- whole solves
 def _check_against_golden(R, s, info, exp, d, tol_rot=1e-6):
     assert info["rank"] == exp["rank"] and info["status"] == exp["status"]

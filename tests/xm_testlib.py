@@ -223,3 +223,30 @@ def stiefel_defect(R):
 
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gen_skewed(n, deg, seed=None, hubs=None):
+    """Block-sparse symmetric Q with a skewed degree distribution: a view graph (path + Erdos-Renyi, mean degree `deg`) plus a few
+    hub cameras that see a large share of all cameras (what a landmark-rich frame does to a real view graph).  Random blocks
+    (kernel tests only; Q_ji = Q_ij^T, identity-like diagonal); returns the BSR3 arrays."""
+    seed = n if seed is None else seed
+    edges, rng = gen_vg_edges(n, deg, seed)
+    hubs = max(1, n // 2000) if hubs is None else hubs
+    extra = []
+    for h in rng.choice(n, size=hubs, replace=False):
+        others = rng.choice(n, size=max(1, n // 4), replace=False)
+        others = others[others != h]
+        extra.append(np.stack([np.minimum(h, others), np.maximum(h, others)], axis=1))
+    e = np.concatenate([edges] + extra, axis=0)
+    key = e[:, 0].astype(np.int64) * n + e[:, 1]
+    _, idx = np.unique(key, return_index=True)
+    e = e[np.sort(idx)]
+    i, j = e[:, 0], e[:, 1]
+    M = rng.standard_normal((e.shape[0], 3, 3))
+    rows = np.concatenate([np.arange(n), i, j]); cols = np.concatenate([np.arange(n), j, i])
+    blocks = np.concatenate([np.eye(3)[None] * (1.0 + np.arange(n))[:, None, None] / n, M, np.transpose(M, (0, 2, 1))], axis=0)
+    order = np.lexsort((cols, rows))
+    rows, cols, blocks = rows[order], cols[order], blocks[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    return dict(n=n, rowptr=np.cumsum(rowptr), colidx=cols.astype(np.int32), blocks=np.ascontiguousarray(blocks))

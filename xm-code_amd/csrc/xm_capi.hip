@@ -6,6 +6,7 @@
 #include <mutex>
 #include <vector>
 
+#include "xm_sell.h"
 #include "xm_solver.h"
 
 struct xm_ctx {
@@ -288,6 +289,61 @@ int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int6
     for (int i = 0; i < 3; ++i) xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr);
     XM_HIP_CHECK(hipEventRecord(e0, nullptr));
     for (int i = 0; i < reps; ++i) xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+    XM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_avg) *ms_avg = (double)ms / reps;
+    return XM_OK;
+    XM_CATCH
+}
+
+
+// ---- sliced-ELL product for large block-sparse Q (xm_sell.h) -------------------------------------------------------------
+int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t sizes[4],
+                   int64_t *slice_off, int32_t *slab_start, uint8_t *kind, int64_t *src, int32_t *pslot, int64_t *pptr) {
+    XM_TRY
+    xm::SellHost h;
+    xm::sell_build_host(rowptr, colidx, n, ncols, slabs, lmax, h);   // host only: no device needed
+    if (sizes) { sizes[0] = h.nslices; sizes[1] = h.nsteps; sizes[2] = h.nparts; sizes[3] = h.nvrows; }
+    if (slice_off) std::copy(h.slice_off.begin(), h.slice_off.end(), slice_off);
+    if (slab_start) std::copy(h.slab_start.begin(), h.slab_start.end(), slab_start);
+    if (kind) std::copy(h.kind.begin(), h.kind.end(), kind);
+    if (src) std::copy(h.src.begin(), h.src.end(), src);
+    if (pslot) std::copy(h.pslot.begin(), h.pslot.end(), pslot);
+    if (pptr) std::copy(h.pptr.begin(), h.pptr.end(), pptr);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
+                   void **handle) {
+    XM_TRY
+    require_device();
+    if (!rowptr || !handle || n < 1) throw xm::Error(XM_ERR_ARG, "bad argument");
+    *handle = new xm::SellMatrix(rowptr, colidx, blocks, n, ncols, slabs, lmax, nullptr);
+    return XM_OK;
+    XM_CATCH
+}
+void xm_sell_destroy(void *handle) { delete static_cast<xm::SellMatrix *>(handle); }
+int xm_qw_sell(void *handle, int o, const double *dW, double *dOut, double alpha, int gather_mode, void *stream) {
+    XM_TRY
+    if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
+    xm::SellMatrix &m = *static_cast<xm::SellMatrix *>(handle);
+    xm::launch_qw_sell(o, xm::EPI_PLAIN, m, dW, alpha, plain_args(m.nloc(), dOut), gather_mode, (hipStream_t)stream);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gather_mode, int reps, double *ms_avg) {
+    XM_TRY
+    if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
+    xm::SellMatrix &m = *static_cast<xm::SellMatrix *>(handle);
+    hipEvent_t e0, e1;
+    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+    const xm::CamArgs a = plain_args(m.nloc(), dOut);
+    for (int i = 0; i < 3; ++i) xm::launch_qw_sell(o, xm::EPI_PLAIN, m, dW, 1.0, a, gather_mode, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) xm::launch_qw_sell(o, xm::EPI_PLAIN, m, dW, 1.0, a, gather_mode, nullptr);
     XM_HIP_CHECK(hipEventRecord(e1, nullptr));
     XM_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;

@@ -29,6 +29,7 @@ __host__ __device__ constexpr int pitch_of(int o) { return o | 1; }
 
 constexpr int kQwWaves = 4;       // cameras (wavefronts) per workgroup in the Q*W kernels
 constexpr int kQwNsub = 2;        // 128-column sub-chunks per LDS-staged W tile (tile = 256 columns)
+constexpr int kBsrRows = 16;     // camera rows per workgroup of the BSR3 kernels (4 wavefronts x 4 lane groups of 16)
 constexpr int kColPad = 128;      // dense leading dimension is a multiple of this (64 lanes x double2)
 constexpr int kMaxRank = 10;      // template instantiations cover o = 1 and 3..10
 constexpr int kMaxInner = 1000;   // trustregion.h:416
@@ -134,5 +135,26 @@ void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hi
 void launch_lz_alpha(const double *c1j, const double *c2j, double *alpha_j, hipStream_t st);
 void launch_lz_next(double *dst, const double *w, const double *ww, double *beta_j, int64_t len, hipStream_t st);
 void launch_gemv_n(double *y, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);  // y = V c
+
+
+// ---- host-side launch helpers shared by the kernel translation units ---------------------------------------------
+#define XM_DISPATCH_O(o, CALL)                                                         \
+    switch (o) {                                                                       \
+        case 1: { constexpr int O_ = 1; CALL; } break;                                 \
+        case 3: { constexpr int O_ = 3; CALL; } break;                                 \
+        case 4: { constexpr int O_ = 4; CALL; } break;                                 \
+        case 5: { constexpr int O_ = 5; CALL; } break;                                 \
+        case 6: { constexpr int O_ = 6; CALL; } break;                                 \
+        case 7: { constexpr int O_ = 7; CALL; } break;                                 \
+        case 8: { constexpr int O_ = 8; CALL; } break;                                 \
+        case 9: { constexpr int O_ = 9; CALL; } break;                                 \
+        case 10: { constexpr int O_ = 10; CALL; } break;                               \
+        default: throw Error(-2, "rank o must be 1 or 3..10, got " + std::to_string(o)); \
+    }
+
+inline void check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Error(-3, std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
+}
 
 }  // namespace xm

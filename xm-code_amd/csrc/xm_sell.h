@@ -1,0 +1,84 @@
+// xm_sell.h — "sliced ELL over virtual rows" storage of a 3x3-block sparse Q for the large-n Q*W product (xm_sell.hip).
+//
+// Why a second sparse layout (the reference has none: its Q is dense, Dense/matmul.h:42-87): with 3x3-block CSR
+// and one 16-lane group per camera row the 100k-camera product is bound twice over (profiles/r01_pmc_bsr3_100k.json) —
+// (i) fabric traffic 2.24x the algorithmic bytes, because the gathered operand W (7.2 MB at o = 3) does not fit the 4 MB L2 of
+// an XCD and every miss pulls a 128-byte line for a 72-byte record, and (ii) the load path: ~11 load instructions per 64 blocks
+// most of which touch many sectors, plus ~290 VALU lane-instructions per block of index arithmetic, LDS staging and reductions
+// around the 27 FMAs that matter.  This layout removes both:
+//   * COLUMN SLABS PER XCD.  The cameras (columns) are cut into S slabs (S = 1, 2, 4, 8); workgroup b runs on XCD b % 8 (observed
+//     dispatch rule, used for speed only) and works on slab (b % 8) * S / 8 only, so an XCD gathers from a 7.2 MB / S slice of W
+//     that stays resident in its own L2.  Every camera row is cut into per-slab segments ("virtual rows", additionally cut at
+//     `lmax` blocks so that a hub camera cannot serialise a lane); a virtual row produces a partial 3 x o result, and a second
+//     small kernel adds the partials of a camera in a fixed order and runs the fused epilogue.
+//   * ONE LANE PER VIRTUAL ROW, blocks stored lane-interleaved (sliced ELL): the virtual rows of a slab are sorted by length and
+//     packed 64 to a slice; step k of a slice holds the k-th block of each of its 64 virtual rows as 9 planes of 64 doubles
+//     (two steps interleaved -> every lane loads 16 aligned bytes, every wave instruction covers 1 KiB of contiguous memory).
+//     No LDS staging, no cross-lane reduction, no per-block index arithmetic: per block a lane issues its share of 9.5 coalesced
+//     loads, gathers its 3 x o rows of W and does the 9*o FMAs.
+// Sorting makes the padding negligible (only slices that straddle two length classes carry any).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "xm_solver.h"
+
+namespace xm {
+
+// host-side description (built by sell_build_host; exported through xm_sell_layout for the CPU tests)
+struct SellHost {
+    int64_t nloc = 0, ncols = 0;
+    int S = 1, lmax = 0;
+    int64_t nvrows = 0, nslices = 0, nsteps = 0, nparts = 0;
+    std::vector<int64_t> slice_off;   // nslices + 1, in steps; a slice of width w owns steps [off, off + w)
+    std::vector<int32_t> slab_start;  // S + 1, in slices
+    std::vector<uint8_t> kind;        // nsteps: 0 = first step of a pair, 1 = second step of a pair, 2 = unpaired last step
+    std::vector<int64_t> src;         // nsteps * 64: source block of (step, lane) in the CSR arrays, -1 = padding
+    std::vector<int32_t> pslot;       // nslices * 64: partial-result slot of (slice, lane), -1 = padding lane
+    std::vector<int64_t> pptr;        // nloc + 1: the partial results of camera r are slots [pptr[r], pptr[r+1])
+};
+
+// rowptr: nloc + 1 offsets (rowptr[0] may be non-zero: offsets into colidx); colidx: global columns in [0, ncols).
+// Throws Error(XM_ERR_ARG) on a malformed description (non-monotone rowptr, column out of range).
+void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc, int64_t ncols, int S, int lmax, SellHost &out);
+
+struct SellArgs {   // what the kernels see
+    const int64_t *slice_off;
+    const int32_t *slab_start;
+    const int32_t *cols;    // step unit = 64 ints: pair [lane][2] over two units, single [lane]
+    const double *blk;      // step unit = 576 doubles: pair [e][lane][2] over two units, single [e][lane]
+    const int32_t *pslot;
+    const int64_t *pptr;
+    int S;
+};
+
+class SellMatrix {
+public:
+    // blocks: host, 9 doubles per block (row-major 3x3), indexed like colidx
+    SellMatrix(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t nloc, int64_t ncols, int S, int lmax,
+               hipStream_t st);
+    SellArgs args() const;
+    double *parts(int o);          // partial-result buffer for rank o (grow-only)
+    int grid() const { return grid_; }
+    int64_t nloc() const { return nloc_; }
+    int64_t nparts() const { return nparts_; }
+    int64_t nsteps() const { return nsteps_; }
+    int S() const { return S_; }
+
+private:
+    int64_t nloc_ = 0, nparts_ = 0, nsteps_ = 0, nslices_ = 0;
+    int S_ = 1, grid_ = 0;
+    DevBuf<int64_t> slice_off_, pptr_;
+    DevBuf<int32_t> slab_start_, cols_, pslot_;
+    DevBuf<double> blk_, parts_;
+    int parts_o_ = 0;
+};
+
+// product = two launches: partial results per virtual row, then per-camera sum + fused epilogue (same CamArgs contract and
+// the same per-workgroup partial sums, grid bsr_grid(nloc), as launch_qw_bsr3).  gm: 0 = each lane loads its own record of W,
+// 1 = records fetched element-per-lane and transposed through LDS.
+void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st);
+bool sell_supports(int o);
+
+}  // namespace xm

@@ -1,0 +1,506 @@
+// xm_sell.hip — large-n block-sparse Q*W: sliced-ELL over per-XCD column slabs (layout and rationale: xm_sell.h).
+// Replaces, for view-graph-sparse Q, the product the reference runs as cublasDgemm on a dense matrix (Dense/matmul.h:42-87,
+// call sites trustregion.h:165,187,237,553, checkeig.h:182); the fused epilogues are the ones of xm_device.h.
+#include "xm_sell.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <type_traits>
+
+#include "xm_device.h"
+
+namespace xm {
+
+// ------------------------------------------------------------------------------------------------------------------
+// host: build the layout description
+// ------------------------------------------------------------------------------------------------------------------
+void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc, int64_t ncols, int S, int lmax, SellHost &out) {
+    if (!(S == 1 || S == 2 || S == 4 || S == 8)) throw Error(XM_ERR_ARG, "SELL: slabs must be 1, 2, 4 or 8");
+    if (lmax < 2) throw Error(XM_ERR_ARG, "SELL: lmax must be >= 2");
+    if (nloc < 0 || ncols < 1 || !rowptr) throw Error(XM_ERR_ARG, "SELL: bad sizes");
+    out = SellHost();
+    out.nloc = nloc; out.ncols = ncols; out.S = S; out.lmax = lmax;
+    const int64_t b0 = rowptr[0], nb = rowptr[nloc] - b0;
+    if (nb < 0) throw Error(XM_ERR_ARG, "BSR3: rowptr is not monotone");
+    if (nb > 0 && !colidx) throw Error(XM_ERR_ARG, "BSR3: colidx missing");
+    // order[i]: i-th block of the matrix with every row in ascending column order (identity when the rows are sorted already)
+    std::vector<int64_t> order((size_t)nb);
+    std::iota(order.begin(), order.end(), b0);
+    for (int64_t r = 0; r < nloc; ++r) {
+        const int64_t a = rowptr[r], e = rowptr[r + 1];
+        if (e < a) throw Error(XM_ERR_ARG, "BSR3: rowptr is not monotone");
+        bool sorted = true;
+        for (int64_t q = a; q < e; ++q) {
+            const int32_t c = colidx[q];
+            if (c < 0 || (int64_t)c >= ncols) throw Error(XM_ERR_ARG, "BSR3: column index out of range");
+            if (q > a && colidx[q - 1] > c) sorted = false;
+        }
+        if (!sorted)
+            std::stable_sort(order.begin() + (a - b0), order.begin() + (e - b0), [&](int64_t x, int64_t y) { return colidx[x] < colidx[y]; });
+    }
+    auto slab_of = [&](int32_t c) { return (int)(((int64_t)c * S) / ncols); };
+    struct VRow { int64_t start; int32_t len; int32_t slot; };   // start: position in `order`
+    std::vector<std::vector<VRow>> per_slab((size_t)S);
+    // Partial results are numbered ROW-major (camera r owns the contiguous slots [pptr[r], pptr[r+1]), slab by slab): the per-camera
+    // sum reads one contiguous run.  Slab-major numbering (each slab's region written by its own XCDs only) was measured and is
+    // slower: 127-145 us against 115-131 us per product at 100k cameras, S = 4.
+    out.pptr.assign((size_t)nloc + 1, 0);
+    int64_t slot = 0;
+    for (int64_t r = 0; r < nloc; ++r) {
+        out.pptr[(size_t)r] = slot;
+        int64_t q = rowptr[r] - b0;
+        const int64_t e = rowptr[r + 1] - b0;
+        while (q < e) {
+            const int s = slab_of(colidx[order[(size_t)q]]);
+            int64_t q2 = q;
+            while (q2 < e && q2 - q < lmax && slab_of(colidx[order[(size_t)q2]]) == s) ++q2;
+            if (slot > 2147483000LL) throw Error(XM_ERR_ARG, "SELL: too many partial results");
+            per_slab[(size_t)s].push_back(VRow{q, (int32_t)(q2 - q), (int32_t)slot});
+            ++slot;
+            q = q2;
+        }
+    }
+    out.pptr[(size_t)nloc] = slot;
+    out.nparts = slot;
+    // per slab: stable counting sort by length (descending), then slices of 64
+    out.slab_start.assign((size_t)S + 1, 0);
+    out.slice_off.clear();
+    out.slice_off.push_back(0);
+    std::vector<VRow> sorted;
+    for (int s = 0; s < S; ++s) {
+        const std::vector<VRow> &v = per_slab[(size_t)s];
+        std::vector<int64_t> cnt((size_t)lmax + 2, 0);
+        for (const VRow &x : v) cnt[(size_t)(lmax - x.len) + 1]++;          // bucket 0 = longest
+        for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+        sorted.resize(v.size());
+        for (const VRow &x : v) sorted[(size_t)cnt[(size_t)(lmax - x.len)]++] = x;
+        out.nvrows += (int64_t)v.size();
+        for (size_t i = 0; i < sorted.size(); i += 64) {
+            const int w = sorted[i].len;
+            const int64_t off = out.slice_off.back();
+            out.slice_off.push_back(off + w);
+            out.kind.resize((size_t)(off + w));
+            out.src.resize((size_t)(off + w) * 64, -1);
+            out.pslot.resize(out.pslot.size() + 64, -1);
+            for (int k = 0; k < w; ++k) out.kind[(size_t)(off + k)] = (uint8_t)((k < (w & ~1)) ? (k & 1) : 2);
+            const size_t cnt_l = std::min<size_t>(64, sorted.size() - i);
+            for (size_t l = 0; l < cnt_l; ++l) {
+                const VRow &x = sorted[i + l];
+                out.pslot[out.pslot.size() - 64 + l] = x.slot;
+                for (int k = 0; k < x.len; ++k) out.src[(size_t)(off + k) * 64 + l] = order[(size_t)(x.start + k)];
+            }
+        }
+        out.slab_start[(size_t)s + 1] = (int32_t)(out.slice_off.size() - 1);
+    }
+    out.nslices = (int64_t)out.slice_off.size() - 1;
+    out.nsteps = out.slice_off.back();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// device: fill the interleaved arrays from the CSR arrays (one thread per (step, lane))
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sell_fill_kernel(int64_t nsteps, const int64_t *__restrict__ src, const uint8_t *__restrict__ kind,
+                                                         const int32_t *__restrict__ colidx, const double *__restrict__ blocks, int64_t b0,
+                                                         int32_t *__restrict__ cols, double *__restrict__ blk) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nsteps * 64) return;
+    const int64_t g = t >> 6;
+    const int lane = (int)(t & 63);
+    const int kd = kind[g];
+    const int64_t s = src[t];
+    const int32_t c = (s < 0) ? 0 : colidx[s - b0];
+    double q[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) q[e] = (s < 0) ? 0.0 : blocks[(s - b0) * 9 + e];
+    if (kd == 2) {
+        cols[g * 64 + lane] = c;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) blk[g * 576 + e * 64 + lane] = q[e];
+    } else {
+        const int64_t gb = g - kd;   // first unit of the pair
+        cols[gb * 64 + lane * 2 + kd] = c;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) blk[gb * 576 + e * 128 + lane * 2 + kd] = q[e];
+    }
+}
+
+SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t nloc, int64_t ncols, int S, int lmax,
+                       hipStream_t st) {
+    SellHost h;
+    sell_build_host(rowptr, colidx, nloc, ncols, S, lmax, h);
+    nloc_ = nloc; nparts_ = h.nparts; nsteps_ = h.nsteps; nslices_ = h.nslices; S_ = S;
+    const int64_t b0 = rowptr[0], nb = rowptr[nloc] - b0;
+    slice_off_.alloc(h.slice_off.size(), false);
+    slab_start_.alloc(h.slab_start.size(), false);
+    pslot_.alloc(std::max<size_t>(h.pslot.size(), 1), false);
+    pptr_.alloc(h.pptr.size(), false);
+    cols_.alloc((size_t)std::max<int64_t>(nsteps_, 1) * 64, false);
+    blk_.alloc((size_t)std::max<int64_t>(nsteps_, 1) * 576, false);
+    XM_HIP_CHECK(hipMemcpy(slice_off_.p, h.slice_off.data(), h.slice_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    XM_HIP_CHECK(hipMemcpy(slab_start_.p, h.slab_start.data(), h.slab_start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!h.pslot.empty()) XM_HIP_CHECK(hipMemcpy(pslot_.p, h.pslot.data(), h.pslot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    XM_HIP_CHECK(hipMemcpy(pptr_.p, h.pptr.data(), h.pptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (nsteps_ > 0) {
+        DevBuf<int64_t> dsrc; DevBuf<uint8_t> dkind; DevBuf<int32_t> dci; DevBuf<double> dbl;
+        dsrc.alloc(h.src.size(), false); dkind.alloc(h.kind.size(), false);
+        dci.alloc((size_t)std::max<int64_t>(nb, 1), false); dbl.alloc((size_t)std::max<int64_t>(nb, 1) * 9, false);
+        XM_HIP_CHECK(hipMemcpy(dsrc.p, h.src.data(), h.src.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        XM_HIP_CHECK(hipMemcpy(dkind.p, h.kind.data(), h.kind.size(), hipMemcpyHostToDevice));
+        XM_HIP_CHECK(hipMemcpy(dci.p, colidx + b0, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice));
+        XM_HIP_CHECK(hipMemcpy(dbl.p, blocks + b0 * 9, (size_t)nb * 9 * sizeof(double), hipMemcpyHostToDevice));
+        const int64_t threads = nsteps_ * 64;
+        hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, nsteps_, dsrc.p, dkind.p, dci.p, dbl.p,
+                           b0, cols_.p, blk_.p);
+        check_launch("sell_fill");
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    // workgroups: 4 slices each, dealt to the XCDs that serve the slab (block b -> XCD b % 8)
+    const int per = 8 / S;
+    int64_t imax = 0;
+    for (int s = 0; s < S; ++s) {
+        const int64_t nsl = h.slab_start[(size_t)s + 1] - h.slab_start[(size_t)s];
+        const int64_t wgs = (nsl + 3) / 4;
+        imax = std::max(imax, (wgs + per - 1) / per);
+    }
+    grid_ = (int)(imax * 8);
+}
+
+SellArgs SellMatrix::args() const {
+    SellArgs a;
+    a.slice_off = slice_off_.p; a.slab_start = slab_start_.p; a.cols = cols_.p; a.blk = blk_.p; a.pslot = pslot_.p; a.pptr = pptr_.p;
+    a.S = S_;
+    return a;
+}
+
+double *SellMatrix::parts(int o) {
+    if (o > parts_o_) {
+        parts_.alloc((size_t)std::max<int64_t>(nparts_, 1) * 3 * (size_t)o, false);
+        parts_o_ = o;
+    }
+    return parts_.p;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// device: the product.  One wavefront per slice, one lane per virtual row.
+// ------------------------------------------------------------------------------------------------------------------
+typedef double d2a __attribute__((ext_vector_type(2)));               // 16-byte aligned pair
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));   // pair at 8-byte alignment (records of W)
+typedef int i2a __attribute__((ext_vector_type(2)));
+
+template <int O, int GM>
+struct SellBuf {   // one pipeline stage: two steps of blocks and the two gathered records of W
+    static constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2;
+    d2a q[9];
+    double w[2][(GM == 0) ? REC : 1];
+    d2u raw[2][(GM == 1) ? NPR : 1];
+};
+
+template <int O, int GM, int ABL = 0, int PIPE = 0>   // PIPE 1: block loads run one pair ahead.  ABL: ablation bits for timing experiments (1 no block loads, 2 no gather, 4 no partial store)
+__global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
+                                                       double *__restrict__ parts) {
+    constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2, RECP = (REC + 1) & ~1;
+    if (scal != nullptr) {
+        if (scal->status != 0) return;
+    }
+    __shared__ __attribute__((aligned(16))) double lds[(GM == 1) ? 4 * 2 * 64 * RECP : 2];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per = 8 / m.S;
+    const int x = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int slab = x / per, sub = x - slab * per;
+    const int c = m.slab_start[slab] + (bi * per + sub) * 4 + wave;
+    if (c >= m.slab_start[slab + 1]) return;   // wave-uniform
+    const int64_t off = m.slice_off[c];
+    const int w = (int)(m.slice_off[c + 1] - off);
+    const int np = w >> 1;
+    const bool tail = (w & 1) != 0;
+    const int32_t *cb = m.cols + off * 64;
+    const double *bb = m.blk + off * 576;
+    double *L = lds + ((GM == 1) ? wave * 2 * 64 * RECP : 0);
+
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+
+    auto load_cols = [&](int p) -> i2a { return __builtin_nontemporal_load(reinterpret_cast<const i2a *>(cb) + (size_t)p * 64 + lane); };
+    auto load_blk = [&](int p, d2a (&q)[9]) {
+        const d2a *b = reinterpret_cast<const d2a *>(bb) + (size_t)p * 576 + lane;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            if constexpr (ABL & 1) { q[e] = d2a{(double)(lane + e), (double)(p - e)}; asm volatile("" : "+v"(q[e])); }
+            else q[e] = __builtin_nontemporal_load(b + e * 64);
+        }
+    };
+    // GM 0: every lane reads its own record (REC doubles at 8-byte alignment)
+    auto gather0 = [&](int j, double (&wv)[REC]) {
+        const double *wp = W + (size_t)j * REC;
+#pragma unroll
+        for (int i = 0; i < REC / 2; ++i) {
+            const d2u t = *reinterpret_cast<const d2u *>(wp + 2 * i);
+            wv[2 * i] = t.x; wv[2 * i + 1] = t.y;
+        }
+        if (REC & 1) wv[REC - 1] = wp[REC - 1];
+    };
+    // GM 1: the 64 records of a step are fetched element-per-lane (one load instruction covers 1 KiB of the concatenated
+    // records, i.e. ~13 records instead of 64) and turned back into lane-per-record through LDS
+    auto gather1 = [&](int j, d2u (&raw)[NPR]) {
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+            const int g = lane + 64 * i;
+            const int rec = g / NPR, part = g - rec * NPR;
+            const int start = (2 * part < REC - 2) ? 2 * part : REC - 2;
+            const int jr = __shfl(j, rec, 64);
+            raw[i] = *reinterpret_cast<const d2u *>(W + (size_t)jr * REC + start);
+        }
+    };
+    auto transpose1 = [&](const d2u (&raw)[NPR], double *Ls, double (&wv)[REC]) {
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+            const int g = lane + 64 * i;
+            const int rec = g / NPR, part = g - rec * NPR;
+            if ((REC & 1) && part == NPR - 1) Ls[rec * RECP + REC - 1] = raw[i].y;
+            else *reinterpret_cast<d2a *>(Ls + rec * RECP + 2 * part) = d2a{raw[i].x, raw[i].y};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < RECP / 2; ++i) {
+            const d2a t = *reinterpret_cast<const d2a *>(Ls + lane * RECP + 2 * i);
+            if (2 * i < REC) wv[2 * i] = t.x;
+            if (2 * i + 1 < REC) wv[2 * i + 1] = t.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto fma_step = [&](const double (&q)[9], const double (&wv)[REC]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k)
+                acc[r][k] = fma(q[3 * r + 2], wv[2 * OP + k], fma(q[3 * r + 1], wv[OP + k], fma(q[3 * r], wv[k], acc[r][k])));
+    };
+    auto gather_pair = [&](const i2a j, SellBuf<O, GM> &B) {
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if constexpr (GM == 0) {
+#pragma unroll
+                    for (int i = 0; i < REC; ++i) { B.w[h][i] = (double)(h ? j.y : j.x) + i; asm volatile("" : "+v"(B.w[h][i])); }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NPR; ++i) { B.raw[h][i] = d2u{(double)(h ? j.y : j.x), (double)i}; asm volatile("" : "+v"(B.raw[h][i])); }
+                }
+            }
+        } else if constexpr (GM == 0) { gather0(j.x, B.w[0]); gather0(j.y, B.w[1]); }
+        else { gather1(j.x, B.raw[0]); gather1(j.y, B.raw[1]); }
+    };
+
+    // One pair of steps per iteration, single-buffered: the memory-level parallelism comes from the resident wavefronts (each has
+    // ~20 KB of loads in flight), not from a per-wave software pipeline, which would double the register footprint and halve
+    // the occupancy.  Only the column indices run one pair ahead (they head the dependent chain index -> gathered record).
+    SellBuf<O, GM> A;
+    if constexpr (PIPE == 1) {
+        // PIPE 1: the block stream (HBM latency) runs one pair ahead of the gathers (L2 latency), the column indices two pairs
+        // ahead; only the blocks are double-buffered (the gathered records would cost another 36-40 registers).
+        d2a qA[9], qB[9];
+        i2a jc = {0, 0}, jn = {0, 0};
+        auto body = [&](int p, d2a (&cur)[9], d2a (&nxt)[9], auto pf) {
+            constexpr bool PF = decltype(pf)::value;
+            i2a jnn = jn;
+            if constexpr (PF) {
+                jnn = load_cols((p + 2 < np) ? p + 2 : p + 1);   // clamped, unconditional
+                load_blk(p + 1, nxt);
+            }
+            gather_pair(jc, A);
+            __builtin_amdgcn_sched_barrier(0);
+            double q0[9], q1[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { q0[e] = cur[e].x; q1[e] = cur[e].y; }
+            if constexpr (GM == 0) {
+                fma_step(q0, A.w[0]);
+                fma_step(q1, A.w[1]);
+            } else {
+                double w0[REC];
+                transpose1(A.raw[0], L, w0);
+                fma_step(q0, w0);
+                transpose1(A.raw[1], L + 64 * RECP, w0);
+                fma_step(q1, w0);
+            }
+            if constexpr (PF) asm volatile("" : "+v"(jnn.x), "+v"(jnn.y));   // keeps the index prefetch in this iteration
+            jc = jn; jn = jnn;
+        };
+        if (np > 0) {
+            jc = load_cols(0);
+            jn = load_cols((np > 1) ? 1 : 0);
+            load_blk(0, qA);
+            int p = 0;
+            for (; p + 2 < np; p += 2) {
+                body(p, qA, qB, std::true_type{});
+                body(p + 1, qB, qA, std::true_type{});
+            }
+            if (np - p == 2) {
+                body(p, qA, qB, std::true_type{});
+                body(p + 1, qB, qA, std::false_type{});
+            } else {
+                body(p, qA, qB, std::false_type{});
+            }
+        }
+    } else
+    if (np > 0) {
+        i2a jc = load_cols(0);
+        for (int p = 0; p < np; ++p) {
+            i2a jn = load_cols((p + 1 < np) ? p + 1 : p);   // clamped, unconditional
+            load_blk(p, A.q);
+            gather_pair(jc, A);
+            __builtin_amdgcn_sched_barrier(0);   // every load of the pair is in flight before the first FMA (the scheduler would
+                                                 // otherwise trickle them to save registers: 4-5 dependent round trips per pair)
+            double q0[9], q1[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { q0[e] = A.q[e].x; q1[e] = A.q[e].y; }
+            if constexpr (GM == 0) {
+                fma_step(q0, A.w[0]);
+                fma_step(q1, A.w[1]);
+            } else {
+                double w0[REC];
+                transpose1(A.raw[0], L, w0);
+                fma_step(q0, w0);
+                transpose1(A.raw[1], L + 64 * RECP, w0);
+                fma_step(q1, w0);
+            }
+            // keep the prefetch in THIS iteration: without a use here the compiler moves the load across the back edge to the top of
+            // the next iteration, where it heads the dependent chain again (seen in the ISA)
+            asm volatile("" : "+v"(jn.x), "+v"(jn.y));
+            jc = jn;
+        }
+    }
+    if (tail) {
+        const int jt = __builtin_nontemporal_load(cb + (size_t)np * 128 + lane);
+        double qt[9];
+        const double *b = bb + (size_t)np * 1152 + lane;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) qt[e] = __builtin_nontemporal_load(b + e * 64);
+        if constexpr (GM == 0) {
+            double wt[REC];
+            gather0(jt, wt);
+            fma_step(qt, wt);
+        } else {
+            d2u rawt[NPR];
+            double w0[REC];
+            gather1(jt, rawt);
+            transpose1(rawt, L, w0);
+            fma_step(qt, w0);
+        }
+    }
+    const int slot = m.pslot[(size_t)c * 64 + lane];
+    if constexpr (ABL & 4) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k) t += acc[r][k];
+        if (t == 1.2345e-300) parts[0] = t;   // keeps the accumulators alive
+    } else if (slot >= 0) {
+        double *o = parts + (size_t)slot * 3 * O;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k) o[r * O + k] = acc[r][k];
+    }
+}
+
+// per camera: partial results added in slot order (fixed -> bit-reproducible), then the common tail of the Q*W kernels
+// (16-lane group per camera, column-per-lane epilogue, per-workgroup partial sums) exactly as in qw_bsr3_kernel
+template <int O, int EPI>
+__global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restrict__ pptr, const double *__restrict__ parts, double alpha,
+                                                           CamArgs a) {
+    if (EPI == EPI_HESS) {
+        if (a.scal->status != 0) return;
+    }
+    __shared__ double red[kBsrRows][3];
+    const int gl = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int cam = blockIdx.x * kBsrRows + slot;
+    const bool active = cam < a.nloc;
+    EpiOps eops;
+    epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+    if (active) {
+        const int64_t p1 = pptr[cam + 1];
+        for (int64_t p = pptr[cam] + gl; p < p1; p += 16) {   // fixed order: lane gl takes slots gl, gl + 16, ...
+            const double *v = parts + (size_t)p * 3 * O;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc[r][k] += v[r * O + k];
+        }
+    }
+    qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red);
+}
+
+bool sell_supports(int o) { return o == 1 || (o >= 3 && o <= 5); }
+
+template <int O>
+static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st) {
+    const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
+    double *parts = m.parts(O);
+    const SellArgs sa = m.args();
+    if (m.grid() > 0) {
+        const dim3 g(m.grid()), b(256);
+        static const int abl = [] { const char *e = std::getenv("XM_SELL_ABLATE"); return (e && *e) ? std::atoi(e) : 0; }();   // timing experiments only
+        if constexpr (O == 3) {
+            if (abl != 0) {
+#define XM_ABL_CASE(G, A) if (gm == G && abl == A) hipLaunchKernelGGL((qw_sell_kernel<3, G, A>), g, b, 0, st, sa, W, sc, parts);
+                XM_ABL_CASE(0, 1) XM_ABL_CASE(0, 2) XM_ABL_CASE(0, 3) XM_ABL_CASE(0, 4) XM_ABL_CASE(0, 6) XM_ABL_CASE(0, 7)
+                XM_ABL_CASE(1, 1) XM_ABL_CASE(1, 2) XM_ABL_CASE(1, 4)
+#undef XM_ABL_CASE
+            }
+        }
+        // block loads one pair ahead: worth 2-3 us at o = 3; beyond that the second block buffer costs the occupancy (o = 5: 256 VGPRs)
+        static const int pipe_env = [] { const char *e = std::getenv("XM_SELL_PIPE"); return (e && *e) ? std::atoi(e) : -1; }();
+        const int pipe = (pipe_env >= 0) ? pipe_env : (O == 3 ? 1 : 0);
+        if (abl == 0 || O != 3) {
+            if (pipe == 1) {
+                if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, 0, 1>), g, b, 0, st, sa, W, sc, parts);
+                else hipLaunchKernelGGL((qw_sell_kernel<O, 0, 0, 1>), g, b, 0, st, sa, W, sc, parts);
+            } else {
+                if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1>), g, b, 0, st, sa, W, sc, parts);
+                else hipLaunchKernelGGL((qw_sell_kernel<O, 0>), g, b, 0, st, sa, W, sc, parts);
+            }
+        }
+    }
+    const dim3 g(bsr_grid(a.nloc)), b(256);
+    switch (epi) {
+        case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, sa.pptr, parts, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, sa.pptr, parts, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_HESS>), g, b, 0, st, sa.pptr, parts, alpha, a); break;
+        default: throw Error(XM_ERR_ARG, "bad epilogue");
+    }
+}
+
+void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st) {
+    if (a.nloc <= 0) return;
+    if (epi == EPI_CERT) {
+        if (o != 1) throw Error(XM_ERR_ARG, "certificate operator needs o == 1");
+        double *parts = m.parts(1);
+        const SellArgs sa = m.args();
+        if (m.grid() > 0) hipLaunchKernelGGL((qw_sell_kernel<1, 0>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
+        hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT>), dim3(bsr_grid(a.nloc)), dim3(256), 0, st, sa.pptr, parts, alpha, a);
+    } else {
+        switch (o) {
+            case 1: qw_sell_o<1>(epi, m, W, alpha, a, 0, st); break;
+            case 3: qw_sell_o<3>(epi, m, W, alpha, a, gm, st); break;
+            case 4: qw_sell_o<4>(epi, m, W, alpha, a, gm, st); break;
+            case 5: qw_sell_o<5>(epi, m, W, alpha, a, gm, st); break;
+            default: throw Error(XM_ERR_ARG, "SELL product is instantiated for o = 1, 3, 4, 5");
+        }
+    }
+    check_launch("qw_sell");
+}
+
+}  // namespace xm

@@ -1,6 +1,7 @@
 // xm_solver.h — host-side driver of the MI355X-native XM solve (C++; mirrors XM_main.cu / trustregion.h / checkeig.h).
 #pragma once
 
+#include <chrono>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -53,6 +54,8 @@ struct DevBuf {
     }
 };
 
+class SellMatrix;   // xm_sell.h
+
 struct PointState {  // everything the gradient epilogue writes for one point (R, s)
     DevBuf<double> G, egs, S0, rgR, rgs;
 };
@@ -91,6 +94,8 @@ private:
     DevBuf<int32_t> colidx_;
     DevBuf<double> blocks_;
     int64_t nb_loc_ = 0;
+    std::unique_ptr<SellMatrix> sell_;   // large block-sparse Q: sliced-ELL layout (xm_sell.h); the CSR arrays stay for the fallback kernels
+    int sell_gm_ = 0;
     hipStream_t st_ = nullptr;
     Comm *comm_ = nullptr;
 
@@ -133,6 +138,7 @@ private:
     double sum_parts(const double *dparts, int count);
     int run_tcg(double rr, double delta, TcgScal &fin);
     volatile double *wait_outer_result();
+    bool stream_idle(std::chrono::steady_clock::time_point t_wait, const char *what);   // true: drained; throws on a device error / watchdog
     bool agree_any(bool local);
     void drain_events();
     void finish_profile();

@@ -10,6 +10,7 @@
 //  * all per-camera state is row-major with an odd pitch (xm_common.h) so no transposes exist (the reference does 4
 //    per inner iteration, Dense/transpose.h:7-22).
 #include "xm_solver.h"
+#include "xm_sell.h"
 
 #include <algorithm>
 #include <chrono>
@@ -111,6 +112,18 @@ Context::Context(const xm_problem_t &prob) {
         if (nb_loc_ > 0) {
             XM_HIP_CHECK(hipMemcpy(colidx_.p, prob.colidx + b0, (size_t)nb_loc_ * sizeof(int32_t), hipMemcpyHostToDevice));
             XM_HIP_CHECK(hipMemcpy(blocks_.p, prob.blocks + b0 * 9, (size_t)nb_loc_ * 9 * sizeof(double), hipMemcpyHostToDevice));
+        }
+        // Large problems: sliced-ELL over per-XCD column slabs (xm_sell.h).  Below ~1M blocks per GPU the product is in the
+        // launch-latency regime (13 us at 13682 cameras) and the one-launch CSR kernel stays.  XM_BSR_SELL=1|0 forces / disables,
+        // XM_SELL_SLABS (1,2,4,8), XM_SELL_LMAX, XM_SELL_GATHER (0|1) tune it.
+        {
+            auto env_int = [](const char *k, int dflt) { const char *e = std::getenv(k); return (e && *e) ? std::atoi(e) : dflt; };
+            const int mode = env_int("XM_BSR_SELL", -1);
+            if (mode == 1 || (mode != 0 && nb_loc_ >= 1000000)) {
+                sell_gm_ = env_int("XM_SELL_GATHER", 1);
+                sell_.reset(new SellMatrix(rp.data(), prob.colidx + b0, prob.blocks + b0 * 9, nloc_, ntot_, env_int("XM_SELL_SLABS", 4),
+                                           env_int("XM_SELL_LMAX", 64), st_));
+            }
         }
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
@@ -255,6 +268,8 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
     if (storage_ == XM_STORAGE_DENSE) {
         if (sym_ok_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT && Pcol_.p) launch_qw_sym(o, epi, dQ_, ld_, W_.p, alpha, a, Prow_.p, Pcol_.p, st_);
         else launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
+    } else if (sell_ && sell_supports(o)) {
+        launch_qw_sell(o, epi, *sell_, W_.p, alpha, a, sell_gm_, st_);
     } else {
         launch_qw_bsr3(o, epi, rowptr_.p, colidx_.p, blocks_.p, W_.p, alpha, a, st_);
     }
@@ -305,15 +320,36 @@ bool Context::agree_any(bool local) {
     return any;
 }
 
+// Every host spin loop looks at the stream through this: a sticky error (launch failure, device fault, aborted collective) is
+// neither hipSuccess nor hipErrorNotReady and must end the wait with XM_ERR_HIP instead of spinning for ever; so must a wait that
+// exceeds the watchdog (XM_WATCHDOG_S seconds, default 600: a dead peer inside an RCCL collective never completes the stream).
+bool Context::stream_idle(clk::time_point t_wait, const char *what) {
+    static const double limit = [] { const char *e = std::getenv("XM_WATCHDOG_S"); return (e && *e) ? std::atof(e) : 600.0; }();
+    const hipError_t q = hipStreamQuery(st_);
+    if (q == hipSuccess) return true;
+    if (q != hipErrorNotReady) {
+        (void)hipGetLastError();
+        throw Error(XM_ERR_HIP, std::string("device error while waiting for ") + what + ": " + hipGetErrorString(q));
+    }
+    if (secs_since(t_wait) > limit)
+        throw Error(XM_ERR_HIP, std::string("watchdog: no progress for ") + std::to_string((int)limit) + " s while waiting for " + what);
+    return false;
+}
+
 // spin on the sequence word of the host-mapped result block (written last by outer_finalize_kernel)
 volatile double *Context::wait_outer_result() {
     volatile unsigned long long *hseq = reinterpret_cast<volatile unsigned long long *>(hstat_) + 8 + 5;
     const unsigned long long seq = outer_seq_;
-    auto t_wait = clk::now();
+    const auto t_wait = clk::now();
+    auto t_check = t_wait;
     while (*hseq != seq) {
-        if (secs_since(t_wait) > 500e-6 && hipStreamQuery(st_) == hipSuccess) {
-            XM_HIP_CHECK(hipStreamSynchronize(st_));
-            if (*hseq != seq) throw Error(XM_ERR_HIP, "outer-iteration results did not reach host-mapped memory");
+        __builtin_ia32_pause();
+        if (secs_since(t_check) > 500e-6) {
+            if (stream_idle(t_wait, "the outer-iteration results")) {
+                XM_HIP_CHECK(hipStreamSynchronize(st_));
+                if (*hseq != seq) throw Error(XM_ERR_HIP, "outer-iteration results did not reach host-mapped memory");
+            }
+            t_check = clk::now();
         }
     }
     return reinterpret_cast<volatile double *>(hstat_) + 8;
@@ -405,19 +441,21 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     } else {
         volatile unsigned long long *hs = hstat_;
         auto last_progress = clk::now();
+        auto last_change = last_progress;   // watchdog reference: the progress word last moved here
         unsigned long long seen = ~0ull;
         for (;;) {
             const unsigned long long v = *hs;
-            if (v != seen) { seen = v; last_progress = clk::now(); }
+            if (v != seen) { seen = v; last_progress = clk::now(); last_change = last_progress; }
             const bool valid = (v != ~0ull);
             const int status = valid ? (int)(v & 0xff) : 0;
             const int done = valid ? (int)(v >> 8) : 0;
             if (status != 0) { fin_status = status; fin_iter = done; break; }
             if (it < kMaxInner && it - done < run_ahead) { enqueue(it++); continue; }
+            __builtin_ia32_pause();
             if (secs_since(last_progress) > 200e-6) {
                 // Nothing new for a while: if the stream has drained the progress word is stale (or this platform does not
                 // make device writes to mapped host memory visible promptly) -> read the truth from the device.
-                if (hipStreamQuery(st_) == hipSuccess) {
+                if (stream_idle(last_change, "the truncated-CG progress word")) {
                     TcgScal sc = read_scal(it & 1);
                     if (sc.status != 0) { fin_status = sc.status; fin_iter = sc.iter; break; }
                     if (it >= kMaxInner) { fin_status = 6; fin_iter = kMaxInner; break; }
@@ -712,6 +750,7 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 a.Wloc = vj + (size_t)cam0_ * 3;
                 a.out = w.p + (size_t)cam0_ * 3;
                 if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
+                else if (sell_) launch_qw_sell(1, EPI_CERT, *sell_, vj, 1.0, a, 0, st_);
                 else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_);
                 res_->qw_products++;
                 if (comm_->active()) comm_->allgather(w.p, (size_t)nloc_ * 3, st_);

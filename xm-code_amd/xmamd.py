@@ -22,6 +22,7 @@ EXPORTS = [
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition",
+    "xm_sell_layout", "xm_sell_create", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
 ]
 
 
@@ -96,6 +97,12 @@ def lib():
         L.xm_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.xm_comm_init_shm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
         L.xm_partition.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.xm_sell_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p] + [C.c_void_p] * 6
+        L.xm_sell_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.xm_sell_destroy.argtypes = [C.c_void_p]
+        L.xm_sell_destroy.restype = None
+        L.xm_qw_sell.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        L.xm_qw_sell_time.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -221,6 +228,58 @@ def qw_bsr3(rowptr, colidx, blocks, W, alpha=1.0):
     for b in (drp, dci, dbl, dW, dO):
         b.free()
     return out
+
+
+def sell_layout(rowptr, colidx, ncols=None, slabs=4, lmax=64):
+    """host-side description of the sliced-ELL layout (xm_sell.h) -- no GPU involved; used by the CPU tests"""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    n = rowptr.size - 1
+    ncols = n if ncols is None else ncols
+    sizes = np.zeros(4, dtype=np.int64)
+    args = (rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), n, ncols, slabs, lmax)
+    _chk(lib().xm_sell_layout(*args, sizes.ctypes.data_as(C.c_void_p), *([None] * 6)))
+    nsl, nst, npart, nvr = (int(x) for x in sizes)
+    out = dict(nslices=nsl, nsteps=nst, nparts=npart, nvrows=nvr, slabs=slabs,
+               slice_off=np.zeros(nsl + 1, dtype=np.int64), slab_start=np.zeros(slabs + 1, dtype=np.int32),
+               kind=np.zeros(max(nst, 1), dtype=np.uint8), src=np.zeros(max(nst, 1) * 64, dtype=np.int64),
+               pslot=np.zeros(max(nsl, 1) * 64, dtype=np.int32), pptr=np.zeros(n + 1, dtype=np.int64))
+    _chk(lib().xm_sell_layout(*args, sizes.ctypes.data_as(C.c_void_p),
+                              *(out[k].ctypes.data_as(C.c_void_p) for k in ("slice_off", "slab_start", "kind", "src", "pslot", "pptr"))))
+    return out
+
+
+class SellMatrix:
+    """3x3-block sparse Q in the sliced-ELL device layout (xm_sell_create); product through xm_qw_sell"""
+
+    def __init__(self, rowptr, colidx, blocks, ncols=None, slabs=4, lmax=64):
+        require_gpu()
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+        blocks = np.ascontiguousarray(blocks, dtype=np.float64)
+        self.n = rowptr.size - 1
+        self.h = C.c_void_p()
+        _chk(lib().xm_sell_create(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
+                                  self.n, self.n if ncols is None else ncols, slabs, lmax, C.byref(self.h)))
+
+    def qw(self, W, alpha=1.0, gather=0):
+        W = np.asarray(W, dtype=np.float64)
+        o = W.shape[1]
+        dW = DevArray(to_rm(W)); dO = DevArray(nbytes=3 * self.n * pitch_of(o) * 8)
+        _chk(lib().xm_qw_sell(self.h, o, dW.ptr, dO.ptr, alpha, gather, None))
+        _chk(lib().xm_dev_sync())
+        out = from_rm(dO.get(), 3 * self.n, o)
+        dW.free(); dO.free()
+        return out
+
+    def close(self):
+        if self.h:
+            lib().xm_sell_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def retract(R, s, D, ds, t):
