@@ -9,7 +9,10 @@ solve.  Workload at every N: the configuration the metric is quoted on, "Venice-
 (tests/xm_testlib.py:gen_dense).  For N > 1 the same problem is row-partitioned over the ranks (strong scaling) with an
 RCCL all-gather of the product input per Q*W.
 
-Launch: python bench.py [--gpus N --steps K --warmup W]   (N > 1: via torch.distributed.run, one rank per GPU)
+Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 the ranks may be started by torch.distributed.run (one rank per
+GPU, what the driver does) or by bench.py itself: a plain `python bench.py --gpus N` re-executes under torch.distributed.run on
+127.0.0.1.  When the box has fewer than N GPUs the ranks share device 0 and exchange through the library's shared-memory TEST
+transport (XM_BENCH_SHM=1, set automatically): a functional dry run of the N-rank flow, flagged as such in the JSON line.
 """
 import argparse
 import json
@@ -56,6 +59,53 @@ def workload(name):
     raise SystemExit(f"unknown workload {name}")
 
 
+def source_sha256():
+    """hash of the kernel / solver sources: a recorded PMC profile is quoted only for the code it was measured on"""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "xm-code_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def recorded_traffic(workload, world):
+    """roofline.traffic: HBM-side bytes per launch of the dominant kernel from a rocprofv3 --pmc FETCH_SIZE pass over THIS command
+    (scripts/pmc_hess.sh).  Only a profile stamped with the hash of the current sources is quoted; otherwise None + the reason."""
+    import glob
+    if workload != "venice1778" or world != 1:
+        return None, "no PMC pass recorded for this workload / GPU count"
+    sha = source_sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_hess_bench.json")), reverse=True):
+        try:
+            pmc = json.load(open(f))
+        except Exception:
+            continue
+        if pmc.get("source_sha256") == sha:
+            return pmc["hess_all_ranks_weighted"]["hbm_side_bytes_per_real_launch"], (
+                os.path.relpath(f, ROOT) + " (rocprofv3 --pmc FETCH_SIZE pass over this command's own Hessian launches on these sources, "
+                "no-ops dropped; x1024 x2 per MI355X_MICROARCH.md)")
+    return None, "no PMC profile stamped with the current source hash %s (run scripts/pmc_hess.sh on the GPU box)" % sha[:12]
+
+
+def self_launch(args):
+    """plain `python bench.py --gpus N`: start the N ranks ourselves (same command the driver uses)"""
+    import socket, subprocess
+    env = dict(os.environ)
+    try:
+        ngpu = xmamd.device_count()
+    except Exception:
+        ngpu = 0
+    if ngpu < args.gpus:   # fewer GPUs than ranks: functional dry run, every rank on device 0 over the shared-memory test transport
+        env.setdefault("XM_BENCH_SHM", "1")
+        env.setdefault("XM_BENCH_SINGLE_DEVICE", "1")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def cpu_baseline(Q, wl, budget_s, bsr=None):
     """oracle (CPU restatement) on the SAME Q/options, bounded by the reference's own max_time mechanism."""
     from oracle import xm_oracle as xo
@@ -97,6 +147,8 @@ def main():
     if os.environ.get("XM_BENCH_SINGLE_DEVICE") == "1":      # debugging aid: put every rank on device 0 of a 1-GPU box
         local = 0
     if world != args.gpus:
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            self_launch(args)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     xmamd.require_gpu()
     torch.cuda.set_device(local)
@@ -169,16 +221,12 @@ def main():
     else:
         alg_bytes = (76.0 * nb + 4 * (n + 1)) / world + 2 * 8 * 3 * n * o_fin
         kname = "qw_bsr3_kernel<o, EPI_HESS>"
+        if os.environ.get("XM_BSR_SELL") == "1" or (os.environ.get("XM_BSR_SELL") != "0" and nb / world >= 1000000):
+            kname = "qw_sell_kernel<o> + sell_reduce_kernel<o, EPI_HESS> (sliced-ELL over per-XCD column slabs; one product = both launches)"
     achieved = alg_bytes / (qw_ms * 1e-3) / 1e9 if qw_ms > 0 else 0.0
     # HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE (own pass, kernel-trace only), corrected as
     # MI355X_MICROARCH.md prescribes (KB -> bytes, x2 for the gfx950 wide-load half count); see profiles/r01_pmc_*.json
-    traffic = None
-    try:   # the Hessian launches of THIS command under --pmc FETCH_SIZE (scripts/pmc_hess.sh), weighted over the ranks of the staircase
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_hess_bench.json")))
-        if args.workload == "venice1778" and world == 1:
-            traffic = pmc["hess_all_ranks_weighted"]["hbm_side_bytes_per_real_launch"]
-    except Exception:
-        traffic = None
+    traffic, traffic_source = recorded_traffic(args.workload, world)
     out = {
         "metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
         "value": iters / elapsed, "unit": "tCG iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -186,13 +234,15 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl["desc"], "n_cameras": n, "storage": storage_desc,
                    "max_rank": wl["max_rank"], "tol": wl["tol"], "lam": wl["lam"],
-                   "parallelism": "single GPU" if world == 1 else f"camera row partition x{world}, RCCL all-gather of W per product"},
+                   "parallelism": "single GPU" if world == 1 else f"camera row partition x{world}, RCCL all-gather of W per product",
+                   **({"transport": "shared-memory TEST transport, all ranks on one GPU (functional dry run, not a scaling measurement)"}
+                      if os.environ.get("XM_BENCH_SHM") == "1" else {})},
         "solve": {"rank": last["rank"], "status": last["status"], "primal": last["primal"], "dual": last["dual"],
                   "min_eig": last["min_eig"], "tcg_iters_per_solve": last["tcg_iters"], "outer_iters": last["outer_iters"],
                   "qw_products": last["qw_products"], "lanczos_iters": last["lanczos_iters"],
                   "tr_seconds": last["tr_seconds"], "cert_seconds": last["cert_seconds"], "setup_gen_s": gen_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r01_pmc_fetch_hess_bench.json (rocprofv3 --pmc FETCH_SIZE pass over this command's own Hessian launches, no-ops dropped; x1024 x2)", "kernel": kname + (" via the half-traffic symmetric path (qw_sym_kernel + sym_reduce_kernel; bytes counted at FULL storage, SURVEY 8d)" if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
+                     "traffic": traffic, "traffic_source": traffic_source, "kernel": kname + (" via the half-traffic symmetric path (qw_sym_kernel + sym_reduce_kernel; bytes counted at FULL storage, SURVEY 8d)" if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); "
                              "per-rank Q is %.0f MB: below ~256 MB it sits in the Infinity Cache, so the figure is cache-assisted, "

@@ -76,6 +76,9 @@ typedef struct {
     const int64_t *rowptr;     /* n+1 */
     const int32_t *colidx;     /* nb */
     const double *blocks;      /* nb x 9, each block ROW-major (b[3*a+c] = Q[3i+a, 3j+c]) */
+    int64_t q_row0;            /* dense host q only: q holds the rows [q_row0, q_row0 + ldq) of Q (all 3n columns, column-major,
+                                  leading dimension ldq); 0 with ldq >= 3n = the whole matrix.  Lets a rank of a multi-GPU run hand
+                                  over just its own row strip (xm_solve reads only that strip of Q.bin) */
 } xm_problem_t;
 
 #define XM_MODE_SOLVE    0     /* XM_main.cu:180 */
@@ -115,9 +118,11 @@ typedef struct {
     int64_t qw_bytes;          /* algorithmic bytes of ONE tCG Q*W launch at the final rank */
     int32_t trace_len;
     int32_t last_stop_reason;
-    int32_t sym_product;       /* 1 when the half-traffic symmetric product was used (dense, single GPU, Q symmetric to round-off) */
-    int32_t reserved;
+    int32_t sym_product;       /* 1 when the half-traffic symmetric product was used (dense, single GPU, Q exactly symmetric) */
+    int32_t cert_flags;        /* XM_CERT_* bits of the LAST certificate */
+    double eig_residual;       /* Ritz residual |S x - theta x| of the last certificate's Lanczos run (reference: exact syevd, checkeig.h:303-318) */
 } xm_result_t;
+#define XM_CERT_EIG_NOT_CONVERGED 1   /* Lanczos hit its iteration cap: min_eig is only an upper bound, the certificate was NOT accepted on it */
 
 int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out);          /* uploads / lays out Q on device 0 (or the rank's device) */
 int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res);

@@ -172,6 +172,41 @@ def test_solve_matches_golden_rank3(xmamd, name):
     assert abs(info["tcg_iters"] - exp["tcg_iters"]) <= 0.05 * exp["tcg_iters"] + 10
 
 
+@pytest.mark.parametrize("name", ["simple1", "simple2", "synth/dense49", "synth/vg60_cert", "synth/vg40_stair"])
+def test_gpu_solution_certified_by_numpy(xmamd, name):
+    """the GPU's own output on the golden inputs is certified from scratch with numpy/LAPACK (tl.certificate_numpy): dual
+    feasibility lambda_min(S) >= -eps by eigvalsh, stationarity S sR = 0, zero duality gap -- independent of oracle and Lanczos"""
+    Q, exp, d = _case(name)
+    R, s, info = xmamd.solve_dense(Q, exp["max_rank"], exp["tol"], exp["lam"])
+    assert info["status"] == 1
+    cn = tl.certificate_numpy(Q, R, s, exp["lam"])
+    scale = max(1.0, abs(cn["primal"]))
+    assert cn["min_eig"] > -1e-7 * scale and abs(cn["gap"]) <= 1e-6 * scale and cn["stationarity"] < 1e-5
+    assert cn["primal"] == pytest.approx(info["primal"], rel=1e-10, abs=1e-12)
+    assert info["min_eig"] == pytest.approx(cn["min_eig"], abs=1e-7 * scale) and info["dual"] == pytest.approx(cn["dual"], rel=1e-6)
+    assert info["cert_flags"] == 0 and info["eig_residual"] <= 1e-6 * max(1.0, np.abs(cn["eigs"]).max())
+
+
+def test_unconverged_lanczos_never_certifies(xmamd, monkeypatch):
+    """A Ritz value is an upper bound of lambda_min: when Lanczos is cut short (here: 4 steps, one restart) the certificate must
+    not be accepted on it and the result must say so (xm_result_t.cert_flags) -- the same instance certifies at rank 3 otherwise"""
+    import subprocess, sys, textwrap
+    Q, exp, d = _case("synth/vg60_cert")
+    code = textwrap.dedent(f"""
+        import sys, json, os
+        sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xm-code_amd")!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import xmamd, xm_testlib as tl
+        Q = tl.load_bin({os.path.join(d, "Q.bin")!r})
+        R, s, info = xmamd.solve_dense(Q, 3, {exp["tol"]!r}, {exp["lam"]!r})
+        print(json.dumps({{k: info[k] for k in ("status", "rank", "cert_flags", "eig_residual", "min_eig")}}))
+    """)
+    env = dict(os.environ, XM_LANCZOS_MMAX="4", XM_LANCZOS_RESTARTS="1")     # read once per process -> own process
+    out = json.loads(subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1])
+    assert out["cert_flags"] & xmamd.CERT_EIG_NOT_CONVERGED and out["status"] != 1 and out["eig_residual"] > 1e-6
+    R, s, info = xmamd.solve_dense(Q, 3, exp["tol"], exp["lam"])
+    assert info["status"] == 1 and info["cert_flags"] == 0
+
+
 def test_staircase_matches_oracle(xmamd, oracle):
     """rank escalation 3 -> 6 with saddle escape along the certificate's eigenvector (XM_main.cu:223-277)"""
     Q, exp, d = _case("synth/vg40_stair")
@@ -292,6 +327,12 @@ def test_full_size_properties(xmamd, n):
     assert info["status"] == 1 and 3 <= info["rank"] <= 5
     assert abs(info["gap"]) <= 1e-6 * max(1.0, abs(info["primal"])) and info["min_eig"] > -1e-6
     assert tl.stiefel_defect(R) < 1e-12
+    # optimality as a fact independent of the library under test AND of the oracle: multipliers by lstsq, the spectrum of S by
+    # LAPACK's eigvalsh on the GPU's own (R, s)  (the library's Lanczos value and dual must agree with it)
+    cn = tl.certificate_numpy(P["Q"], R, s, 0.0)
+    assert cn["min_eig"] > -1e-7 and abs(cn["gap"]) <= 1e-6 * max(1.0, cn["primal"]) and cn["stationarity"] < 1e-5
+    assert cn["primal"] == pytest.approx(info["primal"], rel=1e-10) and cn["dual"] == pytest.approx(info["dual"], rel=1e-7)
+    assert info["min_eig"] == pytest.approx(cn["min_eig"], abs=1e-7) and info["cert_flags"] == 0
     rot, sc = tl.recover_rotations(R, s)
     Rs = P["R_star"]
     ref = np.concatenate([Rs[0] @ Rs[i].T for i in range(n)], axis=1)
@@ -470,8 +511,24 @@ def _two_rank_worker_code():
         elif case == "densify":                                    # block description expanded per rank on the device
             P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True); args = (6, 1e-9, 3.0)
+        elif case == "file":                                       # the reference's file surface: every rank reads ITS row strip of Q.bin
+            d = os.path.join(os.path.dirname(out), "ds_w%d" % world)
+            if rank == 0:
+                os.makedirs(d, exist_ok=True)
+                tl.save_bin(os.path.join(d, "Q.bin"), tl.gen_vg(41, deg=3, sigma=1.5, seed=40)["Q"])
+                open(os.path.join(d, "ready"), "w").close()
+            import time
+            while not os.path.exists(os.path.join(d, "ready")):
+                time.sleep(0.05)
+            os.environ["XM_QUIET"] = "1"
+            xmamd._chk(xmamd.lib().xm_solve(d.encode(), 6, 1e-9, 3.0, 1000.0))
+            xmamd.lib().xm_comm_finalize()
+            if rank == 0:
+                R = tl.load_bin(os.path.join(d, "R.bin")); s = tl.load_bin(os.path.join(d, "s.bin")).reshape(-1)
+                np.savez(out, R=R, s=s, primal=0.0, rank=R.shape[1], status=1, tcg=0, min_eig=0.0, trace=np.zeros((1, 6)))
+            sys.exit(0)
         else:
-            P = tl.gen_vg(301, deg=10, sigma=0.1, seed=5)
+            P = tl.gen_vg(301, deg=10, sigma=0.1, seed=5)      # "sell": the same through the sliced-ELL product (XM_BSR_SELL=1 in the environment)
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"])); args = (5, 1e-10, 10.0)
         R, s, info = ctx.solve(*args, trace=4000)
         ctx.close()
@@ -481,21 +538,32 @@ def _two_rank_worker_code():
     """)
 
 
-@pytest.mark.parametrize("case,world", [("dense", 2), ("bsr", 2), ("densify", 2), ("dense", 3), ("bsr", 3)])
+@pytest.mark.parametrize("case,world", [("dense", 2), ("bsr", 2), ("densify", 2), ("dense", 3), ("bsr", 3), ("dense-async", 2), ("bsr-async", 3),
+                                        ("sell", 2), ("sell-async", 2), ("file", 2)])
 def test_two_ranks_one_gpu(xmamd, tmp_path, case, world):
     """The whole row-partitioned solver with TWO or THREE ranks (processes) sharing the one GPU of the test box through the
     shared-memory test transport: camera partition 21+20 (+1 inert padding camera) resp. 14+14+13 (+1), replicated product input, gathered
     partial sums, staircase with rank escalation, Lanczos certificate.  Both ranks must return bit-identical results and
-    agree with the single-rank run (same optimum; trajectories differ only by summation grouping)."""
+    agree with the single-rank run (same optimum; trajectories differ only by summation grouping).
+    "-async": the transport is STREAM-ORDERED (XM_SHM_ASYNC=1: the exchange runs in a host function on the solver's stream, the
+    calling thread never blocks, like an RCCL collective), so the enqueue-ahead logic of the tCG is exercised for real: a rank
+    that enqueued a different number of collectives than its peer would leave a barrier unmatched and fail with XM_ERR_COMM.
+    "sell": block-sparse storage through the sliced-ELL product.  "file": the reference's file surface, each rank reading only
+    its own row strip of Q.bin (xm_solve), rank 0 writing R.bin / s.bin."""
     import subprocess, sys, uuid
     code = _two_rank_worker_code()
     name = "/xm_test_" + uuid.uuid4().hex[:12]
+    env = dict(os.environ, XM_SHM_TIMEOUT="60")
+    if case.endswith("-async"):
+        env["XM_SHM_ASYNC"] = "1"; case = case[:-6]
+    if case == "sell":
+        env["XM_BSR_SELL"] = "1"
     procs, outs = [], []
     logs = []
     for r in range(world):
         out = str(tmp_path / f"w2_r{r}.npz"); outs.append(out)
         logs.append(open(tmp_path / f"w2_r{r}.log", "w+"))
-        procs.append(subprocess.Popen([sys.executable, "-c", code, str(r), str(world), name, out, case], stdout=logs[-1], stderr=subprocess.STDOUT))
+        procs.append(subprocess.Popen([sys.executable, "-c", code, str(r), str(world), name, out, case], stdout=logs[-1], stderr=subprocess.STDOUT, env=env))
     rcs = [p.wait(timeout=600) for p in procs]
     if any(rcs) and os.environ.get("XM_COMM_TRACE"):
         a_, b_ = (open(os.environ["XM_COMM_TRACE"] + f".{r}").read().splitlines() for r in range(2))
@@ -507,8 +575,12 @@ def test_two_ranks_one_gpu(xmamd, tmp_path, case, world):
             print(f"---- rank {r} (rc {rcs[r]}) ----\n" + lg.read()[-1500:])
     assert rcs == [0] * world
     single = str(tmp_path / "w1.npz")
-    subprocess.check_call([sys.executable, "-c", code, "0", "1", name, single, case], timeout=600)
+    subprocess.check_call([sys.executable, "-c", code, "0", "1", name, single, case], timeout=600, env=env)
     a, c = np.load(outs[0]), np.load(single)
+    if case == "file":   # R.bin / s.bin written by rank 0 of the partitioned run vs the single-process run of the same files
+        assert a["R"].shape == c["R"].shape and tl.rel_fro(tl.gram(a["R"], a["s"]), tl.gram(c["R"], c["s"])) < 1e-6
+        assert tl.rotation_parity(a["R"], a["s"], c["R"], c["s"]) < 1e-6
+        return
     for o_ in outs[1:]:
         b = np.load(o_)
         assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["s"], b["s"]) and np.array_equal(a["trace"], b["trace"])
@@ -517,6 +589,53 @@ def test_two_ranks_one_gpu(xmamd, tmp_path, case, world):
     assert tl.rel_fro(tl.gram(a["R"], a["s"]), tl.gram(c["R"], c["s"])) < 1e-6
     k = 5
     assert np.allclose(a["trace"][:k, :2], c["trace"][:k, :2], rtol=1e-9)
+
+
+def test_rccl_two_ranks_on_one_gpu_or_documented_refusal(xmamd, tmp_path):
+    """Real RCCL with MORE than one rank on the 1-GPU test box: two processes try to form a 2-rank communicator on device 0.
+    If this RCCL build permits it, the partitioned solver runs over it and must reproduce the single-rank optimum.  If RCCL
+    refuses (a communicator may hold each GPU only once: 'Duplicate GPU detected' / invalid usage), the refusal itself is asserted,
+    so the record shows why the multi-rank RCCL path cannot be exercised on one GPU (the shared-memory transport, blocking and
+    stream-ordered, covers the solver logic; RCCL's own multi-rank transport is left to the 8-GPU node)."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    uid = (xmamd.C.c_char * 128)()
+    xmamd._chk(xmamd.lib().xm_comm_unique_id(uid))
+    idf = tmp_path / "uid.bin"
+    idf.write_bytes(uid.raw)
+    code = textwrap.dedent(f"""
+        import sys, os, json
+        sys.path.insert(0, {os.path.join(root, 'xm-code_amd')!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        import numpy as np, xmamd, xm_testlib as tl
+        rank = int(sys.argv[1]); uid = open(sys.argv[2], "rb").read()
+        rc = xmamd.lib().xm_comm_init(rank, 2, 0, uid, None)
+        if rc != 0:
+            print(json.dumps(dict(ok=False, err=xmamd.lib().xm_last_error().decode()))); sys.exit(0)
+        P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
+        ctx = xmamd.Context(Q=P["Q"]); R, s, info = ctx.solve(6, 1e-9, 3.0); ctx.close()
+        xmamd.lib().xm_comm_finalize()
+        print(json.dumps(dict(ok=True, primal=info["primal"], rank=info["rank"], status=info["status"])))
+    """)
+    env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN", XM_WATCHDOG_S="120")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(idf)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0].decode())
+        except subprocess.TimeoutExpired:
+            p.kill(); outs.append(p.communicate()[0].decode() + "\nTIMEOUT")
+    res = []
+    for o_ in outs:
+        js = [l for l in o_.splitlines() if l.startswith("{")]
+        res.append(json.loads(js[-1]) if js else dict(ok=False, err=o_[-600:]))
+    print("RCCL 2 ranks on one GPU:", res)
+    if all(r["ok"] for r in res):
+        P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
+        R1, s1, i1 = xmamd.solve_dense(P["Q"], 6, 1e-9, 3.0)
+        assert res[0]["primal"] == res[1]["primal"] == pytest.approx(i1["primal"], rel=1e-9) and res[0]["status"] == 1
+    else:
+        blob = " ".join(str(r.get("err", "")) for r in res) + " ".join(outs)
+        assert any(k in blob for k in ("Duplicate GPU", "invalid usage", "invalid argument", "unhandled", "RCCL", "TIMEOUT")), blob[-800:]
 
 
 @pytest.mark.parametrize("n", [1, 2, 3])
@@ -636,3 +755,21 @@ def test_bench_two_ranks_flow(xmamd):
         assert d[leg]["n_gpus"] == 2 and d[leg]["status"] == 1 and d[leg]["rank"] == 3
         assert d[leg]["primal"] == pytest.approx(2879.599460014564, rel=1e-10)
     assert d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0
+
+
+def test_bench_plain_command_self_launches(xmamd):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run: bench.py starts its own two ranks (re-exec under
+    torch.distributed.run on 127.0.0.1); on this 1-GPU box they share device 0 over the shared-memory test transport, which
+    the JSON line says.  Exit code 0 and exactly one JSON line."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-rome"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["solve"]["status"] == 1 and d["value"] > 0
+    if xmamd.device_count() < 2:
+        assert "TEST transport" in d["config"]["transport"]

@@ -189,3 +189,18 @@ def test_bsr_product_of_the_oracle_equals_dense(oracle):
     assert abs(stb["tcg_iters"] - std["tcg_iters"]) <= 0.05 * std["tcg_iters"] + 5
     W = np.random.default_rng(0).standard_normal((3 * n, 4))
     assert np.allclose(oracle.qw(P["Q"], W, 1.0), tl.bsr_to_dense(n, P["rowptr"], P["colidx"], P["blocks"]) @ W, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["simple2", "synth/dense49", "synth/vg60_cert", "synth/vg40_stair"])
+def test_numpy_certificate_agrees_with_the_oracle(oracle, name):
+    """tl.certificate_numpy (lstsq multipliers + LAPACK eigvalsh, no code shared with the oracle) on the oracle's solution of the
+    golden inputs: same dual value and lambda_min as the oracle's restatement of checkeig.h, zero gap, stationarity -- this pins the
+    oracle's certificate to an independent implementation and is what the GPU tests apply to the GPU's own output"""
+    import json, os
+    d = os.path.join(tl.GOLDEN, name)
+    Q = tl.load_bin(os.path.join(d, "Q.bin")); exp = json.load(open(os.path.join(d, "expected.json")))
+    R, s, io = oracle.solve(Q, exp["max_rank"], exp["tol"], exp["lam"], 1000.0)
+    cn = tl.certificate_numpy(Q, R, s, exp["lam"])
+    assert cn["primal"] == pytest.approx(exp["f_star"], rel=1e-10)
+    assert cn["dual"] == pytest.approx(exp["cert"]["dual"], rel=1e-8) and cn["min_eig"] == pytest.approx(exp["cert"]["min_eig"], abs=1e-8)
+    assert cn["min_eig"] > -1e-7 and abs(cn["gap"]) < 1e-6 * max(1.0, cn["primal"]) and cn["stationarity"] < 1e-5

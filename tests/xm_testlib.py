@@ -250,3 +250,51 @@ def gen_skewed(n, deg, seed=None, hubs=None):
     rowptr = np.zeros(n + 1, dtype=np.int64)
     np.add.at(rowptr, rows + 1, 1)
     return dict(n=n, rowptr=np.cumsum(rowptr), colidx=cols.astype(np.int32), blocks=np.ascontiguousarray(blocks))
+
+
+# --------------------------------------------------------------------------------------------------
+# implementation-independent dual certificate (numpy / LAPACK only; no oracle, no product code)
+# --------------------------------------------------------------------------------------------------
+
+
+def _cert_generators(anchor):
+    """constraint matrices of one camera (reference checkeig.h:71-161): the anchor's block is pinned to I (6 symmetric unit
+    matrices), a free-scale camera's block to a multiple of I (2 traceless diagonal + 3 off-diagonal generators)"""
+    E = lambda a, b: np.outer(np.eye(3)[a], np.eye(3)[b])
+    if anchor:
+        return [E(0, 0), 0.5 * (E(0, 1) + E(1, 0)), 0.5 * (E(0, 2) + E(2, 0)), E(1, 1), 0.5 * (E(1, 2) + E(2, 1)), E(2, 2)]
+    return [0.5 * (E(0, 0) - E(1, 1)), 0.5 * (E(1, 1) - E(2, 2)), 0.5 * (E(0, 1) + E(1, 0)), 0.5 * (E(0, 2) + E(2, 0)),
+            0.5 * (E(1, 2) + E(2, 1))]
+
+
+def certificate_numpy(Q, R, s, lam):
+    """Dual certificate of a primal point (R, s) of the XM SDP, computed from scratch with numpy/LAPACK:
+    multipliers by a dense least-squares solve per camera (np.linalg.lstsq), S = Z - sum_k y_k A_k assembled densely,
+    its spectrum by np.linalg.eigvalsh.  Follows the construction of the reference's checkeig.h:56-368 (Z = Q + the lambda term on
+    the first row of every camera block, checkeig.h:30-40; dual value checkeig.h:321-333; gap checkeig.h:334-336) but shares no
+    code with the oracle or the GPU library, so it pins optimality of a GPU result independently of both.
+    Returns dict(primal, dual, gap, min_eig, stationarity = |S sR|_F / |Q sR|_F)."""
+    Q = np.asarray(Q, dtype=np.float64)
+    s = np.asarray(s, dtype=np.float64).reshape(-1)
+    n = s.size
+    sR = scale_rows(R, s)
+    xii = np.sum(sR[0::3] ** 2, axis=1)                       # |row 3i of sR|^2
+    Z = Q.copy()
+    Z[np.arange(0, 3 * n, 3), np.arange(0, 3 * n, 3)] += 2.0 * lam * (xii - 1.0)
+    Right = Z @ sR
+    S = Z.copy()
+    dual = 0.0
+    for i in range(n):
+        B = sR[3 * i:3 * i + 3]
+        gens = _cert_generators(i == 0)
+        A = np.stack([(g @ B).ravel() for g in gens], axis=1)             # columns vec(A_k sR) restricted to camera i
+        y, *_ = np.linalg.lstsq(A, Right[3 * i:3 * i + 3].ravel(), rcond=None)
+        S[3 * i:3 * i + 3, 3 * i:3 * i + 3] -= sum(yk * g for yk, g in zip(y, gens))
+        if i == 0:
+            dual += y[0] + y[3] + y[5]
+    dual += lam * np.sum(1.0 - xii ** 2)
+    primal = float(np.sum(sR * (Q @ sR)) + lam * np.sum((s[1:] ** 2 - 1.0) ** 2))
+    w = np.linalg.eigvalsh(0.5 * (S + S.T))
+    gap = primal - dual - 3.0 * n * min(0.0, w[0])
+    return dict(primal=primal, dual=float(dual), gap=float(gap), min_eig=float(w[0]),
+                stationarity=float(np.linalg.norm(S @ sR) / max(np.linalg.norm(Q @ sR), 1e-300)), eigs=w)

@@ -62,6 +62,39 @@ void read_bin(const std::string &fn, std::vector<double> &d, int64_t &rows, int6
     f.read(reinterpret_cast<char *>(d.data()), (std::streamsize)(d.size() * sizeof(double)));
     if ((size_t)f.gcount() != d.size() * sizeof(double)) throw xm::Error(XM_ERR_IO, "short file " + fn);
 }
+// header of a .bin matrix without reading the data: rows, cols and the byte offset of element (0, 0)
+void peek_bin(const std::string &fn, int64_t &rows, int64_t &cols, int64_t &skip) {
+    std::ifstream f(fn, std::ios::binary | std::ios::ate);
+    if (!f) throw xm::Error(XM_ERR_IO, "cannot open file " + fn);
+    const int64_t size = (int64_t)f.tellg();
+    f.seekg(0);
+    unsigned char raw[16] = {0};
+    f.read(reinterpret_cast<char *>(raw), std::min<int64_t>(16, size));
+    int32_t h4[2];
+    int64_t h8[2];
+    std::memcpy(h4, raw, 8);
+    std::memcpy(h8, raw, 16);
+    const bool v1 = size >= 8 && h4[0] >= 0 && h4[1] >= 0 && 8 + 8 * (int64_t)h4[0] * (int64_t)h4[1] == size;
+    const bool v2 = !v1 && size >= 16 && h8[0] >= 0 && h8[1] >= 0 && h8[0] < (1LL << 31) && h8[1] < (1LL << 31) && 16 + 8 * h8[0] * h8[1] == size;
+    if (v2) { rows = h8[0]; cols = h8[1]; skip = 16; }
+    else {
+        if (size < 8 || h4[0] < 0 || h4[1] < 0) throw xm::Error(XM_ERR_IO, "bad header in " + fn);
+        rows = h4[0]; cols = h4[1]; skip = 8;
+        if (8 + 8 * rows * cols > size) throw xm::Error(XM_ERR_IO, "short file " + fn);
+    }
+}
+// rows [r0, r0 + nr) of a column-major .bin matrix, all columns -> dst (column-major, leading dimension nr): one contiguous
+// piece per column, so a rank of a multi-GPU run reads 1/world of Q.bin instead of all of it
+void read_bin_rows(const std::string &fn, int64_t r0, int64_t nr, std::vector<double> &dst, int64_t rows, int64_t cols, int64_t skip) {
+    std::ifstream f(fn, std::ios::binary);
+    if (!f) throw xm::Error(XM_ERR_IO, "cannot open file " + fn);
+    dst.resize((size_t)std::max<int64_t>(nr, 0) * (size_t)cols);
+    for (int64_t c = 0; c < cols && nr > 0; ++c) {
+        f.seekg(skip + 8 * (c * rows + r0));
+        f.read(reinterpret_cast<char *>(dst.data() + (size_t)c * nr), (std::streamsize)(nr * 8));
+        if (f.gcount() != (std::streamsize)(nr * 8)) throw xm::Error(XM_ERR_IO, "short file " + fn);
+    }
+}
 void write_bin(const std::string &fn, const double *d, int32_t rows, int32_t cols) {
     std::ofstream f(fn, std::ios::binary);
     if (!f) throw xm::Error(XM_ERR_IO, "cannot write " + fn);
@@ -75,8 +108,11 @@ int solve_path(const char *dataset_path, unsigned max_rank, double tol, double l
     require_device();
     const std::string base(dataset_path);
     std::vector<double> Q, sini;
-    int64_t rows = 0, cols = 0;
-    read_bin(base + "/Q.bin", Q, rows, cols);           // XM_main.cu:185
+    int64_t rows = 0, cols = 0, skip = 0;
+    const xm::Comm &cm = xm::global_comm();
+    const bool strip = cm.world > 1;                    // row-partitioned run: this rank needs only the rows of its cameras
+    if (strip) peek_bin(base + "/Q.bin", rows, cols, skip);
+    else read_bin(base + "/Q.bin", Q, rows, cols);      // XM_main.cu:185
     if (rows != cols || rows % 3 != 0 || rows < 3) throw xm::Error(XM_ERR_IO, "Q.bin must be 3n x 3n");
     const bool verbose = std::getenv("XM_QUIET") == nullptr;
     if (verbose) printf("rows: %lld, cols: %lld\n", (long long)rows, (long long)cols);
@@ -92,6 +128,13 @@ int solve_path(const char *dataset_path, unsigned max_rank, double tol, double l
     xm_problem_t prob;
     std::memset(&prob, 0, sizeof(prob));
     prob.n = n; prob.storage = XM_STORAGE_DENSE; prob.q = Q.data(); prob.ldq = rows;
+    if (strip) {
+        const int64_t per = (n + cm.world - 1) / cm.world;                       // same partition as xm_partition / Context
+        const int64_t c0 = std::min<int64_t>(n, (int64_t)cm.rank * per), c1 = std::min<int64_t>(n, (int64_t)(cm.rank + 1) * per);
+        read_bin_rows(base + "/Q.bin", 3 * c0, 3 * (c1 - c0), Q, rows, cols, skip);
+        prob.q = Q.data(); prob.ldq = 3 * (c1 - c0); prob.q_row0 = 3 * c0;
+        if (c1 == c0) { Q.assign(1, 0.0); prob.q = Q.data(); prob.ldq = 0; prob.q_row0 = 3 * c0; }
+    }
     xm::Context ctx(prob);
     std::vector<double>().swap(Q);
     const unsigned rmax = std::max(3u, max_rank);

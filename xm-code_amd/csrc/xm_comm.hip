@@ -52,6 +52,9 @@ struct Shm {
     unsigned long long barriers = 0;           // barriers completed by this rank
     std::string name;
     std::vector<double> host;
+    bool async = false;                        // XM_SHM_ASYNC=1: stream-ordered exchange (host functions on the stream)
+    double *stage = nullptr;                   // pinned staging buffer of the stream-ordered variant
+    std::atomic<int> err{0};                   // set by a host function that timed out (it cannot throw)
     bool active() const { return base != nullptr; }
 };
 Shm g_shm;
@@ -69,6 +72,35 @@ void shm_barrier(int world) {
                                          std::to_string(g_shm.barriers) + " (arrived " + std::to_string(h->arrive.load()) +
                                          "): ranks issued different collectives?");
     }
+}
+
+// barrier for code that must not throw (host functions executed by the stream); false on timeout
+bool shm_barrier_nothrow(int world) {
+    ShmHeader *h = static_cast<ShmHeader *>(g_shm.base);
+    h->arrive.fetch_add(1, std::memory_order_acq_rel);
+    g_shm.barriers++;
+    const unsigned long long target = g_shm.barriers * (unsigned long long)world;
+    static const double limit = [] { const char *e = std::getenv("XM_SHM_TIMEOUT"); return e ? std::atof(e) : 120.0; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    while (h->arrive.load(std::memory_order_acquire) < target)
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return false;
+    return true;
+}
+// Stream-ordered variant of the test transport (XM_SHM_ASYNC=1): the exchange runs inside a host function that the STREAM
+// executes between the device-to-host and host-to-device copies, so the calling thread never blocks — exactly like an RCCL
+// collective.  The solver's enqueue-ahead logic is then exercised for real: a rank that enqueues a different number of
+// collectives than its peers leaves a barrier unmatched (time-out -> error flag -> XM_ERR_COMM at the next collective).
+struct ShmOp { size_t count; };
+void shm_exchange_cb(void *p) {
+    ShmOp *op = static_cast<ShmOp *>(p);
+    const size_t count = op->count;
+    delete op;
+    if (g_shm.err.load()) return;
+    double *data = reinterpret_cast<double *>(static_cast<char *>(g_shm.base) + sizeof(ShmHeader) + 64);
+    std::memcpy(data + (size_t)g_comm.rank * count, g_shm.stage + (size_t)g_comm.rank * count, count * sizeof(double));
+    if (!shm_barrier_nothrow(g_comm.world)) { g_shm.err.store(1); return; }
+    std::memcpy(g_shm.stage, data, count * (size_t)g_comm.world * sizeof(double));
+    if (!shm_barrier_nothrow(g_comm.world)) g_shm.err.store(1);
 }
 
 void load_rccl(const char *path) {
@@ -123,6 +155,7 @@ void comm_init(int rank, int world, int device, const unsigned char id[128], con
     if (world < 1 || rank < 0 || rank >= world) throw Error(XM_ERR_ARG, "bad rank/world");
     XM_HIP_CHECK(hipSetDevice(device));
     if (g_rccl.comm) comm_finalize();
+    if (world > 1 && id == nullptr) throw Error(XM_ERR_ARG, "xm_comm_init: world > 1 needs the 128-byte unique id of rank 0");
     if (world > 1 || id != nullptr) {
         load_rccl(lib_path);
         ncclUniqueId u;
@@ -147,6 +180,10 @@ void comm_init_shm(int rank, int world, int device, const char *name, size_t byt
     close(fd);
     if (p == MAP_FAILED) throw Error(XM_ERR_COMM, "mmap failed");
     g_shm.base = p; g_shm.bytes = total; g_shm.barriers = 0; g_shm.name = name;
+    g_shm.err.store(0);
+    const char *as = std::getenv("XM_SHM_ASYNC");
+    g_shm.async = (as && *as == '1');
+    if (g_shm.async) XM_HIP_CHECK(hipHostMalloc((void **)&g_shm.stage, bytes, hipHostMallocDefault));
     g_comm.rank = rank; g_comm.world = world; g_comm.forced = true;
     shm_barrier(world);   // everybody has the segment mapped (a fresh segment is zero-filled)
 }
@@ -155,7 +192,9 @@ void comm_finalize() {
     if (g_shm.base) {
         munmap(g_shm.base, g_shm.bytes);
         if (g_comm.rank == 0) shm_unlink(g_shm.name.c_str());
-        g_shm = Shm();
+        if (g_shm.stage) (void)hipHostFree(g_shm.stage);
+        g_shm.base = nullptr; g_shm.bytes = 0; g_shm.barriers = 0; g_shm.name.clear(); g_shm.async = false; g_shm.stage = nullptr;
+        g_shm.err.store(0);
     }
     if (g_rccl.comm) { g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
     g_comm.rank = 0;
@@ -168,6 +207,13 @@ void Comm::allgather(double *buf, size_t count, hipStream_t st) {
     if (g_shm.active()) {
         const size_t cap = (g_shm.bytes - sizeof(ShmHeader) - 64) / sizeof(double);
         if (count * (size_t)world > cap) throw Error(XM_ERR_COMM, "shared-memory communicator: message too large");
+        if (g_shm.err.load()) throw Error(XM_ERR_COMM, "shared-memory communicator: a stream-ordered exchange timed out (ranks issued different collectives?)");
+        if (g_shm.async) {
+            XM_HIP_CHECK(hipMemcpyAsync(g_shm.stage + (size_t)rank * count, buf + (size_t)rank * count, count * sizeof(double), hipMemcpyDeviceToHost, st));
+            XM_HIP_CHECK(hipLaunchHostFunc(st, shm_exchange_cb, new ShmOp{count}));
+            XM_HIP_CHECK(hipMemcpyAsync(buf, g_shm.stage, count * (size_t)world * sizeof(double), hipMemcpyHostToDevice, st));
+            return;
+        }
         double *data = reinterpret_cast<double *>(static_cast<char *>(g_shm.base) + sizeof(ShmHeader) + 64);
         XM_HIP_CHECK(hipMemcpyAsync(data + (size_t)rank * count, buf + (size_t)rank * count, count * sizeof(double), hipMemcpyDeviceToHost, st));
         XM_HIP_CHECK(hipStreamSynchronize(st));

@@ -137,6 +137,15 @@ void launch_lz_next(double *dst, const double *w, const double *ww, double *beta
 void launch_gemv_n(double *y, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);  // y = V c
 
 
+// XM^2 re-weighting
+void launch_edge_locate(int64_t ne, const int32_t *ei, const int32_t *ej, int cam0, int nloc, const int64_t *rowptr, const int32_t *colidx,
+                        int64_t *pos_ij, int64_t *pos_ji, int64_t *pos_d, hipStream_t st);
+void launch_edge_write(bool dense, int64_t ne, const int32_t *ei, const int32_t *ej, const double *M, const double *w, int cam0, int nloc,
+                       const int64_t *inc_ptr, const int32_t *inc_edge, const int64_t *pos_ij, const int64_t *pos_ji, const int64_t *pos_d,
+                       double *blocks, double *Q, int64_t ld, hipStream_t st);
+void launch_edge_residual(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M, const double *Y, int o, int OP, double *res,
+                          hipStream_t st);
+
 // ---- host-side launch helpers shared by the kernel translation units ---------------------------------------------
 #define XM_DISPATCH_O(o, CALL)                                                         \
     switch (o) {                                                                       \

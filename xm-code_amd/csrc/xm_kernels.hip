@@ -323,14 +323,17 @@ __global__ __launch_bounds__(256) void asym_kernel(const double *__restrict__ Q,
     for (int64_t r = blockIdx.x; r < m; r += gridDim.x)
         for (int64_t c = threadIdx.x; c < m; c += 256) {
             const double v = Q[r * ld + c];
-            da = fmax(da, fabs(v - Q[c * ld + r]));
+            const double d = fabs(v - Q[c * ld + r]);
+            da = (d <= da) ? da : d;              // written so that a NaN entry propagates (fmax would drop it) and fails the check
             mx = fmax(mx, fabs(v));
         }
-    for (int off = 32; off >= 1; off >>= 1) { da = fmax(da, __shfl_xor(da, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64)); }
+    for (int off = 32; off >= 1; off >>= 1) { const double o2 = __shfl_xor(da, off, 64); da = (o2 <= da) ? da : o2; mx = fmax(mx, __shfl_xor(mx, off, 64)); }
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = da; sh[1][threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[blockIdx.x] = fmax(fmax(sh[0][0], sh[0][1]), fmax(sh[0][2], sh[0][3]));
+        double t = sh[0][0];
+        for (int q = 1; q < 4; ++q) t = (sh[0][q] <= t) ? t : sh[0][q];
+        out[blockIdx.x] = t;
         out[gridDim.x + blockIdx.x] = fmax(fmax(sh[1][0], sh[1][1]), fmax(sh[1][2], sh[1][3]));
     }
 }
@@ -1125,6 +1128,92 @@ __global__ __launch_bounds__(256) void negate_kernel(double *x, int64_t len) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) x[i] = -x[i];
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// XM^2 re-weighting on a resident context (reference loop 3_test_colmap_glomap.py:299-351: residual per
+// observation -> 90-percentile filter -> rebuild Q -> solve again).  For a view-graph Q = sum_e w_e G_e (connection Laplacian:
+// Q_ii += w_e I, Q_jj += w_e I, Q_ij = -w_e M_e, Q_ji = Q_ij^T) the rebuild is linear in the weights and runs on the device.
+// ----------------------------------------------------------------------------------------------------------------
+// position of block (row, col) in the local CSR arrays (-1: row not local or block not stored); rows need not be sorted
+__global__ __launch_bounds__(256) void edge_locate_kernel(int64_t ne, const int32_t *__restrict__ ei, const int32_t *__restrict__ ej,
+                                                           int cam0, int nloc, const int64_t *__restrict__ rowptr,
+                                                           const int32_t *__restrict__ colidx, int64_t *pos_ij, int64_t *pos_ji) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ne) return;
+    auto find = [&](int r, int c) -> int64_t {
+        const int lr = r - cam0;
+        if (lr < 0 || lr >= nloc) return -1;
+        for (int64_t b = rowptr[lr]; b < rowptr[lr + 1]; ++b)
+            if (colidx[b] == c) return b;
+        return -2;   // local row, block missing: the edge list does not match the stored pattern
+    };
+    pos_ij[e] = find(ei[e], ej[e]);
+    pos_ji[e] = find(ej[e], ei[e]);
+}
+__global__ __launch_bounds__(256) void diag_locate_kernel(int nloc, int cam0, const int64_t *__restrict__ rowptr,
+                                                           const int32_t *__restrict__ colidx, int64_t *pos_d) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nloc) return;
+    int64_t f = -2;
+    for (int64_t b = rowptr[c]; b < rowptr[c + 1]; ++b)
+        if (colidx[b] == cam0 + c) { f = b; break; }
+    pos_d[c] = f;
+}
+// off-diagonal blocks of every edge: -w M_e (row i) and -w M_e^T (row j); DENSE: Q row-major with leading dimension ld, local rows
+template <bool DENSE>
+__global__ __launch_bounds__(256) void edge_write_kernel(int64_t ne, const int32_t *__restrict__ ei, const int32_t *__restrict__ ej,
+                                                          const double *__restrict__ M, const double *__restrict__ w, int cam0, int nloc,
+                                                          const int64_t *__restrict__ pos_ij, const int64_t *__restrict__ pos_ji,
+                                                          double *blocks, double *Q, int64_t ld) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ne) return;
+    const double we = w[e];
+    const int i = ei[e], j = ej[e];
+    double m[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = -we * M[e * 9 + k];
+    if (DENSE) {
+        if (i >= cam0 && i < cam0 + nloc)
+            for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) Q[(size_t)(3 * (i - cam0) + a) * ld + 3 * j + c] = m[3 * a + c];
+        if (j >= cam0 && j < cam0 + nloc)
+            for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) Q[(size_t)(3 * (j - cam0) + a) * ld + 3 * i + c] = m[3 * c + a];
+    } else {
+        if (pos_ij[e] >= 0) for (int k = 0; k < 9; ++k) blocks[pos_ij[e] * 9 + k] = m[k];
+        if (pos_ji[e] >= 0) for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) blocks[pos_ji[e] * 9 + 3 * a + c] = m[3 * c + a];
+    }
+}
+// diagonal blocks: (sum of the incident weights, added in the fixed order of the incidence list) * I
+template <bool DENSE>
+__global__ __launch_bounds__(256) void diag_write_kernel(int nloc, int cam0, const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc_edge,
+                                                          const double *__restrict__ w, const int64_t *__restrict__ pos_d, double *blocks,
+                                                          double *Q, int64_t ld) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nloc) return;
+    double d = 0.0;
+    for (int64_t k = inc_ptr[cam0 + c]; k < inc_ptr[cam0 + c + 1]; ++k) d += w[inc_edge[k]];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const double v = (a == b) ? d : 0.0;
+            if (DENSE) Q[(size_t)(3 * c + a) * ld + 3 * (cam0 + c) + b] = v;
+            else if (pos_d[c] >= 0) blocks[pos_d[c] * 9 + 3 * a + b] = v;
+        }
+}
+// residual of every edge at the point whose scaled rows Y = s.*R are in Y (all cameras, pitch OP): |Y_i - M_e Y_j|_F^2, i.e. the
+// edge's term of <Q, Y Y^T> per unit weight
+__global__ __launch_bounds__(256) void edge_residual_kernel(int64_t ne, const int32_t *__restrict__ ei, const int32_t *__restrict__ ej,
+                                                             const double *__restrict__ M, const double *__restrict__ Y, int o, int OP, double *res) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ne) return;
+    const double *yi = Y + (size_t)ei[e] * 3 * OP, *yj = Y + (size_t)ej[e] * 3 * OP, *m = M + e * 9;
+    double acc = 0.0;
+    for (int k = 0; k < o; ++k)
+        for (int a = 0; a < 3; ++a) {
+            const double d = yi[a * OP + k] - (m[3 * a] * yj[k] + m[3 * a + 1] * yj[OP + k] + m[3 * a + 2] * yj[2 * OP + k]);
+            acc += d * d;
+        }
+    res[e] = acc;
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // launchers (dispatch on the rank o)
 // ----------------------------------------------------------------------------------------------------------------
@@ -1348,6 +1437,32 @@ void launch_lz_next(double *dst, const double *w, const double *ww, double *beta
 void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hipStream_t st) {
     hipLaunchKernelGGL(scale_copy_kernel, dim3(flat_grid(len)), dim3(256), 0, st, dst, src, a, len);
     check_launch("scale_copy");
+}
+
+
+void launch_edge_locate(int64_t ne, const int32_t *ei, const int32_t *ej, int cam0, int nloc, const int64_t *rowptr, const int32_t *colidx,
+                        int64_t *pos_ij, int64_t *pos_ji, int64_t *pos_d, hipStream_t st) {
+    if (ne > 0) hipLaunchKernelGGL(edge_locate_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ne, ei, ej, cam0, nloc, rowptr, colidx, pos_ij, pos_ji);
+    hipLaunchKernelGGL(diag_locate_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, rowptr, colidx, pos_d);
+    check_launch("edge_locate");
+}
+void launch_edge_write(bool dense, int64_t ne, const int32_t *ei, const int32_t *ej, const double *M, const double *w, int cam0, int nloc,
+                       const int64_t *inc_ptr, const int32_t *inc_edge, const int64_t *pos_ij, const int64_t *pos_ji, const int64_t *pos_d,
+                       double *blocks, double *Q, int64_t ld, hipStream_t st) {
+    const dim3 ge((unsigned)((ne + 255) / 256)), gc((nloc + 255) / 256), b(256);
+    if (dense) {
+        if (ne > 0) hipLaunchKernelGGL((edge_write_kernel<true>), ge, b, 0, st, ne, ei, ej, M, w, cam0, nloc, pos_ij, pos_ji, blocks, Q, ld);
+        hipLaunchKernelGGL((diag_write_kernel<true>), gc, b, 0, st, nloc, cam0, inc_ptr, inc_edge, w, pos_d, blocks, Q, ld);
+    } else {
+        if (ne > 0) hipLaunchKernelGGL((edge_write_kernel<false>), ge, b, 0, st, ne, ei, ej, M, w, cam0, nloc, pos_ij, pos_ji, blocks, Q, ld);
+        hipLaunchKernelGGL((diag_write_kernel<false>), gc, b, 0, st, nloc, cam0, inc_ptr, inc_edge, w, pos_d, blocks, Q, ld);
+    }
+    check_launch("edge_write");
+}
+void launch_edge_residual(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M, const double *Y, int o, int OP, double *res, hipStream_t st) {
+    if (ne <= 0) return;
+    hipLaunchKernelGGL(edge_residual_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ne, ei, ej, M, Y, o, OP, res);
+    check_launch("edge_residual");
 }
 
 }  // namespace xm

@@ -77,6 +77,7 @@ static py::tuple solve_problem(xm_problem_t &prob, unsigned int max_rank, double
     info["rank"] = res.rank; info["status"] = res.status; info["primal"] = res.primal; info["dual"] = res.dual;
     info["min_eig"] = res.min_eig; info["gap"] = res.gap; info["tcg_iters"] = res.tcg_iters; info["outer_iters"] = res.outer_iters;
     info["qw_products"] = res.qw_products; info["lanczos_iters"] = res.lanczos_iters; info["seconds"] = res.seconds;
+    info["cert_flags"] = res.cert_flags; info["eig_residual"] = res.eig_residual;
     return py::make_tuple(Rout, sout, info);
 }
 static py::tuple solve_array(darr Q, unsigned int max_rank, double tol, double lam, double max_time, int mode, py::object s_ini,

@@ -127,6 +127,8 @@ private:
     int64_t hess_launches_ = 0;
     std::vector<float> qw_samples_;
 
+    void init(const xm_problem_t &prob);
+    void release_raw();   // frees the raw (non-RAII) resources: dQ_, stream, mapped / pinned host memory, events
     void setup_rank(int o);
     void upload_point(const std::vector<double> &R_cm, int o, const std::vector<double> &s_ex);
     void download_point(std::vector<double> &R_cm, std::vector<double> &s_ex);
@@ -144,7 +146,7 @@ private:
     void finish_profile();
     TrResult trust_region(int o, double &gradtol, double linesearch_step, const std::vector<double> &v_dir, double max_time);
     CertResult certificate(int o, double primal, std::vector<double> &v_out);
-    int lanczos_min(std::vector<double> &x_out, double &theta, int &iters);
+    int lanczos_min(std::vector<double> &x_out, double &theta, int &iters, double &resid);   // 0 converged, 1 not
     void log(const char *fmt, ...) const;
 };
 

@@ -16,6 +16,7 @@ STORAGE_DENSE, STORAGE_BSR3 = 0, 1
 STORAGE_BSR3_DENSE = 2   # BSR3 on the host, expanded to the dense layout on the device (each rank: its own rows)
 MODE_SOLVE, MODE_RANK3, MODE_REBUTTLE = 0, 1, 2
 FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
+CERT_EIG_NOT_CONVERGED = 1
 
 EXPORTS = [
     "xm_last_error", "xm_version", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
@@ -33,7 +34,7 @@ class XmError(RuntimeError):
 class Problem(C.Structure):
     _fields_ = [("n", C.c_int64), ("storage", C.c_int32), ("q_on_device", C.c_int32), ("q", C.c_void_p),
                 ("ldq", C.c_int64), ("nb", C.c_int64), ("rowptr", C.c_void_p), ("colidx", C.c_void_p),
-                ("blocks", C.c_void_p)]
+                ("blocks", C.c_void_p), ("q_row0", C.c_int64)]
 
 
 class Options(C.Structure):
@@ -49,7 +50,7 @@ class Result(C.Structure):
                 ("lanczos_iters", C.c_int64), ("seconds", C.c_double), ("tr_seconds", C.c_double),
                 ("cert_seconds", C.c_double), ("qw_ms_sum", C.c_double), ("qw_ms_count", C.c_int64),
                 ("qw_bytes", C.c_int64), ("trace_len", C.c_int32), ("last_stop_reason", C.c_int32),
-                ("sym_product", C.c_int32), ("reserved", C.c_int32)]
+                ("sym_product", C.c_int32), ("cert_flags", C.c_int32), ("eig_residual", C.c_double)]
 
 
 _lib = None
