@@ -89,6 +89,9 @@ typedef struct {
 #define XM_FLAG_FIX_STALE_SR   2u   /* recompute sR after the escalation line search (reference does not, trustregion.h:394-422) */
 #define XM_FLAG_PROFILE_QW     4u   /* time every 8th Q*W launch with HIP events (result.qw_*) */
 #define XM_FLAG_HOST_STEPPED   8u   /* debugging: synchronise after every tCG iteration instead of run-ahead polling */
+#define XM_FLAG_WARM_R        16u   /* XM_MODE_REBUTTLE: start the rank-3 stage from opt.R_ini instead of the identity stack.  The reference
+                                       reads R_ini.bin and then overwrites it with the identity (XM_main.cu:41,95-103); this flag honours it,
+                                       which is what makes the second solve of the XM^2 loop cheap */
 
 typedef struct {
     uint32_t max_rank;
@@ -98,6 +101,7 @@ typedef struct {
     const double *s_ini;       /* n values, XM_MODE_REBUTTLE only (may be NULL -> ones) */
     int32_t trace_cap;         /* optional per-outer-iteration trace: records of 6 doubles */
     double *trace;             /*   loss, gradnorm, inner_iters, endreason, trstatus, delta (same as the oracle) */
+    const double *R_ini;       /* XM_FLAG_WARM_R only: 3n x 3 column-major starting point (rows are re-orthonormalised) */
 } xm_options_t;
 
 typedef struct {
@@ -128,6 +132,18 @@ int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out);          /* uploads
 int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res);
 void xm_ctx_destroy(xm_ctx_t *ctx);
 int64_t xm_dense_ld(int64_t n);                                       /* padded leading dimension (doubles) of the device layout */
+
+/* ---- XM^2 re-weighting on a resident context (reference loop 3_test_colmap_glomap.py:299-351: residual per
+ * observation, 90-percentile filter at :321, rebuild Q, solve again).  For a view-graph Q = sum_e w_e G_e (Q_ii += w_e I,
+ * Q_jj += w_e I, Q_ij = -w_e M_e, Q_ji = Q_ij^T) the rebuild is linear in the weights and happens on the device, in the
+ * storage the context was created with (dense or BSR3, incl. its sliced-ELL copy): Q is never uploaded again.
+ *   attach:    edges e = (ei[e], ej[e]), ei != ej, M: ne x 9 row-major; the stored pattern must hold both blocks of every edge and
+ *              every diagonal block.  Does not change Q.
+ *   residuals: res[e] = |Y_i - M_e Y_j|_F^2 with Y = s.*R of the LAST solve (the edge's share of <Q, Y Y^T> per unit weight)
+ *   weights:   rewrites every edge block and every diagonal block from w (w[e] = 0 removes an observation). */
+int xm_ctx_attach_edges(xm_ctx_t *ctx, int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
+int xm_ctx_edge_residuals(xm_ctx_t *ctx, double *res);
+int xm_ctx_set_edge_weights(xm_ctx_t *ctx, const double *w);
 
 /* ================================================================== 3. kernel-level entry points (device pointers) */
 /* device memory helpers so that callers need no other GPU runtime */

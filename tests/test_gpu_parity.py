@@ -773,3 +773,71 @@ def test_bench_plain_command_self_launches(xmamd):
     assert d["n_gpus"] == 2 and d["solve"]["status"] == 1 and d["value"] > 0
     if xmamd.device_count() < 2:
         assert "TEST transport" in d["config"]["transport"]
+
+
+# ---------------------------------------------------------------------------------------------- XM^2 loop
+@pytest.mark.parametrize("storage", ["dense", "bsr", "sell"])
+def test_xm2_reweighting_on_resident_context(xmamd, monkeypatch, storage):
+    """The reference's XM^2 outlier loop (3_test_colmap_glomap.py:299-351: residual per observation, np.percentile(error, 90) filter
+    at :321, rebuild Q, solve again) on a RESIDENT context: residuals per edge from the device, the filtered weights go back as
+    one vector, Q is rewritten on the device in its own storage (dense / block-CSR / sliced-ELL copy) and the second solve starts
+    from the first one's point (XM_MODE_REBUTTLE + R_ini).  Checked against a cold solve of the filtered problem built from
+    scratch: rotations within 1e-6, same optimum; the warm solve needs fewer tCG iterations than the cold one."""
+    import time
+    n, lam = 600, 20.0
+    edges, M, bad, Rs = tl.vg_measurements(n, deg=20, sigma=0.02, seed=77, outlier_frac=0.03)
+    ne = edges.shape[0]
+    w0 = np.ones(ne)
+    rowptr, colidx, blocks = tl.vg_assemble(n, edges, M, w0)
+    if storage == "sell":
+        monkeypatch.setenv("XM_BSR_SELL", "1")
+    Qd = tl.bsr_to_dense(n, rowptr, colidx, blocks)
+    ctx = xmamd.Context(Q=Qd) if storage == "dense" else xmamd.Context(bsr=(rowptr, colidx, blocks))
+    ctx.attach_edges(edges[:, 0], edges[:, 1], M)
+    R1, s1, i1 = ctx.solve(5, 1e-8, lam)
+    assert i1["status"] == 1
+    res = ctx.edge_residuals()
+    Y = tl.scale_rows(R1, s1).reshape(n, 3, -1)
+    ref = np.sum((Y[edges[:, 0]] - M @ Y[edges[:, 1]]) ** 2, axis=(1, 2))
+    assert np.allclose(res, ref, rtol=1e-11, atol=1e-13)
+    assert np.sum(res) == pytest.approx(i1["primal"] - lam * np.sum((s1[1:] ** 2 - 1) ** 2), rel=1e-9)    # the residuals ARE the data term
+    thr = np.percentile(res, 90)                                        # the reference's filter
+    w1 = (res <= thr).astype(float)
+    assert w1[bad].mean() < 0.05 and bad[w1 == 0].mean() > 0.25           # every planted outlier is among the 10 % removed
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    keep = w1 > 0     # (the reference re-checks connectivity after its filter, checklandmarks at 3_test_colmap_glomap.py:327; this instance stays connected)
+    assert connected_components(coo_matrix((np.ones(keep.sum()), (edges[keep, 0], edges[keep, 1])), shape=(n, n)), directed=False)[0] == 1
+    t0 = time.perf_counter(); ctx.set_edge_weights(w1); t_upd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    R2, s2, i2 = ctx.solve(5, 1e-8, lam, mode=xmamd.MODE_REBUTTLE, s_ini=s1, R_ini=R1)
+    t_warm = time.perf_counter() - t0
+    ctx.close()
+    # cold reference: the filtered problem assembled from scratch on the host, fresh context, identity start
+    rp2, ci2, bl2 = tl.vg_assemble(n, edges, M, w1)
+    assert np.array_equal(rp2, rowptr) and np.array_equal(ci2, colidx)
+    cold = xmamd.Context(Q=tl.bsr_to_dense(n, rp2, ci2, bl2)) if storage == "dense" else xmamd.Context(bsr=(rp2, ci2, bl2))
+    t0 = time.perf_counter()
+    Rc, sc, ic = cold.solve(5, 1e-8, lam)
+    t_cold = time.perf_counter() - t0
+    cold.close()
+    assert i2["status"] == ic["status"] == 1 and i2["rank"] == ic["rank"]
+    assert i2["primal"] == pytest.approx(ic["primal"], rel=1e-9)
+    assert tl.rotation_parity(R2, s2, Rc, sc) < 1e-6
+    assert i2["tcg_iters"] < ic["tcg_iters"]
+    rot, _ = tl.recover_rotations(R2, s2)
+    gt = np.concatenate([Rs[0] @ Rs[k].T for k in range(n)], axis=1)
+    assert tl.rel_fro(rot, gt) < 0.02                                    # and the filtered solve recovers the planted rotations
+    print(f"XM^2 [{storage}] n={n} ne={ne}: device re-weighting {t_upd*1e3:.2f} ms; second solve warm {t_warm*1e3:.1f} ms / {i2['tcg_iters']} tCG its "
+          f"vs cold {t_cold*1e3:.1f} ms / {ic['tcg_iters']} tCG its")
+
+
+def test_xm2_round_trip_through_XM_module(xmamd):
+    """XM.solve_array(..., mode=2, s_ini, R_ini): the warm re-solve of an unchanged problem converges in far fewer tCG iterations
+    than the cold one and returns the same optimum (the reference's solve_rebuttle surface, with R_ini honoured)"""
+    XM = xmamd.import_XM()
+    Q = tl.gen_vg(300, deg=8, sigma=0.1, seed=3)["Q"]
+    R1, s1, i1 = XM.solve_array(Q, 5, 1e-8, 10.0, 1000.0)
+    R2, s2, i2 = XM.solve_array(Q, 5, 1e-8, 10.0, 1000.0, mode=2, s_ini=s1, R_ini=R1)
+    assert i1["status"] == i2["status"] == 1 and i2["primal"] == pytest.approx(i1["primal"], rel=1e-10)
+    assert i2["tcg_iters"] < 0.25 * i1["tcg_iters"] and tl.rotation_parity(R2, s2, R1, s1) < 1e-7

@@ -298,3 +298,34 @@ def certificate_numpy(Q, R, s, lam):
     gap = primal - dual - 3.0 * n * min(0.0, w[0])
     return dict(primal=primal, dual=float(dual), gap=float(gap), min_eig=float(w[0]),
                 stationarity=float(np.linalg.norm(S @ sR) / max(np.linalg.norm(Q @ sR), 1e-300)), eigs=w)
+
+
+def vg_measurements(n, deg, sigma, seed, outlier_frac=0.0):
+    """view-graph measurements for the XM^2 tests: edges (i < j), M_e = R*_i Exp(sigma xi) R*_j^T, a fraction of them replaced by
+    random rotations (planted outliers).  Returns edges, M (ne,3,3), is_outlier, R_star."""
+    edges, rng = gen_vg_edges(n, deg, seed)
+    Rs = haar_so3(rng, n)
+    ne = edges.shape[0]
+    M = Rs[edges[:, 0]] @ so3_exp(rng.standard_normal((ne, 3)) * sigma) @ np.transpose(Rs[edges[:, 1]], (0, 2, 1))
+    bad = np.zeros(ne, dtype=bool)
+    if outlier_frac > 0:
+        cand = np.arange(n - 1, ne)                       # keep the spanning path clean so the graph stays connected after filtering
+        bad[rng.choice(cand, size=int(outlier_frac * ne), replace=False)] = True
+        M[bad] = haar_so3(rng, int(bad.sum()))
+    return edges, M, bad, Rs
+
+
+def vg_assemble(n, edges, M, w):
+    """3x3-block CSR of the connection Laplacian Q = sum_e w_e G_e (Q_ii += w I, Q_jj += w I, Q_ij = -w M_e, Q_ji = Q_ij^T); the
+    pattern always holds every edge and every diagonal block (also for w_e = 0), so a re-weighting keeps the structure"""
+    i, j = edges[:, 0], edges[:, 1]
+    degw = np.zeros(n)
+    np.add.at(degw, i, w)
+    np.add.at(degw, j, w)
+    rows = np.concatenate([np.arange(n), i, j]); cols = np.concatenate([np.arange(n), j, i])
+    blocks = np.concatenate([degw[:, None, None] * np.eye(3)[None], -w[:, None, None] * M, -w[:, None, None] * np.transpose(M, (0, 2, 1))], axis=0)
+    order = np.lexsort((cols, rows))
+    rows, cols, blocks = rows[order], cols[order], blocks[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    return np.cumsum(rowptr), cols.astype(np.int32), np.ascontiguousarray(blocks)

@@ -191,6 +191,27 @@ int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res) {
     XM_CATCH
 }
 void xm_ctx_destroy(xm_ctx_t *ctx) { delete ctx; }
+int xm_ctx_attach_edges(xm_ctx_t *ctx, int64_t ne, const int32_t *ei, const int32_t *ej, const double *M) {
+    XM_TRY
+    if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
+    ctx->impl->attach_edges(ne, ei, ej, M);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_ctx_edge_residuals(xm_ctx_t *ctx, double *res) {
+    XM_TRY
+    if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
+    ctx->impl->edge_residuals(res);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_ctx_set_edge_weights(xm_ctx_t *ctx, const double *w) {
+    XM_TRY
+    if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
+    ctx->impl->set_edge_weights(w);
+    return XM_OK;
+    XM_CATCH
+}
 int64_t xm_dense_ld(int64_t n) { return xm::dense_ld(n); }
 
 int xm_dev_count(int *count) {

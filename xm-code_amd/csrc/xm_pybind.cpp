@@ -3,7 +3,7 @@
 //   XM.solve_rebuttle(dataset_path, max_rank, tol, lam, max_time) -> int
 //   XM.solve_rank3(dataset_path, max_rank, tol, lam, max_time)    -> None
 // Additive (not in the reference): the same solve on arrays, without the Q.bin / R.bin round trip
-//   XM.solve_array(Q, max_rank, tol, lam, max_time, mode=0, s_ini=None, flags=0)                  -> (R, s, info)
+//   XM.solve_array(Q, max_rank, tol, lam, max_time, mode=0, s_ini=None, flags=0, R_ini=None)      -> (R, s, info)
 //   XM.solve_bsr(rowptr, colidx, blocks, max_rank, tol, lam, max_time, mode=0, s_ini=None, flags=0) -> (R, s, info)
 // Like the reference, no py::arg names/defaults are registered: all five arguments are positional and required.
 // Unlike the reference (which prints CUDA errors and carries on, Utils/check.h:41-76), I/O and HIP failures raise
@@ -45,7 +45,7 @@ static void solve_rank3(const std::string &dataset_path, unsigned int max_rank, 
 using darr = py::array_t<double, py::array::f_style | py::array::forcecast>;
 
 static py::tuple solve_problem(xm_problem_t &prob, unsigned int max_rank, double tol, double lam, double max_time, int mode,
-                               py::object s_ini, unsigned int flags) {
+                               py::object s_ini, unsigned int flags, py::object R_ini = py::none()) {
     const int64_t n = prob.n;
     const unsigned rmax = max_rank < 3 ? 3u : max_rank;
     std::vector<double> R((size_t)3 * n * (rmax + 1), 0.0), s((size_t)n, 1.0), sini;
@@ -58,6 +58,13 @@ static py::tuple solve_problem(xm_problem_t &prob, unsigned int max_rank, double
     std::memset(&opt, 0, sizeof(opt));
     opt.max_rank = max_rank; opt.tol = tol; opt.lam = lam; opt.max_time = max_time; opt.mode = mode; opt.flags = flags;
     opt.s_ini = sini.empty() ? nullptr : sini.data();
+    std::vector<double> rini;
+    if (!R_ini.is_none()) {   // warm start of the rank-3 stage (XM_FLAG_WARM_R): first three columns of a previous R
+        darr a = R_ini.cast<darr>();
+        if (a.ndim() != 2 || a.shape(0) != 3 * n || a.shape(1) < 3) throw std::invalid_argument("R_ini must be 3n x (>= 3)");
+        rini.assign(a.data(), a.data() + (size_t)3 * n * 3);
+        opt.R_ini = rini.data(); opt.flags |= XM_FLAG_WARM_R;
+    }
     xm_result_t res;
     std::memset(&res, 0, sizeof(res));
     res.R = R.data(); res.s = s.data();
@@ -81,25 +88,25 @@ static py::tuple solve_problem(xm_problem_t &prob, unsigned int max_rank, double
     return py::make_tuple(Rout, sout, info);
 }
 static py::tuple solve_array(darr Q, unsigned int max_rank, double tol, double lam, double max_time, int mode, py::object s_ini,
-                             unsigned int flags) {
+                             unsigned int flags, py::object R_ini) {
     if (Q.ndim() != 2 || Q.shape(0) != Q.shape(1) || Q.shape(0) % 3 != 0 || Q.shape(0) < 3)
         throw std::invalid_argument("Q must be 3n x 3n");
     xm_problem_t prob;
     std::memset(&prob, 0, sizeof(prob));
     prob.n = Q.shape(0) / 3; prob.storage = XM_STORAGE_DENSE; prob.q = Q.data(); prob.ldq = Q.shape(0);
-    return solve_problem(prob, max_rank, tol, lam, max_time, mode, s_ini, flags);
+    return solve_problem(prob, max_rank, tol, lam, max_time, mode, s_ini, flags, R_ini);
 }
 static py::tuple solve_bsr(py::array_t<int64_t, py::array::c_style | py::array::forcecast> rowptr,
                            py::array_t<int32_t, py::array::c_style | py::array::forcecast> colidx,
                            py::array_t<double, py::array::c_style | py::array::forcecast> blocks, unsigned int max_rank, double tol,
-                           double lam, double max_time, int mode, py::object s_ini, unsigned int flags) {
+                           double lam, double max_time, int mode, py::object s_ini, unsigned int flags, py::object R_ini) {
     if (rowptr.size() < 2 || blocks.size() != colidx.size() * 9) throw std::invalid_argument("need rowptr (n+1), colidx (nb), blocks (nb x 3 x 3)");
     xm_problem_t prob;
     std::memset(&prob, 0, sizeof(prob));
     prob.n = rowptr.size() - 1; prob.storage = XM_STORAGE_BSR3; prob.nb = colidx.size();
     prob.rowptr = rowptr.data(); prob.colidx = colidx.data(); prob.blocks = blocks.data();
     if (rowptr.data()[prob.n] != prob.nb) throw std::invalid_argument("rowptr[n] != number of blocks");
-    return solve_problem(prob, max_rank, tol, lam, max_time, mode, s_ini, flags);
+    return solve_problem(prob, max_rank, tol, lam, max_time, mode, s_ini, flags, R_ini);
 }
 
 PYBIND11_MODULE(XM, m) {
@@ -108,8 +115,9 @@ PYBIND11_MODULE(XM, m) {
     m.def("solve_rebuttle", &solve_rebuttle, "permit give initial guess");
     m.def("solve_rank3", &solve_rank3, "XM main function for rank 3 only");
     m.def("solve_array", &solve_array, "in-memory solve of a dense symmetric Q -> (R, s, info)", py::arg("Q"), py::arg("max_rank"),
-          py::arg("tol"), py::arg("lam"), py::arg("max_time"), py::arg("mode") = 0, py::arg("s_ini") = py::none(), py::arg("flags") = 0u);
+          py::arg("tol"), py::arg("lam"), py::arg("max_time"), py::arg("mode") = 0, py::arg("s_ini") = py::none(), py::arg("flags") = 0u,
+          py::arg("R_ini") = py::none());
     m.def("solve_bsr", &solve_bsr, "in-memory solve of a 3x3-block CSR Q -> (R, s, info)", py::arg("rowptr"), py::arg("colidx"),
           py::arg("blocks"), py::arg("max_rank"), py::arg("tol"), py::arg("lam"), py::arg("max_time"), py::arg("mode") = 0,
-          py::arg("s_ini") = py::none(), py::arg("flags") = 0u);
+          py::arg("s_ini") = py::none(), py::arg("flags") = 0u, py::arg("R_ini") = py::none());
 }

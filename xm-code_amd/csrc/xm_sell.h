@@ -59,6 +59,7 @@ public:
     SellMatrix(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t nloc, int64_t ncols, int S, int lmax,
                hipStream_t st);
     SellArgs args() const;
+    void refill(const int32_t *d_colidx, const double *d_blocks, hipStream_t st);   // values changed on the device (XM^2 re-weighting)
     double *parts(int o);          // partial-result buffer for rank o (grow-only)
     int grid() const { return grid_; }
     int64_t nloc() const { return nloc_; }
@@ -72,6 +73,9 @@ private:
     DevBuf<int64_t> slice_off_, pptr_;
     DevBuf<int32_t> slab_start_, cols_, pslot_;
     DevBuf<double> blk_, parts_;
+    DevBuf<int64_t> src_;
+    DevBuf<uint8_t> kind_;
+    int64_t b0_ = 0;
     int parts_o_ = 0;
 };
 

@@ -142,18 +142,16 @@ SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const doubl
     XM_HIP_CHECK(hipMemcpy(slab_start_.p, h.slab_start.data(), h.slab_start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!h.pslot.empty()) XM_HIP_CHECK(hipMemcpy(pslot_.p, h.pslot.data(), h.pslot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     XM_HIP_CHECK(hipMemcpy(pptr_.p, h.pptr.data(), h.pptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    b0_ = b0;
     if (nsteps_ > 0) {
-        DevBuf<int64_t> dsrc; DevBuf<uint8_t> dkind; DevBuf<int32_t> dci; DevBuf<double> dbl;
-        dsrc.alloc(h.src.size(), false); dkind.alloc(h.kind.size(), false);
+        DevBuf<int32_t> dci; DevBuf<double> dbl;
+        src_.alloc(h.src.size(), false); kind_.alloc(h.kind.size(), false);   // kept: refill() after a device-side update of the values
         dci.alloc((size_t)std::max<int64_t>(nb, 1), false); dbl.alloc((size_t)std::max<int64_t>(nb, 1) * 9, false);
-        XM_HIP_CHECK(hipMemcpy(dsrc.p, h.src.data(), h.src.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-        XM_HIP_CHECK(hipMemcpy(dkind.p, h.kind.data(), h.kind.size(), hipMemcpyHostToDevice));
+        XM_HIP_CHECK(hipMemcpy(src_.p, h.src.data(), h.src.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        XM_HIP_CHECK(hipMemcpy(kind_.p, h.kind.data(), h.kind.size(), hipMemcpyHostToDevice));
         XM_HIP_CHECK(hipMemcpy(dci.p, colidx + b0, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice));
         XM_HIP_CHECK(hipMemcpy(dbl.p, blocks + b0 * 9, (size_t)nb * 9 * sizeof(double), hipMemcpyHostToDevice));
-        const int64_t threads = nsteps_ * 64;
-        hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, nsteps_, dsrc.p, dkind.p, dci.p, dbl.p,
-                           b0, cols_.p, blk_.p);
-        check_launch("sell_fill");
+        refill(dci.p, dbl.p, st);
         XM_HIP_CHECK(hipStreamSynchronize(st));
     }
     // workgroups: 4 slices each, dealt to the XCDs that serve the slab (block b -> XCD b % 8)
@@ -165,6 +163,15 @@ SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const doubl
         imax = std::max(imax, (wgs + per - 1) / per);
     }
     grid_ = (int)(imax * 8);
+}
+
+// (re)build the interleaved arrays from block-CSR arrays on the device (colidx / blocks indexed from the first local block)
+void SellMatrix::refill(const int32_t *d_colidx, const double *d_blocks, hipStream_t st) {
+    if (nsteps_ <= 0) return;
+    const int64_t threads = nsteps_ * 64;
+    hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, nsteps_, src_.p, kind_.p, d_colidx, d_blocks,
+                       b0_, cols_.p, blk_.p);
+    check_launch("sell_fill");
 }
 
 SellArgs SellMatrix::args() const {

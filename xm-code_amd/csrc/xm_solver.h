@@ -78,6 +78,10 @@ public:
     explicit Context(const xm_problem_t &prob);
     ~Context();
     void solve(const xm_options_t &opt, xm_result_t &res);
+    // XM^2 re-weighting (include/xm_amd.h section 2)
+    void attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
+    void edge_residuals(double *res);
+    void set_edge_weights(const double *w);
 
 private:
     // ---- problem ------------------------------------------------------------------------------------------------
@@ -96,6 +100,12 @@ private:
     int64_t nb_loc_ = 0;
     std::unique_ptr<SellMatrix> sell_;   // large block-sparse Q: sliced-ELL layout (xm_sell.h); the CSR arrays stay for the fallback kernels
     int sell_gm_ = 0;
+    // XM^2 edge description (attach_edges)
+    int64_t ne_ = 0;
+    DevBuf<int32_t> ei_, ej_, inc_edge_;
+    DevBuf<int64_t> inc_ptr_, pos_ij_, pos_ji_, pos_d_;
+    DevBuf<double> eM_, ew_, eres_;
+    bool solved_ = false;   // R_/s_ hold the end point of a solve
     hipStream_t st_ = nullptr;
     Comm *comm_ = nullptr;
 

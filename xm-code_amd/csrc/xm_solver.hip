@@ -880,6 +880,72 @@ CertResult Context::certificate(int o, double primal, std::vector<double> &v_out
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// XM^2 re-weighting on the resident context (reference loop 3_test_colmap_glomap.py:299-351)
+// ------------------------------------------------------------------------------------------------------------------
+void Context::attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M) {
+    if (ne < 0 || (ne > 0 && (!ei || !ej || !M))) throw Error(XM_ERR_ARG, "attach_edges: bad argument");
+    std::vector<int64_t> inc((size_t)ntot_ + 1, 0);
+    for (int64_t e = 0; e < ne; ++e) {
+        if (ei[e] < 0 || ej[e] < 0 || ei[e] >= n_ || ej[e] >= n_ || ei[e] == ej[e]) throw Error(XM_ERR_ARG, "attach_edges: bad edge");
+        inc[(size_t)ei[e] + 1]++; inc[(size_t)ej[e] + 1]++;
+    }
+    for (int64_t c = 0; c < ntot_; ++c) inc[(size_t)c + 1] += inc[(size_t)c];
+    std::vector<int32_t> ie((size_t)std::max<int64_t>(2 * ne, 1));
+    {   // incidence lists in edge order (fixed -> the diagonal sums are bit-reproducible)
+        std::vector<int64_t> next(inc.begin(), inc.end() - 1);
+        for (int64_t e = 0; e < ne; ++e) { ie[(size_t)next[(size_t)ei[e]]++] = (int32_t)e; ie[(size_t)next[(size_t)ej[e]]++] = (int32_t)e; }
+    }
+    const size_t m = (size_t)std::max<int64_t>(ne, 1);
+    ei_.alloc(m, false); ej_.alloc(m, false); eM_.alloc(m * 9, false); ew_.alloc(m); eres_.alloc(m);
+    inc_ptr_.alloc(inc.size(), false); inc_edge_.alloc(ie.size(), false);
+    pos_ij_.alloc(m); pos_ji_.alloc(m); pos_d_.alloc((size_t)nloc_);
+    if (ne > 0) {
+        XM_HIP_CHECK(hipMemcpy(ei_.p, ei, (size_t)ne * sizeof(int32_t), hipMemcpyHostToDevice));
+        XM_HIP_CHECK(hipMemcpy(ej_.p, ej, (size_t)ne * sizeof(int32_t), hipMemcpyHostToDevice));
+        XM_HIP_CHECK(hipMemcpy(eM_.p, M, (size_t)ne * 9 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    XM_HIP_CHECK(hipMemcpy(inc_ptr_.p, inc.data(), inc.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    XM_HIP_CHECK(hipMemcpy(inc_edge_.p, ie.data(), ie.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    ne_ = ne;
+    if (storage_ == XM_STORAGE_BSR3) {
+        launch_edge_locate(ne, ei_.p, ej_.p, cam0_, nloc_, rowptr_.p, colidx_.p, pos_ij_.p, pos_ji_.p, pos_d_.p, st_);
+        std::vector<int64_t> a(m), b(m), d((size_t)nloc_);
+        XM_HIP_CHECK(hipMemcpyAsync(a.data(), pos_ij_.p, m * sizeof(int64_t), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipMemcpyAsync(b.data(), pos_ji_.p, m * sizeof(int64_t), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipMemcpyAsync(d.data(), pos_d_.p, (size_t)nloc_ * sizeof(int64_t), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        for (int64_t e = 0; e < ne; ++e)
+            if (a[(size_t)e] == -2 || b[(size_t)e] == -2) { ne_ = 0; throw Error(XM_ERR_ARG, "attach_edges: an edge has no stored block in the BSR3 pattern"); }
+        const int64_t true_loc = std::max<int64_t>(0, std::min<int64_t>(n_ - cam0_, nloc_));
+        for (int64_t c = 0; c < true_loc; ++c)
+            if (d[(size_t)c] < 0 && inc[(size_t)(cam0_ + c) + 1] > inc[(size_t)(cam0_ + c)]) { ne_ = 0; throw Error(XM_ERR_ARG, "attach_edges: a camera with edges has no stored diagonal block"); }
+    }
+}
+
+void Context::edge_residuals(double *res) {
+    if (ne_ <= 0 && !ei_.p) throw Error(XM_ERR_ARG, "edge_residuals: no edges attached");
+    if (!solved_) throw Error(XM_ERR_ARG, "edge_residuals: the context holds no solution yet");
+    if (!res) throw Error(XM_ERR_ARG, "edge_residuals: null output");
+    launch_scale_rows(o_, nloc_, R_.p, s_.p, W_.p + (size_t)cam0_ * 3 * OP_, st_);
+    gather_W();
+    launch_edge_residual(ne_, ei_.p, ej_.p, eM_.p, W_.p, o_, OP_, eres_.p, st_);
+    if (ne_ > 0) XM_HIP_CHECK(hipMemcpyAsync(res, eres_.p, (size_t)ne_ * sizeof(double), hipMemcpyDeviceToHost, st_));
+    XM_HIP_CHECK(hipMemsetAsync(W_.p, 0, W_.count * sizeof(double), st_));
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void Context::set_edge_weights(const double *w) {
+    if (!ei_.p) throw Error(XM_ERR_ARG, "set_edge_weights: no edges attached");
+    if (ne_ > 0 && !w) throw Error(XM_ERR_ARG, "set_edge_weights: null weights");
+    if (ne_ > 0) XM_HIP_CHECK(hipMemcpyAsync(ew_.p, w, (size_t)ne_ * sizeof(double), hipMemcpyHostToDevice, st_));
+    const bool dense = (storage_ == XM_STORAGE_DENSE);
+    launch_edge_write(dense, ne_, ei_.p, ej_.p, eM_.p, ew_.p, cam0_, nloc_, inc_ptr_.p, inc_edge_.p, pos_ij_.p, pos_ji_.p, pos_d_.p,
+                      dense ? nullptr : blocks_.p, dense ? dQ_ : nullptr, ld_, st_);
+    if (sell_) sell_->refill(colidx_.p, blocks_.p, st_);   // the sliced-ELL copy follows the CSR values
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // staircase drivers (XM_main.cu:180-310 solve, :312-401 solve_rank3, :35-178 solve_rebuttle)
 // ------------------------------------------------------------------------------------------------------------------
 void Context::solve(const xm_options_t &opt, xm_result_t &res) {
@@ -928,7 +994,14 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
             setup_rank((int)o);
             if (o == 3) {
                 identity_stack();
+                const bool warm = opt.mode == XM_MODE_REBUTTLE && (opt.flags & XM_FLAG_WARM_R) && opt.R_ini;
+                if (warm) std::memcpy(R0.data(), opt.R_ini, m * 3 * sizeof(double));
                 upload_point(R0, 3, s0);
+                if (warm) {   // rows of a previous solution truncated to rank 3 are re-orthonormalised (MGS of R + 0 * D)
+                    XM_HIP_CHECK(hipMemsetAsync(D_.p, 0, D_.count * sizeof(double), st_));
+                    launch_retract(3, nloc_, cam0_, R_.p, s_.p, D_.p, nullptr, 0.0, Rc_.p, nullptr, nullptr, st_);
+                    std::swap(R_.p, Rc_.p);
+                }
                 tr = trust_region(3, gradtol, 0.0, v, opt.max_time);
             } else {
                 upload_point(R0, (int)o, s0);
@@ -969,6 +1042,9 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     if (storage_ == XM_STORAGE_DENSE) res.qw_bytes = 8LL * (3 * n_) * (3 * n_) + 2LL * 8 * 3 * n_ * of;
     else res.qw_bytes = 76LL * nb_loc_ + 4LL * (n_ + 1) + 2LL * 8 * 3 * n_ * of;
     res.seconds = secs_since(t0);
+    // leave the end point resident at its final rank for edge_residuals(): R_/s_ hold the last trust-region point already,
+    // unless the staircase escalated past it (then the last stage's buffers still describe the returned point)
+    solved_ = true;
     opt_ = nullptr;
     res_ = nullptr;
 }

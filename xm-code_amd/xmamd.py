@@ -17,6 +17,7 @@ STORAGE_BSR3_DENSE = 2   # BSR3 on the host, expanded to the dense layout on the
 MODE_SOLVE, MODE_RANK3, MODE_REBUTTLE = 0, 1, 2
 FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 CERT_EIG_NOT_CONVERGED = 1
+FLAG_WARM_R = 16
 
 EXPORTS = [
     "xm_last_error", "xm_version", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
@@ -24,6 +25,7 @@ EXPORTS = [
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition",
     "xm_sell_layout", "xm_sell_create", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
+    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights",
 ]
 
 
@@ -40,7 +42,7 @@ class Problem(C.Structure):
 class Options(C.Structure):
     _fields_ = [("max_rank", C.c_uint32), ("tol", C.c_double), ("lam", C.c_double), ("max_time", C.c_double),
                 ("mode", C.c_int32), ("flags", C.c_uint32), ("s_ini", C.c_void_p), ("trace_cap", C.c_int32),
-                ("trace", C.c_void_p)]
+                ("trace", C.c_void_p), ("R_ini", C.c_void_p)]
 
 
 class Result(C.Structure):
@@ -75,6 +77,9 @@ def lib():
         L.xm_ctx_solve.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Result)]
         L.xm_ctx_destroy.argtypes = [C.c_void_p]
         L.xm_ctx_destroy.restype = None
+        L.xm_ctx_attach_edges.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.xm_ctx_edge_residuals.argtypes = [C.c_void_p, C.c_void_p]
+        L.xm_ctx_set_edge_weights.argtypes = [C.c_void_p, C.c_void_p]
         L.xm_dev_count.argtypes = [C.POINTER(C.c_int)]
         L.xm_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         L.xm_dev_free.argtypes = [C.c_void_p]
@@ -339,7 +344,24 @@ class Context:
         _chk(lib().xm_ctx_create(C.byref(p), C.byref(self.h)))
         self._keep = []   # Q has been copied to the device
 
-    def solve(self, max_rank, tol, lam, max_time=1000.0, mode=MODE_SOLVE, flags=0, s_ini=None, trace=0):
+    # ---- XM^2 re-weighting on the resident Q (reference loop 3_test_colmap_glomap.py:299-351)
+    def attach_edges(self, ei, ej, M):
+        ei = np.ascontiguousarray(ei, dtype=np.int32); ej = np.ascontiguousarray(ej, dtype=np.int32)
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        self.ne = ei.size
+        _chk(lib().xm_ctx_attach_edges(self.h, self.ne, ei.ctypes.data_as(C.c_void_p), ej.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p)))
+
+    def edge_residuals(self):
+        res = np.zeros(self.ne)
+        _chk(lib().xm_ctx_edge_residuals(self.h, res.ctypes.data_as(C.c_void_p)))
+        return res
+
+    def set_edge_weights(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        assert w.size == self.ne
+        _chk(lib().xm_ctx_set_edge_weights(self.h, w.ctypes.data_as(C.c_void_p)))
+
+    def solve(self, max_rank, tol, lam, max_time=1000.0, mode=MODE_SOLVE, flags=0, s_ini=None, trace=0, R_ini=None):
         n = self.n
         rmax = max(int(max_rank), 3)
         R = np.zeros((3 * n, rmax + 1), order="F"); s = np.zeros(n)
@@ -349,6 +371,10 @@ class Context:
         if s_ini is not None:
             si = np.ascontiguousarray(s_ini, dtype=np.float64).reshape(-1)
             opt.s_ini = si.ctypes.data_as(C.c_void_p)
+        ri = None
+        if R_ini is not None:
+            ri = np.asfortranarray(np.asarray(R_ini, dtype=np.float64)[:, :3])
+            opt.R_ini = ri.ctypes.data_as(C.c_void_p); opt.flags |= FLAG_WARM_R
         tr = None
         if trace:
             tr = np.zeros((trace, 6)); opt.trace_cap = trace; opt.trace = tr.ctypes.data_as(C.c_void_p)
