@@ -152,54 +152,65 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
 // Traffic: half of Q + o/24 of it written and read back as partials (12.5 % at o = 3).  Workgroups are dispatched heaviest
 // first (block 0 sweeps every tile), which balances the triangular work over the CUs.
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int kSymWaves = 8;
 constexpr int kSymTile = 128;
 constexpr int kSymChunk = 6;   // column tiles per workgroup: the triangular sweep is cut into equal pieces for load balance
 
-template <int O, bool NT>
-__global__ __launch_bounds__(512) void qw_sym_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc,
+// WV wavefronts of CPW cameras each (G = WV * CPW cameras = 3 G rows per workgroup).  The column partials are written once per
+// (workgroup row group, column): Pcol traffic is (n / G) * 3n * o doubles each way, i.e. o / (3 G) of the half matrix, and the
+// per-tile barrier + LDS exchange is amortised over CPW times more FMAs.  Measured, 13.5 GB matrix, o = 3 (general kernel 2000 us):
+// WV x CPW = 8 x 1 (round 1) 1620-1780 us | 8 x 2 1730 | 8 x 4 1540 (217 VGPRs: ONE workgroup per CU) | 4 x 2 1557 | 4 x 4 1352 us
+// (two workgroups per CU); at Venice size 4 x 4 takes 31.0 us against 33.8 us for the general kernel.
+template <int O, bool NT, int CPW, int WV>
+__global__ __launch_bounds__(64 * WV) void qw_sym_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc,
                                                       const TcgScal *__restrict__ scal, double *__restrict__ Prow,
                                                       double *__restrict__ Pcol) {
     constexpr int OP = pitch_of(O);
     constexpr int TILE = kSymTile;
     constexpr int TILE2 = TILE * OP / 2;   // double2 elements of one W tile (<= 320 < 512 threads)
+    constexpr int G = WV * CPW;            // cameras per workgroup
+    constexpr int NTH = 64 * WV;           // threads
+    constexpr int NWS = (TILE2 + NTH - 1) / NTH;   // staging registers (double2) per thread
     if (scal != nullptr) {
         if (scal->status != 0) return;
     }
     const int b = blockIdx.y, cx = blockIdx.x;
-    const int64_t col_lo = (int64_t)24 * b, col_hi = col_lo + 24;   // the group's diagonal block spans [col_lo, col_hi)
+    const int64_t col_lo = (int64_t)3 * G * b, col_hi = col_lo + 3 * G;   // the group's diagonal block spans [col_lo, col_hi)
     const int ntiles = (int)((ld + TILE - 1) / TILE);
     const int t0 = (int)(col_lo / TILE);
     const int tb = (cx * kSymChunk > t0) ? cx * kSymChunk : t0;
     const int te = ((cx + 1) * kSymChunk < ntiles) ? (cx + 1) * kSymChunk : ntiles;
     if (tb >= te) return;   // chunk entirely left of the diagonal (uniform exit, before any barrier)
     __shared__ __attribute__((aligned(16))) double wt[2][TILE * OP];
-    __shared__ __attribute__((aligned(16))) double cs[2][kSymWaves][TILE * O];
+    __shared__ __attribute__((aligned(16))) double cs[2][WV][TILE * O];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cam = b * kSymWaves + wave;
-    const bool active = cam < nloc;
-    const double *q0p = Q + (size_t)(active ? cam : 0) * 3 * (size_t)ld + 2 * lane;
-    // this camera's rows of W (wave-uniform): operand of the transposed product
-    double wr[3][O];
+    const int camw = b * G + wave * CPW;   // first camera of this wavefront
+    // this wavefront's rows of W (wave-uniform): operand of the transposed product
+    double wr[CPW][3][O];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < CPW; ++c)
 #pragma unroll
-        for (int k = 0; k < O; ++k) wr[r][k] = active ? W[((size_t)cam * 3 + r) * OP + k] : 0.0;
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k) wr[c][r][k] = (camw + c < nloc) ? W[((size_t)(camw + c) * 3 + r) * OP + k] : 0.0;
 
-    double acc[3][O];
+    double acc[CPW][3][O];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < CPW; ++c)
 #pragma unroll
-        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k) acc[c][r][k] = 0.0;
 
-    double2 q1[3], q2[3];   // Q fragments of tiles t+1 and t+2 (two tiles in flight per wavefront)
-    double2 ws;
-    auto load_q = [&](double2 (&dst)[3], int t) {
-        const int64_t c = (int64_t)t * TILE;
-        if (active && t < te) {
+    double2 q1[CPW][3];   // Q fragments of the next tile (CPW = 1 keeps two tiles in flight through q2)
+    double2 q2[(CPW == 1) ? 1 : 1][3];
+    double2 ws[NWS];
+    auto load_q = [&](double2 (&dst)[3], int c, int t) {
+        const int64_t col = (int64_t)t * TILE;
+        if (camw + c < nloc && t < te) {
+            const double *q0p = Q + (size_t)(camw + c) * 3 * (size_t)ld + 2 * lane;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const double2 *qp = reinterpret_cast<const double2 *>(q0p + (size_t)r * ld + c);
+                const double2 *qp = reinterpret_cast<const double2 *>(q0p + (size_t)r * ld + col);
                 if (NT) dst[r] = make_double2(__builtin_nontemporal_load(&qp->x), __builtin_nontemporal_load(&qp->y));
                 else dst[r] = *qp;
             }
@@ -210,27 +221,40 @@ __global__ __launch_bounds__(512) void qw_sym_kernel(const double *__restrict__ 
     };
     auto load_w = [&](int t) {
         const double2 *src = reinterpret_cast<const double2 *>(W + (size_t)t * TILE * OP);
-        ws = ((int)threadIdx.x < TILE2) ? src[threadIdx.x] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < NWS; ++i) ws[i] = ((int)threadIdx.x + i * NTH < TILE2) ? src[threadIdx.x + i * NTH] : make_double2(0.0, 0.0);
     };
     auto store_w = [&](int buf) {
-        if ((int)threadIdx.x < TILE2) reinterpret_cast<double2 *>(wt[buf])[threadIdx.x] = ws;
+#pragma unroll
+        for (int i = 0; i < NWS; ++i)
+            if ((int)threadIdx.x + i * NTH < TILE2) reinterpret_cast<double2 *>(wt[buf])[threadIdx.x + i * NTH] = ws[i];
     };
 
-    load_q(q1, tb);
-    load_q(q2, tb + 1);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) load_q(q1[c], c, tb);
+    if (CPW == 1) load_q(q2[0], 0, tb + 1);
     load_w(tb);
     store_w(tb & 1);
     __syncthreads();
     for (int t = tb; t < te; ++t) {
-        double2 q[3];
+        double2 q[CPW][3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { q[r] = q1[r]; q1[r] = q2[r]; }
-        load_q(q2, t + 2);
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) q[c][r] = q1[c][r];
+        if (CPW == 1) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) q1[0][r] = q2[0][r];
+            load_q(q2[0], 0, t + 2);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) load_q(q1[c], c, t + 1);
+        }
         const bool more = (t + 1 < te);
         if (more) load_w(t + 1);
-        const int64_t c = (int64_t)t * TILE + 2 * lane;            // this lane's two columns: c, c+1 (same class: bounds are even)
-        const double mrow = (c >= col_lo) ? 1.0 : 0.0;             // left of the diagonal block: belongs to a workgroup above
-        const double mcol = (c >= col_hi) ? 1.0 : 0.0;             // inside the diagonal block: used one way only
+        const int64_t c2 = (int64_t)t * TILE + 2 * lane;            // this lane's two columns: c2, c2+1 (same class: bounds are even)
+        const double mrow = (c2 >= col_lo) ? 1.0 : 0.0;             // left of the diagonal block: belongs to a workgroup above
+        const double mcol = (c2 >= col_hi) ? 1.0 : 0.0;             // inside the diagonal block: used one way only
         const double2 *wp = reinterpret_cast<const double2 *>(wt[t & 1]) + (size_t)lane * OP;
         double wv[2 * OP];
 #pragma unroll
@@ -243,44 +267,49 @@ __global__ __launch_bounds__(512) void qw_sym_kernel(const double *__restrict__ 
 #pragma unroll
         for (int k = 0; k < O; ++k) { cxs[k] = 0.0; cys[k] = 0.0; }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double qx = q[r].x * mrow, qy = q[r].y * mrow;
+        for (int c = 0; c < CPW; ++c)
 #pragma unroll
-            for (int k = 0; k < O; ++k) {
-                acc[r][k] += qx * wv[k] + qy * wv[OP + k];
-                cxs[k] += qx * wr[r][k];
-                cys[k] += qy * wr[r][k];
+            for (int r = 0; r < 3; ++r) {
+                const double qx = q[c][r].x * mrow, qy = q[c][r].y * mrow;
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    acc[c][r][k] += qx * wv[k] + qy * wv[OP + k];
+                    cxs[k] += qx * wr[c][r][k];
+                    cys[k] += qy * wr[c][r][k];
+                }
             }
-        }
         double *cw = cs[t & 1][wave] + (size_t)(2 * lane) * O;
 #pragma unroll
         for (int k = 0; k < O; ++k) { cw[k] = cxs[k] * mcol; cw[O + k] = cys[k] * mcol; }
         if (more) store_w((t + 1) & 1);
         __syncthreads();
         // fixed-order sum over the 8 wavefronts -> one partial per (workgroup row group, column, k)
-        for (int i = threadIdx.x; i < TILE * O; i += 512) {
+        for (int i = threadIdx.x; i < TILE * O; i += NTH) {
             double sum = 0.0;
 #pragma unroll
-            for (int w8 = 0; w8 < kSymWaves; ++w8) sum += cs[t & 1][w8][i];
+            for (int w8 = 0; w8 < WV; ++w8) sum += cs[t & 1][w8][i];
             Pcol[((size_t)b * (size_t)ld + (size_t)t * TILE) * O + i] = sum;
         }
     }
     // row results of this chunk: wave reduction, lane k keeps column k, raw sums (alpha is applied by the reducer)
-    double *pr = Prow + (((size_t)b * gridDim.x + cx) * kSymWaves + wave) * 3 * O;
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < CPW; ++c) {
+        double *pr = Prow + (((size_t)b * gridDim.x + cx) * G + wave * CPW + c) * 3 * O;
 #pragma unroll
-        for (int k = 0; k < O; ++k) {
-            const double tsum = wave_sum(acc[r][k]);
-            if (lane == k) pr[r * O + k] = tsum;
-        }
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                const double tsum = wave_sum(acc[c][r][k]);
+                if (lane == k) pr[r * O + k] = tsum;
+            }
+    }
 }
 
 // second half of the symmetric product: y_j = sum_chunks Prow[group(j)][chunk][j] + sum_{b < group(j)} Pcol[b][rows of j]
-// (fixed order, no atomics), then the fused epilogue
+// (fixed order, no atomics), then the fused epilogue.  G = cameras per row group of the first kernel.
 template <int O, int EPI>
 __global__ __launch_bounds__(256) void sym_reduce_kernel(const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t ld,
-                                                          int nchunks, double alpha, CamArgs a) {
+                                                          int nchunks, int G, double alpha, CamArgs a) {
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
@@ -296,7 +325,7 @@ __global__ __launch_bounds__(256) void sym_reduce_kernel(const double *__restric
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
     if (active) {
-        const int g = cam / kSymWaves, w = cam - g * kSymWaves;
+        const int g = cam / G, w = cam - g * G;
         for (int bb = lane; bb < g; bb += 64) {
             const double *p = Pcol + ((size_t)bb * (size_t)ld + (size_t)cam * 3) * O;
 #pragma unroll
@@ -304,9 +333,9 @@ __global__ __launch_bounds__(256) void sym_reduce_kernel(const double *__restric
 #pragma unroll
                 for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
         }
-        const int c0 = (int)(((int64_t)24 * g / kSymTile) / kSymChunk);   // first chunk that holds tiles of this row group
+        const int c0 = (int)(((int64_t)3 * G * g / kSymTile) / kSymChunk);   // first chunk that holds tiles of this row group
         for (int cx = c0 + lane; cx < nchunks; cx += 64) {
-            const double *p = Prow + (((size_t)g * nchunks + cx) * kSymWaves + w) * 3 * O;
+            const double *p = Prow + (((size_t)g * nchunks + cx) * G + w) * 3 * O;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -1274,22 +1303,38 @@ static int bsr_variant() {
     const char *e = std::getenv("XM_BSR_VARIANT");
     return (e && *e >= '0' && *e <= '2') ? (*e - '0') : 2;
 }
-int sym_groups(int nloc) { return (nloc + kSymWaves - 1) / kSymWaves; }
+// shape of the symmetric kernel's workgroup: XM_SYM_CPW = cameras per wavefront (1 | 2 | 4), XM_SYM_WAVES = wavefronts (4 | 8)
+int sym_cpw() {
+    static const int v = [] { const char *e = std::getenv("XM_SYM_CPW"); const int x = (e && *e) ? std::atoi(e) : 4; return (x == 1 || x == 2) ? x : 4; }();
+    return v;
+}
+int sym_waves() {
+    static const int v = [] { const char *e = std::getenv("XM_SYM_WAVES"); const int x = (e && *e) ? std::atoi(e) : 4; return (x == 8) ? 8 : 4; }();
+    return v;
+}
+int sym_groups(int nloc) { const int G = sym_waves() * sym_cpw(); return (nloc + G - 1) / G; }
 int sym_chunks(int64_t ld) { const int nt = (int)((ld + kSymTile - 1) / kSymTile); return (nt + kSymChunk - 1) / kSymChunk; }
-size_t sym_prow_count(int nloc, int64_t ld, int o) { return (size_t)sym_groups(nloc) * sym_chunks(ld) * kSymWaves * 3 * o; }
+size_t sym_prow_count(int nloc, int64_t ld, int o) { return (size_t)sym_groups(nloc) * sym_chunks(ld) * sym_waves() * sym_cpw() * 3 * o; }
 
 template <int O>
 static void qw_sym_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
                        hipStream_t st) {
     const int nch = sym_chunks(ld);
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
-    if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_sym_kernel<O, true>), dim3(nch, sym_groups(a.nloc)), dim3(512), 0, st, Q, ld, W, a.nloc, sc, Prow, Pcol);
-    else hipLaunchKernelGGL((qw_sym_kernel<O, false>), dim3(nch, sym_groups(a.nloc)), dim3(512), 0, st, Q, ld, W, a.nloc, sc, Prow, Pcol);
+    const dim3 gs(nch, sym_groups(a.nloc));
+    const bool nt = qw_stream_nt(a.nloc, ld);
+    const int cpw = sym_cpw(), wv = sym_waves(), G = wv * cpw;
+#define XM_SYM_LAUNCH(C, V)                                                                                                                \
+    if (nt) hipLaunchKernelGGL((qw_sym_kernel<O, true, C, V>), gs, dim3(64 * V), 0, st, Q, ld, W, a.nloc, sc, Prow, Pcol);                 \
+    else hipLaunchKernelGGL((qw_sym_kernel<O, false, C, V>), gs, dim3(64 * V), 0, st, Q, ld, W, a.nloc, sc, Prow, Pcol);
+    if (wv == 8) { if (cpw == 1) { XM_SYM_LAUNCH(1, 8) } else if (cpw == 2) { XM_SYM_LAUNCH(2, 8) } else { XM_SYM_LAUNCH(4, 8) } }
+    else { if (cpw == 1) { XM_SYM_LAUNCH(1, 4) } else if (cpw == 2) { XM_SYM_LAUNCH(2, 4) } else { XM_SYM_LAUNCH(4, 4) } }
+#undef XM_SYM_LAUNCH
     const dim3 g(qw_grid(a.nloc)), b(256);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nch, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nch, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nch, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nch, G, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nch, G, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nch, G, alpha, a); break;
         default: throw Error(-2, "bad epilogue");
     }
 }

@@ -169,13 +169,14 @@ void Context::init(const xm_problem_t &prob) {
     // bound (measured: 13682 cameras 2215 -> 1667 us at o = 3) and not at Venice size, where the per-tile column-sum exchange
     // costs what the halved traffic saves (34.1 vs 33.8 us).  Default: on for 3n >= 12288 and o <= 4; XM_SYM=1 forces it for
     // every size (o <= 5), XM_SYM=0 disables it.
+    auto sym_min_rows = [] { const char *e = std::getenv("XM_SYM_MIN_ROWS"); return (e && *e) ? (int64_t)std::atoll(e) : (int64_t)12288; };
     sym_ok_ = false;
     sym_max_o_ = 4;
     {
         const char *e = std::getenv("XM_SYM");
         const bool force = (e && *e == '1'), off = (e && *e == '0');
         if (force) sym_max_o_ = 5;
-        if (storage_ == XM_STORAGE_DENSE && world == 1 && !off && (force || 3 * n_ >= 12288)) {
+        if (storage_ == XM_STORAGE_DENSE && world == 1 && !off && (force || 3 * n_ >= sym_min_rows())) {
             const int grid = 512;
             DevBuf<double> d;
             d.alloc((size_t)2 * grid);
