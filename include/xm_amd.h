@@ -64,6 +64,9 @@ typedef struct xm_ctx xm_ctx_t;
 #define XM_STORAGE_BSR3  1     /* 3x3-block CSR over view-graph edges, both triangles stored */
 #define XM_STORAGE_BSR3_DENSE 2 /* described as BSR3 on the host (same fields), expanded to the dense layout on the device:
                                   each rank builds only its own camera rows (a >= 10k-camera Q never exists on the host) */
+#define XM_STORAGE_SCHUR 3     /* MATRIX-FREE: Q is never formed.  The problem is the observation list the reference's
+                                  utils/creatematrix.py:create_matrix(weight, edges, landmarks) takes (creatematrix.py:51); the product applies
+                                  Q = Q1 - Vtp_bar Qtp_bar^{-1} Vtp_bar^T as a factor chain (xm-code_amd/csrc/xm_schur.h).  Single GPU. */
 
 typedef struct {
     int64_t n;                 /* cameras */
@@ -76,6 +79,11 @@ typedef struct {
     const int64_t *rowptr;     /* n+1 */
     const int32_t *colidx;     /* nb */
     const double *blocks;      /* nb x 9, each block ROW-major (b[3*a+c] = Q[3i+a, 3j+c]) */
+    /* XM_STORAGE_SCHUR: nobs observations (camera obs_cam[e], landmark obs_lm[e], both 0-based; obs_p: nobs x 3 row-major point in the
+     * camera frame, already normalised with the intrinsics; obs_w: weights) -- i.e. edges - 1, landmarks, weight of create_matrix */
+    int64_t nobs, n_landmarks;
+    const int32_t *obs_cam, *obs_lm;
+    const double *obs_p, *obs_w;
     int64_t q_row0;            /* dense host q only: q holds the rows [q_row0, q_row0 + ldq) of Q (all 3n columns, column-major,
                                   leading dimension ldq); 0 with ldq >= 3n = the whole matrix.  Lets a rank of a multi-GPU run hand
                                   over just its own row strip (xm_solve reads only that strip of Q.bin) */
@@ -131,6 +139,9 @@ typedef struct {
 int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out);          /* uploads / lays out Q on device 0 (or the rank's device) */
 int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res);
 void xm_ctx_destroy(xm_ctx_t *ctx);
+/* out = alpha * Q * W through the storage the context holds (dense, BSR3 / sliced ELL, matrix-free; after a re-weighting: the
+ * updated Q).  W, out: HOST, column-major 3n x o, o in 1, 3..10.  Diagnostic / test entry (single-rank contexts). */
+int xm_ctx_qw(xm_ctx_t *ctx, int o, const double *W, double *out, double alpha);
 int64_t xm_dense_ld(int64_t n);                                       /* padded leading dimension (doubles) of the device layout */
 
 /* ---- XM^2 re-weighting on a resident context (reference loop 3_test_colmap_glomap.py:299-351: residual per

@@ -841,3 +841,66 @@ def test_xm2_round_trip_through_XM_module(xmamd):
     R2, s2, i2 = XM.solve_array(Q, 5, 1e-8, 10.0, 1000.0, mode=2, s_ini=s1, R_ini=R1)
     assert i1["status"] == i2["status"] == 1 and i2["primal"] == pytest.approx(i1["primal"], rel=1e-10)
     assert i2["tcg_iters"] < 0.25 * i1["tcg_iters"] and tl.rotation_parity(R2, s2, R1, s1) < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------- matrix-free Q
+def _simple2_obs():
+    Z = np.load(os.path.join(G, "simple2", "obs.npz"))
+    return Z["cam"], Z["lm"], Z["p"], Z["w"]
+
+
+@pytest.mark.parametrize("o", [1, 3, 4, 5, 8])
+def test_matrix_free_product_equals_dense_Q(xmamd, o):
+    """Q * W applied as the factor chain on the observation list of SIMPLE2 (the arguments the reference's own pipeline hands to
+    create_matrix, tests/golden/make_simple2_obs.py) against the dense Q.bin create_matrix wrote from them"""
+    Q = tl.load_bin(os.path.join(G, "simple2", "Q.bin"))
+    W = np.random.default_rng(o).standard_normal((Q.shape[0], o))
+    ctx = xmamd.Context(obs=_simple2_obs())
+    got = ctx.qw(W, 2.0)
+    ctx.close()
+    assert tl.rel_fro(got, 2.0 * (Q @ W)) < 1e-11
+
+
+def test_matrix_free_solve_matches_dense_solve(xmamd):
+    """SIMPLE2 solved matrix-free (XM_STORAGE_SCHUR: Q never formed) against the solve of the dense Q the reference's create_matrix
+    wrote: same optimum, certificate and rotations <= 1e-6 (north_star), and against the golden of the dense path"""
+    Q, exp, d = _case("simple2")
+    ctx = xmamd.Context(obs=_simple2_obs())
+    R, s, info = ctx.solve(exp["max_rank"], exp["tol"], exp["lam"])
+    ctx.close()
+    Rd, sd, idn = xmamd.solve_dense(Q, exp["max_rank"], exp["tol"], exp["lam"])
+    assert info["rank"] == idn["rank"] == exp["rank"] and info["status"] == idn["status"] == 1
+    # the optimum value is 5e-2 against |Q| ~ 1e3: the factor chain and create_matrix's dense Q agree to 2e-13 |Q| (make_simple2_obs.py),
+    # i.e. to ~1e-10 absolute in f -- the rotations are what must agree (measured 8e-11)
+    assert info["primal"] == pytest.approx(idn["primal"], rel=1e-8)
+    assert tl.rotation_parity(R, s, Rd, sd) < 1e-6
+    rot, _ = tl.recover_rotations(R, s)
+    assert tl.rel_fro(rot, np.load(os.path.join(d, "rot_anchor.npy"))) < 1e-6            # golden of the dense path (north_star: <= 1e-6)
+    assert abs(info["tcg_iters"] - idn["tcg_iters"]) <= 5
+    cn = tl.certificate_numpy(Q, R, s, exp["lam"])                       # certified from scratch against the DENSE matrix
+    assert cn["min_eig"] > -1e-7 and abs(cn["gap"]) < 1e-6 and cn["stationarity"] < 1e-5
+
+
+def test_matrix_free_synthetic_scene(xmamd):
+    """a synthetic scene (random cameras and landmarks, exact observations + noise): matrix-free product and solve against the
+    dense Schur complement assembled in numpy (tl.schur_dense)"""
+    rng = np.random.default_rng(7)
+    N, M = 60, 500
+    Rs = tl.haar_so3(rng, N); ts = rng.standard_normal((N, 3)) * 2; P = rng.standard_normal((M, 3)) * 3
+    vis = rng.random((N, M)) < 0.25
+    vis[:, :3] = True                                                    # a few landmarks seen by everybody keep the graph connected
+    cam, lm = np.nonzero(vis)
+    p = np.einsum("eba,eb->ea", Rs[cam], P[lm] - ts[cam]) + 0.01 * rng.standard_normal((cam.size, 3))     # camera-frame points
+    w = rng.uniform(0.5, 1.5, cam.size)
+    Q = tl.schur_dense(cam, lm, p, w)
+    ctx = xmamd.Context(obs=(cam, lm, p, w))
+    W = rng.standard_normal((3 * N, 3))
+    assert tl.rel_fro(ctx.qw(W), Q @ W) < 1e-10
+    R, s, info = ctx.solve(5, 1e-8, 0.0)
+    ctx.close()
+    Rd, sd, idn = xmamd.solve_dense(Q, 5, 1e-8, 0.0)
+    assert info["status"] == idn["status"] == 1 and info["rank"] == idn["rank"]
+    assert info["primal"] == pytest.approx(idn["primal"], rel=1e-8) and tl.rotation_parity(R, s, Rd, sd) < 1e-6
+    rot, _ = tl.recover_rotations(R, s)                                  # and the planted cameras come back (noise level)
+    gt = np.concatenate([Rs[0].T @ Rs[k] for k in range(N)], axis=1)
+    assert min(tl.rel_fro(rot, gt), tl.rel_fro(rot, np.concatenate([Rs[0] @ Rs[k].T for k in range(N)], axis=1))) < 0.05

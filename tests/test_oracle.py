@@ -204,3 +204,15 @@ def test_numpy_certificate_agrees_with_the_oracle(oracle, name):
     assert cn["primal"] == pytest.approx(exp["f_star"], rel=1e-10)
     assert cn["dual"] == pytest.approx(exp["cert"]["dual"], rel=1e-8) and cn["min_eig"] == pytest.approx(exp["cert"]["min_eig"], abs=1e-8)
     assert cn["min_eig"] > -1e-7 and abs(cn["gap"]) < 1e-6 * max(1.0, cn["primal"]) and cn["stationarity"] < 1e-5
+
+
+def test_simple2_observations_reproduce_the_references_Q():
+    """tests/golden/simple2/obs.npz (the observation list the reference's 2_test_creatematrix.py hands to create_matrix) against the
+    Q.bin create_matrix wrote: the dense Schur complement restated in numpy (tl.schur_dense) and the five-step matrix-free product
+    (tl.schur_qw_numpy, what xm_schur.hip runs on the device) both reproduce it"""
+    import os
+    Z = np.load(os.path.join(tl.GOLDEN, "simple2", "obs.npz"))
+    Q = tl.load_bin(os.path.join(tl.GOLDEN, "simple2", "Q.bin"))
+    assert tl.rel_fro(tl.schur_dense(Z["cam"], Z["lm"], Z["p"], Z["w"]), Q) < 1e-11
+    W = np.random.default_rng(0).standard_normal((Q.shape[0], 4))
+    assert tl.rel_fro(tl.schur_qw_numpy(Z["cam"], Z["lm"], Z["p"], Z["w"], W), Q @ W) < 1e-11

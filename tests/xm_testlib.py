@@ -329,3 +329,60 @@ def vg_assemble(n, edges, M, w):
     rowptr = np.zeros(n + 1, dtype=np.int64)
     np.add.at(rowptr, rows + 1, 1)
     return np.cumsum(rowptr), cols.astype(np.int32), np.ascontiguousarray(blocks)
+
+
+# --------------------------------------------------------------------------------------------------
+# Schur-complement Q from observations (what the reference's utils/creatematrix.py:create_matrix builds, lines 51-339): numpy
+# restatements used by the matrix-free tests.  Q = Q1 - Vtp_bar Qtp_bar^{-1} Vtp_bar^T with the anchor
+# camera's translation removed (bar).
+# --------------------------------------------------------------------------------------------------
+
+
+def schur_parts(cam, lm, p, w):
+    """Q1 (N,3,3), c (N,3) = sum_l w p, Q2 (N), Q3 (M), V3 as (cam, lm, w) — creatematrix.py:71-133"""
+    cam = np.asarray(cam); lm = np.asarray(lm); p = np.asarray(p, dtype=np.float64); w = np.asarray(w, dtype=np.float64).reshape(-1)
+    N, M = int(cam.max()) + 1, int(lm.max()) + 1
+    Q1 = np.zeros((N, 3, 3)); c = np.zeros((N, 3)); Q2 = np.zeros(N); Q3 = np.zeros(M)
+    np.add.at(Q1, cam, w[:, None, None] * p[:, :, None] * p[:, None, :])
+    np.add.at(c, cam, w[:, None] * p)
+    np.add.at(Q2, cam, w); np.add.at(Q3, lm, w)
+    return N, M, Q1, c, Q2, Q3
+
+
+def schur_dense(cam, lm, p, w):
+    """dense 3N x 3N Q by explicit elimination of translations and landmarks (small problems only)"""
+    cam = np.asarray(cam); lm = np.asarray(lm); p = np.asarray(p, dtype=np.float64); w = np.asarray(w, dtype=np.float64).reshape(-1)
+    N, M, Q1, c, Q2, Q3 = schur_parts(cam, lm, p, w)
+    Vtp = np.zeros((3 * N, N + M))
+    for i in range(N):
+        Vtp[3 * i:3 * i + 3, i] = c[i]
+    np.add.at(Vtp, (3 * cam[:, None] + np.arange(3)[None, :], N + lm[:, None]), -(w[:, None] * p))
+    Qtp = np.zeros((N + M, N + M))
+    Qtp[np.arange(N), np.arange(N)] = Q2
+    Qtp[N + np.arange(M), N + np.arange(M)] = Q3
+    np.add.at(Qtp, (cam, N + lm), -w); np.add.at(Qtp, (N + lm, cam), -w)
+    X = np.linalg.solve(Qtp[1:, 1:], Vtp[:, 1:].T)
+    Q = -Vtp[:, 1:] @ X
+    for i in range(N):
+        Q[3 * i:3 * i + 3, 3 * i:3 * i + 3] += Q1[i]
+    return 0.5 * (Q + Q.T)
+
+
+def schur_qw_numpy(cam, lm, p, w, W):
+    """Q @ W without forming Q: the five steps the device runs (xm_schur.hip), in numpy"""
+    cam = np.asarray(cam); lm = np.asarray(lm); p = np.asarray(p, dtype=np.float64); w = np.asarray(w, dtype=np.float64).reshape(-1)
+    N, M, Q1, c, Q2, Q3 = schur_parts(cam, lm, p, w)
+    o = W.shape[1]
+    Wc = W.reshape(N, 3, o)
+    g_lm = np.zeros((M, o)); np.add.at(g_lm, lm, -w[:, None] * np.einsum("ea,eak->ek", p, Wc[cam]))
+    h = g_lm / Q3[:, None]
+    r = np.einsum("ia,iak->ik", c, Wc)
+    np.add.at(r, cam, w[:, None] * h[lm])
+    VT = np.diag(Q2[1:]).astype(np.float64)
+    V3 = np.zeros((N, M)); np.add.at(V3, (cam, lm), w)
+    VT -= (V3[1:] / Q3[None, :]) @ V3[1:].T
+    xc = np.zeros((N, o)); xc[1:] = np.linalg.solve(VT, r[1:])
+    xl = h.copy(); tmp = np.zeros((M, o)); np.add.at(tmp, lm, w[:, None] * xc[cam]); xl += tmp / Q3[:, None]
+    Y = np.einsum("iab,ibk->iak", Q1, Wc) - c[:, :, None] * xc[:, None, :]
+    np.add.at(Y, cam, w[:, None, None] * p[:, :, None] * xl[lm][:, None, :])
+    return Y.reshape(3 * N, o)

@@ -191,6 +191,13 @@ int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res) {
     XM_CATCH
 }
 void xm_ctx_destroy(xm_ctx_t *ctx) { delete ctx; }
+int xm_ctx_qw(xm_ctx_t *ctx, int o, const double *W, double *out, double alpha) {
+    XM_TRY
+    if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
+    ctx->impl->apply(o, W, out, alpha);
+    return XM_OK;
+    XM_CATCH
+}
 int xm_ctx_attach_edges(xm_ctx_t *ctx, int64_t ne, const int32_t *ei, const int32_t *ej, const double *M) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");

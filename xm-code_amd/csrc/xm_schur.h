@@ -1,0 +1,49 @@
+// xm_schur.h — matrix-free Q for the XM solve (the reference's own "TODO: implement sparse Q matrix
+// construction", utils/creatematrix.py:54-56).
+//
+// The reference forms the dense 3N x 3N Schur complement Q = Q1 - Vtp_bar Qtp_bar^{-1} Vtp_bar^T on the host
+// (creatematrix.py:137-339: Q1, V1, V2, V3, the bipartite Laplacian Qtp, two solves with the reduced camera Laplacian
+// VT = Q2_bar - V3_bar Q3^{-1} V3_bar^T) and the solver multiplies with it (72 N^2 bytes per product).  Here the factors stay
+// factors: the context is created from the observation list itself (the arguments of create_matrix: camera, landmark,
+// camera-frame point, weight) and a product Y = alpha * Q * W is the chain
+//      h_l   = -(1/Q3_l) sum_{obs of l} w (p . W_i)                       per landmark      (V2^T W, landmarks eliminated)
+//      r_i   =  c_i . W_i + sum_{obs of i} w h_l                          per camera i >= 1 (right-hand side of the camera system)
+//      x_cam =  VT^{-1} r                                                 dense (N-1)^2, the existing dense Q*W kernel
+//      x_l   =  h_l + (1/Q3_l) sum_{obs of l} w x_cam_i                   per landmark
+//      Y_i   =  Q1_i W_i - c_i x_cam_i + sum_{obs of i} w p x_l           per camera, + the fused epilogue of the Q*W kernels
+// i.e. O(observations) + (N-1)^2 bytes per product instead of 9 N^2: at N = 13682 cameras / 4.5 M observations 0.4 GB + 1.5 GB
+// against 13.5 GB.  First slice: single GPU; VT^{-1} is formed on the host at context creation by a Cholesky factorisation
+// (O(N^3): seconds at N = 2000; refused above kSchurMaxCams cameras until the factorisation moves to the device).
+#pragma once
+
+#include <cstdint>
+
+#include "xm_solver.h"
+
+namespace xm {
+
+constexpr int64_t kSchurMaxCams = 6000;
+
+class SchurOp {
+public:
+    // cam / lm: 0-based indices of the nobs observations, p: nobs x 3 (row-major), w: nobs
+    SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *cam, const int32_t *lm, const double *p, const double *w,
+            hipStream_t st);
+    // Y = alpha * Q * W for all n cameras (W: camera records of 3 * pitch_of(o) doubles), same CamArgs / epilogue contract and
+    // per-workgroup partial sums (grid bsr_grid(n)) as launch_qw_bsr3
+    void product(int o, int epi, const double *W, double alpha, const CamArgs &a, hipStream_t st);
+    int64_t bytes_per_product(int o) const;
+
+private:
+    int64_t n_ = 0, m_ = 0, nobs_ = 0, nred_ = 0, ldv_ = 0;   // nred = cameras of the padded (N-1) system / 3
+    DevBuf<int64_t> cam_ptr_, lm_ptr_;
+    DevBuf<int32_t> cam_lm_, lm_cam_;         // by camera: landmark of each observation; by landmark: camera
+    DevBuf<double> cam_w_, cam_p_, lm_w_, lm_p_;
+    DevBuf<double> Q1_, c_, q3inv_;
+    DevBuf<double> vtinv_;                     // (N-1)^2 inverse in the dense kernel's padded row-major layout
+    DevBuf<double> h_, r_, xc_, xl_;
+    int o_alloc_ = 0, o_last_ = 0;
+    void ensure(int o);
+};
+
+}  // namespace xm

@@ -1,0 +1,317 @@
+// xm_schur.hip — matrix-free Q*W from the observation list (design: xm_schur.h).  Replaces, for the reference's own Q
+// (utils/creatematrix.py:51-339), the dense product Dense/matmul.h:42-87 by the factor chain; the fused epilogues are those of
+// xm_device.h, so the solver above (trust region, certificate, Lanczos) is unchanged.
+#include "xm_schur.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "xm_device.h"
+
+namespace xm {
+
+// ------------------------------------------------------------------------------------------------------------------
+// device kernels
+// ------------------------------------------------------------------------------------------------------------------
+// h_l = -(1/Q3_l) sum_{obs of l} w (p . W_i)      one thread per landmark
+template <int O>
+__global__ __launch_bounds__(256) void schur_lm_h_kernel(int64_t m, const int64_t *__restrict__ lm_ptr, const int32_t *__restrict__ lm_cam,
+                                                          const double *__restrict__ lm_w, const double *__restrict__ lm_p,
+                                                          const double *__restrict__ q3inv, const double *__restrict__ W,
+                                                          const TcgScal *__restrict__ scal, double *__restrict__ h) {
+    constexpr int OP = pitch_of(O);
+    if (scal != nullptr) {
+        if (scal->status != 0) return;
+    }
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= m) return;
+    double acc[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) acc[k] = 0.0;
+    for (int64_t e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
+        const double *Wi = W + (size_t)lm_cam[e] * 3 * OP;
+        const double w = lm_w[e], p0 = lm_p[3 * e], p1 = lm_p[3 * e + 1], p2 = lm_p[3 * e + 2];
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[k] += w * (p0 * Wi[k] + p1 * Wi[OP + k] + p2 * Wi[2 * OP + k]);
+    }
+    const double qi = q3inv[l];
+#pragma unroll
+    for (int k = 0; k < O; ++k) h[(size_t)l * OP + k] = -acc[k] * qi;
+}
+
+// r_{i-1} = c_i . W_i + sum_{obs of i} w h_l      16-lane group per camera (fixed lane-strided order + DPP tree)
+template <int O>
+__global__ __launch_bounds__(256) void schur_cam_r_kernel(int n, const int64_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_lm,
+                                                           const double *__restrict__ cam_w, const double *__restrict__ c,
+                                                           const double *__restrict__ W, const double *__restrict__ h,
+                                                           const TcgScal *__restrict__ scal, double *__restrict__ r) {
+    constexpr int OP = pitch_of(O);
+    if (scal != nullptr) {
+        if (scal->status != 0) return;
+    }
+    const int gl = threadIdx.x & 15, cam = blockIdx.x * kBsrRows + (threadIdx.x >> 4);
+    double acc[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) acc[k] = 0.0;
+    if (cam < n && cam >= 1)
+        for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 16) {
+            const double w = cam_w[e];
+            const double *hl = h + (size_t)cam_lm[e] * OP;
+#pragma unroll
+            for (int k = 0; k < O; ++k) acc[k] += w * hl[k];
+        }
+#pragma unroll
+    for (int k = 0; k < O; ++k) acc[k] = group_sum<16>(acc[k]);
+    if (cam < n && cam >= 1 && gl == 0) {
+        const double *Wi = W + (size_t)cam * 3 * OP, *ci = c + (size_t)cam * 3;
+#pragma unroll
+        for (int k = 0; k < O; ++k) r[(size_t)(cam - 1) * OP + k] = acc[k] + ci[0] * Wi[k] + ci[1] * Wi[OP + k] + ci[2] * Wi[2 * OP + k];
+    }
+}
+
+// x_l = h_l + (1/Q3_l) sum_{obs of l} w x_cam_i     (x_cam of the anchor camera 0 is 0: its translation is the gauge)
+template <int O>
+__global__ __launch_bounds__(256) void schur_lm_x_kernel(int64_t m, const int64_t *__restrict__ lm_ptr, const int32_t *__restrict__ lm_cam,
+                                                          const double *__restrict__ lm_w, const double *__restrict__ q3inv,
+                                                          const double *__restrict__ h, const double *__restrict__ xc,
+                                                          const TcgScal *__restrict__ scal, double *__restrict__ xl) {
+    constexpr int OP = pitch_of(O);
+    if (scal != nullptr) {
+        if (scal->status != 0) return;
+    }
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= m) return;
+    double acc[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) acc[k] = 0.0;
+    for (int64_t e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
+        const int i = lm_cam[e];
+        if (i == 0) continue;
+        const double w = lm_w[e];
+        const double *xi = xc + (size_t)(i - 1) * OP;
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[k] += w * xi[k];
+    }
+    const double qi = q3inv[l];
+#pragma unroll
+    for (int k = 0; k < O; ++k) xl[(size_t)l * OP + k] = h[(size_t)l * OP + k] + acc[k] * qi;
+}
+
+// Y_i = Q1_i W_i - c_i x_cam_i + sum_{obs of i} w p x_l, then the common tail of the Q*W kernels (xm_device.h)
+template <int O, int EPI>
+__global__ __launch_bounds__(256) void schur_cam_y_kernel(const int64_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_lm,
+                                                           const double *__restrict__ cam_w, const double *__restrict__ cam_p,
+                                                           const double *__restrict__ Q1, const double *__restrict__ c,
+                                                           const double *__restrict__ W, const double *__restrict__ xc,
+                                                           const double *__restrict__ xl, double alpha, CamArgs a) {
+    constexpr int OP = pitch_of(O);
+    if (EPI == EPI_HESS) {
+        if (a.scal->status != 0) return;
+    }
+    __shared__ double red[kBsrRows][3];
+    const int gl = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int cam = blockIdx.x * kBsrRows + slot;
+    const bool active = cam < a.nloc;
+    EpiOps eops;
+    epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+    if (active) {
+        for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 16) {
+            const double w = cam_w[e];
+            const double *x = xl + (size_t)cam_lm[e] * OP;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double wp = w * cam_p[3 * e + r];
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc[r][k] += wp * x[k];
+            }
+        }
+        if (gl == 0) {
+            const double *Wi = W + (size_t)cam * 3 * OP, *q = Q1 + (size_t)cam * 9, *ci = c + (size_t)cam * 3;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    const double xk = (cam >= 1) ? xc[(size_t)(cam - 1) * OP + k] : 0.0;
+                    acc[r][k] += q[3 * r] * Wi[k] + q[3 * r + 1] * Wi[OP + k] + q[3 * r + 2] * Wi[2 * OP + k] - ci[r] * xk;
+                }
+        }
+    }
+    qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host: factors from the observation list (utils/creatematrix.py:62-175, restated on the observation level)
+// ------------------------------------------------------------------------------------------------------------------
+// in-place inverse of an SPD matrix (column-major, m x m) by Cholesky: A = L L^T, A^{-1} = L^{-T} L^{-1}
+static void spd_inverse(std::vector<double> &A, int64_t m) {
+    auto at = [&](int64_t r, int64_t c) -> double & { return A[(size_t)r + (size_t)c * m]; };
+    for (int64_t j = 0; j < m; ++j) {   // left-looking Cholesky on the lower triangle, columns contiguous
+        for (int64_t k = 0; k < j; ++k) {
+            const double ljk = at(j, k);
+            if (ljk != 0.0)
+                for (int64_t i = j; i < m; ++i) at(i, j) -= at(i, k) * ljk;
+        }
+        const double d = at(j, j);
+        if (!(d > 0.0)) throw Error(XM_ERR_ARG, "matrix-free Q: the reduced camera Laplacian is not positive definite (observation graph not connected?)");
+        const double s = std::sqrt(d);
+        for (int64_t i = j; i < m; ++i) at(i, j) /= s;
+    }
+    // Li = L^{-1} (lower, column-major): column j by forward substitution, x_i = -(sum_{j <= k < i} L(i,k) x_k) / L(i,i)
+    std::vector<double> Li((size_t)m * (size_t)m, 0.0);
+    for (int64_t j = 0; j < m; ++j) {
+        double *x = &Li[(size_t)j * m];
+        x[j] = 1.0 / at(j, j);
+        for (int64_t k = j; k < m; ++k) {   // right-looking: once x_k is final, subtract its contribution from the rows below
+            const double xk = x[k];
+            if (k + 1 < m) {
+                const double *lk = &A[(size_t)k * m];
+                for (int64_t i = k + 1; i < m; ++i) x[i] -= lk[i] * xk;
+                x[k + 1] /= at(k + 1, k + 1);
+            }
+        }
+    }
+    // A^{-1} = Li^T Li : entry (a, b), a <= b, = sum_{i >= b} Li(i, a) Li(i, b)   (columns of Li are contiguous in i)
+    for (int64_t b = 0; b < m; ++b)
+        for (int64_t a2 = 0; a2 <= b; ++a2) {
+            const double *pa = &Li[(size_t)a2 * m], *pb = &Li[(size_t)b * m];
+            double t = 0.0;
+            for (int64_t i = b; i < m; ++i) t += pa[i] * pb[i];
+            at(a2, b) = t;
+            at(b, a2) = t;
+        }
+}
+
+SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *cam, const int32_t *lm, const double *p, const double *w,
+                 hipStream_t st) {
+    if (n < 1 || n_landmarks < 1 || nobs < 1 || !cam || !lm || !p || !w) throw Error(XM_ERR_ARG, "matrix-free Q: bad observation list");
+    if (n > kSchurMaxCams) throw Error(XM_ERR_ARG, "matrix-free Q: more than " + std::to_string(kSchurMaxCams) + " cameras (host factorisation of the reduced camera Laplacian)");
+    n_ = n; m_ = n_landmarks; nobs_ = nobs;
+    const int64_t N = n, M = n_landmarks;
+    std::vector<int64_t> cp((size_t)N + 1, 0), lp((size_t)M + 1, 0);
+    std::vector<double> Q1((size_t)N * 9, 0.0), c((size_t)N * 3, 0.0), Q2((size_t)N, 0.0), Q3((size_t)M, 0.0);
+    for (int64_t e = 0; e < nobs; ++e) {
+        const int64_t i = cam[e], l = lm[e];
+        if (i < 0 || i >= N || l < 0 || l >= M) throw Error(XM_ERR_ARG, "matrix-free Q: observation index out of range");
+        if (!(w[e] >= 0.0)) throw Error(XM_ERR_ARG, "matrix-free Q: negative or NaN weight");
+        cp[(size_t)i + 1]++; lp[(size_t)l + 1]++;
+        const double *pe = p + 3 * e;
+        for (int a = 0; a < 3; ++a) {
+            c[(size_t)i * 3 + a] += w[e] * pe[a];                                 // V1 block (creatematrix.py:27)
+            for (int b = 0; b < 3; ++b) Q1[(size_t)i * 9 + 3 * a + b] += w[e] * pe[a] * pe[b];   // Q1 block (:26)
+        }
+        Q2[(size_t)i] += w[e]; Q3[(size_t)l] += w[e];                             // :68-69
+    }
+    for (int64_t l = 0; l < M; ++l)
+        if (!(Q3[(size_t)l] > 0.0)) throw Error(XM_ERR_ARG, "matrix-free Q: a landmark has no observation with positive weight");
+    for (int64_t i = 0; i < N; ++i) cp[(size_t)i + 1] += cp[(size_t)i];
+    for (int64_t l = 0; l < M; ++l) lp[(size_t)l + 1] += lp[(size_t)l];
+    std::vector<int32_t> c_lm((size_t)nobs), l_cam((size_t)nobs);
+    std::vector<double> c_w((size_t)nobs), c_p((size_t)nobs * 3), l_w((size_t)nobs), l_p((size_t)nobs * 3);
+    {
+        std::vector<int64_t> nc(cp.begin(), cp.end() - 1), nl(lp.begin(), lp.end() - 1);
+        for (int64_t e = 0; e < nobs; ++e) {   // observation order inside a camera / a landmark = input order (fixed summation order)
+            const int64_t a2 = nc[(size_t)cam[e]]++, b2 = nl[(size_t)lm[e]]++;
+            c_lm[(size_t)a2] = lm[e]; c_w[(size_t)a2] = w[e]; std::memcpy(&c_p[(size_t)a2 * 3], p + 3 * e, 24);
+            l_cam[(size_t)b2] = cam[e]; l_w[(size_t)b2] = w[e]; std::memcpy(&l_p[(size_t)b2 * 3], p + 3 * e, 24);
+        }
+    }
+    // reduced camera Laplacian VT = Q2_bar - V3_bar Q3^{-1} V3_bar^T (creatematrix.py:150-166) and its inverse
+    const int64_t mr = N - 1;
+    std::vector<double> VT((size_t)std::max<int64_t>(mr, 1) * (size_t)std::max<int64_t>(mr, 1), 0.0);
+    for (int64_t i = 1; i < N; ++i) VT[(size_t)(i - 1) + (size_t)(i - 1) * mr] = Q2[(size_t)i];
+    for (int64_t l = 0; l < M; ++l) {
+        const double qi = 1.0 / Q3[(size_t)l];
+        for (int64_t e1 = lp[(size_t)l]; e1 < lp[(size_t)l + 1]; ++e1) {
+            const int64_t a2 = l_cam[(size_t)e1];
+            if (a2 == 0) continue;
+            for (int64_t e2 = lp[(size_t)l]; e2 < lp[(size_t)l + 1]; ++e2) {
+                const int64_t b2 = l_cam[(size_t)e2];
+                if (b2 == 0) continue;
+                VT[(size_t)(a2 - 1) + (size_t)(b2 - 1) * mr] -= l_w[(size_t)e1] * l_w[(size_t)e2] * qi;
+            }
+        }
+    }
+    if (mr > 0) spd_inverse(VT, mr);
+    std::vector<double> q3inv((size_t)M);
+    for (int64_t l = 0; l < M; ++l) q3inv[(size_t)l] = 1.0 / Q3[(size_t)l];
+
+    auto up = [&](auto &buf, const auto &v) {
+        buf.alloc(std::max<size_t>(v.size(), 1), false);
+        if (!v.empty()) XM_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+    };
+    up(cam_ptr_, cp); up(lm_ptr_, lp); up(cam_lm_, c_lm); up(lm_cam_, l_cam); up(cam_w_, c_w); up(cam_p_, c_p); up(lm_w_, l_w); up(lm_p_, l_p);
+    up(Q1_, Q1); up(c_, c); up(q3inv_, q3inv);
+    // VT^{-1} in the dense kernel's layout: (N-1) unknowns padded to nred "cameras" of 3 rows
+    nred_ = std::max<int64_t>(1, (mr + 2) / 3);
+    ldv_ = dense_ld(nred_);
+    vtinv_.alloc((size_t)3 * nred_ * (size_t)ldv_);
+    if (mr > 0) {
+        DevBuf<double> tmp;
+        tmp.alloc((size_t)mr * mr, false);
+        XM_HIP_CHECK(hipMemcpy(tmp.p, VT.data(), (size_t)mr * mr * sizeof(double), hipMemcpyHostToDevice));
+        launch_transpose_pad(tmp.p, mr, mr, mr, vtinv_.p, ldv_, st);
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+}
+
+void SchurOp::ensure(int o) {
+    if (o <= o_alloc_) return;
+    const size_t OP = (size_t)pitch_of(o);
+    h_.alloc((size_t)m_ * OP); xl_.alloc((size_t)m_ * OP);
+    r_.alloc((size_t)ldv_ * OP + 2);            // product input of the dense kernel: ldv rows, zero beyond N-1
+    xc_.alloc((size_t)3 * nred_ * OP + 2);
+    o_alloc_ = o;
+}
+
+int64_t SchurOp::bytes_per_product(int o) const {
+    // observation arrays are streamed twice by camera (w, landmark index; w, p, landmark index) and twice by landmark, VT^{-1} once
+    return nobs_ * (8 + 4) + nobs_ * (8 + 24 + 4) + nobs_ * (8 + 24 + 4) + nobs_ * (8 + 4) + 8 * (n_ - 1) * (n_ - 1) + 2LL * 8 * 3 * n_ * o;
+}
+
+template <int O>
+static void schur_product_o(int epi, int64_t n, int64_t m, const int64_t *cam_ptr, const int32_t *cam_lm, const double *cam_w, const double *cam_p,
+                            const int64_t *lm_ptr, const int32_t *lm_cam, const double *lm_w, const double *lm_p, const double *Q1,
+                            const double *c, const double *q3inv, const double *vtinv, int64_t nred, int64_t ldv, double *h, double *r,
+                            double *xc, double *xl, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+    const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
+    const dim3 b(256), gl((unsigned)((m + 255) / 256)), gc(bsr_grid((int)n));
+    hipLaunchKernelGGL((schur_lm_h_kernel<O>), gl, b, 0, st, m, lm_ptr, lm_cam, lm_w, lm_p, q3inv, W, sc, h);
+    hipLaunchKernelGGL((schur_cam_r_kernel<O>), gc, b, 0, st, (int)n, cam_ptr, cam_lm, cam_w, c, W, h, sc, r);
+    if (n > 1) {
+        CamArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.nloc = (int)nred; pa.out = xc; pa.scal = a.scal;
+        launch_qw_dense(O, EPI_PLAIN, vtinv, ldv, r, 1.0, pa, st);
+    }
+    hipLaunchKernelGGL((schur_lm_x_kernel<O>), gl, b, 0, st, m, lm_ptr, lm_cam, lm_w, q3inv, h, xc, sc, xl);
+    switch (epi) {
+        case EPI_PLAIN: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_PLAIN>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_GRAD>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_HESS>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
+        case EPI_CERT:
+            if constexpr (O == 1) { hipLaunchKernelGGL((schur_cam_y_kernel<1, EPI_CERT>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break; }
+            throw Error(XM_ERR_ARG, "certificate operator needs o == 1");
+        default: throw Error(XM_ERR_ARG, "bad epilogue");
+    }
+}
+
+void SchurOp::product(int o, int epi, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+    ensure(o);
+    if (o != o_last_) {   // the row pitch of the scratch vectors changes with o: start from clean zero padding
+        XM_HIP_CHECK(hipMemsetAsync(r_.p, 0, r_.count * sizeof(double), st));
+        XM_HIP_CHECK(hipMemsetAsync(xc_.p, 0, xc_.count * sizeof(double), st));
+        o_last_ = o;
+    }
+    XM_DISPATCH_O(o, (schur_product_o<O_>(epi, n_, m_, cam_ptr_.p, cam_lm_.p, cam_w_.p, cam_p_.p, lm_ptr_.p, lm_cam_.p, lm_w_.p, lm_p_.p, Q1_.p,
+                                         c_.p, q3inv_.p, vtinv_.p, nred_, ldv_, h_.p, r_.p, xc_.p, xl_.p, W, alpha, a, st)));
+    check_launch("schur_product");
+}
+
+}  // namespace xm

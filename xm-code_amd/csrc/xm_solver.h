@@ -55,6 +55,7 @@ struct DevBuf {
 };
 
 class SellMatrix;   // xm_sell.h
+class SchurOp;      // xm_schur.h
 
 struct PointState {  // everything the gradient epilogue writes for one point (R, s)
     DevBuf<double> G, egs, S0, rgR, rgs;
@@ -78,6 +79,7 @@ public:
     explicit Context(const xm_problem_t &prob);
     ~Context();
     void solve(const xm_options_t &opt, xm_result_t &res);
+    void apply(int o, const double *W_host, double *out_host, double alpha);   // out = alpha Q W (host, column-major)
     // XM^2 re-weighting (include/xm_amd.h section 2)
     void attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
     void edge_residuals(double *res);
@@ -100,6 +102,7 @@ private:
     int64_t nb_loc_ = 0;
     std::unique_ptr<SellMatrix> sell_;   // large block-sparse Q: sliced-ELL layout (xm_sell.h); the CSR arrays stay for the fallback kernels
     int sell_gm_ = 0;
+    std::unique_ptr<SchurOp> schur_;     // XM_STORAGE_SCHUR: matrix-free Q (xm_schur.h)
     // XM^2 edge description (attach_edges)
     int64_t ne_ = 0;
     DevBuf<int32_t> ei_, ej_, inc_edge_;

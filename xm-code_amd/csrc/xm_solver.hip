@@ -11,6 +11,7 @@
 //    per inner iteration, Dense/transpose.h:7-22).
 #include "xm_solver.h"
 #include "xm_sell.h"
+#include "xm_schur.h"
 
 #include <algorithm>
 #include <chrono>
@@ -162,6 +163,9 @@ void Context::init(const xm_problem_t &prob) {
                                            env_int("XM_SELL_LMAX", 64), st_));
             }
         }
+    } else if (storage_ == XM_STORAGE_SCHUR) {
+        if (world != 1) throw Error(XM_ERR_ARG, "matrix-free storage is single-GPU in this version");
+        schur_.reset(new SchurOp(n_, prob.n_landmarks, prob.nobs, prob.obs_cam, prob.obs_lm, prob.obs_p, prob.obs_w, st_));
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
     }
@@ -279,7 +283,7 @@ void Context::download_point(std::vector<double> &R_cm, std::vector<double> &s_e
 }
 
 // workgroups of the product kernels == number of per-workgroup partial sums per epilogue slot
-int Context::prod_grid() const { return storage_ == XM_STORAGE_BSR3 ? bsr_grid(nloc_) : qw_grid(nloc_); }
+int Context::prod_grid() const { return (storage_ == XM_STORAGE_BSR3 || storage_ == XM_STORAGE_SCHUR) ? bsr_grid(nloc_) : qw_grid(nloc_); }
 
 CamArgs Context::cam_args(int state) const {
     CamArgs a;
@@ -303,6 +307,8 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
     if (storage_ == XM_STORAGE_DENSE) {
         if (sym_ok_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT && Pcol_.p) launch_qw_sym(o, epi, dQ_, ld_, W_.p, alpha, a, Prow_.p, Pcol_.p, st_);
         else launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
+    } else if (storage_ == XM_STORAGE_SCHUR) {
+        schur_->product(o, epi, W_.p, alpha, a, st_);
     } else if (sell_ && sell_supports(o)) {
         launch_qw_sell(o, epi, *sell_, W_.p, alpha, a, sell_gm_, st_);
     } else {
@@ -788,6 +794,7 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 a.Wloc = vj + (size_t)cam0_ * 3;
                 a.out = w.p + (size_t)cam0_ * 3;
                 if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
+                else if (storage_ == XM_STORAGE_SCHUR) schur_->product(1, EPI_CERT, vj, 1.0, a, st_);
                 else if (sell_) launch_qw_sell(1, EPI_CERT, *sell_, vj, 1.0, a, 0, st_);
                 else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_);
                 res_->qw_products++;
@@ -878,6 +885,34 @@ CertResult Context::certificate(int o, double primal, std::vector<double> &v_out
     if (cr.accepted) log("BM finished with rank %d\n", o); else log("BM order plus one\n");
     res_->cert_seconds += secs_since(t0);
     return cr;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// out = alpha * Q * W through whatever storage the context holds (tests, diagnostics): host matrices, column-major 3n x o
+// ------------------------------------------------------------------------------------------------------------------
+void Context::apply(int o, const double *Wh, double *out, double alpha) {
+    if (comm_->active()) throw Error(XM_ERR_ARG, "xm_ctx_qw: single-rank contexts only");
+    if (!Wh || !out) throw Error(XM_ERR_ARG, "xm_ctx_qw: null argument");
+    xm_options_t opt;
+    std::memset(&opt, 0, sizeof(opt));
+    opt_ = &opt;
+    setup_rank(o);
+    const size_t m = (size_t)3 * n_;
+    std::vector<double> rm((size_t)ld_ * OP_ + 2, 0.0);
+    for (size_t r = 0; r < m; ++r)
+        for (int k = 0; k < o; ++k) rm[r * OP_ + k] = Wh[r + (size_t)k * m];
+    XM_HIP_CHECK(hipMemcpyAsync(W_.p, rm.data(), rm.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+    CamArgs a = cam_args(cur_);
+    a.out = HpR_.p;
+    product(EPI_PLAIN, o, alpha, a);
+    std::vector<double> res((size_t)nloc_ * 3 * OP_);
+    XM_HIP_CHECK(hipMemcpyAsync(res.data(), HpR_.p, res.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+    XM_HIP_CHECK(hipMemsetAsync(W_.p, 0, W_.count * sizeof(double), st_));
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+    for (size_t r = 0; r < m; ++r)
+        for (int k = 0; k < o; ++k) out[r + (size_t)k * m] = res[r * OP_ + k];
+    opt_ = nullptr;
+    solved_ = false;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1041,6 +1076,7 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     const int of = std::max(3, std::min(out_rank, (int)opt.max_rank));
     res.sym_product = (sym_ok_ && storage_ == XM_STORAGE_DENSE) ? 1 : 0;
     if (storage_ == XM_STORAGE_DENSE) res.qw_bytes = 8LL * (3 * n_) * (3 * n_) + 2LL * 8 * 3 * n_ * of;
+    else if (storage_ == XM_STORAGE_SCHUR) res.qw_bytes = schur_->bytes_per_product(of);
     else res.qw_bytes = 76LL * nb_loc_ + 4LL * (n_ + 1) + 2LL * 8 * 3 * n_ * of;
     res.seconds = secs_since(t0);
     // leave the end point resident at its final rank for edge_residuals(): R_/s_ hold the last trust-region point already,

@@ -14,6 +14,7 @@ MODULE_DIR = os.path.join(_HERE, "build")      # holds XM.cpython-*.so (the refe
 
 STORAGE_DENSE, STORAGE_BSR3 = 0, 1
 STORAGE_BSR3_DENSE = 2   # BSR3 on the host, expanded to the dense layout on the device (each rank: its own rows)
+STORAGE_SCHUR = 3        # matrix-free: the observation list of the reference's create_matrix (cam, lm, p, w)
 MODE_SOLVE, MODE_RANK3, MODE_REBUTTLE = 0, 1, 2
 FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 CERT_EIG_NOT_CONVERGED = 1
@@ -25,7 +26,7 @@ EXPORTS = [
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition",
     "xm_sell_layout", "xm_sell_create", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
-    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights",
+    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights", "xm_ctx_qw",
 ]
 
 
@@ -36,7 +37,8 @@ class XmError(RuntimeError):
 class Problem(C.Structure):
     _fields_ = [("n", C.c_int64), ("storage", C.c_int32), ("q_on_device", C.c_int32), ("q", C.c_void_p),
                 ("ldq", C.c_int64), ("nb", C.c_int64), ("rowptr", C.c_void_p), ("colidx", C.c_void_p),
-                ("blocks", C.c_void_p), ("q_row0", C.c_int64)]
+                ("blocks", C.c_void_p), ("nobs", C.c_int64), ("n_landmarks", C.c_int64), ("obs_cam", C.c_void_p), ("obs_lm", C.c_void_p),
+                ("obs_p", C.c_void_p), ("obs_w", C.c_void_p), ("q_row0", C.c_int64)]
 
 
 class Options(C.Structure):
@@ -77,6 +79,7 @@ def lib():
         L.xm_ctx_solve.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Result)]
         L.xm_ctx_destroy.argtypes = [C.c_void_p]
         L.xm_ctx_destroy.restype = None
+        L.xm_ctx_qw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double]
         L.xm_ctx_attach_edges.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_ctx_edge_residuals.argtypes = [C.c_void_p, C.c_void_p]
         L.xm_ctx_set_edge_weights.argtypes = [C.c_void_p, C.c_void_p]
@@ -319,11 +322,19 @@ def recover_rotations(R, s):
 class Context:
     """Q resident in HBM; solve() == the reference's staircase (XM_main.cu:180 / :312 / :35)."""
 
-    def __init__(self, Q=None, bsr=None, dq=None, n=None, densify=False):
+    def __init__(self, Q=None, bsr=None, dq=None, n=None, densify=False, obs=None):
         require_gpu()
         self._keep = []
         p = Problem()
-        if dq is not None:                      # dense Q already on the device in the solver's layout (borrowed)
+        if obs is not None:                     # matrix-free: (cam, lm, p, w) = (edges[:, 0] - 1, edges[:, 1] - 1, landmarks, weight)
+            cam, lm, pts, w = obs
+            cam = np.ascontiguousarray(cam, dtype=np.int32); lm = np.ascontiguousarray(lm, dtype=np.int32)
+            pts = np.ascontiguousarray(pts, dtype=np.float64); w = np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
+            self.n = int(cam.max()) + 1 if n is None else int(n)
+            p.n, p.storage, p.nobs, p.n_landmarks = self.n, STORAGE_SCHUR, cam.size, int(lm.max()) + 1
+            p.obs_cam, p.obs_lm, p.obs_p, p.obs_w = (a.ctypes.data_as(C.c_void_p) for a in (cam, lm, pts, w))
+            self._keep += [cam, lm, pts, w]
+        elif dq is not None:                      # dense Q already on the device in the solver's layout (borrowed)
             self.n = int(n)
             p.n, p.storage, p.q_on_device, p.q, p.ldq = self.n, STORAGE_DENSE, 1, dq.ptr, dense_ld(self.n)
             self._dq = dq
@@ -343,6 +354,13 @@ class Context:
         self.h = C.c_void_p()
         _chk(lib().xm_ctx_create(C.byref(p), C.byref(self.h)))
         self._keep = []   # Q has been copied to the device
+
+    def qw(self, W, alpha=1.0):
+        """alpha * Q @ W through the context's storage (xm_ctx_qw)"""
+        W = np.asfortranarray(np.asarray(W, dtype=np.float64))
+        out = np.zeros_like(W, order="F")
+        _chk(lib().xm_ctx_qw(self.h, W.shape[1], W.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), alpha))
+        return np.ascontiguousarray(out)
 
     # ---- XM^2 re-weighting on the resident Q (SURVEY 8f N4; reference loop 3_test_colmap_glomap.py:299-351)
     def attach_edges(self, ei, ej, M):
