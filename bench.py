@@ -122,7 +122,9 @@ def cpu_baseline(Q, wl, budget_s, bsr=None):
                 sample=f"rank-3 trust region of the same Q on the host for <= {budget_s:.0f}s of its own max_time clock: "
                        f"{its} tCG iters / {st['outer_iters']} outer in {st['seconds']:.1f}s (stop {st['stop_reason']}), "
                        f"Q*W {st['qw_seconds'] / max(st['qw_products'], 1) * 1e3:.2f} ms each",
-                qw_ms=st["qw_seconds"] / max(st["qw_products"], 1) * 1e3, wall_s=el)
+                qw_ms=st["qw_seconds"] / max(st["qw_products"], 1) * 1e3, wall_s=el,
+                qw_host_GBs=((76.0 * bsr[1].size + 4 * (n + 1)) if bsr is not None else 8.0 * (3 * n) ** 2) / 1e9 /
+                            max(st["qw_seconds"] / max(st["qw_products"], 1), 1e-12))
 
 
 def main():
