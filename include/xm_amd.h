@@ -184,9 +184,9 @@ int xm_qw_bsr3(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d
  * (the reference has no sparse product: Dense/matmul.h:42-87 on a dense Q); the matrix is described on the HOST as 3x3-block CSR
  * (rows n, global columns in [0, ncols)) and re-laid on the device.  slabs in {1,2,4,8}; lmax = longest virtual row (hub
  * cameras are cut); gather_mode 0 | 1 selects how the rows of W are fetched.  xm_sell_layout is host-only (CPU tests): with
- * NULL arrays it fills sizes = {slices, steps, partial slots, virtual rows}. */
-int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t sizes[4],
-                   int64_t *slice_off, int32_t *slab_start, uint8_t *kind, int64_t *src, int32_t *pslot, int64_t *pptr);
+ * NULL arrays it fills sizes = {slices, steps, partial results, virtual rows, entries of the partial-result array}. */
+int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t sizes[5],
+                   int64_t *slice_off, int32_t *slab_start, uint8_t *kind, int64_t *src, int32_t *pslot, int64_t *pptr, int32_t *ridx);
 int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
                    void **handle);
 void xm_sell_destroy(void *handle);

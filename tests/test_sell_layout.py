@@ -26,8 +26,8 @@ def _emulate(L, colidx, blocks, W, o):
                 gb = g - kd
                 cols[gb * 64 + lane * 2 + kd] = c
                 blk[gb * 576 + np.arange(9) * 128 + lane * 2 + kd] = q
-    parts = np.zeros((max(L["nparts"], 1), 3, o))
-    seen = np.zeros(max(L["nparts"], 1), dtype=int)
+    parts = np.zeros((max(L["nstore"], 1), 3, o))
+    seen = np.zeros(max(L["nstore"], 1), dtype=int)
     Wc = W.reshape(-1, 3, o)
     for c in range(L["nslices"]):                          # qw_sell_kernel: wave = slice, lane = virtual row
         off = int(L["slice_off"][c]); w = int(L["slice_off"][c + 1]) - off
@@ -47,11 +47,11 @@ def _emulate(L, colidx, blocks, W, o):
             if slot >= 0:
                 parts[slot] = acc
                 seen[slot] += 1
-    assert np.all(seen[: L["nparts"]] == 1)                 # every partial slot written exactly once
+    assert seen.sum() == L["nparts"] and seen.max() <= 1 and np.all(seen[L["ridx"][: L["nparts"]]] == 1)   # every listed partial result is written exactly once
     n = L["pptr"].size - 1
     out = np.zeros((n, 3, o))
     for r in range(n):                                     # sell_reduce_kernel
-        out[r] = parts[L["pptr"][r]:L["pptr"][r + 1]].sum(axis=0)
+        out[r] = parts[L["ridx"][L["pptr"][r]:L["pptr"][r + 1]]].sum(axis=0)
     return out.reshape(3 * n, o)
 
 

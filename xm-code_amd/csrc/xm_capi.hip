@@ -372,18 +372,19 @@ int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int6
 
 
 // ---- sliced-ELL product for large block-sparse Q (xm_sell.h) -------------------------------------------------------------
-int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t sizes[4],
-                   int64_t *slice_off, int32_t *slab_start, uint8_t *kind, int64_t *src, int32_t *pslot, int64_t *pptr) {
+int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t sizes[5],
+                   int64_t *slice_off, int32_t *slab_start, uint8_t *kind, int64_t *src, int32_t *pslot, int64_t *pptr, int32_t *ridx) {
     XM_TRY
     xm::SellHost h;
     xm::sell_build_host(rowptr, colidx, n, ncols, slabs, lmax, h);   // host only: no device needed
-    if (sizes) { sizes[0] = h.nslices; sizes[1] = h.nsteps; sizes[2] = h.nparts; sizes[3] = h.nvrows; }
+    if (sizes) { sizes[0] = h.nslices; sizes[1] = h.nsteps; sizes[2] = h.nparts; sizes[3] = h.nvrows; sizes[4] = h.nstore; }
     if (slice_off) std::copy(h.slice_off.begin(), h.slice_off.end(), slice_off);
     if (slab_start) std::copy(h.slab_start.begin(), h.slab_start.end(), slab_start);
     if (kind) std::copy(h.kind.begin(), h.kind.end(), kind);
     if (src) std::copy(h.src.begin(), h.src.end(), src);
     if (pslot) std::copy(h.pslot.begin(), h.pslot.end(), pslot);
     if (pptr) std::copy(h.pptr.begin(), h.pptr.end(), pptr);
+    if (ridx) std::copy(h.ridx.begin(), h.ridx.begin() + h.nparts, ridx);
     return XM_OK;
     XM_CATCH
 }

@@ -30,13 +30,14 @@ namespace xm {
 struct SellHost {
     int64_t nloc = 0, ncols = 0;
     int S = 1, lmax = 0;
-    int64_t nvrows = 0, nslices = 0, nsteps = 0, nparts = 0;
+    int64_t nvrows = 0, nslices = 0, nsteps = 0, nparts = 0, nstore = 0;   // nstore: entries of the partial-result array
     std::vector<int64_t> slice_off;   // nslices + 1, in steps; a slice of width w owns steps [off, off + w)
     std::vector<int32_t> slab_start;  // S + 1, in slices
     std::vector<uint8_t> kind;        // nsteps: 0 = first step of a pair, 1 = second step of a pair, 2 = unpaired last step
     std::vector<int64_t> src;         // nsteps * 64: source block of (step, lane) in the CSR arrays, -1 = padding
-    std::vector<int32_t> pslot;       // nslices * 64: partial-result slot of (slice, lane), -1 = padding lane
-    std::vector<int64_t> pptr;        // nloc + 1: the partial results of camera r are slots [pptr[r], pptr[r+1])
+    std::vector<int32_t> pslot;       // nslices * 64: where (slice, lane) stores its partial result, -1 = padding lane
+    std::vector<int32_t> ridx;        // nparts: storage index of the k-th listed partial result (see pptr)
+    std::vector<int64_t> pptr;        // nloc + 1: the partial results of camera r are ridx[pptr[r] .. pptr[r+1])
 };
 
 // rowptr: nloc + 1 offsets (rowptr[0] may be non-zero: offsets into colidx); colidx: global columns in [0, ncols).
@@ -50,6 +51,7 @@ struct SellArgs {   // what the kernels see
     const double *blk;      // step unit = 576 doubles: pair [e][lane][2] over two units, single [e][lane]
     const int32_t *pslot;
     const int64_t *pptr;
+    const int32_t *ridx;
     int S;
 };
 
@@ -71,7 +73,7 @@ private:
     int64_t nloc_ = 0, nparts_ = 0, nsteps_ = 0, nslices_ = 0;
     int S_ = 1, grid_ = 0;
     DevBuf<int64_t> slice_off_, pptr_;
-    DevBuf<int32_t> slab_start_, cols_, pslot_;
+    DevBuf<int32_t> slab_start_, cols_, pslot_, ridx_;
     DevBuf<double> blk_, parts_;
     DevBuf<int64_t> src_;
     DevBuf<uint8_t> kind_;

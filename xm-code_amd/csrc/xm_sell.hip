@@ -64,6 +64,11 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
     }
     out.pptr[(size_t)nloc] = slot;
     out.nparts = slot;
+    // Where a partial result is STORED: XM_SELL_SLOTS=0 at its list position (row-major: the lanes of a slice scatter 72-byte records
+    // over the whole array), 1 (default) at slice * 64 + lane (the 64 records of a slice are one contiguous 4.6 KB run, written once, by
+    // one wavefront; the per-camera sum then looks its records up through ridx).
+    static const bool slice_order = [] { const char *e = std::getenv("XM_SELL_SLOTS"); return !(e && *e == '0'); }();
+    out.ridx.assign((size_t)std::max<int64_t>(slot, 1), 0);
     // per slab: stable counting sort by length (descending), then slices of 64
     out.slab_start.assign((size_t)S + 1, 0);
     out.slice_off.clear();
@@ -88,7 +93,9 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
             const size_t cnt_l = std::min<size_t>(64, sorted.size() - i);
             for (size_t l = 0; l < cnt_l; ++l) {
                 const VRow &x = sorted[i + l];
-                out.pslot[out.pslot.size() - 64 + l] = x.slot;
+                const int64_t store = slice_order ? (int64_t)(out.slice_off.size() - 2) * 64 + (int64_t)l : (int64_t)x.slot;
+                out.pslot[out.pslot.size() - 64 + l] = (int32_t)store;
+                out.ridx[(size_t)x.slot] = (int32_t)store;
                 for (int k = 0; k < x.len; ++k) out.src[(size_t)(off + k) * 64 + l] = order[(size_t)(x.start + k)];
             }
         }
@@ -96,6 +103,8 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
     }
     out.nslices = (int64_t)out.slice_off.size() - 1;
     out.nsteps = out.slice_off.back();
+    out.nstore = slice_order ? out.nslices * 64 : out.nparts;
+    if (out.nstore > 2147483000LL) throw Error(XM_ERR_ARG, "SELL: too many partial results");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -130,12 +139,14 @@ SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const doubl
                        hipStream_t st) {
     SellHost h;
     sell_build_host(rowptr, colidx, nloc, ncols, S, lmax, h);
-    nloc_ = nloc; nparts_ = h.nparts; nsteps_ = h.nsteps; nslices_ = h.nslices; S_ = S;
+    nloc_ = nloc; nparts_ = h.nstore; nsteps_ = h.nsteps; nslices_ = h.nslices; S_ = S;
     const int64_t b0 = rowptr[0], nb = rowptr[nloc] - b0;
     slice_off_.alloc(h.slice_off.size(), false);
     slab_start_.alloc(h.slab_start.size(), false);
     pslot_.alloc(std::max<size_t>(h.pslot.size(), 1), false);
     pptr_.alloc(h.pptr.size(), false);
+    ridx_.alloc(h.ridx.size(), false);
+    XM_HIP_CHECK(hipMemcpy(ridx_.p, h.ridx.data(), h.ridx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     cols_.alloc((size_t)std::max<int64_t>(nsteps_, 1) * 64, false);
     blk_.alloc((size_t)std::max<int64_t>(nsteps_, 1) * 576, false);
     XM_HIP_CHECK(hipMemcpy(slice_off_.p, h.slice_off.data(), h.slice_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -176,7 +187,7 @@ void SellMatrix::refill(const int32_t *d_colidx, const double *d_blocks, hipStre
 
 SellArgs SellMatrix::args() const {
     SellArgs a;
-    a.slice_off = slice_off_.p; a.slab_start = slab_start_.p; a.cols = cols_.p; a.blk = blk_.p; a.pslot = pslot_.p; a.pptr = pptr_.p;
+    a.slice_off = slice_off_.p; a.slab_start = slab_start_.p; a.cols = cols_.p; a.blk = blk_.p; a.pslot = pslot_.p; a.pptr = pptr_.p; a.ridx = ridx_.p;
     a.S = S_;
     return a;
 }
@@ -421,8 +432,8 @@ __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *
 // per camera: partial results added in slot order (fixed -> bit-reproducible), then the common tail of the Q*W kernels
 // (16-lane group per camera, column-per-lane epilogue, per-workgroup partial sums) exactly as in qw_bsr3_kernel
 template <int O, int EPI>
-__global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restrict__ pptr, const double *__restrict__ parts, double alpha,
-                                                           CamArgs a) {
+__global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restrict__ pptr, const int32_t *__restrict__ ridx, const double *__restrict__ parts,
+                                                           double alpha, CamArgs a) {
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restr
     if (active) {
         const int64_t p1 = pptr[cam + 1];
         for (int64_t p = pptr[cam] + gl; p < p1; p += 16) {   // fixed order: lane gl takes slots gl, gl + 16, ...
-            const double *v = parts + (size_t)p * 3 * O;
+            const double *v = parts + (size_t)ridx[p] * 3 * O;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -483,9 +494,9 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
     }
     const dim3 g(bsr_grid(a.nloc)), b(256);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, sa.pptr, parts, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, sa.pptr, parts, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_HESS>), g, b, 0, st, sa.pptr, parts, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_HESS>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;
         default: throw Error(XM_ERR_ARG, "bad epilogue");
     }
 }
@@ -497,7 +508,7 @@ void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha
         double *parts = m.parts(1);
         const SellArgs sa = m.args();
         if (m.grid() > 0) hipLaunchKernelGGL((qw_sell_kernel<1, 0>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
-        hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT>), dim3(bsr_grid(a.nloc)), dim3(256), 0, st, sa.pptr, parts, alpha, a);
+        hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT>), dim3(bsr_grid(a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a);
     } else {
         switch (o) {
             case 1: qw_sell_o<1>(epi, m, W, alpha, a, 0, st); break;

@@ -106,7 +106,7 @@ def lib():
         L.xm_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.xm_comm_init_shm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
         L.xm_partition.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-        L.xm_sell_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p] + [C.c_void_p] * 6
+        L.xm_sell_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p] + [C.c_void_p] * 7
         L.xm_sell_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.xm_sell_destroy.argtypes = [C.c_void_p]
         L.xm_sell_destroy.restype = None
@@ -244,16 +244,16 @@ def sell_layout(rowptr, colidx, ncols=None, slabs=4, lmax=64):
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
     n = rowptr.size - 1
     ncols = n if ncols is None else ncols
-    sizes = np.zeros(4, dtype=np.int64)
+    sizes = np.zeros(5, dtype=np.int64)
     args = (rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), n, ncols, slabs, lmax)
-    _chk(lib().xm_sell_layout(*args, sizes.ctypes.data_as(C.c_void_p), *([None] * 6)))
-    nsl, nst, npart, nvr = (int(x) for x in sizes)
-    out = dict(nslices=nsl, nsteps=nst, nparts=npart, nvrows=nvr, slabs=slabs,
+    _chk(lib().xm_sell_layout(*args, sizes.ctypes.data_as(C.c_void_p), *([None] * 7)))
+    nsl, nst, npart, nvr, nstore = (int(x) for x in sizes)
+    out = dict(nslices=nsl, nsteps=nst, nparts=npart, nvrows=nvr, nstore=nstore, slabs=slabs, ridx=np.zeros(max(npart, 1), dtype=np.int32),
                slice_off=np.zeros(nsl + 1, dtype=np.int64), slab_start=np.zeros(slabs + 1, dtype=np.int32),
                kind=np.zeros(max(nst, 1), dtype=np.uint8), src=np.zeros(max(nst, 1) * 64, dtype=np.int64),
                pslot=np.zeros(max(nsl, 1) * 64, dtype=np.int32), pptr=np.zeros(n + 1, dtype=np.int64))
     _chk(lib().xm_sell_layout(*args, sizes.ctypes.data_as(C.c_void_p),
-                              *(out[k].ctypes.data_as(C.c_void_p) for k in ("slice_off", "slab_start", "kind", "src", "pslot", "pptr"))))
+                              *(out[k].ctypes.data_as(C.c_void_p) for k in ("slice_off", "slab_start", "kind", "src", "pslot", "pptr", "ridx"))))
     return out
 
 
