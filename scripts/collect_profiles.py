@@ -2,7 +2,7 @@
 import csv, glob, json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 def last_json(path):
     for line in reversed(open(path).read().splitlines()):
@@ -37,5 +37,11 @@ out["all_hess_real_avg_us"] = sum(allreal) / max(1, len(allreal))
 out["cg_step_avg_us"] = sum(cg) / max(1, len(cg))
 out["bench_line_hip_event_avg_us"] = b["roofline"]["avg_launch_ms"] * 1e3
 json.dump(out, open(os.path.join(P, f"{tag}_kernel_trace_hess_real_vs_noop.json"), "w"), indent=1)
+for src, dst in (("pmc_sell.json", f"{tag}_pmc_sell_100k.json"), (f"{tag}_pmc_fetch_hess_bench.json", f"{tag}_pmc_fetch_hess_bench.json")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
+vg = glob.glob(os.path.join(G, "prof_vg100k", "**", "*kernel_stats.csv"), recursive=True)
+if vg:
+    shutil.copy(vg[0], os.path.join(P, f"{tag}_kernel_stats_bench_vg100k.csv"))
 print(json.dumps(out, indent=1))
 print("bench:", b["ms_per_step"], b["value"], b["roofline"]["frac"], b.get("roofline_hbm", {}).get("frac"), b.get("cpu_baseline", {}).get("value"))

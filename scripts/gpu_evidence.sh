@@ -1,11 +1,46 @@
 #!/bin/bash
-# Round-end evidence: parity tests, default bench line, rocprofv3 kernel stats of the bench command, kernel micro-benchmarks.
+# Round-end evidence (run on the GPU box through gpurun; results land in gpurun_out/ and are copied to profiles/ by
+# scripts/collect_profiles.py <tag>): parity tests, smoke, the default bench line, the 100k-camera bench line, rocprofv3 kernel
+# stats of both bench commands, PMC traffic of the Hessian launches (stamped with the source hash) and of the sliced-ELL product,
+# kernel micro-benchmarks.
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee gpurun_out/pytest_gpu.log
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee gpurun_out/pytest_gpu.log
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' 2>&1 | tail -2 | tee gpurun_out/smoke.log
-timeout 600 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
-timeout 300 python bench.py --workload vg100k --storage bsr --steps 5 --warmup 1 --cpu-seconds 10 2>&1 | tail -1 > gpurun_out/bench_vg100k.log
-rm -rf gpurun_out/prof_final
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_final -o run -- python $GRAFT_REPO_ROOT/bench.py --cpu-seconds 0 --no-hbm-check > $GRAFT_REPO_ROOT/gpurun_out/prof_final.log 2>&1
-cd $GRAFT_REPO_ROOT
-(python scripts/kbench_dense.py 1778 3 4 5 10; python scripts/kbench_dense.py 13682 3; python scripts/kbench_bsr.py 13682 30 3 5; python scripts/kbench_bsr.py 13682 58 3 5; python scripts/kbench_bsr.py 100000 50 3 5; echo 'banded view graph (XM_KB_BAND=1):'; XM_KB_BAND=1 python scripts/kbench_bsr.py 100000 50 3 5) 2>&1 | tee gpurun_out/kbench.log
+timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
+timeout 600 python bench.py --workload vg100k --storage bsr --steps 5 --warmup 1 --cpu-seconds 10 2>&1 | tail -1 > gpurun_out/bench_vg100k.log
+rm -rf gpurun_out/prof_final gpurun_out/prof_vg100k
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -o run -- python $R/bench.py --cpu-seconds 0 --no-hbm-check > $R/gpurun_out/prof_final.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_vg100k -o run -- python $R/bench.py --workload vg100k --storage bsr --steps 2 --warmup 1 --cpu-seconds 0 > $R/gpurun_out/prof_vg100k.log 2>&1
+cd $R
+XM_PROFILE_TAG=${1:-r02} bash scripts/pmc_hess.sh > gpurun_out/pmc_hess.out 2>&1
+cp profiles/${1:-r02}_pmc_fetch_hess_bench.json gpurun_out/ 2>/dev/null
+(python scripts/kbench_dense.py 1778 3 4 5 10; python scripts/kbench_dense.py 13682 3 4
+ python scripts/kbench_bsr.py 13682 30 3 5; python scripts/kbench_bsr.py 13682 58 3 5
+ python scripts/kbench_sell.py 100000 50 --o 3 5 --slabs 4 --gather 1
+ echo 'banded view graph:'; python scripts/kbench_sell.py 100000 50 --band --o 3 --slabs 4 --gather 1
+ echo 'hub cameras (skewed degrees):'; python scripts/kbench_sell.py 100000 20 --skew --o 3 --slabs 4 --gather 1) 2>&1 | tee gpurun_out/kbench.log
+cd /tmp
+i=0
+for grp in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_sell_$i -o run -- python $R/scripts/kbench_sell.py 100000 50 --o 3 --slabs 4 --gather 1 --no-csr --reps 20 > $R/gpurun_out/pmc_sell_$i.log 2>&1
+done
+cd $R
+python - <<'PY'
+import csv, glob, collections, json
+out = collections.defaultdict(dict)
+for d in sorted(glob.glob("gpurun_out/pmc_sell_*/")):
+    for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if "sell" in k and "fill" not in k:
+                acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in acc.items():
+            out[k][c] = sum(v) / len(v)
+json.dump(out, open("gpurun_out/pmc_sell.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY

@@ -207,6 +207,29 @@ def test_unconverged_lanczos_never_certifies(xmamd, monkeypatch):
     assert info["status"] == 1 and info["cert_flags"] == 0
 
 
+def test_lost_result_kernel_raises_instead_of_hanging(xmamd):
+    """host spin loops: when the kernel that publishes an outer iteration's results never runs (injected: XM_DEBUG_DROP_FINALIZE, what
+    a failed launch or a device fault amounts to) the solve must return XM_ERR_HIP within the poll interval, not spin for ever"""
+    import subprocess, sys, textwrap, time
+    Q, exp, d = _case("synth/dense49")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {os.path.join(root, "xm-code_amd")!r}); sys.path.insert(0, {os.path.join(root, "tests")!r})
+        import xmamd, xm_testlib as tl
+        Q = tl.load_bin({os.path.join(d, "Q.bin")!r})
+        try:
+            xmamd.solve_dense(Q, 3, 1e-9, 0.0)
+            print("NO ERROR")
+        except xmamd.XmError as e:
+            print("XmError:", e)
+    """)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XM_DEBUG_DROP_FINALIZE="4"), capture_output=True, text=True, timeout=120)
+    assert "XmError" in out.stdout and "-3" in out.stdout and "did not reach host-mapped memory" in out.stdout, out.stdout + out.stderr
+    assert time.time() - t0 < 60
+
+
 def test_staircase_matches_oracle(xmamd, oracle):
     """rank escalation 3 -> 6 with saddle escape along the certificate's eigenvector (XM_main.cu:223-277)"""
     Q, exp, d = _case("synth/vg40_stair")

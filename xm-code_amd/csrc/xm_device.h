@@ -36,6 +36,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <int GW>
 __device__ __forceinline__ double group_sum(double v) {
     if (GW == 64) return wave_sum(v);
+    if (GW == 4) {   // one quad: two quad_perm butterflies leave every lane of the quad with its sum
+        v += dpp_mov<0xb1, 0xf>(v);
+        v += dpp_mov<0x4e, 0xf>(v);
+        return v;
+    }
     v += dpp_mov<0xb1, 0xf>(v);
     v += dpp_mov<0x4e, 0xf>(v);
     v += dpp_mov<0x124, 0xf>(v);

@@ -82,9 +82,10 @@ private:
 };
 
 // product = two launches: partial results per virtual row, then per-camera sum + fused epilogue (same CamArgs contract and
-// the same per-workgroup partial sums, grid bsr_grid(nloc), as launch_qw_bsr3).  gm: 0 = each lane loads its own record of W,
+// per-workgroup partial sums of the second launch, grid sell_reduce_grid(o, nloc)).  gm: 0 = each lane loads its own record of W,
 // 1 = records fetched element-per-lane and transposed through LDS.
 void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st);
 bool sell_supports(int o);
+int sell_reduce_grid(int o, int nloc);   // workgroups of the second launch == per-workgroup partial sums per epilogue slot
 
 }  // namespace xm

@@ -429,17 +429,24 @@ __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *
     }
 }
 
-// per camera: partial results added in slot order (fixed -> bit-reproducible), then the common tail of the Q*W kernels
-// (16-lane group per camera, column-per-lane epilogue, per-workgroup partial sums) exactly as in qw_bsr3_kernel
+// per camera: partial results added in list order (fixed -> bit-reproducible), then the common tail of the Q*W kernels
+// (column-per-lane epilogue, per-workgroup partial sums).  A camera has S (plus a few, for hub cameras) partial results and
+// o <= 4 columns, so a QUAD of lanes per camera is enough (GW = 4: 64 cameras per workgroup, two DPP steps per reduction instead
+// of four, 4x fewer wavefronts than the 16-lane groups of qw_bsr3_kernel, which o = 5 keeps).
+template <int O>
+constexpr int sell_gw() { return (O <= 4) ? 4 : 16; }
+int sell_reduce_grid(int o, int nloc) { const int per = 256 / ((o <= 4) ? 4 : 16); return (nloc + per - 1) / per; }
+
 template <int O, int EPI>
 __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restrict__ pptr, const int32_t *__restrict__ ridx, const double *__restrict__ parts,
                                                            double alpha, CamArgs a) {
+    constexpr int GW = sell_gw<O>(), NSLOT = 256 / GW;
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
-    __shared__ double red[kBsrRows][3];
-    const int gl = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    const int cam = blockIdx.x * kBsrRows + slot;
+    __shared__ double red[NSLOT][3];
+    const int gl = threadIdx.x & (GW - 1), slot = threadIdx.x / GW;
+    const int cam = blockIdx.x * NSLOT + slot;
     const bool active = cam < a.nloc;
     EpiOps eops;
     epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restr
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
     if (active) {
         const int64_t p1 = pptr[cam + 1];
-        for (int64_t p = pptr[cam] + gl; p < p1; p += 16) {   // fixed order: lane gl takes slots gl, gl + 16, ...
+        for (int64_t p = pptr[cam] + gl; p < p1; p += GW) {   // fixed order: lane gl takes list entries gl, gl + GW, ...
             const double *v = parts + (size_t)ridx[p] * 3 * O;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restr
                 for (int k = 0; k < O; ++k) acc[r][k] += v[r * O + k];
         }
     }
-    qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red);
+    qw_finish<O, EPI, GW, NSLOT>(cam, gl, slot, active, acc, alpha, a, eops, red);
 }
 
 bool sell_supports(int o) { return o == 1 || (o >= 3 && o <= 5); }
@@ -492,7 +499,7 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
             }
         }
     }
-    const dim3 g(bsr_grid(a.nloc)), b(256);
+    const dim3 g(sell_reduce_grid(O, a.nloc)), b(256);
     switch (epi) {
         case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;
         case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;
@@ -508,7 +515,7 @@ void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha
         double *parts = m.parts(1);
         const SellArgs sa = m.args();
         if (m.grid() > 0) hipLaunchKernelGGL((qw_sell_kernel<1, 0>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
-        hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT>), dim3(bsr_grid(a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a);
+        hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT>), dim3(sell_reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a);
     } else {
         switch (o) {
             case 1: qw_sell_o<1>(epi, m, W, alpha, a, 0, st); break;

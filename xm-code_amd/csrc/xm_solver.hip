@@ -283,7 +283,10 @@ void Context::download_point(std::vector<double> &R_cm, std::vector<double> &s_e
 }
 
 // workgroups of the product kernels == number of per-workgroup partial sums per epilogue slot
-int Context::prod_grid() const { return (storage_ == XM_STORAGE_BSR3 || storage_ == XM_STORAGE_SCHUR) ? bsr_grid(nloc_) : qw_grid(nloc_); }
+int Context::prod_grid() const {
+    if (storage_ == XM_STORAGE_BSR3 && sell_ && sell_supports(o_)) return sell_reduce_grid(o_, nloc_);
+    return (storage_ == XM_STORAGE_BSR3 || storage_ == XM_STORAGE_SCHUR) ? bsr_grid(nloc_) : qw_grid(nloc_);
+}
 
 CamArgs Context::cam_args(int state) const {
     CamArgs a;
@@ -620,6 +623,11 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
             product(EPI_GRAD, o_, 2.0, a);
             if (comm_->active()) comm_->allgather(partsA_.p, (size_t)2 * nA_loc, st_);
         }
+        // XM_DEBUG_DROP_FINALIZE=k (tests): the k-th outer iteration "loses" its result kernel, as a failed launch would: the host
+        // must come back with XM_ERR_HIP from wait_outer_result() instead of spinning on a sequence word that never arrives
+        static const long long drop_at = [] { const char *e = std::getenv("XM_DEBUG_DROP_FINALIZE"); return (e && *e) ? std::atoll(e) : -1LL; }();
+        if (drop_at >= 0 && (long long)outer_seq_ + 1 == drop_at) ++outer_seq_;
+        else
         launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, nB_, scal_.p + (enq & 1),
                               reinterpret_cast<double *>(hstat_dev_) + 8, ++outer_seq_, st_);
         volatile double *hres = wait_outer_result();
