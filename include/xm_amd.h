@@ -180,6 +180,11 @@ int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, d
 int xm_qw_bsr3(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o,
                const double *dW, double *dOut, double alpha, void *stream);
 
+/* A (host, column-major n x n, symmetric positive definite; lower triangle read) is overwritten by its inverse, computed on the device
+ * (blocked Cholesky + triangular solves, xm-code_amd/csrc/xm_dense_la.hip): the set-up step of XM_STORAGE_SCHUR, which the reference
+ * does on the host with scipy.linalg.solve (utils/creatematrix.py:260). */
+int xm_spd_inverse(int64_t n, double *A);
+
 /* Large block-sparse Q: "sliced ELL over per-XCD column slabs" (xm-code_amd/csrc/xm_sell.h).  Same product as xm_qw_bsr3
  * (the reference has no sparse product: Dense/matmul.h:42-87 on a dense Q); the matrix is described on the HOST as 3x3-block CSR
  * (rows n, global columns in [0, ncols)) and re-laid on the device.  slabs in {1,2,4,8}; lmax = longest virtual row (hub

@@ -904,6 +904,20 @@ def test_matrix_free_solve_matches_dense_solve(xmamd):
     assert cn["min_eig"] > -1e-7 and abs(cn["gap"]) < 1e-6 and cn["stationarity"] < 1e-5
 
 
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 200, 777, 1500])
+def test_spd_inverse_on_device(xmamd, n):
+    """blocked Cholesky + triangular solves (xm_dense_la.hip, set-up of the matrix-free storage) against numpy: a graph-Laplacian-like
+    SPD matrix (what the reduced camera Laplacian is), sizes around the 64-row block boundary"""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n + 3))
+    A = B @ B.T + n * np.diag(rng.uniform(0.5, 2.0, n))
+    X = xmamd.spd_inverse(A)
+    assert tl.rel_fro(X, np.linalg.inv(A)) < 1e-11 and np.abs(X - X.T).max() <= 1e-12 * np.abs(X).max()
+    assert np.abs(X @ A - np.eye(n)).max() < 1e-10
+    with pytest.raises(xmamd.XmError):
+        xmamd.spd_inverse(-np.eye(max(n, 2)))
+
+
 def test_matrix_free_synthetic_scene(xmamd):
     """a synthetic scene (random cameras and landmarks, exact observations + noise): matrix-free product and solve against the
     dense Schur complement assembled in numpy (tl.schur_dense)"""
@@ -927,3 +941,23 @@ def test_matrix_free_synthetic_scene(xmamd):
     rot, _ = tl.recover_rotations(R, s)                                  # and the planted cameras come back (noise level)
     gt = np.concatenate([Rs[0].T @ Rs[k] for k in range(N)], axis=1)
     assert min(tl.rel_fro(rot, gt), tl.rel_fro(rot, np.concatenate([Rs[0] @ Rs[k].T for k in range(N)], axis=1))) < 0.05
+
+
+def test_matrix_free_venice_size_scene(xmamd):
+    """a Venice-size synthetic scene (1778 cameras, 200 k landmarks, 1.2 M observations, three landmarks seen by every camera; the
+    dense Q would be 228 MB and O(N^2 M) to build): the matrix-free product against the numpy / scipy.sparse restatement of the same
+    chain, symmetry of the operator, and a certified solve that recovers the planted rotations"""
+    S = tl.gen_scene(1778, 200000, 6, seed=2)
+    ctx = xmamd.Context(obs=(S["cam"], S["lm"], S["p"], S["w"]))
+    rng = np.random.default_rng(0)
+    W = rng.standard_normal((3 * S["n"], 3)); U = rng.standard_normal((3 * S["n"], 3))
+    Y = ctx.qw(W)
+    assert tl.rel_fro(Y, tl.schur_qw_numpy(S["cam"], S["lm"], S["p"], S["w"], W)) < 1e-9
+    assert abs(np.sum(U * Y) - np.sum(ctx.qw(U) * W)) < 1e-9 * abs(np.sum(U * Y))
+    R, s, info = ctx.solve(5, 1e-6, 0.0)
+    ctx.close()
+    assert info["status"] == 1 and info["min_eig"] > -1e-6 and tl.stiefel_defect(R) < 1e-12
+    rot, _ = tl.recover_rotations(R, s)
+    Rs = S["R_star"]
+    gt = np.concatenate([Rs[0].T @ Rs[k] for k in range(S["n"])], axis=1)
+    assert tl.rel_fro(rot, gt) < 0.02

@@ -369,7 +369,8 @@ def schur_dense(cam, lm, p, w):
 
 
 def schur_qw_numpy(cam, lm, p, w, W):
-    """Q @ W without forming Q: the five steps the device runs (xm_schur.hip), in numpy"""
+    """Q @ W without forming Q: the five steps the device runs (xm_schur.hip), in numpy / scipy.sparse"""
+    from scipy.sparse import coo_matrix
     cam = np.asarray(cam); lm = np.asarray(lm); p = np.asarray(p, dtype=np.float64); w = np.asarray(w, dtype=np.float64).reshape(-1)
     N, M, Q1, c, Q2, Q3 = schur_parts(cam, lm, p, w)
     o = W.shape[1]
@@ -378,11 +379,33 @@ def schur_qw_numpy(cam, lm, p, w, W):
     h = g_lm / Q3[:, None]
     r = np.einsum("ia,iak->ik", c, Wc)
     np.add.at(r, cam, w[:, None] * h[lm])
-    VT = np.diag(Q2[1:]).astype(np.float64)
-    V3 = np.zeros((N, M)); np.add.at(V3, (cam, lm), w)
-    VT -= (V3[1:] / Q3[None, :]) @ V3[1:].T
+    V3 = coo_matrix((w, (cam, lm)), shape=(N, M)).tocsr()
+    V3b = V3[1:]
+    VT = np.diag(Q2[1:]) - (V3b.multiply(1.0 / Q3[None, :]) @ V3b.T).toarray()
     xc = np.zeros((N, o)); xc[1:] = np.linalg.solve(VT, r[1:])
     xl = h.copy(); tmp = np.zeros((M, o)); np.add.at(tmp, lm, w[:, None] * xc[cam]); xl += tmp / Q3[:, None]
     Y = np.einsum("iab,ibk->iak", Q1, Wc) - c[:, :, None] * xc[:, None, :]
     np.add.at(Y, cam, w[:, None, None] * p[:, :, None] * xl[lm][:, None, :])
     return Y.reshape(3 * N, o)
+
+
+def gen_scene(N, M, views, seed, noise=0.01, hubs=3):
+    """synthetic SfM scene for the matrix-free tests: N cameras and M landmarks in a box, every landmark observed by `views` cameras
+    drawn at random (a well-connected co-visibility graph: the solve converges in a few hundred iterations, unlike a sequential
+    trajectory whose path-like graph needs 10^4..10^5) plus `hubs` landmarks seen by EVERY camera (connectivity, and the degree
+    skew real scenes have).  Returns dict(cam, lm, p, w, R_star, n, m): p = R_i^T (P_l - t_i) + noise = the camera-frame points
+    create_matrix takes."""
+    rng = np.random.default_rng(seed)
+    Rs = haar_so3(rng, N)
+    ts = rng.uniform(-5.0, 5.0, (N, 3))
+    P = rng.uniform(-8.0, 8.0, (M, 3))
+    cam = np.concatenate([np.repeat(np.arange(N), hubs), rng.integers(0, N, M * views)])
+    lm = np.concatenate([np.tile(np.arange(hubs), N), np.repeat(np.arange(M), views)])
+    _, idx = np.unique(cam.astype(np.int64) * M + lm, return_index=True)
+    cam, lm = cam[idx], lm[idx]
+    keep = np.bincount(lm, minlength=M)[lm] >= 2            # the reference drops landmarks seen once (2_test_creatematrix.py:100)
+    cam, lm = cam[keep], lm[keep]
+    orig, lm = np.unique(lm, return_inverse=True)           # compact landmark numbering
+    pts = np.einsum("eba,eb->ea", Rs[cam], P[orig][lm] - ts[cam]) + noise * rng.standard_normal((cam.size, 3))
+    w = rng.uniform(0.5, 1.5, cam.size)
+    return dict(cam=cam.astype(np.int32), lm=lm.astype(np.int32), p=pts, w=w, R_star=Rs, n=N, m=int(orig.size))

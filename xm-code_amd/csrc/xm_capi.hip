@@ -6,6 +6,7 @@
 #include <mutex>
 #include <vector>
 
+#include "xm_schur.h"
 #include "xm_sell.h"
 #include "xm_solver.h"
 
@@ -370,6 +371,20 @@ int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int6
     XM_CATCH
 }
 
+
+// inverse of a symmetric positive definite matrix on the device (xm_dense_la.hip; set-up step of the matrix-free storage)
+int xm_spd_inverse(int64_t n, double *A) {
+    XM_TRY
+    require_device();
+    if (n < 1 || n > 46000 || !A) throw xm::Error(XM_ERR_ARG, "bad argument");
+    xm::DevBuf<double> a, x;
+    a.alloc((size_t)n * n, false); x.alloc((size_t)n * n, false);
+    XM_HIP_CHECK(hipMemcpy(a.p, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+    if (!xm::spd_inverse_device((int)n, a.p, x.p, nullptr)) throw xm::Error(XM_ERR_ARG, "matrix is not positive definite");
+    XM_HIP_CHECK(hipMemcpy(A, x.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+    return XM_OK;
+    XM_CATCH
+}
 
 // ---- sliced-ELL product for large block-sparse Q (xm_sell.h) -------------------------------------------------------------
 int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t sizes[5],

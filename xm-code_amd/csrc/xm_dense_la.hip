@@ -1,0 +1,184 @@
+// xm_dense_la.hip — inverse of a symmetric positive definite matrix on the device (blocked Cholesky + two blocked triangular
+// solves with the identity), float64.  Used once per matrix-free context for the reduced camera Laplacian VT of
+// utils/creatematrix.py:150-166 (the reference solves with it on the host through scipy.linalg.solve, :260); it is set-up work,
+// O(n^3), so the kernels are plain LDS-tiled VALU code (a few TFLOP/s is seconds at n = 14 000), not a tuned GEMM.
+//
+//   A = L L^T            right-looking: potrf on the 64 x 64 diagonal block, panel solve A21 <- A21 L11^-T, trailing update
+//                        A22 -= A21 A21^T (lower tiles only)
+//   L Y = I, L^T X = Y   block forward / backward substitution, the off-diagonal work as one GEMM per block row
+// All matrices column-major with leading dimension ld; the result is the full symmetric inverse.
+#include <algorithm>
+#include <vector>
+
+#include "xm_solver.h"
+
+namespace xm {
+
+constexpr int kLaB = 64;   // block size
+
+// C[m x n] -= opA(A)[m x k] * opB(B)[k x n];  ta / tb: 0 = as stored, 1 = transposed.  64 x 64 tile per workgroup, 16 x 16
+// threads with 4 x 4 outputs each, K in chunks of 16 through LDS.  lower_only: skip tiles strictly above the diagonal (syrk).
+__global__ __launch_bounds__(256) void la_gemm_sub_kernel(int m, int n, int k, const double *__restrict__ A, int64_t lda, int ta,
+                                                           const double *__restrict__ B, int64_t ldb, int tb, double *__restrict__ C,
+                                                           int64_t ldc, int lower_only) {
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (lower_only && bj > bi) return;
+    __shared__ double As[16][kLaB + 1], Bs[16][kLaB + 1];   // As[kk][i], Bs[kk][j]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = bi * kLaB, j0 = bj * kLaB;
+    double acc[4][4] = {};
+    for (int k0 = 0; k0 < k; k0 += 16) {
+        for (int e = threadIdx.x; e < 16 * kLaB; e += 256) {
+            // consecutive threads run along the contiguous direction of each operand (rows of a stored matrix)
+            const int ia = ta ? e / 16 : e % kLaB, ka = ta ? e % 16 : e / kLaB;
+            const int jb = tb ? e % kLaB : e / 16, kb = tb ? e / kLaB : e % 16;
+            double va = 0.0, vb = 0.0;
+            if (i0 + ia < m && k0 + ka < k) va = ta ? A[(size_t)(k0 + ka) + (size_t)(i0 + ia) * lda] : A[(size_t)(i0 + ia) + (size_t)(k0 + ka) * lda];
+            if (j0 + jb < n && k0 + kb < k) vb = tb ? B[(size_t)(j0 + jb) + (size_t)(k0 + kb) * ldb] : B[(size_t)(k0 + kb) + (size_t)(j0 + jb) * ldb];
+            As[ka][ia] = va;
+            Bs[kb][jb] = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = As[kk][tx + 16 * u]; b[u] = Bs[kk][ty + 16 * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int gi = i0 + tx + 16 * u, gj = j0 + ty + 16 * v;
+            if (gi < m && gj < n) C[(size_t)gi + (size_t)gj * ldc] -= acc[u][v];
+        }
+}
+
+// Cholesky of one b x b diagonal block (b <= 64) in place (lower), one workgroup; *info = 1 when a pivot is not positive
+__global__ __launch_bounds__(256) void la_potrf_kernel(int b, double *__restrict__ A, int64_t lda, int *info) {
+    __shared__ double L[kLaB][kLaB + 1];
+    for (int e = threadIdx.x; e < b * b; e += 256) L[e % b][e / b] = A[(size_t)(e % b) + (size_t)(e / b) * lda];
+    __syncthreads();
+    for (int j = 0; j < b; ++j) {
+        if (threadIdx.x == 0) {
+            const double d = L[j][j];
+            if (!(d > 0.0)) *info = 1;
+            L[j][j] = sqrt(d > 0.0 ? d : 1.0);
+        }
+        __syncthreads();
+        const double dj = L[j][j];
+        for (int i = j + 1 + threadIdx.x; i < b; i += 256) L[i][j] /= dj;
+        __syncthreads();
+        for (int e = threadIdx.x; e < (b - j - 1) * (b - j - 1); e += 256) {   // trailing update of the lower part
+            const int i = j + 1 + e % (b - j - 1), c = j + 1 + e / (b - j - 1);
+            if (i >= c) L[i][c] -= L[i][j] * L[c][j];
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < b * b; e += 256) {
+        const int i = e % b, c = e / b;
+        A[(size_t)i + (size_t)c * lda] = (i >= c) ? L[i][c] : 0.0;
+    }
+}
+
+// rows of P (m x b) <- P * L^-T  with L the b x b lower factor: one thread per row (forward substitution along the row)
+__global__ __launch_bounds__(256) void la_trsm_right_kernel(int m, int b, const double *__restrict__ Lm, int64_t ldl, double *__restrict__ P,
+                                                             int64_t ldp) {
+    __shared__ double L[kLaB][kLaB + 1];
+    for (int e = threadIdx.x; e < b * b; e += 256) L[e % b][e / b] = Lm[(size_t)(e % b) + (size_t)(e / b) * ldl];
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    double x[kLaB];
+    for (int c = 0; c < b; ++c) {
+        double t = P[(size_t)r + (size_t)c * ldp];
+        for (int q = 0; q < c; ++q) t -= x[q] * L[c][q];
+        x[c] = t / L[c][c];
+    }
+    for (int c = 0; c < b; ++c) P[(size_t)r + (size_t)c * ldp] = x[c];
+}
+
+// columns of T (b x n) <- L^-1 T (trans = 0) or L^-T T (trans = 1): one thread per column
+__global__ __launch_bounds__(256) void la_trsm_left_kernel(int b, int n, const double *__restrict__ Lm, int64_t ldl, int trans,
+                                                            double *__restrict__ T, int64_t ldt) {
+    __shared__ double L[kLaB][kLaB + 1];
+    for (int e = threadIdx.x; e < b * b; e += 256) L[e % b][e / b] = Lm[(size_t)(e % b) + (size_t)(e / b) * ldl];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    double x[kLaB];
+    double *col = T + (size_t)c * ldt;
+    if (!trans) {
+        for (int i = 0; i < b; ++i) {
+            double t = col[i];
+            for (int q = 0; q < i; ++q) t -= L[i][q] * x[q];
+            x[i] = t / L[i][i];
+        }
+    } else {
+        for (int i = b - 1; i >= 0; --i) {
+            double t = col[i];
+            for (int q = i + 1; q < b; ++q) t -= L[q][i] * x[q];
+            x[i] = t / L[i][i];
+        }
+    }
+    for (int i = 0; i < b; ++i) col[i] = x[i];
+}
+
+__global__ __launch_bounds__(256) void la_identity_kernel(int n, double *X, int64_t ld) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)n * n) return;
+    X[(size_t)(e % n) + (size_t)(e / n) * ld] = (e % n == e / n) ? 1.0 : 0.0;
+}
+
+static void gemm_sub(int m, int n, int k, const double *A, int64_t lda, int ta, const double *B, int64_t ldb, int tb, double *C, int64_t ldc,
+                     int lower_only, hipStream_t st) {
+    if (m <= 0 || n <= 0 || k <= 0) return;
+    const dim3 g((m + kLaB - 1) / kLaB, (n + kLaB - 1) / kLaB);
+    hipLaunchKernelGGL(la_gemm_sub_kernel, g, dim3(256), 0, st, m, n, k, A, lda, ta, B, ldb, tb, C, ldc, lower_only);
+}
+
+// A (device, column-major n x n, ld = n, lower triangle read) is overwritten by its Cholesky factor; X (device, n x n) receives A^-1.
+// Returns false when A is not positive definite.
+bool spd_inverse_device(int n, double *A, double *X, hipStream_t st) {
+    if (n <= 0) return true;
+    const int64_t ld = n;
+    DevBuf<int> info;
+    info.alloc(1);
+    for (int k = 0; k < n; k += kLaB) {
+        const int b = std::min(kLaB, n - k), m = n - k - b;
+        double *A11 = A + (size_t)k + (size_t)k * ld;
+        hipLaunchKernelGGL(la_potrf_kernel, dim3(1), dim3(256), 0, st, b, A11, ld, info.p);
+        if (m > 0) {
+            double *A21 = A11 + b;
+            hipLaunchKernelGGL(la_trsm_right_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, b, A11, ld, A21, ld);
+            gemm_sub(m, m, b, A21, ld, 0, A21, ld, 1, A11 + b + (size_t)b * ld, ld, 1, st);   // A22 -= A21 A21^T (lower tiles)
+        }
+    }
+    check_launch("spd_inverse(cholesky)");
+    int h = 0;
+    XM_HIP_CHECK(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    XM_HIP_CHECK(hipStreamSynchronize(st));
+    if (h) return false;
+    hipLaunchKernelGGL(la_identity_kernel, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, st, n, X, ld);
+    for (int i = 0; i < n; i += kLaB) {   // forward: Y_i = L_ii^-1 (I_i - L[i, 0:i] Y[0:i, :])
+        const int b = std::min(kLaB, n - i);
+        gemm_sub(b, n, i, A + i, ld, 0, X, ld, 0, X + i, ld, 0, st);
+        hipLaunchKernelGGL(la_trsm_left_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b, n, A + (size_t)i + (size_t)i * ld, ld, 0, X + i, ld);
+    }
+    for (int i = ((n - 1) / kLaB) * kLaB; i >= 0; i -= kLaB) {   // backward: X_i = L_ii^-T (Y_i - L[i+b:, i]^T X[i+b:, :])
+        const int b = std::min(kLaB, n - i), below = n - i - b;
+        gemm_sub(b, n, below, A + (size_t)(i + b) + (size_t)i * ld, ld, 1, X + i + b, ld, 0, X + i, ld, 0, st);
+        hipLaunchKernelGGL(la_trsm_left_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b, n, A + (size_t)i + (size_t)i * ld, ld, 1, X + i, ld);
+    }
+    check_launch("spd_inverse(solve)");
+    XM_HIP_CHECK(hipStreamSynchronize(st));
+    return true;
+}
+
+}  // namespace xm

@@ -12,8 +12,9 @@
 //      x_l   =  h_l + (1/Q3_l) sum_{obs of l} w x_cam_i                   per landmark
 //      Y_i   =  Q1_i W_i - c_i x_cam_i + sum_{obs of i} w p x_l           per camera, + the fused epilogue of the Q*W kernels
 // i.e. O(observations) + (N-1)^2 bytes per product instead of 9 N^2: at N = 13682 cameras / 4.5 M observations 0.4 GB + 1.5 GB
-// against 13.5 GB.  First slice: single GPU; VT^{-1} is formed on the host at context creation by a Cholesky factorisation
-// (O(N^3): seconds at N = 2000; refused above kSchurMaxCams cameras until the factorisation moves to the device).
+// against 13.5 GB.  Single GPU in this version.  VT is assembled on the host from the co-visibility lists (O(sum of squared
+// landmark degrees)) and inverted on the device at context creation (xm_dense_la.hip: blocked Cholesky + two blocked triangular
+// solves, O(N^3): 2 s at N = 14 000).
 #pragma once
 
 #include <cstdint>
@@ -22,7 +23,10 @@
 
 namespace xm {
 
-constexpr int64_t kSchurMaxCams = 6000;
+constexpr int64_t kSchurMaxCams = 40000;   // (N-1)^2 inverse + workspace = 3 x 8 N^2 bytes during set-up: 38 GB at the limit
+
+// A (device, column-major n x n, lower triangle read) -> Cholesky factor; X <- A^-1 (full symmetric).  false: not positive definite
+bool spd_inverse_device(int n, double *A, double *X, hipStream_t st);
 
 class SchurOp {
 public:
@@ -38,6 +42,8 @@ private:
     int64_t n_ = 0, m_ = 0, nobs_ = 0, nred_ = 0, ldv_ = 0;   // nred = cameras of the padded (N-1) system / 3
     DevBuf<int64_t> cam_ptr_, lm_ptr_;
     DevBuf<int32_t> cam_lm_, lm_cam_;         // by camera: landmark of each observation; by landmark: camera
+    DevBuf<int32_t> heavy_;                   // landmarks with more than kSchurHeavy observations (one wavefront each)
+    int64_t nheavy_ = 0;
     DevBuf<double> cam_w_, cam_p_, lm_w_, lm_p_;
     DevBuf<double> Q1_, c_, q3inv_;
     DevBuf<double> vtinv_;                     // (N-1)^2 inverse in the dense kernel's padded row-major layout

@@ -26,7 +26,7 @@ EXPORTS = [
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition",
     "xm_sell_layout", "xm_sell_create", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
-    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights", "xm_ctx_qw",
+    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights", "xm_ctx_qw", "xm_spd_inverse",
 ]
 
 
@@ -79,6 +79,7 @@ def lib():
         L.xm_ctx_solve.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Result)]
         L.xm_ctx_destroy.argtypes = [C.c_void_p]
         L.xm_ctx_destroy.restype = None
+        L.xm_spd_inverse.argtypes = [C.c_int64, C.c_void_p]
         L.xm_ctx_qw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double]
         L.xm_ctx_attach_edges.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_ctx_edge_residuals.argtypes = [C.c_void_p, C.c_void_p]
@@ -237,6 +238,14 @@ def qw_bsr3(rowptr, colidx, blocks, W, alpha=1.0):
     for b in (drp, dci, dbl, dW, dO):
         b.free()
     return out
+
+
+def spd_inverse(A):
+    """inverse of a symmetric positive definite matrix on the GPU (xm_spd_inverse)"""
+    require_gpu()
+    A = np.asfortranarray(np.array(A, dtype=np.float64))
+    _chk(lib().xm_spd_inverse(A.shape[0], A.ctypes.data_as(C.c_void_p)))
+    return np.ascontiguousarray(A)
 
 
 def sell_layout(rowptr, colidx, ncols=None, slabs=4, lmax=64):
