@@ -34,7 +34,7 @@ public:
     SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *cam, const int32_t *lm, const double *p, const double *w,
             hipStream_t st);
     // Y = alpha * Q * W for all n cameras (W: camera records of 3 * pitch_of(o) doubles), same CamArgs / epilogue contract and
-    // per-workgroup partial sums (grid bsr_grid(n)) as launch_qw_bsr3
+    // per-workgroup partial sums (grid qw_grid(n)) as launch_qw_dense
     void product(int o, int epi, const double *W, double alpha, const CamArgs &a, hipStream_t st);
     int64_t bytes_per_product(int o) const;
 

@@ -15,13 +15,35 @@ namespace xm {
 // ------------------------------------------------------------------------------------------------------------------
 // device kernels
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kSchurHeavy = 64;   // landmarks with more observations get a whole wavefront (a thread per landmark serialises them:
-                                  // 963 us per product with three landmarks seen by all 1778 cameras, 297 us once split)
+constexpr int kSchurHeavy = 64;   // landmarks with more observations get a workgroup of their own (a thread per landmark serialises
+                                  // them: 963 us per product with three landmarks seen by all 1778 cameras, 122 us once split)
 
-// h_l = -(1/Q3_l) sum_{obs of l} w (p . W_i)      HEAVY 0: one thread per landmark (heavy ones skipped) | 1: one wavefront per
-// listed heavy landmark, lane-strided + fixed DPP tree
+// h_l = -(1/Q3_l) sum_{obs of l} w (p . W_i)      HEAVY 0: one thread per landmark (heavy ones skipped) | 1: one 1024-thread
+// workgroup per listed heavy landmark (a landmark seen by all 13 682 cameras: 14 strided steps instead of 13 682 serial ones;
+// thread-strided order, DPP tree per wavefront, the 16 wavefront sums added in a fixed order)
+constexpr int kSchurHeavyThreads = 1024;
+template <int O>
+__device__ __forceinline__ bool heavy_block_sum(double (&acc)[O]) {   // result valid in thread 0 (returns true there)
+    __shared__ double part[kSchurHeavyThreads / 64][O];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < O; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < O; ++k) part[wv][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return false;
+#pragma unroll
+    for (int k = 0; k < O; ++k) {
+        double t = 0.0;
+        for (int q = 0; q < kSchurHeavyThreads / 64; ++q) t += part[q][k];
+        acc[k] = t;
+    }
+    return true;
+}
 template <int O, int HEAVY>
-__global__ __launch_bounds__(256) void schur_lm_h_kernel(int64_t m, const int32_t *__restrict__ heavy, const int64_t *__restrict__ lm_ptr,
+__global__ __launch_bounds__(HEAVY ? kSchurHeavyThreads : 256) void schur_lm_h_kernel(int64_t m, const int32_t *__restrict__ heavy, const int64_t *__restrict__ lm_ptr,
                                                           const int32_t *__restrict__ lm_cam, const double *__restrict__ lm_w,
                                                           const double *__restrict__ lm_p, const double *__restrict__ q3inv,
                                                           const double *__restrict__ W, const TcgScal *__restrict__ scal, double *__restrict__ h) {
@@ -29,17 +51,13 @@ __global__ __launch_bounds__(256) void schur_lm_h_kernel(int64_t m, const int32_
     if (scal != nullptr) {
         if (scal->status != 0) return;
     }
-    const int lane = threadIdx.x & 63;
     int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (HEAVY) {
-        const int64_t hi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (hi >= m) return;   // wave-uniform
-        l = heavy[hi];
-    } else if (l >= m || lm_ptr[l + 1] - lm_ptr[l] > kSchurHeavy) return;
+    if (HEAVY) l = heavy[blockIdx.x];
+    else if (l >= m || lm_ptr[l + 1] - lm_ptr[l] > kSchurHeavy) return;
     double acc[O];
 #pragma unroll
     for (int k = 0; k < O; ++k) acc[k] = 0.0;
-    for (int64_t e = lm_ptr[l] + (HEAVY ? lane : 0); e < lm_ptr[l + 1]; e += (HEAVY ? 64 : 1)) {
+    for (int64_t e = lm_ptr[l] + (HEAVY ? (int)threadIdx.x : 0); e < lm_ptr[l + 1]; e += (HEAVY ? kSchurHeavyThreads : 1)) {
         const double *Wi = W + (size_t)lm_cam[e] * 3 * OP;
         const double w = lm_w[e], p0 = lm_p[3 * e], p1 = lm_p[3 * e + 1], p2 = lm_p[3 * e + 2];
 #pragma unroll
@@ -47,15 +65,14 @@ __global__ __launch_bounds__(256) void schur_lm_h_kernel(int64_t m, const int32_
     }
     const double qi = q3inv[l];
     if (HEAVY) {
-#pragma unroll
-        for (int k = 0; k < O; ++k) acc[k] = wave_sum(acc[k]);
-        if (lane != 0) return;
+        if (!heavy_block_sum<O>(acc)) return;
     }
 #pragma unroll
     for (int k = 0; k < O; ++k) h[(size_t)l * OP + k] = -acc[k] * qi;
 }
 
-// r_{i-1} = c_i . W_i + sum_{obs of i} w h_l      16-lane group per camera (fixed lane-strided order + DPP tree)
+// r_{i-1} = c_i . W_i + sum_{obs of i} w h_l      one wavefront per camera (a camera has hundreds of observations; fixed lane-strided
+// order + DPP tree: bit-reproducible)
 template <int O>
 __global__ __launch_bounds__(256) void schur_cam_r_kernel(int n, const int64_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_lm,
                                                            const double *__restrict__ cam_w, const double *__restrict__ c,
@@ -65,19 +82,19 @@ __global__ __launch_bounds__(256) void schur_cam_r_kernel(int n, const int64_t *
     if (scal != nullptr) {
         if (scal->status != 0) return;
     }
-    const int gl = threadIdx.x & 15, cam = blockIdx.x * kBsrRows + (threadIdx.x >> 4);
+    const int gl = threadIdx.x & 63, cam = blockIdx.x * kQwWaves + (threadIdx.x >> 6);
     double acc[O];
 #pragma unroll
     for (int k = 0; k < O; ++k) acc[k] = 0.0;
     if (cam < n && cam >= 1)
-        for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 16) {
+        for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 64) {
             const double w = cam_w[e];
             const double *hl = h + (size_t)cam_lm[e] * OP;
 #pragma unroll
             for (int k = 0; k < O; ++k) acc[k] += w * hl[k];
         }
 #pragma unroll
-    for (int k = 0; k < O; ++k) acc[k] = group_sum<16>(acc[k]);
+    for (int k = 0; k < O; ++k) acc[k] = wave_sum(acc[k]);
     if (cam < n && cam >= 1 && gl == 0) {
         const double *Wi = W + (size_t)cam * 3 * OP, *ci = c + (size_t)cam * 3;
 #pragma unroll
@@ -87,7 +104,7 @@ __global__ __launch_bounds__(256) void schur_cam_r_kernel(int n, const int64_t *
 
 // x_l = h_l + (1/Q3_l) sum_{obs of l} w x_cam_i     (x_cam of the anchor camera 0 is 0: its translation is the gauge)
 template <int O, int HEAVY>
-__global__ __launch_bounds__(256) void schur_lm_x_kernel(int64_t m, const int32_t *__restrict__ heavy, const int64_t *__restrict__ lm_ptr,
+__global__ __launch_bounds__(HEAVY ? kSchurHeavyThreads : 256) void schur_lm_x_kernel(int64_t m, const int32_t *__restrict__ heavy, const int64_t *__restrict__ lm_ptr,
                                                           const int32_t *__restrict__ lm_cam, const double *__restrict__ lm_w,
                                                           const double *__restrict__ q3inv, const double *__restrict__ h,
                                                           const double *__restrict__ xc, const TcgScal *__restrict__ scal,
@@ -96,17 +113,13 @@ __global__ __launch_bounds__(256) void schur_lm_x_kernel(int64_t m, const int32_
     if (scal != nullptr) {
         if (scal->status != 0) return;
     }
-    const int lane = threadIdx.x & 63;
     int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (HEAVY) {
-        const int64_t hi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (hi >= m) return;
-        l = heavy[hi];
-    } else if (l >= m || lm_ptr[l + 1] - lm_ptr[l] > kSchurHeavy) return;
+    if (HEAVY) l = heavy[blockIdx.x];
+    else if (l >= m || lm_ptr[l + 1] - lm_ptr[l] > kSchurHeavy) return;
     double acc[O];
 #pragma unroll
     for (int k = 0; k < O; ++k) acc[k] = 0.0;
-    for (int64_t e = lm_ptr[l] + (HEAVY ? lane : 0); e < lm_ptr[l + 1]; e += (HEAVY ? 64 : 1)) {
+    for (int64_t e = lm_ptr[l] + (HEAVY ? (int)threadIdx.x : 0); e < lm_ptr[l + 1]; e += (HEAVY ? kSchurHeavyThreads : 1)) {
         const int i = lm_cam[e];
         if (i == 0) continue;
         const double w = lm_w[e];
@@ -116,9 +129,7 @@ __global__ __launch_bounds__(256) void schur_lm_x_kernel(int64_t m, const int32_
     }
     const double qi = q3inv[l];
     if (HEAVY) {
-#pragma unroll
-        for (int k = 0; k < O; ++k) acc[k] = wave_sum(acc[k]);
-        if (lane != 0) return;
+        if (!heavy_block_sum<O>(acc)) return;
     }
 #pragma unroll
     for (int k = 0; k < O; ++k) xl[(size_t)l * OP + k] = h[(size_t)l * OP + k] + acc[k] * qi;
@@ -135,9 +146,9 @@ __global__ __launch_bounds__(256) void schur_cam_y_kernel(const int64_t *__restr
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
-    __shared__ double red[kBsrRows][3];
-    const int gl = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    const int cam = blockIdx.x * kBsrRows + slot;
+    __shared__ double red[kQwWaves][3];
+    const int gl = threadIdx.x & 63, slot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cam = blockIdx.x * kQwWaves + slot;
     const bool active = cam < a.nloc;
     EpiOps eops;
     epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) void schur_cam_y_kernel(const int64_t *__restr
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
     if (active) {
-        for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 16) {
+        for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 64) {
             const double w = cam_w[e];
             const double *x = xl + (size_t)cam_lm[e] * OP;
 #pragma unroll
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256) void schur_cam_y_kernel(const int64_t *__restr
                 }
         }
     }
-    qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red);
+    qw_finish<O, EPI, 64, kQwWaves>(cam, gl, slot, active, acc, alpha, a, eops, red);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -274,10 +285,10 @@ static void schur_product_o(int epi, int64_t n, int64_t m, int64_t nheavy, const
                             const double *c, const double *q3inv, const double *vtinv, int64_t nred, int64_t ldv, double *h, double *r,
                             double *xc, double *xl, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
-    const dim3 b(256), gl((unsigned)((m + 255) / 256)), gc(bsr_grid((int)n));
-    const dim3 gh((unsigned)((nheavy + 3) / 4));
+    const dim3 b(256), gl((unsigned)((m + 255) / 256)), gc(qw_grid((int)n));
+    const dim3 gh((unsigned)nheavy), bh(kSchurHeavyThreads);
     hipLaunchKernelGGL((schur_lm_h_kernel<O, 0>), gl, b, 0, st, m, heavy, lm_ptr, lm_cam, lm_w, lm_p, q3inv, W, sc, h);
-    if (nheavy > 0) hipLaunchKernelGGL((schur_lm_h_kernel<O, 1>), gh, b, 0, st, nheavy, heavy, lm_ptr, lm_cam, lm_w, lm_p, q3inv, W, sc, h);
+    if (nheavy > 0) hipLaunchKernelGGL((schur_lm_h_kernel<O, 1>), gh, bh, 0, st, nheavy, heavy, lm_ptr, lm_cam, lm_w, lm_p, q3inv, W, sc, h);
     hipLaunchKernelGGL((schur_cam_r_kernel<O>), gc, b, 0, st, (int)n, cam_ptr, cam_lm, cam_w, c, W, h, sc, r);
     if (n > 1) {
         CamArgs pa;
@@ -286,7 +297,7 @@ static void schur_product_o(int epi, int64_t n, int64_t m, int64_t nheavy, const
         launch_qw_dense(O, EPI_PLAIN, vtinv, ldv, r, 1.0, pa, st);
     }
     hipLaunchKernelGGL((schur_lm_x_kernel<O, 0>), gl, b, 0, st, m, heavy, lm_ptr, lm_cam, lm_w, q3inv, h, xc, sc, xl);
-    if (nheavy > 0) hipLaunchKernelGGL((schur_lm_x_kernel<O, 1>), gh, b, 0, st, nheavy, heavy, lm_ptr, lm_cam, lm_w, q3inv, h, xc, sc, xl);
+    if (nheavy > 0) hipLaunchKernelGGL((schur_lm_x_kernel<O, 1>), gh, bh, 0, st, nheavy, heavy, lm_ptr, lm_cam, lm_w, q3inv, h, xc, sc, xl);
     switch (epi) {
         case EPI_PLAIN: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_PLAIN>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
         case EPI_GRAD: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_GRAD>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
