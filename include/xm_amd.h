@@ -151,7 +151,11 @@ int64_t xm_dense_ld(int64_t n);                                       /* padded 
  *   attach:    edges e = (ei[e], ej[e]), ei != ej, M: ne x 9 row-major; the stored pattern must hold both blocks of every edge and
  *              every diagonal block.  Does not change Q.
  *   residuals: res[e] = |Y_i - M_e Y_j|_F^2 with Y = s.*R of the LAST solve (the edge's share of <Q, Y Y^T> per unit weight)
- *   weights:   rewrites every edge block and every diagonal block from w (w[e] = 0 removes an observation). */
+ *   weights:   rewrites every edge block and every diagonal block from w (w[e] = 0 removes an observation).
+ * XM_STORAGE_SCHUR contexts need no attach: their observations ARE the edges -- residuals: one per observation in input order,
+ * |p^T U_i + t_i - P_l|^2 with the eliminated translations / landmarks of the last solution (what the reference computes from
+ * recover_XM's p_est / t_est, 3_test_colmap_glomap.py:305-316); weights: one per observation (Q1, V1, Q3 and the reduced camera
+ * Laplacian are rebuilt; the latter is re-inverted on the device). */
 int xm_ctx_attach_edges(xm_ctx_t *ctx, int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
 int xm_ctx_edge_residuals(xm_ctx_t *ctx, double *res);
 int xm_ctx_set_edge_weights(xm_ctx_t *ctx, const double *w);

@@ -409,3 +409,25 @@ def gen_scene(N, M, views, seed, noise=0.01, hubs=3):
     pts = np.einsum("eba,eb->ea", Rs[cam], P[orig][lm] - ts[cam]) + noise * rng.standard_normal((cam.size, 3))
     w = rng.uniform(0.5, 1.5, cam.size)
     return dict(cam=cam.astype(np.int32), lm=lm.astype(np.int32), p=pts, w=w, R_star=Rs, n=N, m=int(orig.size))
+
+
+def schur_residuals_numpy(cam, lm, p, w, U):
+    """per-observation residual |p^T U_i + t_i - P_l|^2 at the optimal eliminated translations / landmarks for the scaled rows U
+    (3N x o): [t; P] = -Qtp_bar^{-1} Vtp_bar^T U with t_0 = 0 (numpy / scipy.sparse; what xm_ctx_edge_residuals returns for a
+    matrix-free context).  sum_e w_e res_e == <Q, U U^T>."""
+    from scipy.sparse import coo_matrix
+    cam = np.asarray(cam); lm = np.asarray(lm); p = np.asarray(p, dtype=np.float64); w = np.asarray(w, dtype=np.float64).reshape(-1)
+    N, M, Q1, c, Q2, Q3 = schur_parts(cam, lm, p, w)
+    o = U.shape[1]
+    Uc = U.reshape(N, 3, o)
+    pu = np.einsum("ea,eak->ek", p, Uc[cam])
+    g_lm = np.zeros((M, o)); np.add.at(g_lm, lm, -w[:, None] * pu)
+    q3i = np.where(Q3 > 0, 1.0 / np.where(Q3 > 0, Q3, 1.0), 0.0)
+    h = g_lm * q3i[:, None]
+    r = np.einsum("ia,iak->ik", c, Uc)
+    np.add.at(r, cam, w[:, None] * h[lm])
+    V3b = coo_matrix((w, (cam, lm)), shape=(N, M)).tocsr()[1:]
+    VT = np.diag(Q2[1:]) - (V3b.multiply(q3i[None, :]) @ V3b.T).toarray()
+    xc = np.zeros((N, o)); xc[1:] = np.linalg.solve(VT, r[1:])
+    xl = h.copy(); tmp = np.zeros((M, o)); np.add.at(tmp, lm, w[:, None] * xc[cam]); xl += tmp * q3i[:, None]
+    return np.sum((pu - xc[cam] + xl[lm]) ** 2, axis=1)

@@ -18,6 +18,7 @@
 #pragma once
 
 #include <cstdint>
+#include <vector>
 
 #include "xm_solver.h"
 
@@ -36,6 +37,10 @@ public:
     // Y = alpha * Q * W for all n cameras (W: camera records of 3 * pitch_of(o) doubles), same CamArgs / epilogue contract and
     // per-workgroup partial sums (grid qw_grid(n)) as launch_qw_dense
     void product(int o, int epi, const double *W, double alpha, const CamArgs &a, hipStream_t st);
+    // XM^2 loop on the reference's own Q: per-observation residuals at U = s.*R (input order of the observations) and new weights
+    void residuals(int o, const double *U, double *res_host, const CamArgs &a, hipStream_t st);
+    void set_weights(const double *w, hipStream_t st);
+    int64_t nobs() const { return nobs_; }
     int64_t bytes_per_product(int o) const;
 
 private:
@@ -47,7 +52,12 @@ private:
     DevBuf<double> cam_w_, cam_p_, lm_w_, lm_p_;
     DevBuf<double> Q1_, c_, q3inv_;
     DevBuf<double> vtinv_;                     // (N-1)^2 inverse in the dense kernel's padded row-major layout
-    DevBuf<double> h_, r_, xc_, xl_;
+    DevBuf<double> h_, r_, xc_, xl_, res_;
+    DevBuf<int32_t> obs_cam_, obs_lm_;        // the observations in input order (residual kernel)
+    DevBuf<double> obs_p_;
+    std::vector<int32_t> hcam_, hlm_, lcam_;  // host copies of the structure for set_weights
+    std::vector<double> hp_;
+    std::vector<int64_t> cp_, lp_, pos_c_, pos_l_;
     int o_alloc_ = 0, o_last_ = 0;
     void ensure(int o);
 };

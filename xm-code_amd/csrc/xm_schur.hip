@@ -191,68 +191,92 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     if (n > kSchurMaxCams) throw Error(XM_ERR_ARG, "matrix-free Q: more than " + std::to_string(kSchurMaxCams) + " cameras");
     n_ = n; m_ = n_landmarks; nobs_ = nobs;
     const int64_t N = n, M = n_landmarks;
-    std::vector<int64_t> cp((size_t)N + 1, 0), lp((size_t)M + 1, 0);
-    std::vector<double> Q1((size_t)N * 9, 0.0), c((size_t)N * 3, 0.0), Q2((size_t)N, 0.0), Q3((size_t)M, 0.0);
+    // ---- structure (fixed for the life of the context): observation lists by camera and by landmark, input order inside each
+    // (fixed summation order); pos_*[e] = where observation e of the input sits in them (weights are re-scattered by set_weights)
+    hcam_.assign(cam, cam + nobs); hlm_.assign(lm, lm + nobs); hp_.assign(p, p + 3 * nobs);
+    cp_.assign((size_t)N + 1, 0); lp_.assign((size_t)M + 1, 0);
     for (int64_t e = 0; e < nobs; ++e) {
         const int64_t i = cam[e], l = lm[e];
         if (i < 0 || i >= N || l < 0 || l >= M) throw Error(XM_ERR_ARG, "matrix-free Q: observation index out of range");
-        if (!(w[e] >= 0.0)) throw Error(XM_ERR_ARG, "matrix-free Q: negative or NaN weight");
-        cp[(size_t)i + 1]++; lp[(size_t)l + 1]++;
-        const double *pe = p + 3 * e;
-        for (int a = 0; a < 3; ++a) {
-            c[(size_t)i * 3 + a] += w[e] * pe[a];                                 // V1 block (creatematrix.py:27)
-            for (int b = 0; b < 3; ++b) Q1[(size_t)i * 9 + 3 * a + b] += w[e] * pe[a] * pe[b];   // Q1 block (:26)
-        }
-        Q2[(size_t)i] += w[e]; Q3[(size_t)l] += w[e];                             // :68-69
+        cp_[(size_t)i + 1]++; lp_[(size_t)l + 1]++;
     }
-    for (int64_t l = 0; l < M; ++l)
-        if (!(Q3[(size_t)l] > 0.0)) throw Error(XM_ERR_ARG, "matrix-free Q: a landmark has no observation with positive weight");
-    for (int64_t i = 0; i < N; ++i) cp[(size_t)i + 1] += cp[(size_t)i];
-    for (int64_t l = 0; l < M; ++l) lp[(size_t)l + 1] += lp[(size_t)l];
-    std::vector<int32_t> c_lm((size_t)nobs), l_cam((size_t)nobs);
-    std::vector<double> c_w((size_t)nobs), c_p((size_t)nobs * 3), l_w((size_t)nobs), l_p((size_t)nobs * 3);
+    for (int64_t i = 0; i < N; ++i) cp_[(size_t)i + 1] += cp_[(size_t)i];
+    for (int64_t l = 0; l < M; ++l) lp_[(size_t)l + 1] += lp_[(size_t)l];
+    std::vector<int32_t> c_lm((size_t)nobs);
+    std::vector<double> c_p((size_t)nobs * 3), l_p((size_t)nobs * 3);
+    lcam_.assign((size_t)nobs, 0);
+    pos_c_.assign((size_t)nobs, 0); pos_l_.assign((size_t)nobs, 0);
     {
-        std::vector<int64_t> nc(cp.begin(), cp.end() - 1), nl(lp.begin(), lp.end() - 1);
-        for (int64_t e = 0; e < nobs; ++e) {   // observation order inside a camera / a landmark = input order (fixed summation order)
+        std::vector<int64_t> nc(cp_.begin(), cp_.end() - 1), nl(lp_.begin(), lp_.end() - 1);
+        for (int64_t e = 0; e < nobs; ++e) {
             const int64_t a2 = nc[(size_t)cam[e]]++, b2 = nl[(size_t)lm[e]]++;
-            c_lm[(size_t)a2] = lm[e]; c_w[(size_t)a2] = w[e]; std::memcpy(&c_p[(size_t)a2 * 3], p + 3 * e, 24);
-            l_cam[(size_t)b2] = cam[e]; l_w[(size_t)b2] = w[e]; std::memcpy(&l_p[(size_t)b2 * 3], p + 3 * e, 24);
+            pos_c_[(size_t)e] = a2; pos_l_[(size_t)e] = b2;
+            c_lm[(size_t)a2] = lm[e]; std::memcpy(&c_p[(size_t)a2 * 3], p + 3 * e, 24);
+            lcam_[(size_t)b2] = cam[e]; std::memcpy(&l_p[(size_t)b2 * 3], p + 3 * e, 24);
         }
     }
-    // reduced camera Laplacian VT = Q2_bar - V3_bar Q3^{-1} V3_bar^T (creatematrix.py:150-166) and its inverse
+    auto up = [&](auto &buf, const auto &v) {
+        buf.alloc(std::max<size_t>(v.size(), 1), false);
+        if (!v.empty()) XM_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+    };
+    up(cam_ptr_, cp_); up(lm_ptr_, lp_); up(cam_lm_, c_lm); up(lm_cam_, lcam_); up(cam_p_, c_p); up(lm_p_, l_p);
+    up(obs_cam_, hcam_); up(obs_lm_, hlm_); up(obs_p_, hp_);
+    std::vector<int32_t> heavy;
+    for (int64_t l = 0; l < M; ++l)
+        if (lp_[(size_t)l + 1] - lp_[(size_t)l] > kSchurHeavy) heavy.push_back((int32_t)l);
+    nheavy_ = (int64_t)heavy.size();
+    up(heavy_, heavy);
+    cam_w_.alloc((size_t)nobs, false); lm_w_.alloc((size_t)nobs, false);
+    Q1_.alloc((size_t)N * 9, false); c_.alloc((size_t)N * 3, false); q3inv_.alloc((size_t)M, false);
+    const int64_t mr = N - 1;
+    nred_ = std::max<int64_t>(1, (mr + 2) / 3);
+    ldv_ = dense_ld(nred_);
+    vtinv_.alloc((size_t)3 * nred_ * (size_t)ldv_);
+    set_weights(w, st);
+}
+
+// Everything that depends on the weights (utils/creatematrix.py:62-175 restated on the observation level): Q1, c (= V1), Q3, the
+// reduced camera Laplacian VT = Q2_bar - V3_bar Q3^{-1} V3_bar^T and its inverse.  Called by the constructor and by the XM^2 loop
+// (observations filtered by weight 0).  A landmark whose observations all have weight 0 drops out (1/Q3 := 0); a camera without
+// weight makes VT singular -> XM_ERR_ARG.
+void SchurOp::set_weights(const double *w, hipStream_t st) {
+    if (!w) throw Error(XM_ERR_ARG, "matrix-free Q: null weights");
+    const int64_t N = n_, M = m_, nobs = nobs_;
+    std::vector<double> Q1((size_t)N * 9, 0.0), c((size_t)N * 3, 0.0), Q2((size_t)N, 0.0), Q3((size_t)M, 0.0);
+    std::vector<double> c_w((size_t)nobs), l_w((size_t)nobs);
+    for (int64_t e = 0; e < nobs; ++e) {
+        if (!(w[e] >= 0.0)) throw Error(XM_ERR_ARG, "matrix-free Q: negative or NaN weight");
+        const int64_t i = hcam_[(size_t)e], l = hlm_[(size_t)e];
+        const double *pe = &hp_[(size_t)e * 3];
+        for (int a = 0; a < 3; ++a) {
+            c[(size_t)i * 3 + a] += w[e] * pe[a];                                                 // V1 block (creatematrix.py:27)
+            for (int b = 0; b < 3; ++b) Q1[(size_t)i * 9 + 3 * a + b] += w[e] * pe[a] * pe[b];    // Q1 block (:26)
+        }
+        Q2[(size_t)i] += w[e]; Q3[(size_t)l] += w[e];                                             // :68-69
+        c_w[(size_t)pos_c_[(size_t)e]] = w[e]; l_w[(size_t)pos_l_[(size_t)e]] = w[e];
+    }
+    std::vector<double> q3inv((size_t)M);
+    for (int64_t l = 0; l < M; ++l) q3inv[(size_t)l] = (Q3[(size_t)l] > 0.0) ? 1.0 / Q3[(size_t)l] : 0.0;
     const int64_t mr = N - 1;
     std::vector<double> VT((size_t)std::max<int64_t>(mr, 1) * (size_t)std::max<int64_t>(mr, 1), 0.0);
     for (int64_t i = 1; i < N; ++i) VT[(size_t)(i - 1) + (size_t)(i - 1) * mr] = Q2[(size_t)i];
     for (int64_t l = 0; l < M; ++l) {
-        const double qi = 1.0 / Q3[(size_t)l];
-        for (int64_t e1 = lp[(size_t)l]; e1 < lp[(size_t)l + 1]; ++e1) {
-            const int64_t a2 = l_cam[(size_t)e1];
-            if (a2 == 0) continue;
-            for (int64_t e2 = lp[(size_t)l]; e2 < lp[(size_t)l + 1]; ++e2) {
-                const int64_t b2 = l_cam[(size_t)e2];
+        const double qi = q3inv[(size_t)l];
+        if (qi == 0.0) continue;
+        for (int64_t e1 = lp_[(size_t)l]; e1 < lp_[(size_t)l + 1]; ++e1) {
+            const int64_t a2 = lcam_[(size_t)e1];
+            if (a2 == 0 || l_w[(size_t)e1] == 0.0) continue;
+            for (int64_t e2 = lp_[(size_t)l]; e2 < lp_[(size_t)l + 1]; ++e2) {
+                const int64_t b2 = lcam_[(size_t)e2];
                 if (b2 == 0) continue;
                 VT[(size_t)(a2 - 1) + (size_t)(b2 - 1) * mr] -= l_w[(size_t)e1] * l_w[(size_t)e2] * qi;
             }
         }
     }
-    std::vector<double> q3inv((size_t)M);
-    for (int64_t l = 0; l < M; ++l) q3inv[(size_t)l] = 1.0 / Q3[(size_t)l];
-
-    auto up = [&](auto &buf, const auto &v) {
-        buf.alloc(std::max<size_t>(v.size(), 1), false);
-        if (!v.empty()) XM_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+    auto put = [&](DevBuf<double> &buf, const std::vector<double> &v) {
+        if (!v.empty()) XM_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
     };
-    up(cam_ptr_, cp); up(lm_ptr_, lp); up(cam_lm_, c_lm); up(lm_cam_, l_cam); up(cam_w_, c_w); up(cam_p_, c_p); up(lm_w_, l_w); up(lm_p_, l_p);
-    up(Q1_, Q1); up(c_, c); up(q3inv_, q3inv);
-    std::vector<int32_t> heavy;
-    for (int64_t l = 0; l < M; ++l)
-        if (lp[(size_t)l + 1] - lp[(size_t)l] > kSchurHeavy) heavy.push_back((int32_t)l);
-    nheavy_ = (int64_t)heavy.size();
-    up(heavy_, heavy);
-    // VT^{-1} in the dense kernel's layout: (N-1) unknowns padded to nred "cameras" of 3 rows
-    nred_ = std::max<int64_t>(1, (mr + 2) / 3);
-    ldv_ = dense_ld(nred_);
-    vtinv_.alloc((size_t)3 * nred_ * (size_t)ldv_);
+    put(cam_w_, c_w); put(lm_w_, l_w); put(Q1_, Q1); put(c_, c); put(q3inv_, q3inv);
     if (mr > 0) {   // invert on the device (blocked Cholesky, xm_dense_la.hip), then lay the inverse out like a dense Q
         DevBuf<double> tmp, inv;
         tmp.alloc((size_t)mr * mr, false); inv.alloc((size_t)mr * mr, false);
@@ -263,6 +287,40 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
         launch_transpose_pad(inv.p, mr, mr, mr, vtinv_.p, ldv_, st);   // (symmetric: the transposition is immaterial)
         XM_HIP_CHECK(hipStreamSynchronize(st));
     }
+}
+
+// residual of every observation at the point whose scaled rows are U (camera records of 3 * pitch_of(o) doubles):
+// |p^T U_i + t_i - P_l|^2 with the eliminated translations / landmarks [t; P] = -Qtp_bar^{-1} Vtp_bar^T U, i.e. the observation's share
+// of <Q, U U^T> per unit weight (what the reference's XM^2 loop computes from recover_XM's p_est / t_est, 3_test_colmap_glomap.py:305-316)
+template <int O>
+__global__ __launch_bounds__(256) void schur_obs_residual_kernel(int64_t nobs, const int32_t *__restrict__ cam, const int32_t *__restrict__ lm,
+                                                                  const double *__restrict__ p, const double *__restrict__ U,
+                                                                  const double *__restrict__ xc, const double *__restrict__ xl,
+                                                                  double *__restrict__ res) {
+    constexpr int OP = pitch_of(O);
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nobs) return;
+    const int i = cam[e];
+    const double *Ui = U + (size_t)i * 3 * OP, *x = xl + (size_t)lm[e] * OP;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < O; ++k) {
+        const double xk = (i >= 1) ? xc[(size_t)(i - 1) * OP + k] : 0.0;
+        const double d = p[3 * e] * Ui[k] + p[3 * e + 1] * Ui[OP + k] + p[3 * e + 2] * Ui[2 * OP + k] - xk + x[k];
+        acc += d * d;
+    }
+    res[e] = acc;
+}
+
+void SchurOp::residuals(int o, const double *U, double *res_host, const CamArgs &a, hipStream_t st) {
+    // the chain with the plain epilogue leaves x_cam / x_l of this U in the scratch buffers
+    product(o, EPI_PLAIN, U, 1.0, a, st);
+    res_.alloc((size_t)nobs_, false);
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((schur_obs_residual_kernel<O_>), dim3((unsigned)((nobs_ + 255) / 256)), dim3(256), 0, st, nobs_, obs_cam_.p,
+                                        obs_lm_.p, obs_p_.p, U, xc_.p, xl_.p, res_.p));
+    check_launch("schur_obs_residual");
+    XM_HIP_CHECK(hipMemcpyAsync(res_host, res_.p, (size_t)nobs_ * sizeof(double), hipMemcpyDeviceToHost, st));
+    XM_HIP_CHECK(hipStreamSynchronize(st));
 }
 
 void SchurOp::ensure(int o) {

@@ -967,6 +967,22 @@ void Context::attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, con
 }
 
 void Context::edge_residuals(double *res) {
+    if (storage_ == XM_STORAGE_SCHUR) {   // matrix-free: the observations are the edges (one residual per observation, input order)
+        if (!solved_) throw Error(XM_ERR_ARG, "edge_residuals: the context holds no solution yet");
+        if (!res) throw Error(XM_ERR_ARG, "edge_residuals: null output");
+        xm_options_t opt;
+        std::memset(&opt, 0, sizeof(opt));
+        const xm_options_t *keep = opt_;
+        opt_ = &opt;
+        launch_scale_rows(o_, nloc_, R_.p, s_.p, W_.p, st_);
+        CamArgs a = cam_args(cur_);
+        a.out = HpR_.p;
+        schur_->residuals(o_, W_.p, res, a, st_);
+        XM_HIP_CHECK(hipMemsetAsync(W_.p, 0, W_.count * sizeof(double), st_));
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        opt_ = keep;
+        return;
+    }
     if (ne_ <= 0 && !ei_.p) throw Error(XM_ERR_ARG, "edge_residuals: no edges attached");
     if (!solved_) throw Error(XM_ERR_ARG, "edge_residuals: the context holds no solution yet");
     if (!res) throw Error(XM_ERR_ARG, "edge_residuals: null output");
@@ -979,6 +995,7 @@ void Context::edge_residuals(double *res) {
 }
 
 void Context::set_edge_weights(const double *w) {
+    if (storage_ == XM_STORAGE_SCHUR) { schur_->set_weights(w, st_); return; }
     if (!ei_.p) throw Error(XM_ERR_ARG, "set_edge_weights: no edges attached");
     if (ne_ > 0 && !w) throw Error(XM_ERR_ARG, "set_edge_weights: null weights");
     if (ne_ > 0) XM_HIP_CHECK(hipMemcpyAsync(ew_.p, w, (size_t)ne_ * sizeof(double), hipMemcpyHostToDevice, st_));

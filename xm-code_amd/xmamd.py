@@ -343,6 +343,7 @@ class Context:
             p.n, p.storage, p.nobs, p.n_landmarks = self.n, STORAGE_SCHUR, cam.size, int(lm.max()) + 1
             p.obs_cam, p.obs_lm, p.obs_p, p.obs_w = (a.ctypes.data_as(C.c_void_p) for a in (cam, lm, pts, w))
             self._keep += [cam, lm, pts, w]
+            self.ne = cam.size                      # residuals / weights of the XM^2 loop are per observation
         elif dq is not None:                      # dense Q already on the device in the solver's layout (borrowed)
             self.n = int(n)
             p.n, p.storage, p.q_on_device, p.q, p.ldq = self.n, STORAGE_DENSE, 1, dq.ptr, dense_ld(self.n)
