@@ -417,6 +417,13 @@ def test_rccl_path_single_rank(xmamd, tmp_path):
     assert float(outs[0]["primal"]) == pytest.approx(float(outs[1]["primal"]), rel=1e-12)
     assert tl.rotation_parity(outs[0]["R"], outs[0]["s"], outs[1]["R"], outs[1]["s"]) < 1e-8
     assert abs(int(outs[0]["tcg"]) - int(outs[1]["tcg"])) <= 0.05 * int(outs[0]["tcg"])
+    # the same through the split product (local strip on a second stream beside the RCCL all-gather): real RCCL stream
+    # ordering between the two streams, one rank
+    out = str(tmp_path / "r2.npz")
+    subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, XM_FORCE_COMM="1", XM_OVERLAP_MIN_MB="0"), timeout=600)
+    o2 = np.load(out)
+    assert float(o2["primal"]) == pytest.approx(float(outs[0]["primal"]), rel=1e-12)
+    assert tl.rotation_parity(o2["R"], o2["s"], outs[0]["R"], outs[0]["s"]) < 1e-8
 
 
 def test_dubrovnik356_full_solve_matches_oracle(xmamd, oracle):
@@ -534,6 +541,9 @@ def _two_rank_worker_code():
         elif case == "densify":                                    # block description expanded per rank on the device
             P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True); args = (6, 1e-9, 3.0)
+        elif case == "overlap":                                    # enough columns per rank for whole tiles inside the own strip
+            P = tl.gen_vg(400, deg=8, sigma=0.3, seed=9)
+            ctx = xmamd.Context(Q=P["Q"]); args = (5, 1e-9, 10.0)
         elif case == "file":                                       # the reference's file surface: every rank reads ITS row strip of Q.bin
             d = os.path.join(os.path.dirname(out), "ds_w%d" % world)
             if rank == 0:
@@ -562,7 +572,7 @@ def _two_rank_worker_code():
 
 
 @pytest.mark.parametrize("case,world", [("dense", 2), ("bsr", 2), ("densify", 2), ("dense", 3), ("bsr", 3), ("dense-async", 2), ("bsr-async", 3),
-                                        ("sell", 2), ("sell-async", 2), ("file", 2)])
+                                        ("sell", 2), ("sell-async", 2), ("file", 2), ("overlap", 2), ("overlap-async", 3)])
 def test_two_ranks_one_gpu(xmamd, tmp_path, case, world):
     """The whole row-partitioned solver with TWO or THREE ranks (processes) sharing the one GPU of the test box through the
     shared-memory test transport: camera partition 21+20 (+1 inert padding camera) resp. 14+14+13 (+1), replicated product input, gathered
@@ -571,7 +581,8 @@ def test_two_ranks_one_gpu(xmamd, tmp_path, case, world):
     "-async": the transport is STREAM-ORDERED (XM_SHM_ASYNC=1: the exchange runs in a host function on the solver's stream, the
     calling thread never blocks, like an RCCL collective), so the enqueue-ahead logic of the tCG is exercised for real: a rank
     that enqueued a different number of collectives than its peer would leave a barrier unmatched and fail with XM_ERR_COMM.
-    "sell": block-sparse storage through the sliced-ELL product.  "file": the reference's file surface, each rank reading only
+    "sell": block-sparse storage through the sliced-ELL product.  "overlap": dense products outside the tCG split in two launches
+    around the all-gather (local column strip first, on a second stream).  "file": the reference's file surface, each rank reading only
     its own row strip of Q.bin (xm_solve), rank 0 writing R.bin / s.bin."""
     import subprocess, sys, uuid
     code = _two_rank_worker_code()
@@ -581,6 +592,9 @@ def test_two_ranks_one_gpu(xmamd, tmp_path, case, world):
         env["XM_SHM_ASYNC"] = "1"; case = case[:-6]
     if case == "sell":
         env["XM_BSR_SELL"] = "1"
+    if case == "overlap":     # the local column strip of the dense product runs on a second stream beside the all-gather of W
+        env["XM_OVERLAP_MIN_MB"] = "0"
+        env["XM_COMM_TRACE"] = str(tmp_path / "trace")
     procs, outs = [], []
     logs = []
     for r in range(world):
@@ -597,6 +611,9 @@ def test_two_ranks_one_gpu(xmamd, tmp_path, case, world):
             lg.seek(0)
             print(f"---- rank {r} (rc {rcs[r]}) ----\n" + lg.read()[-1500:])
     assert rcs == [0] * world
+    if case == "overlap":     # the split path really ran (a rank whose column strip holds no whole 256-column tile keeps the single launch)
+        ran = ["overlap_split" in open(str(tmp_path / "trace") + f".{r_}").read() for r_ in range(world)]
+        assert ran[0] and sum(ran) >= world - 1, ran
     single = str(tmp_path / "w1.npz")
     subprocess.check_call([sys.executable, "-c", code, "0", "1", name, single, case], timeout=600, env=env)
     a, c = np.load(outs[0]), np.load(single)

@@ -80,6 +80,10 @@ struct CamArgs {
     const double *dz;    // nloc
     const TcgScal *scal; // tCG kernels return immediately when scal->status != 0
     double *Bout;        // multi-rank tCG only: rows of  s.*Hp_R + Hp_s.*R  (the product-input image of Hp), else nullptr
+    // dense product split in two launches (overlap of the W all-gather with the local column strip, xm_solver.hip:gathered product):
+    int range_mode;      // 0 whole matrix | 1 only the column tiles [t_lo, t_hi) | 2 all tiles except [t_lo, t_hi)
+    int t_lo, t_hi;
+    const double *addend; // range_mode 2: raw row sums of the tiles done earlier (3*nloc x OP, pitch OP), added before the epilogue
 };
 
 enum Epilogue { EPI_PLAIN = 0, EPI_GRAD = 1, EPI_HESS = 2, EPI_CERT = 3 };
@@ -91,6 +95,9 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
 void launch_qw_bsr3(int o, int epi, const int64_t *rowptr, const int32_t *colidx, const double *blocks, const double *W,
                     double alpha, const CamArgs &a, hipStream_t st);
 int qw_grid(int nloc);
+// the same product restricted to a range of column tiles (CamArgs.range_mode / t_lo / t_hi / addend); plain or gradient epilogue
+void launch_qw_dense_split(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st);
+int qw_dense_tile_cols();
 int bsr_grid(int nloc);   // workgroups (= partial sums per epilogue slot) of the BSR3 kernels
 int sym_groups(int nloc);
 size_t sym_prow_count(int nloc, int64_t ld, int o);

@@ -34,7 +34,9 @@ namespace xm {
 // ----------------------------------------------------------------------------------------------------------------
 // Software-pipelined: while a wavefront multiplies tile t (Q fragment in registers, W tile in LDS buffer t&1) the loads
 // of tile t+1 (its 3 rows of Q and the workgroup's share of the next W tile) are already in flight; one barrier per tile.
-template <int O, int EPI, int NSUB, bool NT>
+// SPLIT (separate instantiations, the default ones are untouched): the tile loop runs over a sub-range of the column tiles
+// (CamArgs.range_mode) so that the product can be done in two launches around the all-gather of W.
+template <int O, int EPI, int NSUB, bool NT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict__ Q, int64_t ld,
                                                         const double *__restrict__ W, double alpha, CamArgs a) {
     constexpr int OP = pitch_of(O);
@@ -47,13 +49,28 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
     const int cam = blockIdx.x * kQwWaves + wave;   // wave-uniform (scalar): per-camera scalars load through the scalar cache
     const bool active = cam < a.nloc;
     const double *q0 = Q + (size_t)(active ? cam : 0) * 3 * (size_t)ld + 2 * lane;
-    const int ntiles = (int)((ld + TILE - 1) / TILE);
+    const int ntiles_all = (int)((ld + TILE - 1) / TILE);
+    // tile sequence: i-th tile of this launch (identity unless SPLIT)
+    const int span = SPLIT ? (a.t_hi - a.t_lo) : 0;
+    const int ntiles = !SPLIT ? ntiles_all : (a.range_mode == 1 ? span : ntiles_all - span);
+    auto tile_at = [&](int i) -> int {
+        if (!SPLIT) return i;
+        return (a.range_mode == 1) ? a.t_lo + i : ((i < a.t_lo) ? i : i + span);
+    };
 
     double acc[3][O];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+    if (SPLIT) {
+        if (a.addend != nullptr && active && lane == 0) {   // raw sums of the tiles an earlier launch did
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc[r][k] = a.addend[((size_t)cam * 3 + r) * OP + k];
+        }
+    }
 
     EpiOps eops;
     double2 qn[NSUB][3];   // Q fragment of the NEXT tile
@@ -98,8 +115,15 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
         }
     };
 
-    load_q(0);
-    load_w(0);
+    if (SPLIT) {
+        if (ntiles <= 0) {   // nothing to multiply in this launch (uniform): straight to the tail
+            epi_prefetch<O, EPI>(eops, cam, lane, active, a);
+            qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
+            return;
+        }
+    }
+    load_q(tile_at(0));
+    load_w(tile_at(0));
     if (EPI == EPI_HESS) {
         // tCG already terminated: the enqueued-ahead launch becomes a no-op.  Checked only after the first tile's loads are
         // in flight, so that a live launch does not start with an exposed dependent load (uniform over the grid).
@@ -115,8 +139,8 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
             for (int r = 0; r < 3; ++r) q[u][r] = qn[u][r];
         const bool more = (t + 1 < ntiles);
         if (more) {  // uniform
-            load_q(t + 1);
-            load_w(t + 1);
+            load_q(tile_at(t + 1));
+            load_w(tile_at(t + 1));
         } else {
             epi_prefetch<O, EPI>(eops, cam, lane, active, a);
         }
@@ -1284,6 +1308,26 @@ static void qw_dense_epi(int epi, const double *Q, int64_t ld, const double *W, 
     if (qw_stream_nt(a.nloc, ld)) qw_dense_epi2<O, NSUB, true>(epi, Q, ld, W, alpha, a, st);
     else qw_dense_epi2<O, NSUB, false>(epi, Q, ld, W, alpha, a, st);
 }
+// split launches (range_mode 1 / 2): plain or gradient epilogue, default tile width, default load policy by size
+template <int O>
+static void qw_dense_split_o(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+    const dim3 g(qw_grid(a.nloc)), b(256);
+    const bool nt = qw_stream_nt(a.nloc, ld);
+    if (epi == EPI_PLAIN) {
+        if (nt) hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, 2, true, true>), g, b, 0, st, Q, ld, W, alpha, a);
+        else hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, 2, false, true>), g, b, 0, st, Q, ld, W, alpha, a);
+    } else if (epi == EPI_GRAD) {
+        if (nt) hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, 2, true, true>), g, b, 0, st, Q, ld, W, alpha, a);
+        else hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, 2, false, true>), g, b, 0, st, Q, ld, W, alpha, a);
+    } else throw Error(-2, "split dense product: plain or gradient epilogue only");
+}
+void launch_qw_dense_split(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+    if (a.nloc <= 0) return;
+    XM_DISPATCH_O(o, (qw_dense_split_o<O_>(epi, Q, ld, W, alpha, a, st)));
+    check_launch("qw_dense_split");
+}
+int qw_dense_tile_cols() { return 2 * 128; }   // column tile of the split launches
+
 void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
     if (a.nloc <= 0) return;
     if (epi == EPI_CERT) {

@@ -110,6 +110,10 @@ private:
     DevBuf<double> eM_, ew_, eres_;
     bool solved_ = false;   // R_/s_ hold the end point of a solve
     hipStream_t st_ = nullptr;
+    hipStream_t st2_ = nullptr;          // local-strip product running beside the all-gather of W (multi-rank, dense)
+    hipEvent_t ev_w_ = nullptr, ev_p_ = nullptr;
+    DevBuf<double> Pstrip_;              // raw row sums of the local column strip
+    bool w_pending_ = false;             // gather_W() was deferred into the next product()
     Comm *comm_ = nullptr;
 
     // ---- per-rank workspace -------------------------------------------------------------------------------------
@@ -148,7 +152,9 @@ private:
     CamArgs cam_args(int state) const;
     int prod_grid() const;
     void product(int epi, int o, double alpha, const CamArgs &a);
-    void gather_W();
+    void gather_W();          // all-gather of the product input; deferred into the next product() when the overlap applies
+    void flush_gather();      // perform a deferred gather now
+    bool overlap_applies() const;
     void eval_point(int state, const double *Rp, const double *sp, double &f, double &rr);
     double sum_parts(const double *dparts, int count);
     int run_tcg(double rr, double delta, TcgScal &fin);

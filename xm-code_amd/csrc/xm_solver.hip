@@ -56,6 +56,11 @@ void Context::release_raw() {
     hstat_ = nullptr;
     if (hpin_) (void)hipHostFree(hpin_);
     hpin_ = nullptr;
+    if (ev_w_) (void)hipEventDestroy(ev_w_);
+    if (ev_p_) (void)hipEventDestroy(ev_p_);
+    ev_w_ = ev_p_ = nullptr;
+    if (st2_) (void)hipStreamDestroy(st2_);
+    st2_ = nullptr;
     if (st_) (void)hipStreamDestroy(st_);
     st_ = nullptr;
 }
@@ -234,6 +239,14 @@ void Context::setup_rank(int o) {
     } else {
         Prow_.release(); Pcol_.release();
     }
+    if (overlap_applies()) {
+        if (!st2_) {
+            XM_HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
+            XM_HIP_CHECK(hipEventCreateWithFlags(&ev_w_, hipEventDisableTiming));
+            XM_HIP_CHECK(hipEventCreateWithFlags(&ev_p_, hipEventDisableTiming));
+        }
+        Pstrip_.alloc(mat);
+    }
     scal_.alloc(2);
     const size_t need = (size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64;
     if (need > hpin_count_) {
@@ -307,6 +320,28 @@ CamArgs Context::cam_args(int state) const {
 }
 
 void Context::product(int epi, int o, double alpha, const CamArgs &a) {
+    if (w_pending_) {
+        if (storage_ == XM_STORAGE_DENSE && (epi == EPI_PLAIN || epi == EPI_GRAD) && o == o_) {
+            // local column strip on the second stream beside the all-gather, the rest after it
+            w_pending_ = false;
+            const int tc = qw_dense_tile_cols();
+            const int64_t c0 = 3 * (int64_t)cam0_, c1 = 3 * ((int64_t)cam0_ + nloc_);
+            CamArgs s1 = a, s2 = a;
+            s1.range_mode = 1; s1.t_lo = (int)((c0 + tc - 1) / tc); s1.t_hi = (int)(c1 / tc); s1.out = Pstrip_.p; s1.addend = nullptr;
+            s2.range_mode = 2; s2.t_lo = s1.t_lo; s2.t_hi = s1.t_hi; s2.addend = Pstrip_.p;
+            comm_->note("overlap_split", (double)s1.t_lo, (double)s1.t_hi);
+            XM_HIP_CHECK(hipEventRecord(ev_w_, st_));
+            XM_HIP_CHECK(hipStreamWaitEvent(st2_, ev_w_, 0));
+            launch_qw_dense_split(o, EPI_PLAIN, dQ_, ld_, W_.p, 1.0, s1, st2_);
+            XM_HIP_CHECK(hipEventRecord(ev_p_, st2_));
+            comm_->allgather(W_.p, (size_t)nloc_ * 3 * OP_, st_);
+            XM_HIP_CHECK(hipStreamWaitEvent(st_, ev_p_, 0));
+            launch_qw_dense_split(o, epi, dQ_, ld_, W_.p, alpha, s2, st_);
+            if (res_) res_->qw_products++;
+            return;
+        }
+        flush_gather();
+    }
     if (storage_ == XM_STORAGE_DENSE) {
         if (sym_ok_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT && Pcol_.p) launch_qw_sym(o, epi, dQ_, ld_, W_.p, alpha, a, Prow_.p, Pcol_.p, st_);
         else launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
@@ -320,8 +355,32 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
     if (res_) res_->qw_products++;
 }
 
+// "overlap the gather with the local (diagonal-strip) part of Q*W".  The rows of W this rank owns are final before the
+// all-gather starts, so the column tiles of Q that lie entirely inside the rank's own column range can be multiplied on a second
+// stream WHILE the collective runs; the rest of the product (all other tiles, + those raw sums, + the epilogue) follows the
+// gather.  Applies to the dense products OUTSIDE the tCG (cost/gradient of a candidate point, line search, certificate right-hand
+// side) — inside the tCG the product input comes from replicated data and there is no gather to hide.  It costs
+// an extra launch, so it is used only when the per-rank matrix is large (XM_OVERLAP_MIN_MB, default 64; XM_OVERLAP=0 disables).
+bool Context::overlap_applies() const {
+    static const int mode = [] { const char *e = std::getenv("XM_OVERLAP"); return (e && *e) ? std::atoi(e) : 1; }();
+    static const double min_mb = [] { const char *e = std::getenv("XM_OVERLAP_MIN_MB"); return (e && *e) ? std::atof(e) : 64.0; }();
+    if (mode == 0 || !comm_->active() || storage_ != XM_STORAGE_DENSE || sym_ok_) return false;
+    if ((double)nloc_ * 3.0 * (double)ld_ * 8.0 < min_mb * 1048576.0) return false;
+    const int tc = qw_dense_tile_cols();
+    const int64_t c0 = 3 * (int64_t)cam0_, c1 = 3 * ((int64_t)cam0_ + nloc_);
+    return (c1 / tc) > ((c0 + tc - 1) / tc);
+}
+
 void Context::gather_W() {
-    if (comm_->active()) comm_->allgather(W_.p, (size_t)nloc_ * 3 * OP_, st_);
+    if (!comm_->active()) return;
+    if (overlap_applies()) { w_pending_ = true; return; }   // resolved by the next product()
+    comm_->allgather(W_.p, (size_t)nloc_ * 3 * OP_, st_);
+}
+
+void Context::flush_gather() {
+    if (!w_pending_) return;
+    w_pending_ = false;
+    comm_->allgather(W_.p, (size_t)nloc_ * 3 * OP_, st_);
 }
 
 double Context::sum_parts(const double *dparts, int count) {
@@ -988,6 +1047,7 @@ void Context::edge_residuals(double *res) {
     if (!res) throw Error(XM_ERR_ARG, "edge_residuals: null output");
     launch_scale_rows(o_, nloc_, R_.p, s_.p, W_.p + (size_t)cam0_ * 3 * OP_, st_);
     gather_W();
+    flush_gather();
     launch_edge_residual(ne_, ei_.p, ej_.p, eM_.p, W_.p, o_, OP_, eres_.p, st_);
     if (ne_ > 0) XM_HIP_CHECK(hipMemcpyAsync(res, eres_.p, (size_t)ne_ * sizeof(double), hipMemcpyDeviceToHost, st_));
     XM_HIP_CHECK(hipMemsetAsync(W_.p, 0, W_.count * sizeof(double), st_));
