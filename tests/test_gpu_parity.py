@@ -471,7 +471,7 @@ def test_recover_rotations_matches_reference_recover_XM(xmamd, oracle, name):
     assert np.allclose(np.abs(rot[:, :3]), np.eye(3), atol=1e-13)     # +-I (the reference flips the global sign on a negative-det majority)
 
 
-@pytest.mark.parametrize("n,o", [(1, 3), (7, 3), (8, 4), (9, 5), (43, 3), (149, 4), (171, 5), (700, 3), (1031, 5)])
+@pytest.mark.parametrize("n,o", [(1, 3), (2, 3), (7, 3), (8, 4), (9, 5), (43, 3), (85, 3), (86, 4), (87, 5), (128, 3), (149, 4), (171, 5), (700, 3), (1031, 5)])
 def test_qw_dense_symmetric_kernel_matches_oracle(xmamd, oracle, n, o):
     """half-traffic product (reads only the upper block triangle) on a symmetric Q == the full product"""
     rng = np.random.default_rng(7 * n + o)
@@ -497,13 +497,14 @@ def test_symmetric_path_equals_general_path(xmamd, tmp_path):
         np.savez(sys.argv[1], R=R, s=s, primal=info['primal'], sym=info['sym_product'], rank=info['rank'])
     """)
     outs = []
-    for flag in ("1", "0"):
-        out = str(tmp_path / f"s{flag}.npz")
-        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, XM_SYM=flag), timeout=600)
+    for flag, variant in (("1", "1"), ("0", "1"), ("1", "0")):   # vertical sweep (default) | general kernel | horizontal sweep
+        out = str(tmp_path / f"s{flag}{variant}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, XM_SYM=flag, XM_SYM_VARIANT=variant), timeout=600)
         outs.append(np.load(out))
-    assert int(outs[0]["sym"]) == 1 and int(outs[1]["sym"]) == 0
-    assert int(outs[0]["rank"]) == int(outs[1]["rank"]) == 3
+    assert int(outs[0]["sym"]) == 1 and int(outs[1]["sym"]) == 0 and int(outs[2]["sym"]) == 1
+    assert int(outs[0]["rank"]) == int(outs[1]["rank"]) == int(outs[2]["rank"]) == 3
     assert float(outs[0]["primal"]) == pytest.approx(float(outs[1]["primal"]), rel=1e-11)
+    assert float(outs[2]["primal"]) == pytest.approx(float(outs[1]["primal"]), rel=1e-11)
     assert tl.rotation_parity(outs[0]["R"], outs[0]["s"], outs[1]["R"], outs[1]["s"]) < 1e-7
 
 

@@ -292,7 +292,7 @@ int xm_qw_dense_sym(const double *dq, int64_t n, int o, const double *dW, double
     const int64_t ld = xm::dense_ld(n);
     xm::DevBuf<double> prow, pcol;
     prow.alloc(xm::sym_prow_count((int)n, ld, o));
-    pcol.alloc((size_t)xm::sym_groups((int)n) * (size_t)ld * o, false);
+    pcol.alloc(xm::sym_pcol_count((int)n, ld, o), false);
     xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, alpha, plain_args(n, dOut), prow.p, pcol.p, (hipStream_t)stream);
     XM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return XM_OK;
@@ -303,7 +303,7 @@ int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, d
     const int64_t ld = xm::dense_ld(n);
     xm::DevBuf<double> prow, pcol;
     prow.alloc(xm::sym_prow_count((int)n, ld, o));
-    pcol.alloc((size_t)xm::sym_groups((int)n) * (size_t)ld * o, false);
+    pcol.alloc(xm::sym_pcol_count((int)n, ld, o), false);
     hipEvent_t e0, e1;
     XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
     const xm::CamArgs a = plain_args(n, dOut);

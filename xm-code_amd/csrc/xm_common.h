@@ -101,6 +101,7 @@ int qw_dense_tile_cols();
 int bsr_grid(int nloc);   // workgroups (= partial sums per epilogue slot) of the BSR3 kernels
 int sym_groups(int nloc);
 size_t sym_prow_count(int nloc, int64_t ld, int o);
+size_t sym_pcol_count(int nloc, int64_t ld, int o);
 void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,
                    double *Pcol, hipStream_t st);
 void launch_asym(const double *Q, int64_t ld, int64_t m, double *out, int grid, hipStream_t st);

@@ -21,6 +21,7 @@
 //
 // No MFMA on this path (no dense contraction with reuse); everything is float64 like the reference
 // (Optimization/optimization.h:9).
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -364,6 +365,207 @@ __global__ __launch_bounds__(256) void sym_reduce_kernel(const double *__restric
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
+        }
+    }
+    qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Vertical-sweep variant of the symmetric product (XM_SYM_VARIANT=1).  The horizontal sweep above keeps the ROW sums in registers
+// and flushes one column partial per (16-camera row group, column): o / (3 G) of the half matrix written and read back, and
+// a workgroup barrier + LDS exchange per tile.  Here a WAVEFRONT owns a strip of 256 columns (lane: 2 + 2 adjacent columns, W of its
+// columns in registers for the whole sweep) and walks DOWN it in steps of two cameras (6 rows x 256 columns = 12 KB per step):
+//   column direction  y_cols += Q_step^T w_rows : per-lane accumulators that live in registers for the whole chunk of K steps,
+//                     written ONCE per chunk (w_rows is wave-uniform: scalar loads);
+//   row direction     y_rows  = Q_step w_cols   : 6 * o per-lane partial sums per step, summed over the 64 lanes through LDS
+//                     (transposed write, 16-lane DPP row sums) and written as 6 * o doubles per step.
+// Partial-result traffic: o / (6 K) + o / 256 of the half matrix each way (K = 32: 3 % at o = 3 against 25 %), no workgroup
+// barrier anywhere (the four wavefronts of a workgroup are independent: four adjacent strips, same rows -> 8 KB contiguous per row).
+// Element (r, c) of step j (rows [6j, 6j+6)): used both ways when c >= 6j + 6, in the row direction only when 6j <= c < 6j + 6
+// (the 6 x 6 diagonal block is read in full), not at all when c < 6j (its mirror image serves it).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int kSvStrip = 256;
+
+template <int O, bool NT>
+__global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc, int K,
+                                                       const TcgScal *__restrict__ scal, double *__restrict__ Prow,
+                                                       double *__restrict__ Pcol) {
+    constexpr int OP = pitch_of(O), V = 6 * O;
+    if (scal != nullptr) {
+        if (scal->status != 0) return;
+    }
+    __shared__ __attribute__((aligned(16))) double lds[4][V * 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = blockIdx.y * 4 + wave, ch = blockIdx.x;
+    const int nsteps = (nloc + 1) >> 1, nrows = 3 * nloc;
+    const int64_t c0 = (int64_t)s * kSvStrip;
+    if (c0 >= ld) return;                                        // wave-uniform exits: no workgroup barrier in this kernel
+    int jend = (int)((c0 + kSvStrip + 5) / 6);                   // steps whose rows start above the end of the strip
+    if (jend > nsteps) jend = nsteps;
+    const int jb = ch * K;
+    if (jb >= jend) return;
+    const int je = (jb + K < jend) ? jb + K : jend;
+    const int jfull = (int)(c0 / 6);                             // steps j < jfull lie entirely above the diagonal: no masks
+    const bool half1 = c0 + 128 < ld;                            // ld is a multiple of 128: the strip may end after its first half
+    const int64_t R = (int64_t)6 * nsteps;
+    double *L = lds[wave];
+    const int64_t cA = c0 + 2 * lane;
+
+    double wc[2][2][O], ca[2][2][O];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                wc[h][e][k] = (h == 0 || half1) ? W[(size_t)(cA + 128 * h + e) * OP + k] : 0.0;
+                ca[h][e][k] = 0.0;
+            }
+
+    // branch-free loads: rows past the end (odd camera count: three rows of the last step) and the absent second half of the last
+    // strip read a valid address instead and are zeroed by a select
+    const int64_t cB = half1 ? cA + 128 : cA;
+    auto load_q = [&](int j, double2 (&q)[6][2]) {
+        const int64_t r0 = (int64_t)6 * j;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const bool ok = r0 + r < nrows;   // wave-uniform
+            const double *row = Q + (size_t)(ok ? r0 + r : nrows - 1) * (size_t)ld;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double2 *qp = reinterpret_cast<const double2 *>(row + (h ? cB : cA));
+                double2 v;
+                if (NT) v = make_double2(__builtin_nontemporal_load(&qp->x), __builtin_nontemporal_load(&qp->y));
+                else v = *qp;
+                const bool keep = ok && (h == 0 || half1);
+                q[r][h] = make_double2(keep ? v.x : 0.0, keep ? v.y : 0.0);
+            }
+        }
+    };
+    auto step = [&](int j, const double2 (&q)[6][2], auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
+        const int64_t r0 = (int64_t)6 * j;
+        double mr[2] = {1.0, 1.0}, mc[2] = {1.0, 1.0};
+        if constexpr (MASK) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {   // both columns of a pair fall on the same side (all bounds are even)
+                mr[h] = (cA + 128 * h >= r0) ? 1.0 : 0.0;
+                mc[h] = (cA + 128 * h >= r0 + 6) ? 1.0 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double wr[O];
+            const int64_t rw = (r0 + r < nrows) ? r0 + r : nrows - 1;   // rows past the end: Q was zeroed, any finite w will do
+#pragma unroll
+            for (int k = 0; k < O; ++k) wr[k] = W[(size_t)rw * OP + k];   // wave-uniform: scalar loads
+            double qr[2][2], qc[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                qr[h][0] = MASK ? q[r][h].x * mr[h] : q[r][h].x; qr[h][1] = MASK ? q[r][h].y * mr[h] : q[r][h].y;
+                qc[h][0] = MASK ? q[r][h].x * mc[h] : q[r][h].x; qc[h][1] = MASK ? q[r][h].y * mc[h] : q[r][h].y;
+            }
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                double t = qr[0][0] * wc[0][0][k];
+                t = fma(qr[0][1], wc[0][1][k], t);
+                t = fma(qr[1][0], wc[1][0][k], t);
+                t = fma(qr[1][1], wc[1][1][k], t);
+                L[(r * O + k) * 64 + lane] = t;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) ca[h][e][k] = fma(qc[h][e], wr[k], ca[h][e][k]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 64 addends per value: a 16-lane row takes value v = 4 i + (lane / 16), each lane four addends, DPP row sum
+        const int g = lane >> 4, jl = lane & 15;
+#pragma unroll
+        for (int v0 = 0; v0 < V; v0 += 4) {
+            const int v = v0 + g;
+            double t = 0.0;
+            if (v < V) {
+                const double2 a = *reinterpret_cast<const double2 *>(L + v * 64 + 4 * jl), b = *reinterpret_cast<const double2 *>(L + v * 64 + 4 * jl + 2);
+                t = (a.x + a.y) + (b.x + b.y);
+            }
+            t = group_sum<16>(t);
+            if (jl == 0 && v < V) Prow[((size_t)s * (size_t)R + (size_t)r0) * O + v] = t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto run = [&](int j, const double2 (&q)[6][2]) {
+        if (j < jfull) step(j, q, std::false_type{});
+        else step(j, q, std::true_type{});
+    };
+
+    double2 qA[6][2], qB[6][2];
+    load_q(jb, qA);
+    int j = jb;
+    for (; j + 1 < je; j += 2) {
+        load_q(j + 1, qB);
+        run(j, qA);
+        if (j + 2 < je) load_q(j + 2, qA);
+        run(j + 1, qB);
+    }
+    if (j < je) run(j, qA);
+
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 0 || half1) {
+            double *pc = Pcol + ((size_t)ch * (size_t)ld + (size_t)(cA + 128 * h)) * O;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int k = 0; k < O; ++k) pc[e * O + k] = ca[h][e][k];
+        }
+    }
+}
+
+// second half: y_cam = sum_{strips s >= s_lo} Prow[s][rows of cam] + sum_{chunks above} Pcol[chunk][rows of cam] (fixed order), fused epilogue
+template <int O, int EPI>
+__global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t ld,
+                                                           int nstrips, int K, double alpha, CamArgs a) {
+    if (EPI == EPI_HESS) {
+        if (a.scal->status != 0) return;
+    }
+    __shared__ double red[kQwWaves][3];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cam = blockIdx.x * kQwWaves + wave;
+    const bool active = cam < a.nloc;
+    EpiOps eops;
+    epi_prefetch<O, EPI>(eops, cam, lane, active, a);
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+    if (active) {
+        const int64_t R = (int64_t)6 * ((a.nloc + 1) >> 1);
+        const int s_lo = (6 * (cam >> 1)) / kSvStrip;
+        const int nrow = nstrips - s_lo;
+        int cnt[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const int c = 3 * cam + r; cnt[r] = (c >= 6) ? (c - 6) / (6 * K) + 1 : 0; }
+        for (int i = lane; i < nrow + cnt[2]; i += 64) {
+            if (i < nrow) {
+                const double *p = Prow + ((size_t)(s_lo + i) * (size_t)R + (size_t)cam * 3) * O;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
+            } else {
+                const int ch = i - nrow;
+                const double *p = Pcol + ((size_t)ch * (size_t)ld + (size_t)cam * 3) * O;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    if (ch < cnt[r]) {
+#pragma unroll
+                        for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
+                    }
+            }
         }
     }
     qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
@@ -1356,9 +1558,50 @@ int sym_waves() {
     static const int v = [] { const char *e = std::getenv("XM_SYM_WAVES"); const int x = (e && *e) ? std::atoi(e) : 4; return (x == 8) ? 8 : 4; }();
     return v;
 }
+int sym_variant() {   // 1 (default): vertical sweep (column sums in registers) | 0: horizontal sweep (row sums in registers; round 1)
+    static const int v = [] { const char *e = std::getenv("XM_SYM_VARIANT"); return (e && *e) ? std::atoi(e) : 1; }();
+    return v;
+}
 int sym_groups(int nloc) { const int G = sym_waves() * sym_cpw(); return (nloc + G - 1) / G; }
 int sym_chunks(int64_t ld) { const int nt = (int)((ld + kSymTile - 1) / kSymTile); return (nt + kSymChunk - 1) / kSymChunk; }
-size_t sym_prow_count(int nloc, int64_t ld, int o) { return (size_t)sym_groups(nloc) * sym_chunks(ld) * sym_waves() * sym_cpw() * 3 * o; }
+// vertical sweep: steps (two cameras) per chunk.  A long chunk amortises the column flush and shortens the reducer's lists
+// (n / (2 K) column partials per camera), a short one yields more wavefronts and a shorter serial chain per wavefront; the
+// optimum grows like the square root of the triangle's step count T (measured best K, o = 3: T = 9.3 k (Venice size) 8,
+// 49 k (n = 4096) 16, 197 k (n = 8192) 32, 550 k (n = 13682) 64) -> K = sqrt(T) / 13, 2 <= K <= 64.  XM_SYMV_K overrides.
+int symv_k(int nloc, int64_t ld) {
+    static const int fixed = [] { const char *e = std::getenv("XM_SYMV_K"); return (e && *e) ? std::atoi(e) : 0; }();
+    if (fixed > 0) return fixed;
+    const int64_t nsteps = (nloc + 1) / 2, nstrips = (ld + kSvStrip - 1) / kSvStrip;
+    int64_t total = 0;
+    for (int64_t s = 0; s < nstrips; ++s) total += std::min<int64_t>(nsteps, (s * kSvStrip + kSvStrip + 5) / 6);
+    const int64_t k = (int64_t)(std::sqrt((double)total) / 13.0 + 0.5);
+    return (int)std::min<int64_t>(64, std::max<int64_t>(2, k));
+}
+size_t sym_prow_count(int nloc, int64_t ld, int o) {
+    if (sym_variant() == 1) return (size_t)((ld + kSvStrip - 1) / kSvStrip) * 6 * (size_t)((nloc + 1) / 2) * o;
+    return (size_t)sym_groups(nloc) * sym_chunks(ld) * sym_waves() * sym_cpw() * 3 * o;
+}
+size_t sym_pcol_count(int nloc, int64_t ld, int o) {
+    if (sym_variant() == 1) { const int K = symv_k(nloc, ld); return (size_t)(((nloc + 1) / 2 + K - 1) / K) * (size_t)ld * o; }
+    return (size_t)sym_groups(nloc) * (size_t)ld * o;
+}
+
+template <int O>
+static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
+                        hipStream_t st) {
+    const int K = symv_k(a.nloc, ld), nsteps = (a.nloc + 1) / 2, nstrips = (int)((ld + kSvStrip - 1) / kSvStrip);
+    const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
+    const dim3 gs((nsteps + K - 1) / K, (nstrips + 3) / 4);
+    if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, K, sc, Prow, Pcol);
+    else hipLaunchKernelGGL((qw_symv_kernel<O, false>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, K, sc, Prow, Pcol);
+    const dim3 g(qw_grid(a.nloc)), b(256);
+    switch (epi) {
+        case EPI_PLAIN: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break;
+        default: throw Error(-2, "bad epilogue");
+    }
+}
 
 template <int O>
 static void qw_sym_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
@@ -1386,6 +1629,16 @@ static void qw_sym_epi(int epi, const double *Q, int64_t ld, const double *W, do
 void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,
                    double *Pcol, hipStream_t st) {
     if (a.nloc <= 0) return;
+    if (sym_variant() == 1) {
+        switch (o) {
+            case 3: qw_symv_epi<3>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+            case 4: qw_symv_epi<4>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+            case 5: qw_symv_epi<5>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+            default: throw Error(-2, "symmetric product is instantiated for o = 3..5");
+        }
+        check_launch("qw_symv");
+        return;
+    }
     switch (o) {
         case 3: qw_sym_epi<3>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
         case 4: qw_sym_epi<4>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;

@@ -178,7 +178,7 @@ void Context::init(const xm_problem_t &prob) {
     // bound (measured: 13682 cameras 2215 -> 1667 us at o = 3) and not at Venice size, where the per-tile column-sum exchange
     // costs what the halved traffic saves (34.1 vs 33.8 us).  Default: on for 3n >= 12288 and o <= 4; XM_SYM=1 forces it for
     // every size (o <= 5), XM_SYM=0 disables it.
-    auto sym_min_rows = [] { const char *e = std::getenv("XM_SYM_MIN_ROWS"); return (e && *e) ? (int64_t)std::atoll(e) : (int64_t)12288; };
+    auto sym_min_rows = [] { const char *e = std::getenv("XM_SYM_MIN_ROWS"); return (e && *e) ? (int64_t)std::atoll(e) : (int64_t)6144; };
     sym_ok_ = false;
     sym_max_o_ = 4;
     {
@@ -235,7 +235,7 @@ void Context::setup_rank(int o) {
     partsM_.alloc((size_t)std::max(nB_, 2 * ((nloc_ + 255) / 256) * world));
     if (sym_ok_ && o >= 3 && o <= sym_max_o_) {
         Prow_.alloc(sym_prow_count(nloc_, ld_, o));
-        Pcol_.alloc((size_t)sym_groups(nloc_) * (size_t)ld_ * o, false);
+        Pcol_.alloc(sym_pcol_count(nloc_, ld_, o), false);
     } else {
         Prow_.release(); Pcol_.release();
     }
