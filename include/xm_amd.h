@@ -159,6 +159,13 @@ int64_t xm_dense_ld(int64_t n);                                       /* padded 
 int xm_ctx_attach_edges(xm_ctx_t *ctx, int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
 int xm_ctx_edge_residuals(xm_ctx_t *ctx, double *res);
 int xm_ctx_set_edge_weights(xm_ctx_t *ctx, const double *w);
+/* Translations and landmarks of a solution: the last step of utils/recoversolution.py:recover_XM (lines 77-86,
+ * ybar_est = Abar @ sR_real.T; t_est = [0 | first N-1 columns], p_est = the rest) for an XM_STORAGE_SCHUR context.  The reference
+ * needs the dense (N-1+M) x 3N matrix Abar.bin that create_matrix writes (creatematrix.py:283-311; 80 GB at Final-13682 with 800 k
+ * landmarks); here Abar = -Qtp_bar^-1 Vtp_bar^T is applied through the factor chain of the matrix-free product, O(observations +
+ * N^2).  rot: 3 x 3n column-major and scale: n as returned by xm_recover_rotations; t: 3 x n column-major (t[:, 0] = 0, the
+ * anchor), p: 3 x n_landmarks column-major.  Uses the context's CURRENT observation weights. */
+int xm_ctx_recover_tp(xm_ctx_t *ctx, const double *rot, const double *scale, double *t, double *p);
 
 /* ================================================================== 3. kernel-level entry points (device pointers) */
 /* device memory helpers so that callers need no other GPU runtime */

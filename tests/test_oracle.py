@@ -216,3 +216,15 @@ def test_simple2_observations_reproduce_the_references_Q():
     assert tl.rel_fro(tl.schur_dense(Z["cam"], Z["lm"], Z["p"], Z["w"]), Q) < 1e-11
     W = np.random.default_rng(0).standard_normal((Q.shape[0], 4))
     assert tl.rel_fro(tl.schur_qw_numpy(Z["cam"], Z["lm"], Z["p"], Z["w"], W), Q @ W) < 1e-11
+
+
+def test_schur_tp_restatement_matches_reference_recover():
+    """tests/golden/simple2/tp.npz holds what the reference's own pipeline got from recover_XM for SIMPLE2 (anchored rotations, scales,
+    t_est, p_est = Abar @ sR_real^T; tests/golden/make_simple2_tp.py).  The numpy restatement of the device chain (tl.schur_tp_numpy: the
+    eliminated variables recomputed from the observation list, no Abar) reproduces t_est / p_est."""
+    Z = np.load(os.path.join(tl.GOLDEN, "simple2", "obs.npz")); T = np.load(os.path.join(tl.GOLDEN, "simple2", "tp.npz"))
+    t, p = tl.schur_tp_numpy(Z["cam"], Z["lm"], Z["p"], Z["w"], T["R_real"], T["s_real"])
+    assert t.shape == T["t_est"].shape and p.shape == T["p_est"].shape
+    assert np.abs(t - T["t_est"]).max() < 1e-9 * np.abs(T["t_est"]).max()
+    assert np.abs(p - T["p_est"]).max() < 1e-9 * np.abs(T["p_est"]).max()
+    assert np.all(t[:, 0] == 0.0)

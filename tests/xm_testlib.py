@@ -389,6 +389,26 @@ def schur_qw_numpy(cam, lm, p, w, W):
     return Y.reshape(3 * N, o)
 
 
+def schur_tp_numpy(cam, lm, p, w, R_real, s_real):
+    """translations (3 x N, camera 1 at the origin) and landmarks (3 x M) of a solution: the minimiser of
+    sum_obs w |s_i R_i p + t_i - P_l|^2 over (t, P) with t_1 = 0, i.e. -Qtp_bar^-1 Vtp_bar^T (sR)^T — what the reference computes as
+    Abar @ sR_real.T (recoversolution.py:77-86) with the dense Abar of creatematrix.py:283-311.  R_real: 3 x 3N, s_real: N.
+    The same four steps as the first four of schur_qw_numpy."""
+    from scipy.sparse import coo_matrix
+    cam = np.asarray(cam); lm = np.asarray(lm); p = np.asarray(p, dtype=np.float64); w = np.asarray(w, dtype=np.float64).reshape(-1)
+    N, M, Q1, c, Q2, Q3 = schur_parts(cam, lm, p, w)
+    R_real = np.asarray(R_real, dtype=np.float64); s_real = np.asarray(s_real, dtype=np.float64).reshape(-1)
+    Wc = np.stack([(s_real[i] * R_real[:, 3 * i:3 * i + 3]).T for i in range(N)])          # (N, 3, 3): rows of (sR_real)^T
+    h = np.zeros((M, 3)); np.add.at(h, lm, -w[:, None] * np.einsum("ea,eak->ek", p, Wc[cam])); h /= Q3[:, None]
+    r = np.einsum("ia,iak->ik", c, Wc)
+    np.add.at(r, cam, w[:, None] * h[lm])
+    V3b = coo_matrix((w, (cam, lm)), shape=(N, M)).tocsr()[1:]
+    VT = np.diag(Q2[1:]) - (V3b.multiply(1.0 / Q3[None, :]) @ V3b.T).toarray()
+    xc = np.zeros((N, 3)); xc[1:] = np.linalg.solve(VT, r[1:])
+    xl = h.copy(); tmp = np.zeros((M, 3)); np.add.at(tmp, lm, w[:, None] * xc[cam]); xl += tmp / Q3[:, None]
+    return -xc.T, -xl.T
+
+
 def gen_scene(N, M, views, seed, noise=0.01, hubs=3):
     """synthetic SfM scene for the matrix-free tests: N cameras and M landmarks in a box, every landmark observed by `views` cameras
     drawn at random (a well-connected co-visibility graph: the solve converges in a few hundred iterations, unlike a sequential

@@ -213,6 +213,13 @@ int xm_ctx_edge_residuals(xm_ctx_t *ctx, double *res) {
     return XM_OK;
     XM_CATCH
 }
+int xm_ctx_recover_tp(xm_ctx_t *ctx, const double *rot, const double *scale, double *t, double *p) {
+    XM_TRY
+    if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
+    ctx->impl->recover_tp(rot, scale, t, p);
+    return XM_OK;
+    XM_CATCH
+}
 int xm_ctx_set_edge_weights(xm_ctx_t *ctx, const double *w) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");

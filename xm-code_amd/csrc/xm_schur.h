@@ -40,6 +40,10 @@ public:
     // XM^2 loop on the reference's own Q: per-observation residuals at U = s.*R (input order of the observations) and new weights
     void residuals(int o, const double *U, double *res_host, const CamArgs &a, hipStream_t st);
     void set_weights(const double *w, hipStream_t st);
+    // translations t (3 x n column-major, camera 0 at the origin) and landmarks p (3 x m column-major) of a rank-3 solution given as
+    // anchored rotations rot (3 x 3n column-major) and scales (n): the eliminated variables of the chain at U = (s.*R)^T, negated
+    void recover_tp(const double *rot, const double *scale, double *t, double *p, hipStream_t st);
+    int64_t n_landmarks() const { return m_; }
     int64_t nobs() const { return nobs_; }
     int64_t bytes_per_product(int o) const;
 

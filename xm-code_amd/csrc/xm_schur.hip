@@ -323,6 +323,34 @@ void SchurOp::residuals(int o, const double *U, double *res_host, const CamArgs 
     XM_HIP_CHECK(hipStreamSynchronize(st));
 }
 
+// ybar_est = Abar @ sR_real^T of utils/recoversolution.py:77-86 without Abar (the dense (N-1+M) x 3N matrix of creatematrix.py:283-311):
+// Abar = -Qtp_bar^-1 Vtp_bar^T, and the first four steps of the product chain at W = (sR_real)^T leave exactly Qtp_bar^-1 Vtp_bar^T W
+// in x_cam (cameras 1..N-1) and x_l (landmarks).
+void SchurOp::recover_tp(const double *rot, const double *scale, double *t, double *p, hipStream_t st) {
+    if (!rot || !scale || !t || !p) throw Error(XM_ERR_ARG, "recover_tp: null argument");
+    constexpr int OP = pitch_of(3);
+    std::vector<double> hW((size_t)(n_ + kColPad) * 3 * OP, 0.0);
+    for (int64_t i = 0; i < n_; ++i)
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < 3; ++k) hW[((size_t)i * 3 + a) * OP + k] = scale[i] * rot[(size_t)k + 3 * ((size_t)3 * i + a)];
+    DevBuf<double> dW, dY;
+    dW.alloc(hW.size(), false); dY.alloc((size_t)n_ * 3 * OP + 2);
+    XM_HIP_CHECK(hipMemcpyAsync(dW.p, hW.data(), hW.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    CamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.nloc = (int)n_; a.out = dY.p;
+    product(3, EPI_PLAIN, dW.p, 1.0, a, st);
+    std::vector<double> hx((size_t)std::max<int64_t>(n_ - 1, 0) * OP), hl((size_t)m_ * OP);
+    if (!hx.empty()) XM_HIP_CHECK(hipMemcpyAsync(hx.data(), xc_.p, hx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    XM_HIP_CHECK(hipMemcpyAsync(hl.data(), xl_.p, hl.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    XM_HIP_CHECK(hipStreamSynchronize(st));
+    for (int k = 0; k < 3; ++k) t[k] = 0.0;                                   // the anchor
+    for (int64_t i = 1; i < n_; ++i)
+        for (int k = 0; k < 3; ++k) t[(size_t)3 * i + k] = -hx[(size_t)(i - 1) * OP + k];
+    for (int64_t l = 0; l < m_; ++l)
+        for (int k = 0; k < 3; ++k) p[(size_t)3 * l + k] = -hl[(size_t)l * OP + k];
+}
+
 void SchurOp::ensure(int o) {
     if (o <= o_alloc_) return;
     const size_t OP = (size_t)pitch_of(o);

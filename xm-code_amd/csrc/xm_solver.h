@@ -84,6 +84,8 @@ public:
     void attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
     void edge_residuals(double *res);
     void set_edge_weights(const double *w);
+    void recover_tp(const double *rot, const double *scale, double *t, double *p);   // matrix-free storage only
+    int64_t n_landmarks() const;
 
 private:
     // ---- problem ------------------------------------------------------------------------------------------------

@@ -1054,6 +1054,12 @@ void Context::edge_residuals(double *res) {
     XM_HIP_CHECK(hipStreamSynchronize(st_));
 }
 
+void Context::recover_tp(const double *rot, const double *scale, double *t, double *p) {
+    if (storage_ != XM_STORAGE_SCHUR || !schur_) throw Error(XM_ERR_ARG, "recover_tp: needs a matrix-free context (XM_STORAGE_SCHUR): the translations and landmarks are functions of the observations");
+    schur_->recover_tp(rot, scale, t, p, st_);
+}
+int64_t Context::n_landmarks() const { return schur_ ? schur_->n_landmarks() : 0; }
+
 void Context::set_edge_weights(const double *w) {
     if (storage_ == XM_STORAGE_SCHUR) { schur_->set_weights(w, st_); return; }
     if (!ei_.p) throw Error(XM_ERR_ARG, "set_edge_weights: no edges attached");

@@ -26,7 +26,7 @@ EXPORTS = [
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition",
     "xm_sell_layout", "xm_sell_create", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
-    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights", "xm_ctx_qw", "xm_spd_inverse",
+    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse",
 ]
 
 
@@ -84,6 +84,7 @@ def lib():
         L.xm_ctx_attach_edges.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_ctx_edge_residuals.argtypes = [C.c_void_p, C.c_void_p]
         L.xm_ctx_set_edge_weights.argtypes = [C.c_void_p, C.c_void_p]
+        L.xm_ctx_recover_tp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_dev_count.argtypes = [C.POINTER(C.c_int)]
         L.xm_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         L.xm_dev_free.argtypes = [C.c_void_p]
@@ -341,6 +342,7 @@ class Context:
             pts = np.ascontiguousarray(pts, dtype=np.float64); w = np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
             self.n = int(cam.max()) + 1 if n is None else int(n)
             p.n, p.storage, p.nobs, p.n_landmarks = self.n, STORAGE_SCHUR, cam.size, int(lm.max()) + 1
+            self.n_landmarks = int(lm.max()) + 1
             p.obs_cam, p.obs_lm, p.obs_p, p.obs_w = (a.ctypes.data_as(C.c_void_p) for a in (cam, lm, pts, w))
             self._keep += [cam, lm, pts, w]
             self.ne = cam.size                      # residuals / weights of the XM^2 loop are per observation
@@ -383,6 +385,16 @@ class Context:
         res = np.zeros(self.ne)
         _chk(lib().xm_ctx_edge_residuals(self.h, res.ctypes.data_as(C.c_void_p)))
         return res
+
+    def recover_tp(self, rot, scale):
+        """translations (3 x n, camera 1 at the origin) and landmarks (3 x m) of a solution given as anchored rotations (3 x 3n) and
+        scales (n) — recover_XM's t_est / p_est without Abar (matrix-free contexts only)"""
+        rot = np.asfortranarray(np.asarray(rot, dtype=np.float64)); scale = np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(-1))
+        assert rot.shape == (3, 3 * self.n) and scale.size == self.n
+        t = np.zeros((3, self.n), order="F"); p = np.zeros((3, self.n_landmarks), order="F")
+        _chk(lib().xm_ctx_recover_tp(self.h, rot.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p),
+                                     t.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p)))
+        return np.ascontiguousarray(t), np.ascontiguousarray(p)
 
     def set_edge_weights(self, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
