@@ -30,6 +30,7 @@ namespace xm {
 struct SellHost {
     int64_t nloc = 0, ncols = 0;
     int S = 1, lmax = 0;
+    bool slice_order = true;   // partial result of (slice, lane) stored at slice * 64 + lane
     int64_t nvrows = 0, nslices = 0, nsteps = 0, nparts = 0, nstore = 0;   // nstore: entries of the partial-result array
     std::vector<int64_t> slice_off;   // nslices + 1, in steps; a slice of width w owns steps [off, off + w)
     std::vector<int32_t> slab_start;  // S + 1, in slices
@@ -53,6 +54,8 @@ struct SellArgs {   // what the kernels see
     const int64_t *pptr;
     const int32_t *ridx;
     int S;
+    int wstride;           // doubles between camera records in the W the kernel reads (3 * pitch natively; 16 = one cache line per record)
+    int coalesced_store;   // 1: partial results stored at slice * 64 + lane AND written as one contiguous run per slice (through LDS)
 };
 
 class SellMatrix {
@@ -62,7 +65,9 @@ public:
                hipStream_t st);
     SellArgs args() const;
     void refill(const int32_t *d_colidx, const double *d_blocks, hipStream_t st);   // values changed on the device (XM^2 re-weighting)
-    double *parts(int o);          // partial-result buffer for rank o (grow-only)
+    double *parts(int o);
+    const double *pack_w(int o, const double *W, hipStream_t st);   // W as the kernel wants it (repacked when the stride differs)
+    int wstride(int o) const;          // partial-result buffer for rank o (grow-only)
     int grid() const { return grid_; }
     int64_t nloc() const { return nloc_; }
     int64_t nparts() const { return nparts_; }
@@ -72,6 +77,9 @@ public:
 private:
     int64_t nloc_ = 0, nparts_ = 0, nsteps_ = 0, nslices_ = 0;
     int S_ = 1, grid_ = 0;
+    int64_t ncols_ = 0;
+    DevBuf<double> wpad_;      // W repacked at 16 doubles per camera (XM_SELL_WSTRIDE=16)
+    bool coalesced_ = false;   // partial results written as one contiguous run per slice (slice-order slots)
     DevBuf<int64_t> slice_off_, pptr_;
     DevBuf<int32_t> slab_start_, cols_, pslot_, ridx_;
     DevBuf<double> blk_, parts_;

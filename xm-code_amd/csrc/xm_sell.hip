@@ -104,6 +104,7 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
     out.nslices = (int64_t)out.slice_off.size() - 1;
     out.nsteps = out.slice_off.back();
     out.nstore = slice_order ? out.nslices * 64 : out.nparts;
+    out.slice_order = slice_order;
     if (out.nstore > 2147483000LL) throw Error(XM_ERR_ARG, "SELL: too many partial results");
 }
 
@@ -139,7 +140,12 @@ SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const doubl
                        hipStream_t st) {
     SellHost h;
     sell_build_host(rowptr, colidx, nloc, ncols, S, lmax, h);
+    ncols_ = ncols;
     nloc_ = nloc; nparts_ = h.nstore; nsteps_ = h.nsteps; nslices_ = h.nslices; S_ = S;
+    {   // XM_SELL_CSTORE=0 keeps the per-lane 72-byte record stores (needs the slice-order slots)
+        const char *e = std::getenv("XM_SELL_CSTORE");
+        coalesced_ = h.slice_order && !(e && *e == '0');
+    }
     const int64_t b0 = rowptr[0], nb = rowptr[nloc] - b0;
     slice_off_.alloc(h.slice_off.size(), false);
     slab_start_.alloc(h.slab_start.size(), false);
@@ -189,7 +195,35 @@ SellArgs SellMatrix::args() const {
     SellArgs a;
     a.slice_off = slice_off_.p; a.slab_start = slab_start_.p; a.cols = cols_.p; a.blk = blk_.p; a.pslot = pslot_.p; a.pptr = pptr_.p; a.ridx = ridx_.p;
     a.S = S_;
+    a.wstride = 0;   // set per rank by the launcher (wstride(o))
+    a.coalesced_store = coalesced_ ? 1 : 0;
     return a;
+}
+
+// XM_SELL_WSTRIDE=16 (experiment, default off): W repacked at 16 doubles per camera so that a gathered record is ONE 128-byte line
+// instead of 1.8 (PMC at the native 72-byte stride: 9.3 M L2 hits for 5.1 M gathered records + 3.4 M misses of the block stream).
+// Measured at 100 k cameras incl. the 7 -> 13 MB repack launch: o = 3 112.3 vs 111.5 us, o = 4 123.3 vs 126.3, o = 5 132.1 vs 137.8,
+// banded graph 113.6 vs 93.0 (the padded slab no longer fits the L2 share) -- the L2 request count is not what bounds the product.
+static int sell_wstride_env() {
+    static const int v = [] { const char *e = std::getenv("XM_SELL_WSTRIDE"); return (e && *e) ? std::atoi(e) : 0; }();
+    return v;
+}
+int SellMatrix::wstride(int o) const {
+    const int rec = 3 * pitch_of(o);
+    return (sell_wstride_env() == 16 && rec < 16 && o >= 3) ? 16 : rec;
+}
+__global__ __launch_bounds__(256) void sell_pack_w_kernel(int64_t n, int rec, const double *__restrict__ W, double *__restrict__ Wp) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * 16) return;
+    const int64_t c = t >> 4;
+    const int e = (int)(t & 15);
+    Wp[t] = (e < rec) ? W[c * rec + e] : 0.0;
+}
+const double *SellMatrix::pack_w(int o, const double *W, hipStream_t st) {
+    if (wstride(o) != 16) return W;
+    if (!wpad_.p) wpad_.alloc((size_t)ncols_ * 16 + 2);
+    hipLaunchKernelGGL(sell_pack_w_kernel, dim3((unsigned)((ncols_ * 16 + 255) / 256)), dim3(256), 0, st, ncols_, 3 * pitch_of(o), W, wpad_.p);
+    return wpad_.p;
 }
 
 double *SellMatrix::parts(int o) {
@@ -216,8 +250,8 @@ struct SellBuf {   // one pipeline stage: two steps of blocks and the two gather
 };
 
 template <int O, int GM, int ABL = 0, int PIPE = 0>   // PIPE 1: block loads run one pair ahead.  ABL: ablation bits for timing experiments (1 no block loads, 2 no gather, 4 no partial store)
-__global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
-                                                       double *__restrict__ parts) {
+__device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
+                                             double *__restrict__ parts) {
     constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2, RECP = (REC + 1) & ~1;
     if (scal != nullptr) {
         if (scal->status != 0) return;
@@ -254,7 +288,7 @@ __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *
     };
     // GM 0: every lane reads its own record (REC doubles at 8-byte alignment)
     auto gather0 = [&](int j, double (&wv)[REC]) {
-        const double *wp = W + (size_t)j * REC;
+        const double *wp = W + (size_t)j * m.wstride;
 #pragma unroll
         for (int i = 0; i < REC / 2; ++i) {
             const d2u t = *reinterpret_cast<const d2u *>(wp + 2 * i);
@@ -271,7 +305,7 @@ __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *
             const int rec = g / NPR, part = g - rec * NPR;
             const int start = (2 * part < REC - 2) ? 2 * part : REC - 2;
             const int jr = __shfl(j, rec, 64);
-            raw[i] = *reinterpret_cast<const d2u *>(W + (size_t)jr * REC + start);
+            raw[i] = *reinterpret_cast<const d2u *>(W + (size_t)jr * m.wstride + start);
         }
     };
     auto transpose1 = [&](const d2u (&raw)[NPR], double *Ls, double (&wv)[REC]) {
@@ -412,6 +446,28 @@ __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *
             fma_step(qt, w0);
         }
     }
+    if constexpr (GM == 1 && !(ABL & 4)) {
+        if (m.coalesced_store) {
+            // the 64 records of the slice are one contiguous run of 64 * 3 * O doubles (slot = slice * 64 + lane): transposed through
+            // LDS and written with lane-consecutive 16-byte stores (5 fully coalesced instructions at o = 3) instead of 3 * O
+            // 8-byte stores per lane at a 72-byte stride (each touching 36 cache lines)
+            constexpr int NV = 3 * O, TOT2 = 64 * NV / 2;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) L[lane * NV + r * O + k] = acc[r][k];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            d2a *o2 = reinterpret_cast<d2a *>(parts + (size_t)c * 64 * NV);
+            const d2a *l2 = reinterpret_cast<const d2a *>(L);
+#pragma unroll
+            for (int i = 0; i < (TOT2 + 63) / 64; ++i) {
+                const int idx = i * 64 + lane;
+                if (idx < TOT2) o2[idx] = l2[idx];
+            }
+            return;
+        }
+    }
     const int slot = m.pslot[(size_t)c * 64 + lane];
     if constexpr (ABL & 4) {
         double t = 0.0;
@@ -427,6 +483,20 @@ __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *
 #pragma unroll
             for (int k = 0; k < O; ++k) o[r * O + k] = acc[r][k];
     }
+}
+
+template <int O, int GM, int ABL = 0, int PIPE = 0>
+__global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
+                                                       double *__restrict__ parts) {
+    qw_sell_body<O, GM, ABL, PIPE>(m, W, scal, parts);
+}
+// the same body compiled for FOUR wavefronts per SIMD (<= 128 VGPRs; XM_SELL_PIPE=2): the product is bound by the bytes a CU keeps
+// in flight (PMC: 64 % of the wave cycles wait on memory, ~6 wavefronts resident per CU), not by issue slots
+template <int O, int GM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void qw_sell_kernel_occ4(SellArgs m, const double *__restrict__ W,
+                                                                                                    const TcgScal *__restrict__ scal,
+                                                                                                    double *__restrict__ parts) {
+    qw_sell_body<O, GM, 0, 0>(m, W, scal, parts);
 }
 
 // per camera: partial results added in list order (fixed -> bit-reproducible), then the common tail of the Q*W kernels
@@ -474,8 +544,10 @@ template <int O>
 static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st) {
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
     double *parts = m.parts(O);
-    const SellArgs sa = m.args();
+    SellArgs sa = m.args();
+    sa.wstride = m.wstride(O);
     if (m.grid() > 0) {
+        W = m.pack_w(O, W, st);
         const dim3 g(m.grid()), b(256);
         static const int abl = [] { const char *e = std::getenv("XM_SELL_ABLATE"); return (e && *e) ? std::atoi(e) : 0; }();   // timing experiments only
         if constexpr (O == 3) {
@@ -490,7 +562,10 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
         static const int pipe_env = [] { const char *e = std::getenv("XM_SELL_PIPE"); return (e && *e) ? std::atoi(e) : -1; }();
         const int pipe = (pipe_env >= 0) ? pipe_env : (O == 3 ? 1 : 0);
         if (abl == 0 || O != 3) {
-            if (pipe == 1) {
+            if (pipe == 2 && O == 3) {
+                if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_occ4<3, 1>), g, b, 0, st, sa, W, sc, parts);
+                else hipLaunchKernelGGL((qw_sell_kernel_occ4<3, 0>), g, b, 0, st, sa, W, sc, parts);
+            } else if (pipe == 1) {
                 if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, 0, 1>), g, b, 0, st, sa, W, sc, parts);
                 else hipLaunchKernelGGL((qw_sell_kernel<O, 0, 0, 1>), g, b, 0, st, sa, W, sc, parts);
             } else {
@@ -513,7 +588,8 @@ void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(XM_ERR_ARG, "certificate operator needs o == 1");
         double *parts = m.parts(1);
-        const SellArgs sa = m.args();
+        SellArgs sa = m.args();
+        sa.wstride = 3;
         if (m.grid() > 0) hipLaunchKernelGGL((qw_sell_kernel<1, 0>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
         hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT>), dim3(sell_reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a);
     } else {
