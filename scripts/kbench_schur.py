@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "xm-code_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, xmamd, xm_testlib as tl
 N, M, views = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+PRODUCT_ONLY = "--product-only" in sys.argv      # for rocprofv3 --kernel-trace: 20 products, no solve
 S = tl.gen_scene(N, M, views, seed=N)
 nobs = S["cam"].size
 t0 = time.time(); ctx = xmamd.Context(obs=(S["cam"], S["lm"], S["p"], S["w"])); t_setup = time.time() - t0
@@ -15,6 +16,11 @@ if N <= 4000:
     print(f"product vs numpy restatement: {tl.rel_fro(Y, ref):.2e}")
 U = rng.standard_normal((3 * N, 3))
 print(f"symmetry <U,QW> vs <QU,W>: {abs(np.sum(U * Y) - np.sum(ctx.qw(U) * W)) / abs(np.sum(U * Y)):.2e}")
+if PRODUCT_ONLY:
+    for _ in range(20):
+        ctx.qw(W)
+    print(f"N={N} landmarks={S['m']} observations={nobs}: set-up {t_setup:.2f} s, 20 products done")
+    ctx.close(); sys.exit(0)
 t0 = time.time(); R, s, i = ctx.solve(5, 1e-6, 0.0, flags=xmamd.FLAG_PROFILE_QW); t_solve = time.time() - t0
 qw_us = i["qw_ms_sum"] / max(i["qw_ms_count"], 1) * 1e3
 rot, _ = tl.recover_rotations(R, s)

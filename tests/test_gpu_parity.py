@@ -990,6 +990,37 @@ def test_matrix_free_synthetic_scene(xmamd):
     assert min(tl.rel_fro(rot, gt), tl.rel_fro(rot, np.concatenate([Rs[0] @ Rs[k].T for k in range(N)], axis=1))) < 0.05
 
 
+def test_matrix_free_symmetric_reduced_inverse(xmamd, tmp_path):
+    """large scenes apply VT^-1 with the half-traffic symmetric kernel (upper triangle only, rows >= XM_SCHUR_SYM_MIN_ROWS); forced
+    here on a 300-camera scene: product (o = 3, 4 symmetric kernel; o = 5 general kernel) against the numpy restatement, and the
+    solve against the default path"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys, os
+        sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'xm-code_amd')!r})
+        sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import numpy as np, xmamd, xm_testlib as tl
+        S = tl.gen_scene(300, 6000, 5, seed=11)
+        ctx = xmamd.Context(obs=(S["cam"], S["lm"], S["p"], S["w"]))
+        errs = []
+        for o in (3, 4, 5):
+            W = np.random.default_rng(o).standard_normal((900, o))
+            errs.append(tl.rel_fro(ctx.qw(W), tl.schur_qw_numpy(S["cam"], S["lm"], S["p"], S["w"], W)))
+        R, s, info = ctx.solve(5, 1e-8, 0.0)
+        ctx.close()
+        np.savez(sys.argv[1], errs=np.array(errs), R=R, s=s, primal=info["primal"], rank=info["rank"], status=info["status"])
+    """)
+    outs = []
+    for rows in ("0", "1000000000"):
+        out = str(tmp_path / f"v{rows}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, XM_SCHUR_SYM_MIN_ROWS=rows), timeout=600)
+        outs.append(np.load(out))
+    assert outs[0]["errs"].max() < 1e-10 and outs[1]["errs"].max() < 1e-10
+    assert int(outs[0]["status"]) == int(outs[1]["status"]) == 1 and int(outs[0]["rank"]) == int(outs[1]["rank"])
+    assert float(outs[0]["primal"]) == pytest.approx(float(outs[1]["primal"]), rel=1e-8)
+    assert tl.rotation_parity(outs[0]["R"], outs[0]["s"], outs[1]["R"], outs[1]["s"]) < 1e-6
+
+
 def test_matrix_free_venice_size_scene(xmamd):
     """a Venice-size synthetic scene (1778 cameras, 200 k landmarks, 1.2 M observations, three landmarks seen by every camera; the
     dense Q would be 228 MB and O(N^2 M) to build): the matrix-free product against the numpy / scipy.sparse restatement of the same

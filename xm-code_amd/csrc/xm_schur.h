@@ -51,12 +51,19 @@ private:
     int64_t n_ = 0, m_ = 0, nobs_ = 0, nred_ = 0, ldv_ = 0;   // nred = cameras of the padded (N-1) system / 3
     DevBuf<int64_t> cam_ptr_, lm_ptr_;
     DevBuf<int32_t> cam_lm_, lm_cam_;         // by camera: landmark of each observation; by landmark: camera
-    DevBuf<int32_t> heavy_;                   // landmarks with more than kSchurHeavy observations (one wavefront each)
-    int64_t nheavy_ = 0;
+    // landmarks are numbered by degree (descending) on the device; the first nheavy_ (more than kSchurHeavy observations) keep contiguous
+    // lists (lm_ptr_), the others are packed 64 to a group (gbase_, ldeg_): xm_schur.hip, SchurLm
+    DevBuf<int64_t> gbase_;
+    DevBuf<int32_t> ldeg_;
+    int64_t nheavy_ = 0, ltotal_ = 1;
+    std::vector<int32_t> slot_of_;            // landmark -> device number
+    std::vector<int64_t> dpos_l_;             // observation -> position in the device's by-landmark arrays
     DevBuf<double> cam_w_, cam_p_, lm_w_, lm_p_;
     DevBuf<double> Q1_, c_, q3inv_;
     DevBuf<double> vtinv_;                     // (N-1)^2 inverse in the dense kernel's padded row-major layout
     DevBuf<double> h_, r_, xc_, xl_, res_;
+    DevBuf<double> sym_prow_, sym_pcol_;       // partial sums of the half-traffic product with VT^-1 (large N only)
+    bool vt_sym_ = false;
     DevBuf<int32_t> obs_cam_, obs_lm_;        // the observations in input order (residual kernel)
     DevBuf<double> obs_p_;
     std::vector<int32_t> hcam_, hlm_, lcam_;  // host copies of the structure for set_weights

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -22,6 +23,18 @@ constexpr int kSchurHeavy = 64;   // landmarks with more observations get a work
 // workgroup per listed heavy landmark (a landmark seen by all 13 682 cameras: 14 strided steps instead of 13 682 serial ones;
 // thread-strided order, DPP tree per wavefront, the 16 wavefront sums added in a fixed order)
 constexpr int kSchurHeavyThreads = 1024;
+// a gathered record of N doubles at 8-byte alignment with 16-byte loads (5 instead of 9 instructions for the 72-byte row block of W: the
+// scattered gathers are bound by the address path, one lane = one cache line, not by bytes)
+typedef double schur_d2 __attribute__((ext_vector_type(2), aligned(8)));
+template <int N>
+__device__ __forceinline__ void load_rec(const double *__restrict__ p, double (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i + 1 < N; i += 2) {
+        const schur_d2 t = *reinterpret_cast<const schur_d2 *>(p + i);
+        v[i] = t.x; v[i + 1] = t.y;
+    }
+    if (N & 1) v[N - 1] = p[N - 1];
+}
 template <int O>
 __device__ __forceinline__ bool heavy_block_sum(double (&acc)[O]) {   // result valid in thread 0 (returns true there)
     __shared__ double part[kSchurHeavyThreads / 64][O];
@@ -42,29 +55,51 @@ __device__ __forceinline__ bool heavy_block_sum(double (&acc)[O]) {   // result 
     }
     return true;
 }
-template <int O, int HEAVY>
-__global__ __launch_bounds__(HEAVY ? kSchurHeavyThreads : 256) void schur_lm_h_kernel(int64_t m, const int32_t *__restrict__ heavy, const int64_t *__restrict__ lm_ptr,
-                                                          const int32_t *__restrict__ lm_cam, const double *__restrict__ lm_w,
-                                                          const double *__restrict__ lm_p, const double *__restrict__ q3inv,
+// Landmark lists on the device (SchurLm): landmarks are numbered by degree, descending ("slot").  The first nheavy slots keep contiguous
+// lists [ptr[s], ptr[s+1]) (one workgroup each); the others are packed 64 to a group in slot order -- observation k of the group's lane
+// j sits at gbase[group] + 64 k + j, so the thread-per-landmark kernels read cam / w / p as coalesced 64-wide rows (a contiguous list
+// per thread made every load instruction touch 64 cache lines: 180 us for h at 800 k landmarks / 6.4 M observations, 5 x its traffic).
+// p is stored as three planes of `total` doubles.
+struct SchurLm {
+    int64_t m, nheavy, total;
+    const int64_t *ptr;      // nheavy + 1
+    const int64_t *gbase;    // per group of 64 light slots
+    const int32_t *deg;      // per slot
+    const int32_t *cam;
+    const double *w, *p;
+};
+// ONE launch for both kinds: workgroups [0, nheavy) take a heavy landmark each (1024 threads stride its list), the others 1024 light
+// landmarks each -- the few heavy workgroups (14 serial steps for a landmark seen by all 13 682 cameras) run beside the light ones
+// instead of after them (32 + 14 us of the chain at Final-13682 size)
+template <int O>
+__global__ __launch_bounds__(kSchurHeavyThreads) void schur_lm_h_kernel(SchurLm L, const double *__restrict__ q3inv,
                                                           const double *__restrict__ W, const TcgScal *__restrict__ scal, double *__restrict__ h) {
     constexpr int OP = pitch_of(O);
     if (scal != nullptr) {
         if (scal->status != 0) return;
     }
-    int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (HEAVY) l = heavy[blockIdx.x];
-    else if (l >= m || lm_ptr[l + 1] - lm_ptr[l] > kSchurHeavy) return;
+    const bool heavy = (int64_t)blockIdx.x < L.nheavy;   // workgroup-uniform
+    int64_t l, e, e_end, step;
+    if (heavy) {
+        l = blockIdx.x; e = L.ptr[l] + threadIdx.x; e_end = L.ptr[l + 1]; step = kSchurHeavyThreads;
+    } else {
+        const int64_t t = ((int64_t)blockIdx.x - L.nheavy) * kSchurHeavyThreads + threadIdx.x;
+        l = L.nheavy + t;
+        if (l >= L.m) return;
+        e = L.gbase[t >> 6] + (t & 63); e_end = e + (int64_t)64 * L.deg[l]; step = 64;
+    }
     double acc[O];
 #pragma unroll
     for (int k = 0; k < O; ++k) acc[k] = 0.0;
-    for (int64_t e = lm_ptr[l] + (HEAVY ? (int)threadIdx.x : 0); e < lm_ptr[l + 1]; e += (HEAVY ? kSchurHeavyThreads : 1)) {
-        const double *Wi = W + (size_t)lm_cam[e] * 3 * OP;
-        const double w = lm_w[e], p0 = lm_p[3 * e], p1 = lm_p[3 * e + 1], p2 = lm_p[3 * e + 2];
+    for (; e < e_end; e += step) {
+        double Wi[3 * OP];
+        load_rec<3 * OP>(W + (size_t)L.cam[e] * 3 * OP, Wi);
+        const double w = L.w[e], p0 = L.p[e], p1 = L.p[L.total + e], p2 = L.p[2 * L.total + e];
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[k] += w * (p0 * Wi[k] + p1 * Wi[OP + k] + p2 * Wi[2 * OP + k]);
     }
     const double qi = q3inv[l];
-    if (HEAVY) {
+    if (heavy) {
         if (!heavy_block_sum<O>(acc)) return;
     }
 #pragma unroll
@@ -89,7 +124,8 @@ __global__ __launch_bounds__(256) void schur_cam_r_kernel(int n, const int64_t *
     if (cam < n && cam >= 1)
         for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 64) {
             const double w = cam_w[e];
-            const double *hl = h + (size_t)cam_lm[e] * OP;
+            double hl[O];
+            load_rec<O>(h + (size_t)cam_lm[e] * OP, hl);
 #pragma unroll
             for (int k = 0; k < O; ++k) acc[k] += w * hl[k];
         }
@@ -103,32 +139,38 @@ __global__ __launch_bounds__(256) void schur_cam_r_kernel(int n, const int64_t *
 }
 
 // x_l = h_l + (1/Q3_l) sum_{obs of l} w x_cam_i     (x_cam of the anchor camera 0 is 0: its translation is the gauge)
-template <int O, int HEAVY>
-__global__ __launch_bounds__(HEAVY ? kSchurHeavyThreads : 256) void schur_lm_x_kernel(int64_t m, const int32_t *__restrict__ heavy, const int64_t *__restrict__ lm_ptr,
-                                                          const int32_t *__restrict__ lm_cam, const double *__restrict__ lm_w,
-                                                          const double *__restrict__ q3inv, const double *__restrict__ h,
+template <int O>
+__global__ __launch_bounds__(kSchurHeavyThreads) void schur_lm_x_kernel(SchurLm L, const double *__restrict__ q3inv, const double *__restrict__ h,
                                                           const double *__restrict__ xc, const TcgScal *__restrict__ scal,
                                                           double *__restrict__ xl) {
     constexpr int OP = pitch_of(O);
     if (scal != nullptr) {
         if (scal->status != 0) return;
     }
-    int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (HEAVY) l = heavy[blockIdx.x];
-    else if (l >= m || lm_ptr[l + 1] - lm_ptr[l] > kSchurHeavy) return;
+    const bool heavy = (int64_t)blockIdx.x < L.nheavy;
+    int64_t l, e, e_end, step;
+    if (heavy) {
+        l = blockIdx.x; e = L.ptr[l] + threadIdx.x; e_end = L.ptr[l + 1]; step = kSchurHeavyThreads;
+    } else {
+        const int64_t t = ((int64_t)blockIdx.x - L.nheavy) * kSchurHeavyThreads + threadIdx.x;
+        l = L.nheavy + t;
+        if (l >= L.m) return;
+        e = L.gbase[t >> 6] + (t & 63); e_end = e + (int64_t)64 * L.deg[l]; step = 64;
+    }
     double acc[O];
 #pragma unroll
     for (int k = 0; k < O; ++k) acc[k] = 0.0;
-    for (int64_t e = lm_ptr[l] + (HEAVY ? (int)threadIdx.x : 0); e < lm_ptr[l + 1]; e += (HEAVY ? kSchurHeavyThreads : 1)) {
-        const int i = lm_cam[e];
+    for (; e < e_end; e += step) {
+        const int i = L.cam[e];
         if (i == 0) continue;
-        const double w = lm_w[e];
-        const double *xi = xc + (size_t)(i - 1) * OP;
+        const double w = L.w[e];
+        double xi[O];
+        load_rec<O>(xc + (size_t)(i - 1) * OP, xi);
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[k] += w * xi[k];
     }
     const double qi = q3inv[l];
-    if (HEAVY) {
+    if (heavy) {
         if (!heavy_block_sum<O>(acc)) return;
     }
 #pragma unroll
@@ -137,7 +179,7 @@ __global__ __launch_bounds__(HEAVY ? kSchurHeavyThreads : 256) void schur_lm_x_k
 
 // Y_i = Q1_i W_i - c_i x_cam_i + sum_{obs of i} w p x_l, then the common tail of the Q*W kernels (xm_device.h)
 template <int O, int EPI>
-__global__ __launch_bounds__(256) void schur_cam_y_kernel(const int64_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_lm,
+__global__ __launch_bounds__(256) void schur_cam_y_kernel(int64_t nobs, const int64_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_lm,
                                                            const double *__restrict__ cam_w, const double *__restrict__ cam_p,
                                                            const double *__restrict__ Q1, const double *__restrict__ c,
                                                            const double *__restrict__ W, const double *__restrict__ xc,
@@ -160,10 +202,11 @@ __global__ __launch_bounds__(256) void schur_cam_y_kernel(const int64_t *__restr
     if (active) {
         for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 64) {
             const double w = cam_w[e];
-            const double *x = xl + (size_t)cam_lm[e] * OP;
+            double x[O];
+            load_rec<O>(xl + (size_t)cam_lm[e] * OP, x);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const double wp = w * cam_p[3 * e + r];
+                const double wp = w * cam_p[(size_t)r * (size_t)nobs + e];   // three planes: coalesced
 #pragma unroll
                 for (int k = 0; k < O; ++k) acc[r][k] += wp * x[k];
             }
@@ -202,31 +245,54 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     }
     for (int64_t i = 0; i < N; ++i) cp_[(size_t)i + 1] += cp_[(size_t)i];
     for (int64_t l = 0; l < M; ++l) lp_[(size_t)l + 1] += lp_[(size_t)l];
-    std::vector<int32_t> c_lm((size_t)nobs);
-    std::vector<double> c_p((size_t)nobs * 3), l_p((size_t)nobs * 3);
+    // device numbering of the landmarks ("slot"): by degree, descending, stable
+    std::vector<int32_t> order((size_t)M);
+    for (int64_t l = 0; l < M; ++l) order[(size_t)l] = (int32_t)l;
+    auto deg_of = [&](int64_t l) { return lp_[(size_t)l + 1] - lp_[(size_t)l]; };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return deg_of(x) > deg_of(y); });
+    slot_of_.assign((size_t)M, 0);
+    std::vector<int32_t> ldeg((size_t)M);
+    nheavy_ = 0;
+    for (int64_t sl = 0; sl < M; ++sl) {
+        slot_of_[(size_t)order[(size_t)sl]] = (int32_t)sl;
+        ldeg[(size_t)sl] = (int32_t)deg_of(order[(size_t)sl]);
+        if (ldeg[(size_t)sl] > kSchurHeavy) nheavy_ = sl + 1;
+    }
+    std::vector<int64_t> hptr((size_t)nheavy_ + 1, 0);
+    for (int64_t sl = 0; sl < nheavy_; ++sl) hptr[(size_t)sl + 1] = hptr[(size_t)sl] + ldeg[(size_t)sl];
+    int64_t total = hptr[(size_t)nheavy_];
+    const int64_t ngroups = (M - nheavy_ + 63) / 64;
+    std::vector<int64_t> gbase((size_t)std::max<int64_t>(ngroups, 1), 0);
+    for (int64_t g = 0; g < ngroups; ++g) {
+        gbase[(size_t)g] = total;
+        total += (int64_t)64 * ldeg[(size_t)(nheavy_ + 64 * g)];   // the group's first slot has its longest list
+    }
+    ltotal_ = std::max<int64_t>(total, 1);
+    std::vector<int32_t> c_lm((size_t)nobs), d_lcam((size_t)ltotal_, 0), o_lm((size_t)nobs);
+    std::vector<double> c_p((size_t)nobs * 3), d_lp((size_t)ltotal_ * 3, 0.0);
     lcam_.assign((size_t)nobs, 0);
-    pos_c_.assign((size_t)nobs, 0); pos_l_.assign((size_t)nobs, 0);
+    pos_c_.assign((size_t)nobs, 0); pos_l_.assign((size_t)nobs, 0); dpos_l_.assign((size_t)nobs, 0);
     {
         std::vector<int64_t> nc(cp_.begin(), cp_.end() - 1), nl(lp_.begin(), lp_.end() - 1);
         for (int64_t e = 0; e < nobs; ++e) {
             const int64_t a2 = nc[(size_t)cam[e]]++, b2 = nl[(size_t)lm[e]]++;
-            pos_c_[(size_t)e] = a2; pos_l_[(size_t)e] = b2;
-            c_lm[(size_t)a2] = lm[e]; std::memcpy(&c_p[(size_t)a2 * 3], p + 3 * e, 24);
-            lcam_[(size_t)b2] = cam[e]; std::memcpy(&l_p[(size_t)b2 * 3], p + 3 * e, 24);
+            const int64_t sl = slot_of_[(size_t)lm[e]], k = b2 - lp_[(size_t)lm[e]];
+            const int64_t d2 = (sl < nheavy_) ? hptr[(size_t)sl] + k : gbase[(size_t)((sl - nheavy_) >> 6)] + 64 * k + ((sl - nheavy_) & 63);
+            pos_c_[(size_t)e] = a2; pos_l_[(size_t)e] = b2; dpos_l_[(size_t)e] = d2;
+            c_lm[(size_t)a2] = (int32_t)sl; o_lm[(size_t)e] = (int32_t)sl;
+            for (int a = 0; a < 3; ++a) c_p[(size_t)a * (size_t)nobs + (size_t)a2] = p[3 * e + a];   // three planes
+            lcam_[(size_t)b2] = cam[e];                           // host copy (by landmark, contiguous): assembly of VT
+            d_lcam[(size_t)d2] = cam[e];
+            for (int a = 0; a < 3; ++a) d_lp[(size_t)a * (size_t)ltotal_ + (size_t)d2] = p[3 * e + a];
         }
     }
     auto up = [&](auto &buf, const auto &v) {
         buf.alloc(std::max<size_t>(v.size(), 1), false);
         if (!v.empty()) XM_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
     };
-    up(cam_ptr_, cp_); up(lm_ptr_, lp_); up(cam_lm_, c_lm); up(lm_cam_, lcam_); up(cam_p_, c_p); up(lm_p_, l_p);
-    up(obs_cam_, hcam_); up(obs_lm_, hlm_); up(obs_p_, hp_);
-    std::vector<int32_t> heavy;
-    for (int64_t l = 0; l < M; ++l)
-        if (lp_[(size_t)l + 1] - lp_[(size_t)l] > kSchurHeavy) heavy.push_back((int32_t)l);
-    nheavy_ = (int64_t)heavy.size();
-    up(heavy_, heavy);
-    cam_w_.alloc((size_t)nobs, false); lm_w_.alloc((size_t)nobs, false);
+    up(cam_ptr_, cp_); up(lm_ptr_, hptr); up(gbase_, gbase); up(ldeg_, ldeg); up(cam_lm_, c_lm); up(lm_cam_, d_lcam); up(cam_p_, c_p); up(lm_p_, d_lp);
+    up(obs_cam_, hcam_); up(obs_lm_, o_lm); up(obs_p_, hp_);
+    cam_w_.alloc((size_t)nobs, false); lm_w_.alloc((size_t)ltotal_, false);
     Q1_.alloc((size_t)N * 9, false); c_.alloc((size_t)N * 3, false); q3inv_.alloc((size_t)M, false);
     const int64_t mr = N - 1;
     nred_ = std::max<int64_t>(1, (mr + 2) / 3);
@@ -243,7 +309,7 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
     if (!w) throw Error(XM_ERR_ARG, "matrix-free Q: null weights");
     const int64_t N = n_, M = m_, nobs = nobs_;
     std::vector<double> Q1((size_t)N * 9, 0.0), c((size_t)N * 3, 0.0), Q2((size_t)N, 0.0), Q3((size_t)M, 0.0);
-    std::vector<double> c_w((size_t)nobs), l_w((size_t)nobs);
+    std::vector<double> c_w((size_t)nobs), l_w((size_t)nobs), d_lw((size_t)ltotal_, 0.0);
     for (int64_t e = 0; e < nobs; ++e) {
         if (!(w[e] >= 0.0)) throw Error(XM_ERR_ARG, "matrix-free Q: negative or NaN weight");
         const int64_t i = hcam_[(size_t)e], l = hlm_[(size_t)e];
@@ -253,10 +319,13 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
             for (int b = 0; b < 3; ++b) Q1[(size_t)i * 9 + 3 * a + b] += w[e] * pe[a] * pe[b];    // Q1 block (:26)
         }
         Q2[(size_t)i] += w[e]; Q3[(size_t)l] += w[e];                                             // :68-69
-        c_w[(size_t)pos_c_[(size_t)e]] = w[e]; l_w[(size_t)pos_l_[(size_t)e]] = w[e];
+        c_w[(size_t)pos_c_[(size_t)e]] = w[e]; l_w[(size_t)pos_l_[(size_t)e]] = w[e]; d_lw[(size_t)dpos_l_[(size_t)e]] = w[e];
     }
-    std::vector<double> q3inv((size_t)M);
-    for (int64_t l = 0; l < M; ++l) q3inv[(size_t)l] = (Q3[(size_t)l] > 0.0) ? 1.0 / Q3[(size_t)l] : 0.0;
+    std::vector<double> q3inv((size_t)M), q3inv_slot((size_t)M);   // by landmark (host: VT) and by slot (device)
+    for (int64_t l = 0; l < M; ++l) {
+        q3inv[(size_t)l] = (Q3[(size_t)l] > 0.0) ? 1.0 / Q3[(size_t)l] : 0.0;
+        q3inv_slot[(size_t)slot_of_[(size_t)l]] = q3inv[(size_t)l];
+    }
     const int64_t mr = N - 1;
     std::vector<double> VT((size_t)std::max<int64_t>(mr, 1) * (size_t)std::max<int64_t>(mr, 1), 0.0);
     for (int64_t i = 1; i < N; ++i) VT[(size_t)(i - 1) + (size_t)(i - 1) * mr] = Q2[(size_t)i];
@@ -276,7 +345,7 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
     auto put = [&](DevBuf<double> &buf, const std::vector<double> &v) {
         if (!v.empty()) XM_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
     };
-    put(cam_w_, c_w); put(lm_w_, l_w); put(Q1_, Q1); put(c_, c); put(q3inv_, q3inv);
+    put(cam_w_, c_w); put(lm_w_, d_lw); put(Q1_, Q1); put(c_, c); put(q3inv_, q3inv_slot);
     if (mr > 0) {   // invert on the device (blocked Cholesky, xm_dense_la.hip), then lay the inverse out like a dense Q
         DevBuf<double> tmp, inv;
         tmp.alloc((size_t)mr * mr, false); inv.alloc((size_t)mr * mr, false);
@@ -348,7 +417,7 @@ void SchurOp::recover_tp(const double *rot, const double *scale, double *t, doub
     for (int64_t i = 1; i < n_; ++i)
         for (int k = 0; k < 3; ++k) t[(size_t)3 * i + k] = -hx[(size_t)(i - 1) * OP + k];
     for (int64_t l = 0; l < m_; ++l)
-        for (int k = 0; k < 3; ++k) p[(size_t)3 * l + k] = -hl[(size_t)l * OP + k];
+        for (int k = 0; k < 3; ++k) p[(size_t)3 * l + k] = -hl[(size_t)slot_of_[(size_t)l] * OP + k];
 }
 
 void SchurOp::ensure(int o) {
@@ -357,6 +426,15 @@ void SchurOp::ensure(int o) {
     h_.alloc((size_t)m_ * OP); xl_.alloc((size_t)m_ * OP);
     r_.alloc((size_t)ldv_ * OP + 2);            // product input of the dense kernel: ldv rows, zero beyond N-1
     xc_.alloc((size_t)3 * nred_ * OP + 2);
+    // VT^-1 is symmetric: above XM_SCHUR_SYM_MIN_ROWS rows (default 6144, the threshold of the dense solver) the chain applies it with
+    // the half-traffic kernel (upper triangle only; o = 3, 4)
+    static const int64_t sym_min = [] { const char *e = std::getenv("XM_SCHUR_SYM_MIN_ROWS"); return (e && *e) ? (int64_t)std::atoll(e) : (int64_t)6144; }();
+    vt_sym_ = 3 * nred_ >= sym_min;
+    if (vt_sym_ && o >= 3) {
+        const int os = std::min(o, 4);
+        sym_prow_.alloc(sym_prow_count((int)nred_, ldv_, os));
+        sym_pcol_.alloc(sym_pcol_count((int)nred_, ldv_, os), false);
+    }
     o_alloc_ = o;
 }
 
@@ -366,30 +444,30 @@ int64_t SchurOp::bytes_per_product(int o) const {
 }
 
 template <int O>
-static void schur_product_o(int epi, int64_t n, int64_t m, int64_t nheavy, const int32_t *heavy, const int64_t *cam_ptr, const int32_t *cam_lm, const double *cam_w, const double *cam_p,
-                            const int64_t *lm_ptr, const int32_t *lm_cam, const double *lm_w, const double *lm_p, const double *Q1,
+static void schur_product_o(int epi, int64_t n, int64_t nobs, const SchurLm &L, const int64_t *cam_ptr, const int32_t *cam_lm, const double *cam_w, const double *cam_p,
+                            const double *Q1,
                             const double *c, const double *q3inv, const double *vtinv, int64_t nred, int64_t ldv, double *h, double *r,
-                            double *xc, double *xl, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+                            double *xc, double *xl, const double *W, double alpha, const CamArgs &a, double *sym_prow, double *sym_pcol, hipStream_t st) {
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
-    const dim3 b(256), gl((unsigned)((m + 255) / 256)), gc(qw_grid((int)n));
-    const dim3 gh((unsigned)nheavy), bh(kSchurHeavyThreads);
-    hipLaunchKernelGGL((schur_lm_h_kernel<O, 0>), gl, b, 0, st, m, heavy, lm_ptr, lm_cam, lm_w, lm_p, q3inv, W, sc, h);
-    if (nheavy > 0) hipLaunchKernelGGL((schur_lm_h_kernel<O, 1>), gh, bh, 0, st, nheavy, heavy, lm_ptr, lm_cam, lm_w, lm_p, q3inv, W, sc, h);
+    const int64_t nheavy = L.nheavy, nlight = L.m - L.nheavy;
+    const dim3 b(256), gc(qw_grid((int)n));
+    const dim3 glm((unsigned)(nheavy + (nlight + kSchurHeavyThreads - 1) / kSchurHeavyThreads)), blm(kSchurHeavyThreads);
+    hipLaunchKernelGGL((schur_lm_h_kernel<O>), glm, blm, 0, st, L, q3inv, W, sc, h);
     hipLaunchKernelGGL((schur_cam_r_kernel<O>), gc, b, 0, st, (int)n, cam_ptr, cam_lm, cam_w, c, W, h, sc, r);
     if (n > 1) {
         CamArgs pa;
         std::memset(&pa, 0, sizeof(pa));
         pa.nloc = (int)nred; pa.out = xc; pa.scal = a.scal;
-        launch_qw_dense(O, EPI_PLAIN, vtinv, ldv, r, 1.0, pa, st);
+        if (sym_prow && (O == 3 || O == 4)) launch_qw_sym(O, EPI_PLAIN, vtinv, ldv, r, 1.0, pa, sym_prow, sym_pcol, st);
+        else launch_qw_dense(O, EPI_PLAIN, vtinv, ldv, r, 1.0, pa, st);
     }
-    hipLaunchKernelGGL((schur_lm_x_kernel<O, 0>), gl, b, 0, st, m, heavy, lm_ptr, lm_cam, lm_w, q3inv, h, xc, sc, xl);
-    if (nheavy > 0) hipLaunchKernelGGL((schur_lm_x_kernel<O, 1>), gh, bh, 0, st, nheavy, heavy, lm_ptr, lm_cam, lm_w, q3inv, h, xc, sc, xl);
+    hipLaunchKernelGGL((schur_lm_x_kernel<O>), glm, blm, 0, st, L, q3inv, h, xc, sc, xl);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_PLAIN>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_GRAD>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_HESS>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_PLAIN>), gc, b, 0, st, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_GRAD>), gc, b, 0, st, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_HESS>), gc, b, 0, st, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
         case EPI_CERT:
-            if constexpr (O == 1) { hipLaunchKernelGGL((schur_cam_y_kernel<1, EPI_CERT>), gc, b, 0, st, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break; }
+            if constexpr (O == 1) { hipLaunchKernelGGL((schur_cam_y_kernel<1, EPI_CERT>), gc, b, 0, st, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break; }
             throw Error(XM_ERR_ARG, "certificate operator needs o == 1");
         default: throw Error(XM_ERR_ARG, "bad epilogue");
     }
@@ -402,8 +480,10 @@ void SchurOp::product(int o, int epi, const double *W, double alpha, const CamAr
         XM_HIP_CHECK(hipMemsetAsync(xc_.p, 0, xc_.count * sizeof(double), st));
         o_last_ = o;
     }
-    XM_DISPATCH_O(o, (schur_product_o<O_>(epi, n_, m_, nheavy_, heavy_.p, cam_ptr_.p, cam_lm_.p, cam_w_.p, cam_p_.p, lm_ptr_.p, lm_cam_.p, lm_w_.p, lm_p_.p, Q1_.p,
-                                         c_.p, q3inv_.p, vtinv_.p, nred_, ldv_, h_.p, r_.p, xc_.p, xl_.p, W, alpha, a, st)));
+    SchurLm L;
+    L.m = m_; L.nheavy = nheavy_; L.total = ltotal_; L.ptr = lm_ptr_.p; L.gbase = gbase_.p; L.deg = ldeg_.p; L.cam = lm_cam_.p; L.w = lm_w_.p; L.p = lm_p_.p;
+    XM_DISPATCH_O(o, (schur_product_o<O_>(epi, n_, nobs_, L, cam_ptr_.p, cam_lm_.p, cam_w_.p, cam_p_.p, Q1_.p,
+                                         c_.p, q3inv_.p, vtinv_.p, nred_, ldv_, h_.p, r_.p, xc_.p, xl_.p, W, alpha, a, vt_sym_ ? sym_prow_.p : (double *)nullptr, sym_pcol_.p, st)));
     check_launch("schur_product");
 }
 
