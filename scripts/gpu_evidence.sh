@@ -8,6 +8,9 @@ R=$GRAFT_REPO_ROOT
 cd $R
 timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee gpurun_out/pytest_gpu.log
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' 2>&1 | tail -2 | tee gpurun_out/smoke.log
+# the PMC pass first: it stamps profiles/<tag>_pmc_fetch_hess_bench.json with the hash of the sources, and the bench line below quotes it
+XM_PROFILE_TAG=${1:-r02} bash scripts/pmc_hess.sh > gpurun_out/pmc_hess.out 2>&1
+cp profiles/${1:-r02}_pmc_fetch_hess_bench.json gpurun_out/ 2>/dev/null
 timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
 timeout 600 python bench.py --workload vg100k --storage bsr --steps 5 --warmup 1 --cpu-seconds 10 2>&1 | tail -1 > gpurun_out/bench_vg100k.log
 rm -rf gpurun_out/prof_final gpurun_out/prof_vg100k
@@ -15,9 +18,8 @@ cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -o run -- python $R/bench.py --cpu-seconds 0 --no-hbm-check > $R/gpurun_out/prof_final.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_vg100k -o run -- python $R/bench.py --workload vg100k --storage bsr --steps 2 --warmup 1 --cpu-seconds 0 > $R/gpurun_out/prof_vg100k.log 2>&1
 cd $R
-XM_PROFILE_TAG=${1:-r02} bash scripts/pmc_hess.sh > gpurun_out/pmc_hess.out 2>&1
-cp profiles/${1:-r02}_pmc_fetch_hess_bench.json gpurun_out/ 2>/dev/null
-(python scripts/kbench_dense.py 1778 3 4 5 10; python scripts/kbench_dense.py 13682 3 4
+(python scripts/kbench_dense.py 1778 3 4 5 10; python scripts/kbench_dense.py 4096 3 4; python scripts/kbench_dense.py 13682 3 4
+ echo 'matrix-free chain:'; python scripts/kbench_schur.py 1778 200000 6; python scripts/kbench_schur.py 6000 350000 8
  python scripts/kbench_bsr.py 13682 30 3 5; python scripts/kbench_bsr.py 13682 58 3 5
  python scripts/kbench_sell.py 100000 50 --o 3 5 --slabs 4 --gather 1
  echo 'banded view graph:'; python scripts/kbench_sell.py 100000 50 --band --o 3 --slabs 4 --gather 1

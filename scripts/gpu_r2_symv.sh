@@ -1,10 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out; export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "symmetric or sym" 2>&1 | tail -3
-(for n in 1778 2048 3000; do timeout 300 python scripts/kbench_dense.py $n 3 4; done
- J='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d["value"], d["solve"]["tcg_iters_per_solve"], d["roofline"]["avg_launch_ms"], d["roofline"]["kernel"][:60])'
- echo "bench venice default"; timeout 600 python bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-hbm-check --no-rome | python -c "$J"
- echo "bench venice sym everywhere (XM_SYM_MIN_ROWS=0)"; XM_SYM_MIN_ROWS=0 timeout 600 python bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-hbm-check --no-rome | python -c "$J"
- echo "rome dense"; timeout 900 python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-hbm-check | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['rome_scale_dense'])"
-) 2>&1 | tee gpurun_out/symv3.log
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+for k in 4 6 8 12; do
+  cd /tmp; XM_SYMV_K=$k timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_symv_k$k -o run -- python $GRAFT_REPO_ROOT/scripts/kbench_dense.py 1778 3 4 > /dev/null 2>&1
+  cd $GRAFT_REPO_ROOT; f=$(find gpurun_out/prof_symv_k$k -name "*kernel_stats.csv" | head -1)
+  echo "K=$k"; grep -E "symv" $f | awk -F'","' '{printf "  %-50s calls %s avg %.1f us\n", substr($1,2,50), $2, $4/1000}'
+done 2>&1 | tee gpurun_out/symv4.log

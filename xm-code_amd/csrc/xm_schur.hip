@@ -19,12 +19,12 @@ namespace xm {
 constexpr int kSchurHeavy = 64;   // landmarks with more observations get a workgroup of their own (a thread per landmark serialises
                                   // them: 963 us per product with three landmarks seen by all 1778 cameras, 122 us once split)
 
-// h_l = -(1/Q3_l) sum_{obs of l} w (p . W_i)      HEAVY 0: one thread per landmark (heavy ones skipped) | 1: one 1024-thread
-// workgroup per listed heavy landmark (a landmark seen by all 13 682 cameras: 14 strided steps instead of 13 682 serial ones;
-// thread-strided order, DPP tree per wavefront, the 16 wavefront sums added in a fixed order)
+// h_l = -(1/Q3_l) sum_{obs of l} w (p . W_i)      a light landmark: one thread | a heavy one: a 1024-thread workgroup (a landmark
+// seen by all 13 682 cameras: 14 strided steps instead of 13 682 serial ones; thread-strided order, DPP tree per wavefront, the 16
+// wavefront sums added in a fixed order)
 constexpr int kSchurHeavyThreads = 1024;
-// a gathered record of N doubles at 8-byte alignment with 16-byte loads (5 instead of 9 instructions for the 72-byte row block of W: the
-// scattered gathers are bound by the address path, one lane = one cache line, not by bytes)
+// a gathered record of N doubles at 8-byte alignment with 16-byte loads (5 instead of 9 instructions for the 72-byte row block of W).
+// Measured neutral at Final-13682 size: the scattered gathers are bound by cache LINES (one per lane), not by instructions.
 typedef double schur_d2 __attribute__((ext_vector_type(2), aligned(8)));
 template <int N>
 __device__ __forceinline__ void load_rec(const double *__restrict__ p, double (&v)[N]) {
