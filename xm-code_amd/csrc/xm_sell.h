@@ -67,7 +67,9 @@ public:
     void refill(const int32_t *d_colidx, const double *d_blocks, hipStream_t st);   // values changed on the device (XM^2 re-weighting)
     double *parts(int o);
     const double *pack_w(int o, const double *W, hipStream_t st);   // W as the kernel wants it (repacked when the stride differs)
-    int wstride(int o) const;          // partial-result buffer for rank o (grow-only)
+    int wstride(int o) const;
+    int reduce_gw(int o) const;                 // lanes per camera in the second launch (4 | 16)
+    int reduce_grid(int o, int nloc) const;     // workgroups of the second launch == per-workgroup partial sums per epilogue slot          // partial-result buffer for rank o (grow-only)
     int grid() const { return grid_; }
     int64_t nloc() const { return nloc_; }
     int64_t nparts() const { return nparts_; }
@@ -77,7 +79,7 @@ public:
 private:
     int64_t nloc_ = 0, nparts_ = 0, nsteps_ = 0, nslices_ = 0;
     int S_ = 1, grid_ = 0;
-    int64_t ncols_ = 0;
+    int64_t ncols_ = 0, max_list_ = 0;   // max_list_: most partial results of one camera
     DevBuf<double> wpad_;      // W repacked at 16 doubles per camera (XM_SELL_WSTRIDE=16)
     bool coalesced_ = false;   // partial results written as one contiguous run per slice (slice-order slots)
     DevBuf<int64_t> slice_off_, pptr_;
@@ -90,10 +92,9 @@ private:
 };
 
 // product = two launches: partial results per virtual row, then per-camera sum + fused epilogue (same CamArgs contract and
-// per-workgroup partial sums of the second launch, grid sell_reduce_grid(o, nloc)).  gm: 0 = each lane loads its own record of W,
+// per-workgroup partial sums of the second launch, grid SellMatrix::reduce_grid(o, nloc)).  gm: 0 = each lane loads its own record of W,
 // 1 = records fetched element-per-lane and transposed through LDS.
 void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st);
 bool sell_supports(int o);
-int sell_reduce_grid(int o, int nloc);   // workgroups of the second launch == per-workgroup partial sums per epilogue slot
 
 }  // namespace xm

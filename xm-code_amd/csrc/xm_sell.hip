@@ -141,6 +141,8 @@ SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const doubl
     SellHost h;
     sell_build_host(rowptr, colidx, nloc, ncols, S, lmax, h);
     ncols_ = ncols;
+    max_list_ = 0;
+    for (int64_t r = 0; r < nloc; ++r) max_list_ = std::max<int64_t>(max_list_, h.pptr[(size_t)r + 1] - h.pptr[(size_t)r]);
     nloc_ = nloc; nparts_ = h.nstore; nsteps_ = h.nsteps; nslices_ = h.nslices; S_ = S;
     {   // XM_SELL_CSTORE=0 keeps the per-lane 72-byte record stores (needs the slice-order slots)
         const char *e = std::getenv("XM_SELL_CSTORE");
@@ -500,17 +502,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // per camera: partial results added in list order (fixed -> bit-reproducible), then the common tail of the Q*W kernels
-// (column-per-lane epilogue, per-workgroup partial sums).  A camera has S (plus a few, for hub cameras) partial results and
-// o <= 4 columns, so a QUAD of lanes per camera is enough (GW = 4: 64 cameras per workgroup, two DPP steps per reduction instead
-// of four, 4x fewer wavefronts than the 16-lane groups of qw_bsr3_kernel, which o = 5 keeps).
-template <int O>
-constexpr int sell_gw() { return (O <= 4) ? 4 : 16; }
-int sell_reduce_grid(int o, int nloc) { const int per = 256 / ((o <= 4) ? 4 : 16); return (nloc + per - 1) / per; }
+// (column-per-lane epilogue, per-workgroup partial sums).  A camera normally has S partial results and o <= 4 columns, so a QUAD of
+// lanes per camera is enough (GW = 4: 64 cameras per workgroup, two DPP steps per reduction instead of four, 4x fewer wavefronts
+// than the 16-lane groups of qw_bsr3_kernel, which o = 5 keeps).  A matrix with hub cameras (a row cut into hundreds of virtual
+// rows: four lanes would walk ~100 dependent loads each) takes the 16-lane groups too: measured 152.8 -> 119 us on the
+// 100 k-camera graph with 50 hubs.
+int SellMatrix::reduce_gw(int o) const { return (o <= 4 && max_list_ <= 32) ? 4 : 16; }
+int SellMatrix::reduce_grid(int o, int nloc) const { const int per = 256 / reduce_gw(o); return (nloc + per - 1) / per; }
 
-template <int O, int EPI>
+template <int O, int EPI, int GW>
 __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restrict__ pptr, const int32_t *__restrict__ ridx, const double *__restrict__ parts,
                                                            double alpha, CamArgs a) {
-    constexpr int GW = sell_gw<O>(), NSLOT = 256 / GW;
+    constexpr int NSLOT = 256 / GW;
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
@@ -574,13 +577,16 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
             }
         }
     }
-    const dim3 g(sell_reduce_grid(O, a.nloc)), b(256);
-    switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_HESS>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;
-        default: throw Error(XM_ERR_ARG, "bad epilogue");
+    const dim3 g(m.reduce_grid(O, a.nloc)), b(256);
+#define XM_SELL_REDUCE(GW_)                                                                                                                          \
+    switch (epi) {                                                                                                                                  \
+        case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;          \
+        case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;            \
+        case EPI_HESS: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_HESS, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;            \
+        default: throw Error(XM_ERR_ARG, "bad epilogue");                                                                                           \
     }
+    if (m.reduce_gw(O) == 4) { XM_SELL_REDUCE(4) } else { XM_SELL_REDUCE(16) }
+#undef XM_SELL_REDUCE
 }
 
 void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st) {
@@ -591,7 +597,8 @@ void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha
         SellArgs sa = m.args();
         sa.wstride = 3;
         if (m.grid() > 0) hipLaunchKernelGGL((qw_sell_kernel<1, 0>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
-        hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT>), dim3(sell_reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a);
+        if (m.reduce_gw(1) == 4) hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT, 4>), dim3(m.reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a);
+        else hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT, 16>), dim3(m.reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a);
     } else {
         switch (o) {
             case 1: qw_sell_o<1>(epi, m, W, alpha, a, 0, st); break;

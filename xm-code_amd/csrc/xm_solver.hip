@@ -297,7 +297,7 @@ void Context::download_point(std::vector<double> &R_cm, std::vector<double> &s_e
 
 // workgroups of the product kernels == number of per-workgroup partial sums per epilogue slot
 int Context::prod_grid() const {
-    if (storage_ == XM_STORAGE_BSR3 && sell_ && sell_supports(o_)) return sell_reduce_grid(o_, nloc_);
+    if (storage_ == XM_STORAGE_BSR3 && sell_ && sell_supports(o_)) return sell_->reduce_grid(o_, nloc_);
     return (storage_ == XM_STORAGE_BSR3) ? bsr_grid(nloc_) : qw_grid(nloc_);   // dense and matrix-free: one wavefront per camera
 }
 
