@@ -37,7 +37,7 @@ out["all_hess_real_avg_us"] = sum(allreal) / max(1, len(allreal))
 out["cg_step_avg_us"] = sum(cg) / max(1, len(cg))
 out["bench_line_hip_event_avg_us"] = b["roofline"]["avg_launch_ms"] * 1e3
 json.dump(out, open(os.path.join(P, f"{tag}_kernel_trace_hess_real_vs_noop.json"), "w"), indent=1)
-for src, dst in (("pmc_sell.json", f"{tag}_pmc_sell_100k.json"), (f"{tag}_pmc_fetch_hess_bench.json", f"{tag}_pmc_fetch_hess_bench.json")):
+for src, dst in (("pmc_sell.json", f"{tag}_pmc_sell_100k.json"), ("pmc_symv.json", f"{tag}_pmc_symv_13682.json"), (f"{tag}_pmc_fetch_hess_bench.json", f"{tag}_pmc_fetch_hess_bench.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, dst))
 vg = glob.glob(os.path.join(G, "prof_vg100k", "**", "*kernel_stats.csv"), recursive=True)

@@ -30,6 +30,26 @@ for grp in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_sell_$i -o run -- python $R/scripts/kbench_sell.py 100000 50 --o 3 --slabs 4 --gather 1 --no-csr --reps 20 > $R/gpurun_out/pmc_sell_$i.log 2>&1
 done
+for grp in "FETCH_SIZE" "WRITE_SIZE"; do   # HBM-side traffic of the half-traffic symmetric product on the 13.5 GB matrix
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_symv_$grp -o run -- python $R/scripts/kbench_dense.py 13682 3 > /dev/null 2>&1
+done
+cd $R
+python - <<'PY'
+import csv, glob, collections, json
+out = collections.defaultdict(dict)
+for d in sorted(glob.glob("gpurun_out/pmc_symv_*/")):
+    for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if "symv" in k or "qw_dense_kernel" in k:
+                acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in acc.items():
+            out[k][c] = sum(v) / len(v)
+            out[k][c + ("_bytes_x1024x2" if c == "FETCH_SIZE" else "_bytes_x1024")] = sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1)
+out["note"] = "kbench_dense.py 13682 3 (13.5 GB matrix, half matrix 6.74 GB); FETCH_SIZE in KB, x2 on gfx950 (MI355X_MICROARCH.md HBM section); WRITE_SIZE in KB"
+json.dump(out, open("gpurun_out/pmc_symv.json", "w"), indent=1)
+PY
 cd $R
 python - <<'PY'
 import csv, glob, collections, json

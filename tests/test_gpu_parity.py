@@ -483,6 +483,24 @@ def test_qw_dense_symmetric_kernel_matches_oracle(xmamd, oracle, n, o):
     assert tl.rel_fro(xmamd.qw_dense(Q, W, 2.0), ref) < 1e-13
 
 
+def test_symmetry_check_decides_the_dense_path(xmamd):
+    """the half-traffic product reads the upper triangle only, so it is taken (3n >= 6144 rows) for an EXACTLY symmetric Q alone: one
+    entry of the lower triangle off by 1e-9, or a NaN, and the general kernel runs (asym_kernel: tiled transposed compare, sticky NaN)"""
+    rng = np.random.default_rng(5)
+    n = 2100
+    A = rng.standard_normal((3 * n, 64))
+    Q = A @ A.T / 64 + np.eye(3 * n)
+    Q = 0.5 * (Q + Q.T)
+    def picked(Qx):
+        _, _, info = xmamd.solve_dense(Qx, 3, 1e-1, 0.0, max_time=0.0, mode=xmamd.MODE_RANK3)   # no iterations, no certificate: the decision is taken at upload
+        return int(info["sym_product"])
+    assert picked(Q) == 1
+    Q2 = Q.copy(); Q2[4000, 17] += 1e-9
+    assert picked(Q2) == 0
+    Q3 = Q.copy(); Q3[6299, 6200] = np.nan
+    assert picked(Q3) == 0
+
+
 def test_symmetric_path_equals_general_path(xmamd, tmp_path):
     """the solver picks the symmetric product when Q is symmetric to round-off; XM_SYM=0 forces the general kernel.
     Both must land on the same certified optimum (trajectories differ only by summation order)."""

@@ -100,6 +100,7 @@ void launch_qw_dense_split(int o, int epi, const double *Q, int64_t ld, const do
 int qw_dense_tile_cols();
 int bsr_grid(int nloc);   // workgroups (= partial sums per epilogue slot) of the BSR3 kernels
 int sym_groups(int nloc);
+int sym_variant();   // 1: vertical sweep (also instantiated for the rank-1 certificate operator)
 size_t sym_prow_count(int nloc, int64_t ld, int o);
 size_t sym_pcol_count(int nloc, int64_t ld, int o);
 void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,

@@ -571,24 +571,48 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restri
     qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }
 
-// max |Q[r][c] - Q[c][r]| and max |Q| over the device layout (decides whether the symmetric path may be used)
+// max |Q[r][c] - Q[c][r]| and max |Q| over the device layout (decides whether the symmetric path may be used).  Tile pairs (ti <= tj)
+// of 64 x 64: the upper tile goes through LDS and is compared, transposed, with the coalesced read of its mirror image (a
+// row-against-column sweep read 64 cache lines per instruction: 23 ms for 13.5 GB; this one streams the matrix once).  A NaN anywhere
+// makes the asymmetry NaN (sticky flag: a max written with comparisons alone drops a NaN at the next finite element).
 __global__ __launch_bounds__(256) void asym_kernel(const double *__restrict__ Q, int64_t ld, int64_t m, double *out /* [2*grid] */) {
-    __shared__ double sh[2][4];
-    double da = 0.0, mx = 0.0;
-    for (int64_t r = blockIdx.x; r < m; r += gridDim.x)
-        for (int64_t c = threadIdx.x; c < m; c += 256) {
-            const double v = Q[r * ld + c];
-            const double d = fabs(v - Q[c * ld + r]);
-            da = (d <= da) ? da : d;              // written so that a NaN entry propagates (fmax would drop it) and fails the check
+    __shared__ double T[64][65];
+    __shared__ double sh[3][4];
+    const int64_t nt = (m + 63) / 64;
+    double da = 0.0, mx = 0.0, bad = 0.0;
+    for (int64_t p = blockIdx.x; p < nt * nt; p += gridDim.x) {
+        const int64_t ti = p / nt, tj = p - ti * nt;
+        if (ti > tj) continue;   // block-uniform
+#pragma unroll 4
+        for (int e = threadIdx.x; e < 4096; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            const int64_t gr = ti * 64 + r, gc = tj * 64 + c;
+            const double v = (gr < m && gc < m) ? Q[gr * ld + gc] : 0.0;
+            T[r][c] = v;
             mx = fmax(mx, fabs(v));
+            if (v != v) bad = 1.0;
         }
-    for (int off = 32; off >= 1; off >>= 1) { const double o2 = __shfl_xor(da, off, 64); da = (o2 <= da) ? da : o2; mx = fmax(mx, __shfl_xor(mx, off, 64)); }
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = da; sh[1][threadIdx.x >> 6] = mx; }
+        __syncthreads();
+#pragma unroll 4
+        for (int e = threadIdx.x; e < 4096; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            const int64_t gr = tj * 64 + r, gc = ti * 64 + c;
+            const double v = (gr < m && gc < m) ? Q[gr * ld + gc] : 0.0;
+            da = fmax(da, fabs(v - T[c][r]));
+            mx = fmax(mx, fabs(v));
+            if (v != v) bad = 1.0;
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        da = fmax(da, __shfl_xor(da, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64)); bad = fmax(bad, __shfl_xor(bad, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = da; sh[1][threadIdx.x >> 6] = mx; sh[2][threadIdx.x >> 6] = bad; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = sh[0][0];
-        for (int q = 1; q < 4; ++q) t = (sh[0][q] <= t) ? t : sh[0][q];
-        out[blockIdx.x] = t;
+        const double b4 = fmax(fmax(sh[2][0], sh[2][1]), fmax(sh[2][2], sh[2][3]));
+        const double t = fmax(fmax(sh[0][0], sh[0][1]), fmax(sh[0][2], sh[0][3]));
+        out[blockIdx.x] = (b4 > 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : t;
         out[gridDim.x + blockIdx.x] = fmax(fmax(sh[1][0], sh[1][1]), fmax(sh[1][2], sh[1][3]));
     }
 }
@@ -1574,7 +1598,8 @@ int symv_k(int nloc, int64_t ld) {
     const int64_t nsteps = (nloc + 1) / 2, nstrips = (ld + kSvStrip - 1) / kSvStrip;
     int64_t total = 0;
     for (int64_t s = 0; s < nstrips; ++s) total += std::min<int64_t>(nsteps, (s * kSvStrip + kSvStrip + 5) / 6);
-    const int64_t k = (int64_t)(std::sqrt((double)total) / 13.0 + 0.5);
+    int64_t k = (int64_t)(std::sqrt((double)total) / 13.0 + 0.5);
+    if (k > 48) k = 64;   // 13.5 GB: 48 -> 1 190 us, 64 -> 1 147 us, 128 -> 1 265 us
     return (int)std::min<int64_t>(64, std::max<int64_t>(2, k));
 }
 size_t sym_prow_count(int nloc, int64_t ld, int o) {
@@ -1599,6 +1624,9 @@ static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, d
         case EPI_PLAIN: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break;
         case EPI_GRAD: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break;
         case EPI_HESS: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break;
+        case EPI_CERT:   // certificate operator (rank-1 input): the Lanczos products of a large dense Q at half the traffic too
+            if constexpr (O == 1) { hipLaunchKernelGGL((symv_reduce_kernel<1, EPI_CERT>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break; }
+            throw Error(-2, "certificate operator needs o == 1");
         default: throw Error(-2, "bad epilogue");
     }
 }
@@ -1631,6 +1659,7 @@ void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W,
     if (a.nloc <= 0) return;
     if (sym_variant() == 1) {
         switch (o) {
+            case 1: qw_symv_epi<1>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
             case 3: qw_symv_epi<3>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
             case 4: qw_symv_epi<4>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
             case 5: qw_symv_epi<5>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;

@@ -186,7 +186,7 @@ void Context::init(const xm_problem_t &prob) {
         const bool force = (e && *e == '1'), off = (e && *e == '0');
         if (force) sym_max_o_ = 5;
         if (storage_ == XM_STORAGE_DENSE && world == 1 && !off && (force || 3 * n_ >= sym_min_rows())) {
-            const int grid = 512;
+            const int grid = 2048;
             DevBuf<double> d;
             d.alloc((size_t)2 * grid);
             launch_asym(dQ_, ld_, 3 * n_, d.p, grid, st_);
@@ -194,7 +194,13 @@ void Context::init(const xm_problem_t &prob) {
             XM_HIP_CHECK(hipMemcpyAsync(h.data(), d.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
             XM_HIP_CHECK(hipStreamSynchronize(st_));
             double da = 0, mx = 0;
-            for (int i = 0; i < grid; ++i) { da = (h[(size_t)i] <= da) ? da : h[(size_t)i]; mx = std::max(mx, h[(size_t)grid + i]); }   // NaN propagates
+            bool nan = false;
+            for (int i = 0; i < grid; ++i) {
+                if (h[(size_t)i] != h[(size_t)i]) nan = true;   // a NaN entry anywhere: never symmetric
+                else da = std::max(da, h[(size_t)i]);
+                mx = std::max(mx, h[(size_t)grid + i]);
+            }
+            if (nan) da = std::nan("");
             q_asym_ = da; q_max_ = mx;
             // The lower triangle is never read on this path, so by default it is taken only for an EXACTLY symmetric matrix (what
             // utils/creatematrix.py:326-328 writes): round-off asymmetry in a Q.bin is honoured like cublasDgemm does, at every
@@ -860,7 +866,8 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 // w = S v_j : the product input is v_j itself (pitch 1); output rows land in w at this rank's offset
                 a.Wloc = vj + (size_t)cam0_ * 3;
                 a.out = w.p + (size_t)cam0_ * 3;
-                if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
+                if (storage_ == XM_STORAGE_DENSE && sym_ok_ && Pcol_.p && sym_variant() == 1) launch_qw_sym(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, Prow_.p, Pcol_.p, st_);
+                else if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
                 else if (storage_ == XM_STORAGE_SCHUR) schur_->product(1, EPI_CERT, vj, 1.0, a, st_);
                 else if (sell_) launch_qw_sell(1, EPI_CERT, *sell_, vj, 1.0, a, 0, st_);
                 else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_);
