@@ -135,6 +135,10 @@ typedef struct {
     double eig_residual;       /* Ritz residual |S x - theta x| of the last certificate's Lanczos run (reference: exact syevd, checkeig.h:303-318) */
 } xm_result_t;
 #define XM_CERT_EIG_NOT_CONVERGED 1   /* Lanczos hit its iteration cap: min_eig is only an upper bound, the certificate was NOT accepted on it */
+#define XM_CERT_EIG_EXACT 2           /* small problem (3n <= XM_CERT_DENSE_ROWS, default 384): the tridiagonalisation of S was run to
+                                       * completion and min_eig is the smallest eigenvalue of the FULL tridiagonal matrix -- the dense
+                                       * path of the reference (Dense/eig.h:35-73 dsyevd, checkeig.h:303-318) with the reduction done
+                                       * matrix-free */
 
 int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out);          /* uploads / lays out Q on device 0 (or the rank's device) */
 int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res);

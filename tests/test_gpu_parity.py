@@ -184,7 +184,13 @@ def test_gpu_solution_certified_by_numpy(xmamd, name):
     assert cn["min_eig"] > -1e-7 * scale and abs(cn["gap"]) <= 1e-6 * scale and cn["stationarity"] < 1e-5
     assert cn["primal"] == pytest.approx(info["primal"], rel=1e-10, abs=1e-12)
     assert info["min_eig"] == pytest.approx(cn["min_eig"], abs=1e-7 * scale) and info["dual"] == pytest.approx(cn["dual"], rel=1e-6)
-    assert info["cert_flags"] == 0 and info["eig_residual"] <= 1e-6 * max(1.0, np.abs(cn["eigs"]).max())
+    # small problems (3n <= 384 rows) take the dense route: the tridiagonalisation runs to completion, min_eig is an eigenvalue of S
+    # to round-off (the reference: cusolverDnDsyevd on S, Dense/eig.h:35-73); larger ones stop at a converged Ritz pair
+    exact = 3 * exp["n"] <= 384
+    assert info["cert_flags"] == (2 if exact else 0) and info["eig_residual"] <= 1e-6 * max(1.0, np.abs(cn["eigs"]).max())
+    if exact:
+        assert info["min_eig"] == pytest.approx(cn["min_eig"], abs=1e-11 * max(1.0, np.abs(cn["eigs"]).max()))
+        assert info["eig_residual"] <= 1e-11 * max(1.0, np.abs(cn["eigs"]).max())
 
 
 def test_unconverged_lanczos_never_certifies(xmamd, monkeypatch):
@@ -204,7 +210,7 @@ def test_unconverged_lanczos_never_certifies(xmamd, monkeypatch):
     out = json.loads(subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1])
     assert out["cert_flags"] & xmamd.CERT_EIG_NOT_CONVERGED and out["status"] != 1 and out["eig_residual"] > 1e-6
     R, s, info = xmamd.solve_dense(Q, 3, exp["tol"], exp["lam"])
-    assert info["status"] == 1 and info["cert_flags"] == 0
+    assert info["status"] == 1 and not (info["cert_flags"] & xmamd.CERT_EIG_NOT_CONVERGED)
 
 
 def test_lost_result_kernel_raises_instead_of_hanging(xmamd):

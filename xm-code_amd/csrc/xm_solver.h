@@ -128,6 +128,7 @@ private:
     DevBuf<double> Prow_, Pcol_;               // symmetric product: row results and per-workgroup column partials
     bool sym_ok_ = false;
     int sym_max_o_ = 4;
+    bool eig_exact_ = false;                   // the last certificate ran the tridiagonalisation to completion (small n)
     double q_asym_ = 0, q_max_ = 0;
     DevBuf<TcgScal> scal_;
     unsigned long long *hstat_ = nullptr;      // host-mapped progress word (iter << 8 | status)

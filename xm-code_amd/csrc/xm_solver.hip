@@ -827,6 +827,12 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
     static const int env_mmax = [] { const char *e = std::getenv("XM_LANCZOS_MMAX"); return (e && *e) ? std::atoi(e) : 400; }();
     static const int env_restarts = [] { const char *e = std::getenv("XM_LANCZOS_RESTARTS"); return (e && *e) ? std::atoi(e) : 12; }();
     const int mmax = (int)std::min<int64_t>(m3, std::max(2, env_mmax));
+    // Small problems take the DENSE route of the reference (cusolverDnDsyevd on S, Dense/eig.h:35-73): Householder-free, the same
+    // three-term recurrence with full re-orthogonalisation IS the reduction of S to tridiagonal form when it runs all 3n steps, and
+    // the QL sweep on T then returns the smallest eigenvalue of S itself (no convergence test, Ritz residual = round-off).
+    static const int64_t dense_rows = [] { const char *e = std::getenv("XM_CERT_DENSE_ROWS"); return (e && *e) ? (int64_t)std::atoll(e) : (int64_t)384; }();
+    const bool exact = m3 <= dense_rows && m3 <= mmax;
+    eig_exact_ = exact;
     DevBuf<double> V, c, w;
     V.alloc((size_t)len * (mmax + 1));
     c.alloc((size_t)mmax + 2);
@@ -892,7 +898,7 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 tridiag_min(al, be, m, theta, y, tmax);
                 resid = std::fabs(beta * y[(size_t)m - 1]);
                 m_use = m;
-                if (resid <= 1e-9 * std::max(1.0, tmax) || beta < 1e-13 * std::max(1.0, tmax) || m == (int)m3 || !std::isfinite(beta)) { done = true; break; }
+                if ((!exact && resid <= 1e-9 * std::max(1.0, tmax)) || beta < 1e-13 * std::max(1.0, tmax) || m == (int)m3 || !std::isfinite(beta)) { done = true; break; }
                 be.push_back(beta);
             }
         }
@@ -947,6 +953,7 @@ CertResult Context::certificate(int o, double primal, std::vector<double> &v_out
     } else {
         res_->cert_flags &= ~XM_CERT_EIG_NOT_CONVERGED;
     }
+    if (eig_exact_) res_->cert_flags |= XM_CERT_EIG_EXACT; else res_->cert_flags &= ~XM_CERT_EIG_EXACT;
     log("The min eig is: %1.3e \n", theta);
     log("Primal value: %g\nnew dual%g\n", primal, dual);
     const double K = 3.0 * (double)n_;

@@ -18,6 +18,7 @@ STORAGE_SCHUR = 3        # matrix-free: the observation list of the reference's 
 MODE_SOLVE, MODE_RANK3, MODE_REBUTTLE = 0, 1, 2
 FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 CERT_EIG_NOT_CONVERGED = 1
+CERT_EIG_EXACT = 2           # small problem: the certificate's tridiagonalisation ran to completion (dense route)
 FLAG_WARM_R = 16
 
 EXPORTS = [
