@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void sym_reduce_kernel(const double *__restric
 constexpr int kSvStrip = 256;
 
 template <int O, bool NT>
-__global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc, int K,
+__global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc, int Kc, int Kf, int ysplit,
                                                        const TcgScal *__restrict__ scal, double *__restrict__ Prow,
                                                        double *__restrict__ Pcol) {
     constexpr int OP = pitch_of(O), V = 6 * O;
@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
     __shared__ __attribute__((aligned(16))) double lds[4][V * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = blockIdx.y * 4 + wave, ch = blockIdx.x;
+    const int K = ((int)blockIdx.y >= ysplit) ? Kf : Kc;   // the strip groups dispatched last are cut finer: they are the launch's tail
     const int nsteps = (nloc + 1) >> 1, nrows = 3 * nloc;
     const int64_t c0 = (int64_t)s * kSvStrip;
     if (c0 >= ld) return;                                        // wave-uniform exits: no workgroup barrier in this kernel
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
 // second half: y_cam = sum_{strips s >= s_lo} Prow[s][rows of cam] + sum_{chunks above} Pcol[chunk][rows of cam] (fixed order), fused epilogue
 template <int O, int EPI>
 __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t ld,
-                                                           int nstrips, int K, double alpha, CamArgs a) {
+                                                           int nstrips, int Kc, int Kf, int ysplit, double alpha, CamArgs a) {
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
@@ -548,8 +549,13 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restri
         const int nrow = nstrips - s_lo;
         int cnt[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { const int c = 3 * cam + r; cnt[r] = (c >= 6) ? (c - 6) / (6 * K) + 1 : 0; }
-        for (int i = lane; i < nrow + cnt[2]; i += 64) {
+        for (int r = 0; r < 3; ++r) {
+            const int c = 3 * cam + r;
+            const int K = ((c / kSvStrip) / 4 >= ysplit) ? Kf : Kc;   // chunk length of the strip group that owns column c
+            cnt[r] = (c >= 6) ? (c - 6) / (6 * K) + 1 : 0;
+        }
+        const int ncol = max(cnt[0], max(cnt[1], cnt[2]));
+        for (int i = lane; i < nrow + ncol; i += 64) {
             if (i < nrow) {
                 const double *p = Prow + ((size_t)(s_lo + i) * (size_t)R + (size_t)cam * 3) * O;
 #pragma unroll
@@ -1606,26 +1612,49 @@ size_t sym_prow_count(int nloc, int64_t ld, int o) {
     if (sym_variant() == 1) return (size_t)((ld + kSvStrip - 1) / kSvStrip) * 6 * (size_t)((nloc + 1) / 2) * o;
     return (size_t)sym_groups(nloc) * sym_chunks(ld) * sym_waves() * sym_cpw() * 3 * o;
 }
+// The launch's tail: workgroups are dispatched strip group by strip group (left to right) and a chunk of K = 64 steps is a quarter
+// of a millisecond at 13.5 GB with only ~4.5 chunks per resident workgroup, so with equal chunks the last "round" runs part empty.
+// The strip groups dispatched last (the rightmost 13 %, a quarter of the work) are cut four times finer -- guided self-scheduling by
+// construction, no atomics: n = 8192 494 -> 445 us, 13.5 GB at K = 72 1 213 -> 1 144 us (K = 64: 1 145 either way).  A dynamic
+// work counter instead (workgroups pulling item numbers) was measured too: no steadier at 13.5 GB and 1.5 x slower at Venice size
+// (a barrier and an atomic per item).  The remaining +-6 % between MI355X boxes for one K (1 145 / 1 290 us) is not scheduling noise
+// of this kind: it repeats on a box.
+struct SymvPlan { int K, Kf, ysplit, nchunks; };
+static SymvPlan symv_plan(int nloc, int64_t ld) {
+    SymvPlan p;
+    p.K = symv_k(nloc, ld);
+    const int nsteps = (nloc + 1) / 2, ngy = (int)(((ld + kSvStrip - 1) / kSvStrip + 3) / 4);
+    static const int fine = [] { const char *e = std::getenv("XM_SYMV_TAIL"); return (e && *e) ? std::atoi(e) : 1; }();
+    if (fine && p.K >= 16 && ngy >= 8) {
+        p.Kf = p.K / 4;
+        p.ysplit = (int)(0.866 * ngy);          // work grows linearly with the strip index: the last 13 % of the groups hold 25 % of it
+    } else {
+        p.Kf = p.K; p.ysplit = ngy;
+    }
+    p.nchunks = (nsteps + p.Kf - 1) / p.Kf;
+    return p;
+}
 size_t sym_pcol_count(int nloc, int64_t ld, int o) {
-    if (sym_variant() == 1) { const int K = symv_k(nloc, ld); return (size_t)(((nloc + 1) / 2 + K - 1) / K) * (size_t)ld * o; }
+    if (sym_variant() == 1) return (size_t)symv_plan(nloc, ld).nchunks * (size_t)ld * o;
     return (size_t)sym_groups(nloc) * (size_t)ld * o;
 }
 
 template <int O>
 static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
                         hipStream_t st) {
-    const int K = symv_k(a.nloc, ld), nsteps = (a.nloc + 1) / 2, nstrips = (int)((ld + kSvStrip - 1) / kSvStrip);
+    const SymvPlan pl = symv_plan(a.nloc, ld);
+    const int nstrips = (int)((ld + kSvStrip - 1) / kSvStrip);
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
-    const dim3 gs((nsteps + K - 1) / K, (nstrips + 3) / 4);
-    if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, K, sc, Prow, Pcol);
-    else hipLaunchKernelGGL((qw_symv_kernel<O, false>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, K, sc, Prow, Pcol);
+    const dim3 gs(pl.nchunks, (nstrips + 3) / 4);
+    if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, pl.ysplit, sc, Prow, Pcol);
+    else hipLaunchKernelGGL((qw_symv_kernel<O, false>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, pl.ysplit, sc, Prow, Pcol);
     const dim3 g(qw_grid(a.nloc)), b(256);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nstrips, pl.K, pl.Kf, pl.ysplit, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nstrips, pl.K, pl.Kf, pl.ysplit, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nstrips, pl.K, pl.Kf, pl.ysplit, alpha, a); break;
         case EPI_CERT:   // certificate operator (rank-1 input): the Lanczos products of a large dense Q at half the traffic too
-            if constexpr (O == 1) { hipLaunchKernelGGL((symv_reduce_kernel<1, EPI_CERT>), g, b, 0, st, Prow, Pcol, ld, nstrips, K, alpha, a); break; }
+            if constexpr (O == 1) { hipLaunchKernelGGL((symv_reduce_kernel<1, EPI_CERT>), g, b, 0, st, Prow, Pcol, ld, nstrips, pl.K, pl.Kf, pl.ysplit, alpha, a); break; }
             throw Error(-2, "certificate operator needs o == 1");
         default: throw Error(-2, "bad epilogue");
     }
