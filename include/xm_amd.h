@@ -200,6 +200,11 @@ int xm_qw_bsr3(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d
  * does on the host with scipy.linalg.solve (utils/creatematrix.py:260). */
 int xm_spd_inverse(int64_t n, double *A);
 
+/* Work decomposition of the half-traffic symmetric dense product (xm_qw_dense_sym, vertical sweep) for n cameras, host-only (CPU
+ * test of the index arithmetic, tests/test_symv_layout.py): plan = { K steps (of two cameras) per chunk, Kf for the strip groups
+ * dispatched last, first such group, chunks }. */
+int xm_symv_plan(int64_t n, int32_t plan[4]);
+
 /* Large block-sparse Q: "sliced ELL over per-XCD column slabs" (xm-code_amd/csrc/xm_sell.h).  Same product as xm_qw_bsr3
  * (the reference has no sparse product: Dense/matmul.h:42-87 on a dense Q); the matrix is described on the HOST as 3x3-block CSR
  * (rows n, global columns in [0, ncols)) and re-laid on the device.  slabs in {1,2,4,8}; lmax = longest virtual row (hub

@@ -1,0 +1,74 @@
+"""CPU emulation of the half-traffic symmetric dense product (xm_kernels.hip: qw_symv_kernel + symv_reduce_kernel): the strip / chunk /
+diagonal-mask rules and the reducer's list lengths, with the chunk plan the library computes (xm_symv_plan, host only).  The sum of the
+partial results the reducer reads must be Q @ W for a symmetric Q, every entry it reads must have been written by exactly one
+wavefront, and nothing may depend on the lower triangle."""
+import ctypes as C, os, sys
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xm-code_amd"))
+import xmamd
+
+STRIP = 256
+
+
+def emulate(Q, W, K, Kf, ysplit):
+    m, o = W.shape
+    n = m // 3
+    ld = xmamd.dense_ld(n)
+    nsteps, nstrips = (n + 1) // 2, (ld + STRIP - 1) // STRIP
+    Qp = np.zeros((6 * nsteps, ld)); Qp[:m, :m] = Q
+    Wp = np.zeros((max(ld, 6 * nsteps), o)); Wp[:m] = W
+    nch = (nsteps + Kf - 1) // Kf
+    Prow = np.full((nstrips, 6 * nsteps, o), np.nan); Pcol = np.full((nch, ld, o), np.nan)
+    for s in range(nstrips):
+        Ks = Kf if s // 4 >= ysplit else K
+        c0 = s * STRIP
+        cols = np.arange(c0, min(c0 + STRIP, ld))
+        jend = min(nsteps, (c0 + STRIP + 5) // 6)
+        for ch in range((jend + Ks - 1) // Ks):
+            acc = np.zeros((cols.size, o))
+            for j in range(ch * Ks, min(ch * Ks + Ks, jend)):
+                rows = np.arange(6 * j, 6 * j + 6)
+                q = Qp[np.ix_(rows, cols)]
+                Prow[s, rows] = (q * (cols >= 6 * j)[None, :]) @ Wp[cols]              # used row-wise from the diagonal block on
+                acc += (q * (cols >= 6 * j + 6)[None, :]).T @ Wp[rows]                 # and column-wise strictly right of it
+            assert np.all(np.isnan(Pcol[ch, cols]))                                     # written once
+            Pcol[ch, cols] = acc
+    Y = np.zeros((m, o))
+    for cam in range(n):
+        s_lo = (6 * (cam // 2)) // STRIP
+        for r in range(3):
+            c = 3 * cam + r
+            Kc = Kf if (c // STRIP) // 4 >= ysplit else K
+            cnt = (c - 6) // (6 * Kc) + 1 if c >= 6 else 0
+            Y[c] = Prow[s_lo:, c].sum(axis=0) + Pcol[:cnt, c].sum(axis=0)
+    assert np.all(np.isfinite(Y))                                                        # everything read had been written
+    return Y
+
+
+@pytest.mark.parametrize("n,o,plan", [(1, 3, None), (7, 3, None), (43, 3, None), (86, 4, None), (171, 5, None), (700, 3, None),
+                                      (700, 3, (16, 4, 2)), (700, 4, (32, 8, 1)), (1031, 3, (16, 4, 4)), (1031, 3, (5, 5, 99))])
+def test_symv_partition_sums_to_the_product(n, o, plan):
+    rng = np.random.default_rng(n + o)
+    A = rng.standard_normal((3 * n, 3 * n)); Q = A + A.T
+    W = rng.standard_normal((3 * n, o))
+    if plan is None:
+        p = (C.c_int32 * 4)()
+        assert xmamd.lib().xm_symv_plan(n, p) == 0
+        K, Kf, ysplit, nch = (int(x) for x in p)
+        assert 2 <= K <= 64 and 1 <= Kf <= K and nch == ((n + 1) // 2 + Kf - 1) // Kf
+    else:
+        K, Kf, ysplit = plan
+    Y = emulate(Q, W, K, Kf, ysplit)
+    ref = Q @ W
+    assert np.abs(Y - ref).max() <= 1e-11 * np.abs(ref).max()
+    Ql = Q.copy(); Ql[np.tril_indices(3 * n, -6)] = 1e6            # far enough below the diagonal nothing may be read
+    assert np.array_equal(emulate(Ql, W, K, Kf, ysplit), Y)
+
+
+def test_symv_plan_of_the_benchmark_sizes():
+    for n, kmin, kmax in ((1778, 4, 12), (4096, 12, 24), (8192, 24, 48), (13682, 64, 64)):
+        p = (C.c_int32 * 4)()
+        assert xmamd.lib().xm_symv_plan(n, p) == 0
+        assert kmin <= p[0] <= kmax and (p[1] == p[0] // 4 if p[0] >= 16 else p[1] == p[0])

@@ -393,6 +393,16 @@ int xm_spd_inverse(int64_t n, double *A) {
     XM_CATCH
 }
 
+int xm_symv_plan(int64_t n, int32_t plan[4]) {
+    XM_TRY
+    if (n < 1 || !plan) throw xm::Error(XM_ERR_ARG, "bad argument");
+    int out[4];
+    xm::symv_plan_get((int)n, xm::dense_ld(n), out);   // host only: no device needed
+    for (int i = 0; i < 4; ++i) plan[i] = out[i];
+    return XM_OK;
+    XM_CATCH
+}
+
 // ---- sliced-ELL product for large block-sparse Q (xm_sell.h) -------------------------------------------------------------
 int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t sizes[5],
                    int64_t *slice_off, int32_t *slab_start, uint8_t *kind, int64_t *src, int32_t *pslot, int64_t *pptr, int32_t *ridx) {

@@ -103,6 +103,7 @@ int sym_groups(int nloc);
 int sym_variant();   // 1: vertical sweep (also instantiated for the rank-1 certificate operator)
 size_t sym_prow_count(int nloc, int64_t ld, int o);
 size_t sym_pcol_count(int nloc, int64_t ld, int o);
+void symv_plan_get(int nloc, int64_t ld, int out[4]);   // K, Kf, ysplit, nchunks of the vertical-sweep symmetric product
 void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,
                    double *Pcol, hipStream_t st);
 void launch_asym(const double *Q, int64_t ld, int64_t m, double *out, int grid, hipStream_t st);

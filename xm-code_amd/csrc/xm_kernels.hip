@@ -1634,6 +1634,10 @@ static SymvPlan symv_plan(int nloc, int64_t ld) {
     p.nchunks = (nsteps + p.Kf - 1) / p.Kf;
     return p;
 }
+void symv_plan_get(int nloc, int64_t ld, int out[4]) {   // host-only view of the plan (CPU test of the index arithmetic)
+    const SymvPlan p = symv_plan(nloc, ld);
+    out[0] = p.K; out[1] = p.Kf; out[2] = p.ysplit; out[3] = p.nchunks;
+}
 size_t sym_pcol_count(int nloc, int64_t ld, int o) {
     if (sym_variant() == 1) return (size_t)symv_plan(nloc, ld).nchunks * (size_t)ld * o;
     return (size_t)sym_groups(nloc) * (size_t)ld * o;

@@ -26,7 +26,7 @@ EXPORTS = [
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition",
-    "xm_sell_layout", "xm_sell_create", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
+    "xm_symv_plan", "xm_sell_layout", "xm_sell_create", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
     "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse",
 ]
 
