@@ -961,7 +961,9 @@ def test_matrix_free_recover_translations_and_landmarks(xmamd):
     R, s, info = ctx.solve(exp["max_rank"], exp["tol"], exp["lam"])
     rot, sc, _ = xmamd.recover_rotations(R, s)
     t2, p2 = ctx.recover_tp(rot, sc)
+    res = ctx.edge_residuals()                 # |s_i R_i p + t_i - P_l|^2 per observation: their weighted sum IS the objective (lam = 0)
     ctx.close()
+    assert float(np.sum(_simple2_obs()[3].reshape(-1) * res)) == pytest.approx(info["primal"], rel=1e-9)
     obs = _simple2_obs()
     tn, pn = tl.schur_tp_numpy(obs[0], obs[1], obs[2], obs[3], rot, sc)
     assert np.abs(t2 - tn).max() < 1e-9 * st and np.abs(p2 - pn).max() < 1e-9 * sp
