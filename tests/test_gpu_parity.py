@@ -963,7 +963,8 @@ def test_matrix_free_recover_translations_and_landmarks(xmamd):
     t2, p2 = ctx.recover_tp(rot, sc)
     res = ctx.edge_residuals()                 # |s_i R_i p + t_i - P_l|^2 per observation: their weighted sum IS the objective (lam = 0)
     ctx.close()
-    assert float(np.sum(_simple2_obs()[3].reshape(-1) * res)) == pytest.approx(info["primal"], rel=1e-9)
+    # (the objective is 5e-2 against |Q| ~ 1e3: the quadratic form carries ~1e-9 of cancellation, the residual sum does not)
+    assert float(np.sum(_simple2_obs()[3].reshape(-1) * res)) == pytest.approx(info["primal"], rel=1e-7)
     obs = _simple2_obs()
     tn, pn = tl.schur_tp_numpy(obs[0], obs[1], obs[2], obs[3], rot, sc)
     assert np.abs(t2 - tn).max() < 1e-9 * st and np.abs(p2 - pn).max() < 1e-9 * sp
