@@ -489,6 +489,31 @@ def test_qw_dense_symmetric_kernel_matches_oracle(xmamd, oracle, n, o):
     assert tl.rel_fro(xmamd.qw_dense(Q, W, 2.0), ref) < 1e-13
 
 
+def test_new_products_are_bit_reproducible(xmamd):
+    """fixed summation orders everywhere: the half-traffic symmetric product (per-strip row sums through LDS, per-chunk column sums,
+    list-ordered reducer) and the matrix-free chain (degree-sorted landmark groups, hub landmarks in the same launch) give the same
+    bits on every call, and so does a whole matrix-free solve"""
+    rng = np.random.default_rng(3)
+    n = 700
+    A = rng.standard_normal((3 * n, 3 * n)); Q = A + A.T
+    dq = xmamd.dense_upload(Q)
+    for o in (3, 4):
+        W = rng.standard_normal((3 * n, o))
+        a = xmamd.qw_dense(Q, W, 1.5, dq=dq, sym=True)
+        for _ in range(3):
+            assert np.array_equal(xmamd.qw_dense(Q, W, 1.5, dq=dq, sym=True), a)
+    dq.free()
+    S = tl.gen_scene(300, 6000, 5, seed=11)
+    ctx = xmamd.Context(obs=(S["cam"], S["lm"], S["p"], S["w"]))
+    W = rng.standard_normal((900, 3))
+    y = ctx.qw(W)
+    assert np.array_equal(ctx.qw(W), y) and np.array_equal(ctx.qw(W), y)
+    R1, s1, i1 = ctx.solve(5, 1e-8, 0.0)
+    R2, s2, i2 = ctx.solve(5, 1e-8, 0.0)
+    ctx.close()
+    assert np.array_equal(R1, R2) and np.array_equal(s1, s2) and i1["tcg_iters"] == i2["tcg_iters"] and i1["primal"] == i2["primal"]
+
+
 def test_symmetry_check_decides_the_dense_path(xmamd):
     """the half-traffic product reads the upper triangle only, so it is taken (3n >= 6144 rows) for an EXACTLY symmetric Q alone: one
     entry of the lower triangle off by 1e-9, or a NaN, and the general kernel runs (asym_kernel: tiled transposed compare, sticky NaN)"""
