@@ -139,7 +139,8 @@ void launch_recover_project(int64_t n, int r, const double *R, const double *s, 
                             hipStream_t st);
 void launch_negate(double *x, int64_t len, hipStream_t st);
 // small vector kernels used by Lanczos
-void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, hipStream_t st);
+int dots_multi_segments(int64_t len);
+void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, double *scratch, hipStream_t st);
 void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);
 void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hipStream_t st);
 void launch_lz_alpha(const double *c1j, const double *c2j, double *alpha_j, hipStream_t st);

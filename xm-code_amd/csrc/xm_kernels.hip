@@ -1292,6 +1292,25 @@ __global__ __launch_bounds__(256) void dots_multi_kernel(const double *__restric
     const double tot = block_sum256(acc, sh);
     if (threadIdx.x == 0) c[blockIdx.x] = tot;
 }
+// the same for long vectors (100 k cameras: one block per column walked 300 k elements alone, 295 us per call and three calls per
+// Lanczos step): block (j, ch) sums one segment, the partial sums of a column are added in segment order by the second kernel
+__global__ __launch_bounds__(256) void dots_multi_seg_kernel(const double *__restrict__ V, int64_t ldv, const double *__restrict__ w,
+                                                              int64_t len, int64_t seg, double *__restrict__ part) {
+    __shared__ double sh[4];
+    const double *v = V + (size_t)blockIdx.x * ldv;
+    const int64_t i0 = (int64_t)blockIdx.y * seg, i1 = (i0 + seg < len) ? i0 + seg : len;
+    double acc = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) acc += v[i] * w[i];
+    const double tot = block_sum256(acc, sh);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = tot;
+}
+__global__ __launch_bounds__(256) void dots_multi_fin_kernel(const double *__restrict__ part, int m, int nseg, double *__restrict__ c) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    double t = 0.0;
+    for (int q = 0; q < nseg; ++q) t += part[(size_t)j * nseg + q];
+    c[j] = t;
+}
 // w -= V c
 __global__ __launch_bounds__(256) void sub_vc_kernel(double *w, const double *__restrict__ V, int64_t ldv,
                                                       const double *__restrict__ c, int m, int64_t len) {
@@ -1816,9 +1835,18 @@ void launch_negate(double *x, int64_t len, hipStream_t st) {
     hipLaunchKernelGGL(negate_kernel, dim3(flat_grid(len)), dim3(256), 0, st, x, len);
     check_launch("negate");
 }
-void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, hipStream_t st) {
+int dots_multi_segments(int64_t len) { return (int)std::min<int64_t>(64, std::max<int64_t>(1, len / 16384)); }
+// scratch: m * dots_multi_segments(len) doubles (may be null when that is 1 segment: short vectors keep the single-kernel sum)
+void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, double *scratch, hipStream_t st) {
     if (m <= 0) return;
-    hipLaunchKernelGGL(dots_multi_kernel, dim3(m), dim3(256), 0, st, V, ldv, w, len, c);
+    const int nseg = dots_multi_segments(len);
+    if (nseg <= 1 || !scratch) {
+        hipLaunchKernelGGL(dots_multi_kernel, dim3(m), dim3(256), 0, st, V, ldv, w, len, c);
+    } else {
+        const int64_t seg = ((len + nseg - 1) / nseg + 255) / 256 * 256;
+        hipLaunchKernelGGL(dots_multi_seg_kernel, dim3(m, nseg), dim3(256), 0, st, V, ldv, w, len, seg, scratch);
+        hipLaunchKernelGGL(dots_multi_fin_kernel, dim3((m + 255) / 256), dim3(256), 0, st, scratch, m, nseg, c);
+    }
     check_launch("dots_multi");
 }
 void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st) {

@@ -855,8 +855,9 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
     std::vector<double> al, be, y;
     int total = 0;
     // device-side bookkeeping: c1 / c2 = Gram-Schmidt coefficients of the two passes, ab = [alpha_0.. | beta_0..]
-    DevBuf<double> c2, ab;
+    DevBuf<double> c2, ab, dscr;
     c2.alloc((size_t)mmax + 2);
+    dscr.alloc((size_t)(mmax + 1) * (size_t)dots_multi_segments(len));   // segment sums of the Gram-Schmidt dot products (long vectors)
     ab.alloc((size_t)2 * (mmax + 1));
     std::vector<double> hab((size_t)2 * (mmax + 1));
     const int batch = 8;   // Lanczos steps enqueued between two host checks
@@ -880,12 +881,12 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 res_->qw_products++;
                 if (comm_->active()) comm_->allgather(w.p, (size_t)nloc_ * 3, st_);
                 // classical Gram-Schmidt twice against V(:,0..j); alpha_j = c1[j] + c2[j]; beta_j = |w|; v_{j+1} = w / beta_j
-                launch_dots_multi(V.p, len, j + 1, w.p, len, c.p, st_);
+                launch_dots_multi(V.p, len, j + 1, w.p, len, c.p, dscr.p, st_);
                 launch_sub_vc(w.p, V.p, len, c.p, j + 1, len, st_);
-                launch_dots_multi(V.p, len, j + 1, w.p, len, c2.p, st_);
+                launch_dots_multi(V.p, len, j + 1, w.p, len, c2.p, dscr.p, st_);
                 launch_sub_vc(w.p, V.p, len, c2.p, j + 1, len, st_);
                 launch_lz_alpha(c.p + j, c2.p + j, ab.p + j, st_);
-                launch_dots_multi(w.p, len, 1, w.p, len, c.p + mmax + 1, st_);
+                launch_dots_multi(w.p, len, 1, w.p, len, c.p + mmax + 1, dscr.p, st_);
                 launch_lz_next(V.p + (size_t)(j + 1) * len, w.p, c.p + mmax + 1, ab.p + (mmax + 1) + j, len, st_);
                 total++;
             }
