@@ -28,6 +28,8 @@ constexpr int64_t kSchurMaxCams = 40000;   // (N-1)^2 inverse + workspace = 3 x 
 
 // A (device, column-major n x n, lower triangle read) -> Cholesky factor; X <- A^-1 (full symmetric).  false: not positive definite
 bool spd_inverse_device(int n, double *A, double *X, hipStream_t st);
+// A (device, column-major n x n) -= q * u u^T  (u: device, n doubles)
+void rank1_sub_device(int n, double *A, const double *u, double q, hipStream_t st);
 
 class SchurOp {
 public:

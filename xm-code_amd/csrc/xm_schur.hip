@@ -329,9 +329,11 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
     const int64_t mr = N - 1;
     std::vector<double> VT((size_t)std::max<int64_t>(mr, 1) * (size_t)std::max<int64_t>(mr, 1), 0.0);
     for (int64_t i = 1; i < N; ++i) VT[(size_t)(i - 1) + (size_t)(i - 1) * mr] = Q2[(size_t)i];
+    std::vector<int64_t> hubs;   // landmarks with more than kSchurHeavy observations: their (dense) rank-1 terms are applied on the device
     for (int64_t l = 0; l < M; ++l) {
         const double qi = q3inv[(size_t)l];
         if (qi == 0.0) continue;
+        if (lp_[(size_t)l + 1] - lp_[(size_t)l] > kSchurHeavy && mr > 0) { hubs.push_back(l); continue; }
         for (int64_t e1 = lp_[(size_t)l]; e1 < lp_[(size_t)l + 1]; ++e1) {
             const int64_t a2 = lcam_[(size_t)e1];
             if (a2 == 0 || l_w[(size_t)e1] == 0.0) continue;
@@ -351,6 +353,19 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
         tmp.alloc((size_t)mr * mr, false); inv.alloc((size_t)mr * mr, false);
         XM_HIP_CHECK(hipMemcpy(tmp.p, VT.data(), (size_t)mr * mr * sizeof(double), hipMemcpyHostToDevice));
         std::vector<double>().swap(VT);
+        if (!hubs.empty()) {
+            DevBuf<double> du;
+            du.alloc((size_t)mr, false);
+            std::vector<double> u((size_t)mr);
+            for (int64_t l : hubs) {   // in landmark order (fixed): VT -= (1/Q3_l) u u^T, u = the weights of l's observations by camera
+                std::fill(u.begin(), u.end(), 0.0);
+                for (int64_t e1 = lp_[(size_t)l]; e1 < lp_[(size_t)l + 1]; ++e1)
+                    if (lcam_[(size_t)e1] != 0) u[(size_t)lcam_[(size_t)e1] - 1] += l_w[(size_t)e1];
+                XM_HIP_CHECK(hipMemcpyAsync(du.p, u.data(), (size_t)mr * sizeof(double), hipMemcpyHostToDevice, st));
+                rank1_sub_device((int)mr, tmp.p, du.p, q3inv[(size_t)l], st);
+                XM_HIP_CHECK(hipStreamSynchronize(st));   // u is reused
+            }
+        }
         if (!spd_inverse_device((int)mr, tmp.p, inv.p, st))
             throw Error(XM_ERR_ARG, "matrix-free Q: the reduced camera Laplacian is not positive definite (observation graph not connected?)");
         launch_transpose_pad(inv.p, mr, mr, mr, vtinv_.p, ldv_, st);   // (symmetric: the transposition is immaterial)
