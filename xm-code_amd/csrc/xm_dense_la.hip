@@ -1,7 +1,8 @@
 // xm_dense_la.hip — inverse of a symmetric positive definite matrix on the device (blocked Cholesky + two blocked triangular
 // solves with the identity), float64.  Used once per matrix-free context for the reduced camera Laplacian VT of
 // utils/creatematrix.py:150-166 (the reference solves with it on the host through scipy.linalg.solve, :260); it is set-up work,
-// O(n^3), so the kernels are plain LDS-tiled VALU code (a few TFLOP/s is seconds at n = 14 000), not a tuned GEMM.
+// O(n^3): the GEMM-shaped updates (all but O(n^2 b) of the flops) run on the f64 matrix cores, the 64-wide panel kernels are plain
+// VALU code.
 //
 //   A = L L^T            right-looking: potrf on the 64 x 64 diagonal block, panel solve A21 <- A21 L11^-T, trailing update
 //                        A22 -= A21 A21^T (lower tiles only)
@@ -16,17 +17,29 @@ namespace xm {
 
 constexpr int kLaB = 64;   // block size
 
-// C[m x n] -= opA(A)[m x k] * opB(B)[k x n];  ta / tb: 0 = as stored, 1 = transposed.  64 x 64 tile per workgroup, 16 x 16
-// threads with 4 x 4 outputs each, K in chunks of 16 through LDS.  lower_only: skip tiles strictly above the diagonal (syrk).
+// C[m x n] -= opA(A)[m x k] * opB(B)[k x n];  ta / tb: 0 = as stored, 1 = transposed.  64 x 64 tile per workgroup, K in chunks of 16
+// through LDS, the products on the f64 matrix cores: each of the four wavefronts owns a 32 x 32 quarter as 2 x 2 blocks of
+// v_mfma_f64_16x16x4_f64.  The MFMA computes the TRANSPOSED block (its "A" operand is taken from the B tile, its "B" operand from the
+// A tile), so that the 16 lanes that share an accumulator register hold 16 consecutive ROWS of one column of C: C is column-major
+// and the read-modify-write of the result is coalesced.  Operand / result maps of the f64 form (cdna_hip_programming.md): A[i = lane %
+// 16][k = lane / 16], B[k = lane / 16][j = lane % 16], D[row = lane / 16 + 4 reg][col = lane % 16].
+// lower_only: skip tiles strictly above the diagonal (syrk).
+typedef double la_v4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void la_gemm_sub_kernel(int m, int n, int k, const double *__restrict__ A, int64_t lda, int ta,
                                                            const double *__restrict__ B, int64_t ldb, int tb, double *__restrict__ C,
                                                            int64_t ldc, int lower_only) {
     const int bi = blockIdx.x, bj = blockIdx.y;
     if (lower_only && bj > bi) return;
     __shared__ double As[16][kLaB + 1], Bs[16][kLaB + 1];   // As[kk][i], Bs[kk][j]
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = bi * kLaB, j0 = bj * kLaB;
-    double acc[4][4] = {};
+    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;   // this wavefront's quarter of the tile
+    const int l16 = lane & 15, lk = lane >> 4;
+    la_v4 acc[2][2];   // [column block][row block] of the quarter, transposed blocks (see above)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = la_v4{0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; k0 < k; k0 += 16) {
         for (int e = threadIdx.x; e < 16 * kLaB; e += 256) {
             // consecutive threads run along the contiguous direction of each operand (rows of a stored matrix)
@@ -40,24 +53,27 @@ __global__ __launch_bounds__(256) void la_gemm_sub_kernel(int m, int n, int k, c
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            double a[4], b[4];
+        for (int kq = 0; kq < 4; ++kq) {
+            const int kk = kq * 4 + lk;
+            double av[2], bv[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = As[kk][tx + 16 * u]; b[u] = Bs[kk][ty + 16 * u]; }
+            for (int u = 0; u < 2; ++u) { av[u] = As[kk][r0 + 16 * u + l16]; bv[u] = Bs[kk][c0 + 16 * u + l16]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[x], av[y], acc[x][y], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int gi = i0 + tx + 16 * u, gj = j0 + ty + 16 * v;
-            if (gi < m && gj < n) C[(size_t)gi + (size_t)gj * ldc] -= acc[u][v];
-        }
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = i0 + r0 + 16 * y + l16, gj = j0 + c0 + 16 * x + lk + 4 * r;   // D row <-> column of C, D column <-> row of C
+                if (gi < m && gj < n) C[(size_t)gi + (size_t)gj * ldc] -= acc[x][y][r];
+            }
 }
 
 // Cholesky of one b x b diagonal block (b <= 64) in place (lower), one workgroup; *info = 1 when a pivot is not positive
