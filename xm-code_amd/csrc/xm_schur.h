@@ -71,6 +71,7 @@ private:
     std::vector<int32_t> hcam_, hlm_, lcam_;  // host copies of the structure for set_weights
     std::vector<double> hp_;
     std::vector<int64_t> cp_, lp_, pos_c_, pos_l_;
+    std::vector<int64_t> cam_obs_;            // observation (input index) at each position of the by-camera lists
     int o_alloc_ = 0, o_last_ = 0;
     void ensure(int o);
 };

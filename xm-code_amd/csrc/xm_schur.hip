@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "xm_device.h"
@@ -271,7 +272,7 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     std::vector<int32_t> c_lm((size_t)nobs), d_lcam((size_t)ltotal_, 0), o_lm((size_t)nobs);
     std::vector<double> c_p((size_t)nobs * 3), d_lp((size_t)ltotal_ * 3, 0.0);
     lcam_.assign((size_t)nobs, 0);
-    pos_c_.assign((size_t)nobs, 0); pos_l_.assign((size_t)nobs, 0); dpos_l_.assign((size_t)nobs, 0);
+    pos_c_.assign((size_t)nobs, 0); pos_l_.assign((size_t)nobs, 0); dpos_l_.assign((size_t)nobs, 0); cam_obs_.assign((size_t)nobs, 0);
     {
         std::vector<int64_t> nc(cp_.begin(), cp_.end() - 1), nl(lp_.begin(), lp_.end() - 1);
         for (int64_t e = 0; e < nobs; ++e) {
@@ -279,6 +280,7 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
             const int64_t sl = slot_of_[(size_t)lm[e]], k = b2 - lp_[(size_t)lm[e]];
             const int64_t d2 = (sl < nheavy_) ? hptr[(size_t)sl] + k : gbase[(size_t)((sl - nheavy_) >> 6)] + 64 * k + ((sl - nheavy_) & 63);
             pos_c_[(size_t)e] = a2; pos_l_[(size_t)e] = b2; dpos_l_[(size_t)e] = d2;
+            cam_obs_[(size_t)a2] = e;
             c_lm[(size_t)a2] = (int32_t)sl; o_lm[(size_t)e] = (int32_t)sl;
             for (int a = 0; a < 3; ++a) c_p[(size_t)a * (size_t)nobs + (size_t)a2] = p[3 * e + a];   // three planes
             lcam_[(size_t)b2] = cam[e];                           // host copy (by landmark, contiguous): assembly of VT
@@ -329,19 +331,35 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
     const int64_t mr = N - 1;
     std::vector<double> VT((size_t)std::max<int64_t>(mr, 1) * (size_t)std::max<int64_t>(mr, 1), 0.0);
     for (int64_t i = 1; i < N; ++i) VT[(size_t)(i - 1) + (size_t)(i - 1) * mr] = Q2[(size_t)i];
-    std::vector<int64_t> hubs;   // landmarks with more than kSchurHeavy observations: their (dense) rank-1 terms are applied on the device
-    for (int64_t l = 0; l < M; ++l) {
-        const double qi = q3inv[(size_t)l];
-        if (qi == 0.0) continue;
-        if (lp_[(size_t)l + 1] - lp_[(size_t)l] > kSchurHeavy && mr > 0) { hubs.push_back(l); continue; }
-        for (int64_t e1 = lp_[(size_t)l]; e1 < lp_[(size_t)l + 1]; ++e1) {
-            const int64_t a2 = lcam_[(size_t)e1];
-            if (a2 == 0 || l_w[(size_t)e1] == 0.0) continue;
-            for (int64_t e2 = lp_[(size_t)l]; e2 < lp_[(size_t)l + 1]; ++e2) {
-                const int64_t b2 = lcam_[(size_t)e2];
-                if (b2 == 0) continue;
-                VT[(size_t)(a2 - 1) + (size_t)(b2 - 1) * mr] -= l_w[(size_t)e1] * l_w[(size_t)e2] * qi;
+    // VT is assembled ROW BY ROW (camera a: its observations in list order, for each the cameras of that landmark): a row of N-1
+    // doubles stays in the cache while its ~deg(a) * deg(l) updates land, rows are independent (threads own row ranges; the order of
+    // the additions into an entry is the camera's observation order whatever the thread count), and the matrix is symmetric, so the
+    // row-major image is the column-major one.  By landmark instead, the same 51 M updates at 13 682 cameras scatter over 1.5 GB: 1.7 s
+    // against 0.1 s.  Landmarks with more than kSchurHeavy observations are full rank-1 terms and are applied on the device below.
+    std::vector<int64_t> hubs;
+    for (int64_t l = 0; l < M; ++l)
+        if (q3inv[(size_t)l] != 0.0 && lp_[(size_t)l + 1] - lp_[(size_t)l] > kSchurHeavy && mr > 0) hubs.push_back(l);
+    if (mr > 0) {
+        auto rows = [&](int64_t a0, int64_t a1) {
+            for (int64_t a = std::max<int64_t>(a0, 1); a < a1; ++a) {
+                double *row = VT.data() + (size_t)(a - 1) * (size_t)mr;
+                for (int64_t pc = cp_[(size_t)a]; pc < cp_[(size_t)a + 1]; ++pc) {
+                    const int64_t e = cam_obs_[(size_t)pc], l = hlm_[(size_t)e];
+                    const double qi = q3inv[(size_t)l], wa = w[e];
+                    if (qi == 0.0 || wa == 0.0 || lp_[(size_t)l + 1] - lp_[(size_t)l] > kSchurHeavy) continue;
+                    for (int64_t e2 = lp_[(size_t)l]; e2 < lp_[(size_t)l + 1]; ++e2) {
+                        const int64_t b = lcam_[(size_t)e2];
+                        if (b != 0) row[b - 1] -= wa * l_w[(size_t)e2] * qi;
+                    }
+                }
             }
+        };
+        const int nthr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, (int64_t)std::thread::hardware_concurrency()), N / 256));
+        if (nthr <= 1) rows(1, N);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthr; ++t) pool.emplace_back(rows, N * t / nthr, N * (t + 1) / nthr);
+            for (auto &th : pool) th.join();
         }
     }
     auto put = [&](DevBuf<double> &buf, const std::vector<double> &v) {
