@@ -488,9 +488,10 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
             const int v = v0 + g;
             double t = 0.0;
             if (v < V) {
-                // lane jl takes elements 2 jl, 2 jl + 1 and 32 + 2 jl, 33 + 2 jl: the 16 lanes of a row read 256 contiguous bytes per
-                // instruction (every LDS bank once; with 4 jl / 4 jl + 2 the PMC pass showed 65 % of the LDS cycles in bank conflicts)
-                const double2 a = *reinterpret_cast<const double2 *>(L + v * 64 + 2 * jl), b = *reinterpret_cast<const double2 *>(L + v * 64 + 32 + 2 * jl);
+                // (lane jl: elements 4 jl .. 4 jl + 3.  The PMC pass shows 65 % of the LDS cycles of this kernel in bank conflicts from
+                // this pattern; the conflict-free mapping 2 jl / 32 + 2 jl was measured: no faster (LDS is 8 % of the wave cycles), and
+                // it changes the summation grouping, so it was not kept.)
+                const double2 a = *reinterpret_cast<const double2 *>(L + v * 64 + 4 * jl), b = *reinterpret_cast<const double2 *>(L + v * 64 + 4 * jl + 2);
                 t = (a.x + a.y) + (b.x + b.y);
             }
             t = group_sum<16>(t);
