@@ -16,7 +16,10 @@ def _sym(M):
 
 
 class RankModel:
-    def __init__(self, Q, o, lam, rank, world, allgather):
+    def __init__(self, Q, o, lam, rank, world, allgather, overlap=False):
+        # overlap: the products outside the tCG multiply the rank's OWN column strip before the all-gather of W is awaited and add
+        # the other columns afterwards (Context::product with a pending gather); `events` records the order
+        self.overlap, self.events = overlap, []
         n = Q.shape[0] // 3
         self.n, self.o, self.lam, self.rank, self.world, self.ag = n, o, lam, rank, world, allgather
         self.nloc = -(-n // world)
@@ -42,8 +45,17 @@ class RankModel:
 
     # ---- epilogues (xm_kernels.hip: epi_grad / epi_hess) -------------------------------------------------------------
     def eval_point(self, R, s):
-        W = self.gather_rows(s[:, None, None] * R)
-        G = 2.0 * (self.Qloc @ W).reshape(self.nloc, 3, self.o)
+        if self.overlap:
+            Xloc = (s[:, None, None] * R).reshape(3 * self.nloc, self.o)
+            c0, c1 = 3 * self.cam0, 3 * (self.cam0 + self.nloc)
+            strip = self.Qloc[:, c0:c1] @ Xloc                         # needs no communication: runs beside the gather
+            self.events.append("strip")
+            W = self.gather_rows(s[:, None, None] * R)
+            self.events.append("gather")
+            G = 2.0 * (strip + self.Qloc[:, :c0] @ W[:c0] + self.Qloc[:, c1:] @ W[c1:]).reshape(self.nloc, 3, self.o)
+        else:
+            W = self.gather_rows(s[:, None, None] * R)
+            G = 2.0 * (self.Qloc @ W).reshape(self.nloc, 3, self.o)
         Wl = W.reshape(self.ntot, 3, self.o)[self.cam0:self.cam0 + self.nloc]
         q = s * s - 1.0
         f = self.gsum(np.sum(0.5 * np.sum(G * Wl, axis=(1, 2)) + np.where(self.anchor, 0.0, self.lam * q * q)))

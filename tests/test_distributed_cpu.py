@@ -34,7 +34,7 @@ def test_partition_model_world1_matches_oracle(oracle):
     assert abs(info["tcg_iters"] - st["tcg_iters"]) <= 0.05 * st["tcg_iters"] + 5
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, overlap=False):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, HERE)
@@ -50,10 +50,10 @@ def _worker(rank, world, port, out_dir):
 
     Q, lam = _problem()
     n = Q.shape[0] // 3
-    m = RankModel(Q, 3, lam, rank, world, allgather)
+    m = RankModel(Q, 3, lam, rank, world, allgather, overlap=overlap)
     R, s, info = m.trust_region(np.tile(np.eye(3), (n, 1)), np.ones(n), 1e-9)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), R=R, s=s, primal=info["primal"], tcg=info["tcg_iters"],
-             trace=info["trace"], nloc=m.nloc, cam0=m.cam0)
+             trace=info["trace"], nloc=m.nloc, cam0=m.cam0, strip_first=bool(m.events[:2] == ["strip", "gather"]) if overlap else False)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -95,3 +95,21 @@ def test_partition_model_world2_gloo(oracle, tmp_path):
     Ro, so, primal, _, st = oracle.trustregion(Q, R0, s0, lam=lam, gradtol=1e-9)
     assert float(a["primal"]) == pytest.approx(primal, rel=1e-10)
     assert tl.rotation_parity(a["R"], a["s"], Ro, so) < 1e-8
+
+
+def test_partition_model_overlap_world2_gloo(tmp_path):
+    """SURVEY 8e on the model: outside the tCG each rank multiplies its own column strip BEFORE the all-gather of W returns and adds
+    the other columns afterwards; both ranks stay bit-identical with each other and land on the optimum of the plain schedule"""
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    a = np.load(tmp_path / "rank0.npz"); b = np.load(tmp_path / "rank1.npz")
+    assert bool(a["strip_first"]) and bool(b["strip_first"])
+    assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["s"], b["s"]) and np.array_equal(a["trace"], b["trace"])
+    Q, lam = _problem()
+    n = Q.shape[0] // 3
+    R1, s1, i1 = RankModel(Q, 3, lam, 0, 1, lambda v: v).trust_region(np.tile(np.eye(3), (n, 1)), np.ones(n), 1e-9)
+    assert float(a["primal"]) == pytest.approx(i1["primal"], rel=1e-11)
+    assert tl.rotation_parity(a["R"], a["s"], R1, s1) < 1e-8
