@@ -6,13 +6,16 @@ with Q already resident in HBM.  value = tCG inner iterations (each = one Q*W He
 "Total iteration", trustregion.h:666/711) per second over the K timed solves; ms_per_step = wall-clock-to-KKT of one
 solve.  Workload at every N: the configuration the metric is quoted on, "Venice-1778": the reference ships no BAL Q
 (SURVEY.md F7), so it is the seeded dense SBA-like generator of SURVEY.md §8d with n = 1778 cameras
-(tests/xm_testlib.py:gen_dense).  For N > 1 the same problem is row-partitioned over the ranks (strong scaling) with an
-RCCL all-gather of the product input per Q*W.
+(tests/xm_testlib.py:gen_dense).  For N > 1 the same problem is row-partitioned over the ranks (strong scaling).
 
-Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 the ranks may be started by torch.distributed.run (one rank per
-GPU, what the driver does) or by bench.py itself: a plain `python bench.py --gpus N` re-executes under torch.distributed.run on
-127.0.0.1.  When the box has fewer than N GPUs the ranks share device 0 and exchange through the library's shared-memory TEST
-transport (XM_BENCH_SHM=1, set automatically): a functional dry run of the N-rank flow, flagged as such in the JSON line.
+Launch: python bench.py [--gpus N --steps K --warmup W].
+  * under torch.distributed.run (one rank per GPU, what the driver does): one process per GPU, RCCL all-gathers inside the solver;
+  * plain `python bench.py --gpus N`: NO launcher -- the library's single-process multi-GPU mode (xm_problem_t.n_gpus: one host thread
+    per GPU, direct peer-write exchange fused into the tCG).  When the box has fewer than N GPUs the N ranks are "virtual devices" on
+    device 0 (gpu_map = 1): a functional run of the N-rank flow, flagged as such in the JSON line, not a scaling measurement.
+The K timed solves rotate through the three summation groupings of xm_options_t.sum_grouping (step i uses grouping i mod 3): every
+grouping is a fixed, bit-reproducible order, but the iteration count of this staircase moves by +-10 % with the last bits of the
+sums (ranks 3 and 4 end at saddle points), so one grouping alone would make the headline a lottery draw.
 """
 import argparse
 import json
@@ -30,6 +33,9 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:   # torchrun pins OMP_NUM_THREADS
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")              # control-plane rendezvous on loopback (hostname may not resolve)
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")              # RCCL bootstrap of the single-node communicator likewise
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (multi-process runs)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # virtual devices (N ranks on one GPU) need a hardware queue per rank's stream
+os.environ.setdefault("OMP_PROC_BIND", "close")            # cpu_baseline: threads stay where they first touched their share of Q
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
 
@@ -87,25 +93,6 @@ def recorded_traffic(workload, world):
     return None, "no PMC profile stamped with the current source hash %s (run scripts/pmc_hess.sh on the GPU box)" % sha[:12]
 
 
-def self_launch(args):
-    """plain `python bench.py --gpus N`: start the N ranks ourselves (same command the driver uses)"""
-    import socket, subprocess
-    env = dict(os.environ)
-    try:
-        ngpu = xmamd.device_count()
-    except Exception:
-        ngpu = 0
-    if ngpu < args.gpus:   # fewer GPUs than ranks: functional dry run, every rank on device 0 over the shared-memory test transport
-        env.setdefault("XM_BENCH_SHM", "1")
-        env.setdefault("XM_BENCH_SINGLE_DEVICE", "1")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd, env=env))
-
-
 def cpu_baseline(Q, wl, budget_s, bsr=None):
     """oracle (CPU restatement) on the SAME Q/options, bounded by the reference's own max_time mechanism."""
     from oracle import xm_oracle as xo
@@ -115,7 +102,11 @@ def cpu_baseline(Q, wl, budget_s, bsr=None):
     if bsr is not None:   # block-sparse workloads: the oracle's test-only BSR3 product (the dense matrix would not fit)
         _, _, primal, _, st = xo.trustregion_bsr(bsr[0], bsr[1], bsr[2], R0, np.ones(n), lam=wl["lam"], gradtol=wl["tol"], maxtime=budget_s)
     else:
-        _, _, primal, _, st = xo.trustregion(Q, R0, np.ones(n), lam=wl["lam"], gradtol=wl["tol"], maxtime=budget_s)
+        xo.numa_prepare(Q)   # NUMA-distributed first-touch copy: the host product then streams from every memory controller
+        try:
+            _, _, primal, _, st = xo.trustregion(Q, R0, np.ones(n), lam=wl["lam"], gradtol=wl["tol"], maxtime=budget_s)
+        finally:
+            xo.numa_release()
     el = time.time() - t0
     its = st["tcg_iters"]
     return dict(value=its / max(st["seconds"], 1e-9), unit="tCG iters/s", cores=xo.num_threads(), kind="port",
@@ -134,7 +125,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="venice1778")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--storage", default="dense", choices=["dense", "bsr"], help="storage of view-graph workloads")
+    ap.add_argument("--storage", default="dense", choices=["dense", "bsr", "vg"],
+                    help="storage of view-graph workloads: dense, 3x3-block CSR, or the edge list (XM_STORAGE_VIEWGRAPH: compressed sliced ELL)")
+    ap.add_argument("--retraction", default="qr", choices=["qr", "polar"])
     ap.add_argument("--no-hbm-check", action="store_true", help="skip the 13.5 GB HBM-bound run of the same kernel")
     ap.add_argument("--no-rome", action="store_true", help="skip the Rome-scale (13682-camera view-graph) legs")
     ap.add_argument("--no-rome-dense", action="store_true", help="skip the dense-storage (13.5 GB) Rome-scale leg only")
@@ -148,10 +141,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("XM_BENCH_SINGLE_DEVICE") == "1":      # debugging aid: put every rank on device 0 of a 1-GPU box
         local = 0
+    team = 1            # ranks driven by THIS process (single-process multi-GPU mode of the library)
+    gpu_map = 0
     if world != args.gpus:
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-            self_launch(args)
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+            team = args.gpus
+            gpu_map = 1 if xmamd.device_count() < args.gpus else 0
+        else:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    tkw = dict(n_gpus=team, gpu_map=gpu_map) if team > 1 else {}
+    ngp = world * team   # GPUs (ranks) of the whole job
+    retr = xmamd.RETRACT_POLAR if args.retraction == "polar" else xmamd.RETRACT_QR
     xmamd.require_gpu()
     torch.cuda.set_device(local)
     if world > 1:
@@ -175,16 +175,21 @@ def main():
     Q = None
     if wl["kind"] == "dense":
         Q = tl.gen_dense(wl["n"], seed=wl["seed"])["Q"]
-        ctx = xmamd.Context(Q=Q)
+        ctx = xmamd.Context(Q=Q, **tkw)
         storage_desc = "dense 3n x 3n f64 (%.1f MB)" % (72.0 * wl["n"] ** 2 / 1e6)
     else:
         P = tl.gen_vg(wl["n"], deg=wl["deg"], sigma=wl["sigma"], seed=wl["seed"], dense=False)
         nb = int(P["colidx"].size)
         if args.storage == "dense":
-            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True)   # every rank expands its own rows
+            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True, **tkw)   # every rank expands its own rows
             storage_desc = "dense 3n x 3n f64 built on device from %d blocks (%.1f MB)" % (nb, 72.0 * wl["n"] ** 2 / 1e6)
+        elif args.storage == "vg":
+            e = P["edges"]
+            ctx = xmamd.Context(vg=(e[:, 0], e[:, 1], P["w"], P["M"]), n=wl["n"], **tkw)
+            storage_desc = ("view-graph edge list, %d edges = %d stored blocks (%.1f MB as 3x3-block CSR; the products stream the "
+                            "quaternion-compressed sliced-ELL copy, %.1f MB)" % (e.shape[0], nb, 76.0 * nb / 1e6, 36.0 * (nb - wl["n"]) / 1e6))
         else:
-            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), **tkw)
             storage_desc = "3x3-block CSR, %d blocks (%.1f MB)" % (nb, 76.0 * nb / 1e6)
     gen_s = time.time() - t0
 
@@ -193,16 +198,16 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def one_solve(flags=0):
-        return ctx.solve(wl["max_rank"], wl["tol"], wl["lam"], flags=flags)
+    def one_solve(flags=0, grouping=0):
+        return ctx.solve(wl["max_rank"], wl["tol"], wl["lam"], flags=flags, retraction=retr, grouping=grouping)
 
-    for _ in range(args.warmup):
-        one_solve()
+    for i in range(args.warmup):
+        one_solve(grouping=i % 3)
     barrier()
     t0 = time.perf_counter()
     infos = []
-    for _ in range(args.steps):
-        infos.append(one_solve(flags=xmamd.FLAG_PROFILE_QW)[2])
+    for i in range(args.steps):
+        infos.append(one_solve(flags=xmamd.FLAG_PROFILE_QW, grouping=i % 3)[2])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -218,37 +223,47 @@ def main():
     n = wl["n"]
     o_fin = max(3, last["rank"])
     if wl["kind"] == "dense" or args.storage == "dense":
-        alg_bytes = (8.0 * (3 * n) ** 2) / world + 2 * 8 * 3 * n * o_fin
+        alg_bytes = (8.0 * (3 * n) ** 2) / ngp + 2 * 8 * 3 * n * o_fin
         kname = "qw_dense_kernel<o, EPI_HESS>"
     else:
-        alg_bytes = (76.0 * nb + 4 * (n + 1)) / world + 2 * 8 * 3 * n * o_fin
+        alg_bytes = (76.0 * nb + 4 * (n + 1)) / ngp + 2 * 8 * 3 * n * o_fin      # FULL-storage accounting whatever is streamed
         kname = "qw_bsr3_kernel<o, EPI_HESS>"
-        if os.environ.get("XM_BSR_SELL") == "1" or (os.environ.get("XM_BSR_SELL") != "0" and nb / world >= 1000000):
+        if os.environ.get("XM_BSR_SELL") == "1" or (os.environ.get("XM_BSR_SELL") != "0" and nb / ngp >= 1000000):
             kname = "qw_sell_kernel<o> + sell_reduce_kernel<o, EPI_HESS> (sliced-ELL over per-XCD column slabs; one product = both launches)"
+            if args.storage == "vg":
+                kname += ", view-graph codec: %.1f MB streamed per product for %.1f MB of full storage" % (last["qw_stream_bytes"] / 1e6, 76.0 * nb / ngp / 1e6)
     achieved = alg_bytes / (qw_ms * 1e-3) / 1e9 if qw_ms > 0 else 0.0
     # HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE (own pass, kernel-trace only), corrected as
     # MI355X_MICROARCH.md prescribes (KB -> bytes, x2 for the gfx950 wide-load half count); see profiles/r01_pmc_*.json
     traffic, traffic_source = recorded_traffic(args.workload, world)
     out = {
         "metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
-        "value": iters / elapsed, "unit": "tCG iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": iters / elapsed, "unit": "tCG iters/s", "n_gpus": ngp, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl["desc"], "n_cameras": n, "storage": storage_desc,
                    "max_rank": wl["max_rank"], "tol": wl["tol"], "lam": wl["lam"],
-                   "parallelism": "single GPU" if world == 1 else f"camera row partition x{world}, RCCL all-gather of W per product",
+                   "retraction": args.retraction,
+                   "summation_groupings": "step i uses xm_options_t.sum_grouping = i mod 3; tcg_iters_by_step lists what each drew",
+                   "parallelism": ("single GPU" if ngp == 1 else
+                                   f"camera row partition x{world}, one process per GPU, RCCL all-gather per exchange" if team == 1 else
+                                   f"camera row partition x{team} inside ONE process (xm_problem_t.n_gpus), direct peer-write exchange fused into the tCG"),
                    **({"transport": "shared-memory TEST transport, all ranks on one GPU (functional dry run, not a scaling measurement)"}
-                      if os.environ.get("XM_BENCH_SHM") == "1" else {})},
+                      if os.environ.get("XM_BENCH_SHM") == "1" else {}),
+                   **({"devices": "%d VIRTUAL devices on one GPU (gpu_map = 1): functional run of the %d-rank flow, not a scaling measurement" % (team, team)}
+                      if gpu_map == 1 else {})},
         "solve": {"rank": last["rank"], "status": last["status"], "primal": last["primal"], "dual": last["dual"],
                   "min_eig": last["min_eig"], "tcg_iters_per_solve": last["tcg_iters"], "outer_iters": last["outer_iters"],
                   "qw_products": last["qw_products"], "lanczos_iters": last["lanczos_iters"],
-                  "tr_seconds": last["tr_seconds"], "cert_seconds": last["cert_seconds"], "setup_gen_s": gen_s},
+                  "tr_seconds": last["tr_seconds"], "cert_seconds": last["cert_seconds"], "setup_gen_s": gen_s,
+                  "tcg_iters_by_step": [i["tcg_iters"] for i in infos], "exchange": last.get("exchange")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source, "kernel": kname + (" via the half-traffic symmetric path (qw_sym_kernel + sym_reduce_kernel; bytes counted at FULL storage, SURVEY 8d)" if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); "
-                             "per-rank Q is %.0f MB: below ~256 MB it sits in the Infinity Cache, so the figure is cache-assisted, "
-                             "see roofline_hbm for the HBM-bound run of the same kernel" % (alg_bytes / 1e6)},
+                     "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); " + (
+                             "per-rank Q is %.0f MB, inside the 256 MB Infinity Cache: the figure is cache-assisted, see roofline_hbm for the "
+                             "HBM-bound run of the same kernel" % (alg_bytes / 1e6) if alg_bytes < 250e6 else
+                             "per-rank Q is %.0f MB, beyond the 256 MB Infinity Cache: HBM-bound" % (alg_bytes / 1e6))},
     }
     ctx.close()
     if not args.no_rome and args.workload == "venice1778":
@@ -257,7 +272,7 @@ def main():
         # `value` above stays the Venice-1778 metric.
         wr = workload("final13682")
         Pr = tl.gen_vg(wr["n"], deg=wr["deg"], sigma=wr["sigma"], seed=wr["seed"], dense=False)
-        cr = xmamd.Context(bsr=(Pr["rowptr"], Pr["colidx"], Pr["blocks"]))
+        cr = xmamd.Context(bsr=(Pr["rowptr"], Pr["colidx"], Pr["blocks"]), **tkw)
         cr.solve(wr["max_rank"], wr["tol"], wr["lam"])
         barrier()
         t0 = time.perf_counter()
@@ -272,8 +287,8 @@ def main():
         cr.close()
         nbr = int(Pr["colidx"].size)
         rq = sum(i["qw_ms_sum"] for i in ri) / max(1, sum(i["qw_ms_count"] for i in ri))
-        rb = (76.0 * nbr + 4 * (wr["n"] + 1)) / world + 2 * 8 * 3 * wr["n"] * max(3, ri[-1]["rank"])
-        out["rome_scale"] = {"workload": wr["desc"] + ", 3x3-block CSR, %d blocks (%.1f MB)" % (nbr, 76.0 * nbr / 1e6), "n_gpus": world,
+        rb = (76.0 * nbr + 4 * (wr["n"] + 1)) / ngp + 2 * 8 * 3 * wr["n"] * max(3, ri[-1]["rank"])
+        out["rome_scale"] = {"workload": wr["desc"] + ", 3x3-block CSR, %d blocks (%.1f MB)" % (nbr, 76.0 * nbr / 1e6), "n_gpus": ngp,
                              "value": sum(i["tcg_iters"] for i in ri) / el, "unit": "tCG iters/s", "steps": 2, "warmup": 1,
                              "ms_per_step": el / 2 * 1e3, "rank": ri[-1]["rank"], "status": ri[-1]["status"],
                              "tcg_iters_per_solve": ri[-1]["tcg_iters"], "primal": ri[-1]["primal"],
@@ -281,7 +296,8 @@ def main():
         if not args.no_rome_dense:
             # the same Q in the reference's own storage (dense 3n x 3n f64, 13.5 GB; every rank expands its camera rows on its
             # GPU): the HBM-bound regime where the row partition pays.  ONE timed solve, no warmup (about 700 products of 2 ms each).
-            cd = xmamd.Context(bsr=(Pr["rowptr"], Pr["colidx"], Pr["blocks"]), densify=True)
+            cd = xmamd.Context(bsr=(Pr["rowptr"], Pr["colidx"], Pr["blocks"]), densify=True, **tkw)
+            cd.solve(wr["max_rank"], wr["tol"], wr["lam"], max_time=-1.0)   # warm-up: every rank level stops at its first time check (clocks, first-touch of the workspaces)
             barrier()
             t0 = time.perf_counter()
             di = cd.solve(wr["max_rank"], wr["tol"], wr["lam"], flags=xmamd.FLAG_PROFILE_QW)[2]
@@ -294,13 +310,13 @@ def main():
                 el = float(t[0])
             cd.close()
             dq_ms = di["qw_ms_sum"] / max(1, di["qw_ms_count"])
-            db = 8.0 * (3 * wr["n"]) ** 2 / world + 2 * 8 * 3 * wr["n"] * max(3, di["rank"])
-            out["rome_scale_dense"] = {"workload": wr["desc"] + ", dense 3n x 3n f64 (%.1f GB over %d GPU%s)" % (72.0 * wr["n"] ** 2 / 1e9, world, "" if world == 1 else "s"),
-                                       "n_gpus": world, "value": di["tcg_iters"] / el, "unit": "tCG iters/s", "steps": 1, "warmup": 0,
+            db = 8.0 * (3 * wr["n"]) ** 2 / ngp + 2 * 8 * 3 * wr["n"] * max(3, di["rank"])
+            out["rome_scale_dense"] = {"workload": wr["desc"] + ", dense 3n x 3n f64 (%.1f GB over %d GPU%s)" % (72.0 * wr["n"] ** 2 / 1e9, ngp, "" if ngp == 1 else "s"),
+                                       "n_gpus": ngp, "value": di["tcg_iters"] / el, "unit": "tCG iters/s", "steps": 1, "warmup": "one outer iteration",
                                        "ms_per_step": el * 1e3, "rank": di["rank"], "status": di["status"], "tcg_iters_per_solve": di["tcg_iters"],
                                        "primal": di["primal"], "sym_product": di.get("sym_product"), "hess_launch_ms": dq_ms,
                                        "hess_algorithmic_GBs": db / (dq_ms * 1e-3) / 1e9 if dq_ms > 0 else None}
-    if rank == 0 and world == 1 and not args.no_hbm_check and wl["kind"] == "dense":
+    if rank == 0 and ngp == 1 and not args.no_hbm_check and wl["kind"] == "dense":
         # same kernel, matrix far beyond every cache: 13682 cameras = 13.5 GB of random f64 generated on the device
         nb_, o_ = 13682, 3
         ld_ = xmamd.dense_ld(nb_)
@@ -317,9 +333,9 @@ def main():
                                "algorithmic_bytes_per_launch": by, "kernel": "qw_dense_kernel<3, EPI_PLAIN>",
                                "workload": "same kernel on a 13682-camera (Final-13682-size) 13.5 GB random matrix, 20 launches"}
         del Qbig, Wbig, Obig
-    if rank == 0 and world == 1 and args.cpu_seconds > 0 and Q is not None:
+    if rank == 0 and ngp == 1 and args.cpu_seconds > 0 and Q is not None:
         out["cpu_baseline"] = cpu_baseline(Q, wl, args.cpu_seconds)
-    elif rank == 0 and world == 1 and args.cpu_seconds > 0 and wl["kind"] == "vg" and args.storage == "bsr":
+    elif rank == 0 and ngp == 1 and args.cpu_seconds > 0 and wl["kind"] == "vg" and args.storage in ("bsr", "vg"):
         out["cpu_baseline"] = cpu_baseline(None, wl, args.cpu_seconds, bsr=(P["rowptr"], P["colidx"], P["blocks"]))
     if world > 1:
         xmamd.lib().xm_comm_finalize()

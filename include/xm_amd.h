@@ -45,6 +45,12 @@ extern "C" {
 
 const char *xm_last_error(void);
 const char *xm_version(void);
+/* ABI revision of the structs below.  Revision 3 (this one): xm_problem_t, xm_options_t and xm_result_t START with `struct_size`, which the
+ * caller sets to sizeof(its own struct).  The library copies min(struct_size, its own sizeof) bytes, treats what the caller did not
+ * pass as zero and never writes past the caller's size, so a caller compiled against a shorter (older, revision >= 3) header keeps
+ * working; struct_size == 0 is rejected with XM_ERR_ARG (revisions 1-2 had no size field and are NOT binary compatible). */
+#define XM_ABI_REVISION 3
+int xm_abi_revision(void);
 
 /* ================================================================== 1. file-based surface == the reference's pybind functions */
 /* replaces XM_main.cu:180  solve(): reads <path>/Q.bin, writes <path>/R.bin and <path>/s.bin
@@ -64,11 +70,40 @@ typedef struct xm_ctx xm_ctx_t;
 #define XM_STORAGE_BSR3  1     /* 3x3-block CSR over view-graph edges, both triangles stored */
 #define XM_STORAGE_BSR3_DENSE 2 /* described as BSR3 on the host (same fields), expanded to the dense layout on the device:
                                   each rank builds only its own camera rows (a >= 10k-camera Q never exists on the host) */
+#define XM_STORAGE_VIEWGRAPH 4 /* the north_star workload described by its EDGE LIST: Q = sum_e w_e G_e over view-graph edges e = (i, j), Q_ii += w_e I,
+                                  Q_jj += w_e I, Q_ij = -w_e M_e, Q_ji = Q_ij^T with M_e the measured relative rotation (what xm_ctx_attach_edges takes).
+                                  Stored as 3x3-block CSR; with >= 1 M blocks per GPU the products stream the compressed sliced-ELL copy
+                                  (quaternion per off-diagonal block, one double per diagonal block: 36 B per stored block instead of 76,
+                                  xm-code_amd/csrc/xm_sell.h).  The edges are attached for the XM^2 calls at creation. */
 #define XM_STORAGE_SCHUR 3     /* MATRIX-FREE: Q is never formed.  The problem is the observation list the reference's
                                   utils/creatematrix.py:create_matrix(weight, edges, landmarks) takes (creatematrix.py:51); the product applies
                                   Q = Q1 - Vtp_bar Qtp_bar^{-1} Vtp_bar^T as a factor chain (xm-code_amd/csrc/xm_schur.h).  Single GPU. */
 
+/* Context-creation settings that select kernels / layouts (all 0 = the defaults = automatic choice).  Environment variables of the
+ * same meaning (XM_SYM, XM_BSR_SELL, ... -- scripts/README.md) override a zero field, are read ONCE inside xm_ctx_create and never
+ * afterwards (no getenv during a solve). */
 typedef struct {
+    int32_t sym;               /* half-traffic symmetric dense product: 0 auto (3n >= sym_min_rows, exactly symmetric Q), 1 force (1e-9 asymmetry accepted), -1 off */
+    int32_t sym_min_rows;      /* 0 = 6144 */
+    int32_t sell;              /* sliced-ELL copy of a block-sparse Q: 0 auto (>= 1 M blocks per GPU), 1 force, -1 off */
+    int32_t sell_slabs;        /* 0 = 4 (1, 2, 4, 8) */
+    int32_t sell_lmax;         /* 0 = 64 */
+    int32_t sell_gather;       /* how the rows of W are fetched: 0 = default (records fetched element-per-lane, transposed through LDS), 1 = one record per lane */
+    int32_t sell_codec;        /* 0 auto (view-graph storage: quaternion codec; BSR3: full blocks), 1 full blocks, 2 quaternion codec (XM_ERR_ARG if Q is not a view-graph matrix) */
+    int32_t overlap;           /* split dense products outside the tCG around the all-gather of W: 0 auto (>= overlap_min_mb per rank), -1 off */
+    int32_t overlap_min_mb;    /* 0 = 64 */
+    int32_t cert_dense_rows;   /* certificate: complete tridiagonalisation for 3n <= this; 0 = 384 */
+    int32_t lanczos_mmax;      /* 0 = 400 */
+    int32_t lanczos_restarts;  /* 0 = 12 */
+    int32_t watchdog_s;        /* host spin loops give up after this many seconds without progress; 0 = 600 */
+    int32_t balance;           /* row partition of block-sparse storage: 0 = by stored blocks, 1 = equal camera ranges */
+    int32_t exchange;          /* multi-GPU tCG exchange: 0 auto (direct peer writes when the ranks share this process or IPC is set up, else RCCL),
+                                  1 RCCL all-gather, 2 direct peer writes */
+    int32_t reserved[5];
+} xm_tuning_t;
+
+typedef struct {
+    uint32_t struct_size;      /* sizeof(xm_problem_t) of the CALLER (XM_ABI_REVISION) */
     int64_t n;                 /* cameras */
     int32_t storage;           /* XM_STORAGE_* */
     int32_t q_on_device;       /* dense only: q is a DEVICE pointer already in the solver's padded row-major layout
@@ -87,6 +122,19 @@ typedef struct {
     int64_t q_row0;            /* dense host q only: q holds the rows [q_row0, q_row0 + ldq) of Q (all 3n columns, column-major,
                                   leading dimension ldq); 0 with ldq >= 3n = the whole matrix.  Lets a rank of a multi-GPU run hand
                                   over just its own row strip (xm_solve reads only that strip of Q.bin) */
+    /* XM_STORAGE_VIEWGRAPH: ne edges (edge_i[e], edge_j[e]), 0-based, i != j, no unordered pair twice; edge_w: ne weights;
+     * edge_M: ne x 9 row-major rotations */
+    int64_t ne;
+    const int32_t *edge_i, *edge_j;
+    const double *edge_w, *edge_M;
+    /* SINGLE-PROCESS MULTI-GPU (SURVEY.md 8b "Threading"): n_gpus > 1 row-partitions the cameras over n_gpus devices driven by one host
+     * thread each inside THIS process; every xm_ctx_* call fans out to them and returns the (identical) result of rank 0.  The
+     * reference's callers (1_test_solve.py:42, 3_test_colmap_glomap.py:285) stay single-process scripts.  0 / 1 = one GPU.  The file
+     * surface (xm_solve...) takes the count from the environment variable XM_GPUS. */
+    int32_t n_gpus;
+    int32_t gpu_map;           /* 0: rank g on device g;  1: every rank on device 0 with its own stream ("virtual devices": exercises the
+                                  whole multi-GPU path, peer writes included, on a 1-GPU box) */
+    const xm_tuning_t *tuning; /* NULL = all defaults */
 } xm_problem_t;
 
 #define XM_MODE_SOLVE    0     /* XM_main.cu:180 */
@@ -101,7 +149,13 @@ typedef struct {
                                        reads R_ini.bin and then overwrites it with the identity (XM_main.cu:41,95-103); this flag honours it,
                                        which is what makes the second solve of the XM^2 loop cheap */
 
+#define XM_RETRACT_QR    0     /* the reference's retraction: modified Gram-Schmidt of the 3 rows (Dense/batchedQR.h:9-69, trustregion.h:341-351) */
+#define XM_RETRACT_POLAR 1     /* polar retraction R_i <- (M M^T)^{-1/2} M, M = R_i + xi_i (the orthogonal factor of the 3 x o block, via the 3x3 Gram
+                                  matrix; BASELINE.json north_star names it, the reference uses it only in utils/recoversolution.py:65-86).  Same
+                                  fixed points and certified optimum, different trajectory. */
+
 typedef struct {
+    uint32_t struct_size;      /* sizeof(xm_options_t) of the CALLER */
     uint32_t max_rank;
     double tol, lam, max_time;
     int32_t mode;
@@ -110,9 +164,15 @@ typedef struct {
     int32_t trace_cap;         /* optional per-outer-iteration trace: records of 6 doubles */
     double *trace;             /*   loss, gradnorm, inner_iters, endreason, trstatus, delta (same as the oracle) */
     const double *R_ini;       /* XM_FLAG_WARM_R only: 3n x 3 column-major starting point (rows are re-orthonormalised) */
+    int32_t retraction;        /* XM_RETRACT_* */
+    int32_t sum_grouping;      /* order in which the per-workgroup partial sums of the tCG / outer iteration are added: 0 ascending (default),
+                                  1 descending, 2 even-then-odd.  Every grouping is fixed and bit-reproducible; they differ in the last bits, which
+                                  is enough to change the iteration count at the saddle points of a staircase -- bench.py
+                                  rotates through them so that the headline is not one draw of that lottery */
 } xm_options_t;
 
 typedef struct {
+    uint32_t struct_size;      /* sizeof(xm_result_t) of the CALLER */
     double *R;                 /* caller-allocated 3n x max(max_rank,3)+1, column-major, leading dim 3n */
     double *s;                 /* caller-allocated n (s[0] == 1) */
     int32_t rank;              /* columns of R that are valid (what R.bin would hold) */
@@ -133,12 +193,16 @@ typedef struct {
     int32_t sym_product;       /* 1 when the half-traffic symmetric product was used (dense, single GPU, Q exactly symmetric) */
     int32_t cert_flags;        /* XM_CERT_* bits of the LAST certificate */
     double eig_residual;       /* Ritz residual |S x - theta x| of the last certificate's Lanczos run (reference: exact syevd, checkeig.h:303-318) */
+    int32_t n_gpus;            /* ranks that took part in the solve */
+    int32_t exchange;          /* multi-GPU tCG exchange used: 1 RCCL all-gather, 2 direct peer writes (0 single GPU) */
+    int64_t qw_stream_bytes;   /* bytes of Q one tCG product actually streams (== the matrix part of qw_bytes unless a compressed or
+                                  symmetric path is used) */
 } xm_result_t;
 #define XM_CERT_EIG_NOT_CONVERGED 1   /* Lanczos hit its iteration cap: min_eig is only an upper bound, the certificate was NOT accepted on it */
-#define XM_CERT_EIG_EXACT 2           /* small problem (3n <= XM_CERT_DENSE_ROWS, default 384): the tridiagonalisation of S was run to
-                                       * completion and min_eig is the smallest eigenvalue of the FULL tridiagonal matrix -- the dense
-                                       * path of the reference (Dense/eig.h:35-73 dsyevd, checkeig.h:303-318) with the reduction done
-                                       * matrix-free */
+#define XM_CERT_EIG_EXACT 2           /* small problem (3n <= cert_dense_rows, default 384): the Krylov space of S was EXHAUSTED (3n steps, or an
+                                       * invariant subspace was hit: beta below round-off under full re-orthogonalisation) and min_eig is the
+                                       * smallest eigenvalue of the complete tridiagonal matrix -- the dense path of the reference
+                                       * (Dense/eig.h:35-73 dsyevd, checkeig.h:303-318) with the reduction done matrix-free.  Set AFTER the run. */
 
 int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out);          /* uploads / lays out Q on device 0 (or the rank's device) */
 int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res);
@@ -214,6 +278,13 @@ int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int6
                    int64_t *slice_off, int32_t *slab_start, uint8_t *kind, int64_t *src, int32_t *pslot, int64_t *pptr, int32_t *ridx);
 int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
                    void **handle);
+/* the same with a block codec (xm-code_amd/csrc/xm_sell.h): codec 0 = 9 doubles per block, 1 = view-graph codec (off-diagonal blocks
+ * -w * rotation stored as 4 doubles, diagonal blocks d * I as one double per camera; XM_ERR_ARG when the matrix is not of that form).
+ * row0 = global camera index of row 0 (which column is "the diagonal"). */
+int xm_sell_create2(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
+                    int codec, int64_t row0, void **handle);
+/* host-only: block (row-major 3x3, -w * rotation) -> stored quaternion -> the block the product kernel rebuilds (CPU test of the codec) */
+int xm_sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]);
 void xm_sell_destroy(void *handle);
 int xm_qw_sell(void *handle, int o, const double *dW, double *dOut, double alpha, int gather_mode, void *stream);
 int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gather_mode, int reps, double *ms_avg);
@@ -221,6 +292,9 @@ int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gat
  * Rout = MGS_rows(R + t*D) (Dense/batchedQR.h:42-67), sout = s*exp(t*ds/s) (trustregion.h:19-24), s[0] stays 1 */
 int xm_retract(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t,
                double *dRout, double *dsout, void *stream);
+/* the same with the polar retraction (XM_RETRACT_POLAR): Rout_i = (M M^T)^{-1/2} M, M = R_i + t D_i */
+int xm_retract_polar(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t,
+                     double *dRout, double *dsout, void *stream);
 /* timing helper for bench.py: average milliseconds of `reps` back-to-back xm_qw_dense launches (HIP events) */
 int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
 int xm_qw_bsr3_time(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o, const double *dW,
@@ -241,9 +315,12 @@ int xm_comm_init(int rank, int world, int device, const unsigned char id[128], c
  * 1-GPU box (tests/test_gpu_parity.py::test_two_ranks_one_gpu); `bytes` = capacity of the exchange area */
 int xm_comm_init_shm(int rank, int world, int device, const char *name, size_t bytes);
 int xm_comm_finalize(void);
-/* contiguous camera range [*c0, *c1) owned by `rank`: equal ranges of ceil(n / world) cameras for every storage kind (the
- * last rank is padded with inert cameras inside the solver) */
+/* contiguous camera range [*c0, *c1) owned by `rank` for DENSE storage: equal ranges of ceil(n / world) cameras (the last rank is
+ * padded with inert cameras inside the solver) */
 int xm_partition(int64_t n, int world, int rank, int64_t *c0, int64_t *c1);
+/* the same for block-sparse storage (XM_STORAGE_BSR3 / _VIEWGRAPH): ranges balanced by STORED BLOCKS (rowptr: n + 1 offsets), which
+ * is what a context uses unless xm_tuning_t.balance == 1.  Host only. */
+int xm_partition_blocks(int64_t n, const int64_t *rowptr, int world, int rank, int64_t *c0, int64_t *c1);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,10 @@ int  xmo_read_bin(const char *file, double **data, int *rows, int *cols);       
 int  xmo_write_bin(const char *file, const double *data, int rows, int cols);                   /* main.cu:284-305 */
 void xmo_free(void *p);
 int  xmo_num_threads(void);
+/* host-bandwidth mode of the dense product for bench.py's cpu_baseline (never used by the parity tests): a NUMA-distributed,
+ * first-touch copy of C; while prepared, xmo_qw on a matrix of that size multiplies from it.  0 on success. */
+int  xmo_numa_prepare(int n, const double *C);
+void xmo_numa_release(void);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,16 @@ def trustregion(Cm, R0, s0_ex, lam=0.0, gradtol=1e-6, linesearch_step=0.0, v=Non
     return R, s, pr.value, gt.value, _stats_dict(st, tr)
 
 
+def numa_prepare(Cm):
+    """bench.py's cpu_baseline only: a NUMA-distributed first-touch copy of the dense matrix for the host product"""
+    Cm = _f(Cm)
+    return lib().xmo_numa_prepare(Cm.shape[0] // 3, _p(Cm))
+
+
+def numa_release():
+    lib().xmo_numa_release()
+
+
 def trustregion_bsr(rowptr, colidx, blocks, R0, s0_ex, lam=0.0, gradtol=1e-6, maxtime=1000.0, flags=0, trace=0):
     """The same trust region with Q given as 3x3-block CSR (test-only extension of the oracle: the reference's Q is dense).
     Returns what trustregion() returns."""

@@ -17,13 +17,26 @@ ap.add_argument("--skew", action="store_true", help="add hub cameras (power-law 
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--no-csr", action="store_true")
 ap.add_argument("--reps", type=int, default=100)
+ap.add_argument("--codec", type=int, nargs="+", default=[0], help="0 = 9 doubles per block, 1 = view-graph codec (quaternion per block)")
 a = ap.parse_args()
 n, deg = a.n, a.deg
-tag = f"/tmp/xm_kb_{n}_{deg}_{int(a.band)}{int(a.skew)}.npz"
+vgform = 1 in a.codec        # the codec needs a real view-graph matrix (rotation blocks), also for the banded / hub graphs
+tag = f"/tmp/xm_kb_{n}_{deg}_{int(a.band)}{int(a.skew)}{int(vgform)}.npz"
 if os.path.exists(tag):
     Z = np.load(tag); P = dict(rowptr=Z["rowptr"], colidx=Z["colidx"], blocks=Z["blocks"])
 else:
-    if a.band:
+    if (a.band or a.skew) and vgform:
+        rng0 = np.random.default_rng(n)
+        if a.band:
+            h = deg // 2
+            ei = np.concatenate([np.arange(n - k) for k in range(1, h + 1)]); ej = np.concatenate([np.arange(k, n) for k in range(1, h + 1)])
+        else:
+            H = tl.gen_vg_hubs(n, deg, 50, 0.25, 0.05, seed=n); ei, ej = H["ei"], H["ej"]
+        Rs = tl.haar_so3(rng0, n)
+        M = Rs[ei] @ tl.so3_exp(rng0.standard_normal((ei.size, 3)) * 0.05) @ np.transpose(Rs[ej], (0, 2, 1))
+        rp, ci, bl = tl.vg_from_edges(n, ei, ej, np.ones(ei.size), M)
+        P = dict(rowptr=rp, colidx=ci, blocks=bl)
+    elif a.band:
         h = deg // 2
         lo = np.maximum(np.arange(n) - h, 0); hi = np.minimum(np.arange(n) + h, n - 1)
         cnt = hi - lo + 1
@@ -54,14 +67,15 @@ for o in a.o:
         print(f"CSR  n={n} deg={deg} nb={nb} o={o}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s algorithmic ({by/1e6:.1f} MB)", flush=True)
         if a.check:
             ref = xmamd.from_rm(dO.get(), 3 * n, o)
-    for S in a.slabs:
-        if S not in mats:
-            mats[S] = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=S, lmax=a.lmax)
+    for S in [(S, cd) for S in a.slabs for cd in a.codec]:
+        S, cd = S
+        if (S, cd) not in mats:
+            mats[(S, cd)] = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=S, lmax=a.lmax, codec=cd)
         for gm in a.gather:
             if o == 1 and gm == 1:
                 continue
-            xmamd._chk(L.xm_qw_sell_time(mats[S].h, o, dW.ptr, dO.ptr, gm, a.reps, C.byref(ms)))
-            line = f"SELL n={n} deg={deg} nb={nb} o={o} slabs={S} gather={gm}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s algorithmic = {by/ms.value/1e6/8000:.3f} of 8 TB/s"
+            xmamd._chk(L.xm_qw_sell_time(mats[(S, cd)].h, o, dW.ptr, dO.ptr, gm, a.reps, C.byref(ms)))
+            line = f"SELL n={n} deg={deg} nb={nb} o={o} slabs={S} gather={gm} codec={cd} pipe={os.environ.get('XM_SELL_PIPE', 'dflt')}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s in full-storage accounting = {by/ms.value/1e6/8000:.3f} of 8 TB/s"
             if ref is not None:
                 got = xmamd.from_rm(dO.get(), 3 * n, o)
                 line += f"   rel.err vs CSR kernel {tl.rel_fro(got, ref):.2e}"

@@ -1,0 +1,375 @@
+"""GPU tests of the round-3 additions (run with -m gpu on an MI355X), all through the C ABI of libxm_amd.so:
+view-graph codec of the sliced-ELL product, XM_STORAGE_VIEWGRAPH, polar retraction, single-process multi-GPU (virtual devices:
+every rank on device 0) with the direct peer-write exchange, block-balanced partition, summation groupings, the dense 13.5 GB path."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import uuid
+
+import numpy as np
+import pytest
+
+import xm_testlib as tl
+
+pytestmark = pytest.mark.gpu
+G = tl.GOLDEN
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _weighted_vg(n, deg, seed, sigma=0.3):
+    """view graph with NON-unit weights (the codec folds the weight into the quaternion's norm) and two removed edges (w = 0)"""
+    P = tl.gen_vg(n, deg=deg, sigma=sigma, seed=seed, dense=False)
+    rng = np.random.default_rng(seed + 1)
+    e = P["edges"]
+    w = 10.0 ** rng.uniform(-1.5, 1.5, e.shape[0])
+    if e.shape[0] > 4:
+        w[1] = 0.0; w[-1] = 0.0
+    rowptr, colidx, blocks = tl.vg_from_edges(n, e[:, 0], e[:, 1], w, P["M"])
+    return dict(n=n, ei=e[:, 0].astype(np.int32), ej=e[:, 1].astype(np.int32), w=w, M=P["M"], rowptr=rowptr, colidx=colidx, blocks=blocks)
+
+
+# ---------------------------------------------------------------------------------------------- view-graph codec
+@pytest.mark.parametrize("n,deg,o,slabs,lmax", [(1, 2, 3, 4, 64), (7, 3, 3, 8, 64), (200, 8, 3, 4, 64), (300, 20, 5, 2, 64), (1000, 12, 4, 8, 5),
+                                                (150, 40, 3, 1, 64), (211, 9, 1, 4, 64), (4000, 30, 3, 4, 64)])
+@pytest.mark.parametrize("gather", [0, 1])
+def test_qw_sell_quaternion_codec_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather):
+    """the sliced-ELL product streaming 36 bytes per stored block (quaternion of the relative rotation scaled by sqrt(2w) + column index,
+    diagonal blocks as one double per camera) equals the dense product of the same Q to 1e-12 (blocks are rebuilt in registers, so the
+    difference to the 9-double storage is the codec's 1e-15 round trip); every slab count, both gather modes, cut rows, odd widths"""
+    if o == 1 and gather == 1:
+        pytest.skip("o = 1 has one gather mode")
+    P = _weighted_vg(n, deg, seed=n + o)
+    Q = tl.bsr_to_dense(n, P["rowptr"], P["colidx"], P["blocks"])
+    W = np.random.default_rng(n).standard_normal((3 * n, o))
+    ref = oracle.qw(Q, W, 1.5)
+    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=1)
+    got = M.qw(W, 1.5, gather=gather)
+    M.close()
+    assert tl.rel_fro(got, ref) < 1e-12
+    Mf = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=0)     # general blocks: unchanged bar
+    assert tl.rel_fro(Mf.qw(W, 1.5, gather=gather), ref) < 1e-13
+    Mf.close()
+
+
+def test_quaternion_codec_rejects_general_blocks(xmamd):
+    P = tl.gen_skewed(300, 10, seed=3)                      # random 3x3 blocks: not a view-graph matrix
+    with pytest.raises(xmamd.XmError, match="view-graph codec"):
+        xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], codec=1)
+    V = _weighted_vg(50, 6, seed=9)
+    bad = V["blocks"].copy()
+    d = int(np.nonzero(V["colidx"] == 0)[0][0])            # camera 0's diagonal block gets an off-diagonal entry
+    bad[d, 0, 1] = 0.3
+    with pytest.raises(xmamd.XmError, match="diagonal block"):
+        xmamd.SellMatrix(V["rowptr"], V["colidx"], bad, codec=1)
+
+
+def test_viewgraph_storage_equals_bsr_storage(xmamd, monkeypatch):
+    """XM_STORAGE_VIEWGRAPH (edge list in, quaternion-compressed sliced ELL on the device) against XM_STORAGE_BSR3 of the same Q:
+    same certified optimum; the compressed stream is reported; the edges are attached for the XM^2 calls without xm_ctx_attach_edges"""
+    monkeypatch.setenv("XM_BSR_SELL", "1")                 # force the large-n layout on a test-sized graph
+    P = _weighted_vg(700, 10, seed=11, sigma=0.2)
+    lam = 20.0
+    cb = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+    Rb, sb, ib = cb.solve(5, 1e-9, lam)
+    cb.close()
+    cv = xmamd.Context(vg=(P["ei"], P["ej"], P["w"], P["M"]), n=700)
+    Rv, sv, iv = cv.solve(5, 1e-9, lam)
+    assert iv["rank"] == ib["rank"] and iv["status"] == ib["status"] == 1
+    assert iv["primal"] == pytest.approx(ib["primal"], rel=1e-11)
+    assert tl.rotation_parity(Rv, sv, Rb, sb) < 1e-8
+    nb = P["colidx"].size
+    assert ib["qw_stream_bytes"] >= 76 * nb and iv["qw_stream_bytes"] < 0.52 * ib["qw_stream_bytes"]
+    # XM^2 calls on the view-graph context: residuals sum to the data term, re-weighting rebuilds Q (CSR + compressed copy)
+    res = cv.edge_residuals()
+    sR = tl.scale_rows(Rv, sv)
+    Q = tl.bsr_to_dense(700, P["rowptr"], P["colidx"], P["blocks"])
+    assert float(P["w"] @ res) == pytest.approx(float(np.sum(sR * (Q @ sR))), rel=1e-9)
+    w2 = P["w"].copy(); w2[::7] = 0.0
+    cv.set_edge_weights(w2)
+    r2, c2, b2 = tl.vg_from_edges(700, P["ei"], P["ej"], w2, P["M"])
+    Wt = np.random.default_rng(5).standard_normal((2100, 3))
+    assert tl.rel_fro(cv.qw(Wt), tl.bsr_to_dense(700, r2, c2, b2) @ Wt) < 1e-12
+    cv.close()
+
+
+def test_viewgraph_rejects_duplicate_pairs_and_attach_too(xmamd):
+    """the same unordered pair listed twice would race on one off-diagonal block while the diagonal counts both"""
+    P = tl.gen_vg(30, deg=4, sigma=0.1, seed=2)
+    e = P["edges"]
+    ei = np.concatenate([e[:, 0], e[:1, 1]]).astype(np.int32); ej = np.concatenate([e[:, 1], e[:1, 0]]).astype(np.int32)   # (j, i) of edge 0 again
+    M = np.concatenate([P["M"], P["M"][:1].transpose(0, 2, 1)])
+    with pytest.raises(xmamd.XmError, match="listed twice"):
+        xmamd.Context(vg=(ei, ej, np.ones(ei.size), M), n=30)
+    ctx = xmamd.Context(Q=P["Q"])
+    with pytest.raises(xmamd.XmError, match="listed twice"):
+        ctx.attach_edges(ei, ej, M)
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------- polar retraction
+@pytest.mark.parametrize("o", [3, 4, 6, 10])
+def test_polar_retraction_matches_svd(xmamd, o):
+    """xm_retract_polar: the orthogonal polar factor of every 3 x o block of R + t D (numpy: U V^T of the SVD), small and LARGE steps"""
+    rng = np.random.default_rng(o)
+    n = 77
+    R = np.concatenate([np.linalg.qr(rng.standard_normal((o, 3)))[0].T for _ in range(n)])
+    D = rng.standard_normal((3 * n, o)) * np.repeat(10.0 ** rng.uniform(-3, 2, n), 3)[:, None]
+    s = rng.uniform(0.5, 2.0, n); s[0] = 1.0
+    ds = rng.standard_normal(n)
+    Rn, sn = xmamd.retract(R, s, D, ds, 0.7, polar=True)
+    ref = np.zeros_like(Rn)
+    for i in range(n):
+        U, _, Vt = np.linalg.svd(R[3 * i:3 * i + 3] + 0.7 * D[3 * i:3 * i + 3], full_matrices=False)
+        ref[3 * i:3 * i + 3] = U @ Vt
+    assert np.abs(Rn - ref).max() < 1e-12
+    assert tl.stiefel_defect(Rn) < 1e-13
+    exp = s * np.exp(0.7 * ds / s); exp[0] = 1.0
+    assert np.allclose(sn, exp, rtol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["simple1", "simple2", "synth/dense49", "synth/vg60_cert", "synth/vg40_stair"])
+def test_polar_retraction_reaches_the_golden_optimum(xmamd, name):
+    """XM_RETRACT_POLAR (north_star's retraction; the reference uses MGS-QR): a different trajectory to the same certified
+    optimum -- rank, status, f* and anchored rotations of the goldens to the same bars as the QR runs"""
+    d = os.path.join(G, name)
+    Q = tl.load_bin(os.path.join(d, "Q.bin")); exp = json.load(open(os.path.join(d, "expected.json")))
+    ctx = xmamd.Context(Q=Q)
+    Rq, sq, iq = ctx.solve(exp["max_rank"], exp["tol"], exp["lam"])
+    Rp, sp, ip = ctx.solve(exp["max_rank"], exp["tol"], exp["lam"], retraction=xmamd.RETRACT_POLAR)
+    ctx.close()
+    print(f"{name}: tCG iterations QR {iq['tcg_iters']} / polar {ip['tcg_iters']}, outer {iq['outer_iters']} / {ip['outer_iters']}")
+    assert ip["rank"] == exp["rank"] and ip["status"] == exp["status"]
+    assert ip["primal"] == pytest.approx(exp["f_star"], rel=1e-9, abs=1e-12)
+    assert tl.stiefel_defect(Rp) < 1e-12
+    rot, _ = tl.recover_rotations(Rp, sp)
+    assert tl.rel_fro(rot, np.load(os.path.join(d, "rot_anchor.npy"))) < 1e-6
+    assert tl.rotation_parity(Rp, sp, Rq, sq) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- options that used to be silent
+def test_warm_start_is_honoured_in_the_default_mode(xmamd):
+    """R_ini with MODE_SOLVE used to fall back to the identity start silently"""
+    P = tl.gen_vg(300, deg=8, sigma=0.2, seed=4)
+    ctx = xmamd.Context(Q=P["Q"])
+    R0, s0, i0 = ctx.solve(5, 1e-9, 10.0)
+    R1, s1, i1 = ctx.solve(5, 1e-9, 10.0, R_ini=R0, s_ini=s0, mode=xmamd.MODE_REBUTTLE)
+    R2, s2, i2 = ctx.solve(5, 1e-9, 10.0, R_ini=R0)                      # MODE_SOLVE: scales restart from 1, rotations warm
+    ctx.close()
+    assert i0["status"] == i1["status"] == i2["status"] == 1
+    assert i1["tcg_iters"] < 0.2 * i0["tcg_iters"] and i2["tcg_iters"] < 0.8 * i0["tcg_iters"]
+    assert tl.rotation_parity(R2, s2, R0, s0) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["synth/dense49", "synth/vg40_stair"])
+def test_summation_groupings_reach_the_same_optimum(xmamd, name):
+    """xm_options_t.sum_grouping: three fixed orders for the per-workgroup partial sums -- each bit-reproducible, all at the same
+    certified optimum; iteration counts may differ where a stage ends at a saddle point (what bench.py averages over)"""
+    d = os.path.join(G, name)
+    Q = tl.load_bin(os.path.join(d, "Q.bin")); exp = json.load(open(os.path.join(d, "expected.json")))
+    ctx = xmamd.Context(Q=Q)
+    runs = [ctx.solve(exp["max_rank"], exp["tol"], exp["lam"], grouping=g) for g in (0, 1, 2, 1)]
+    ctx.close()
+    print(name, "tCG iterations by grouping:", [r[2]["tcg_iters"] for r in runs[:3]])
+    assert np.array_equal(runs[1][0], runs[3][0]) and runs[1][2]["tcg_iters"] == runs[3][2]["tcg_iters"]     # a grouping is deterministic
+    for R, s, info in runs:
+        assert info["rank"] == exp["rank"] and info["status"] == exp["status"]
+        assert info["primal"] == pytest.approx(exp["f_star"], rel=1e-9, abs=1e-12)
+        assert tl.rotation_parity(R, s, runs[0][0], runs[0][1]) < 1e-6
+
+
+def test_abi_struct_size_is_checked(xmamd):
+    C = xmamd.C
+    p = xmamd.Problem()                                     # struct_size left at 0: ABI revision < 3 caller
+    h = C.c_void_p()
+    assert xmamd.lib().xm_ctx_create(C.byref(p), C.byref(h)) == -2 and b"struct_size" in xmamd.lib().xm_last_error()
+    # a SHORTER (older revision-3) options struct: everything the caller did not pass is zero = defaults
+    Q = tl.load_bin(os.path.join(G, "synth/dense49", "Q.bin"))
+    ctx = xmamd.Context(Q=Q)
+
+    class OldOptions(C.Structure):
+        _fields_ = xmamd.Options._fields_[:-2]             # without retraction / sum_grouping
+    n = 49
+    R = np.zeros((3 * n, 6), order="F"); s = np.zeros(n)
+    opt = OldOptions(); res = xmamd.Result()
+    opt.struct_size, res.struct_size = C.sizeof(OldOptions), C.sizeof(xmamd.Result)
+    opt.max_rank, opt.tol, opt.lam, opt.max_time = 5, 1e-9, 0.0, 100.0
+    res.R = R.ctypes.data_as(C.c_void_p); res.s = s.ctypes.data_as(C.c_void_p)
+    xmamd._chk(xmamd.lib().xm_ctx_solve(ctx.h, C.cast(C.byref(opt), C.POINTER(xmamd.Options)), C.byref(res)))
+    assert res.status == 1 and res.struct_size == C.sizeof(xmamd.Result)
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------- single-process multi-GPU
+def _team_worker_code():
+    return textwrap.dedent(f"""
+        import sys, os, json
+        sys.path.insert(0, {os.path.join(ROOT, 'xm-code_amd')!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+        import numpy as np, xmamd, xm_testlib as tl
+        mode, world, out, case = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
+        rank = 0
+        kw = {{}}
+        if mode == "team":
+            kw = dict(n_gpus=world, gpu_map=1)
+        elif mode.startswith("shm"):
+            rank = int(mode[3:])
+            xmamd._chk(xmamd.lib().xm_comm_init_shm(rank, world, 0, sys.argv[5].encode(), 64 << 20))
+        if case == "dense":
+            P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)         # odd camera count (padding camera), needs rank escalation
+            ctx = xmamd.Context(Q=P["Q"], **kw); args = (6, 1e-9, 3.0)
+        elif case == "bsr" or case == "sell":
+            P = tl.gen_vg(301, deg=10, sigma=0.1, seed=5)
+            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), **kw); args = (5, 1e-10, 10.0)
+        elif case == "vg":                                        # view-graph storage, quaternion codec forced on, hub cameras
+            H = tl.gen_vg_hubs(600, 8, 3, 0.3, 0.1, seed=8)
+            ctx = xmamd.Context(vg=(H["ei"], H["ej"], H["w"], H["M"]), n=600, **kw); args = (5, 1e-9, 20.0)
+        R, s, info = ctx.solve(*args, trace=4000)
+        extra = {{}}
+        if case == "vg":                                          # XM^2 calls fan out to every rank
+            res = ctx.edge_residuals()
+            w = np.ones(res.size); w[res > np.percentile(res, 95)] = 0.0
+            ctx.set_edge_weights(w)
+            R2, s2, i2 = ctx.solve(*args, R_ini=R, s_ini=s, mode=xmamd.MODE_REBUTTLE)
+            extra = dict(res=res, R2=R2, s2=s2, primal2=i2["primal"], tcg2=i2["tcg_iters"])
+        ctx.close()
+        if rank == 0 or mode.startswith("shm"):
+            np.savez(out, R=R, s=s, primal=info["primal"], rank=info["rank"], status=info["status"], tcg=info["tcg_iters"],
+                     min_eig=info["min_eig"], trace=info["trace"], n_gpus=info["n_gpus"], exchange=info["exchange"], **extra)
+        if mode.startswith("shm"):
+            xmamd.lib().xm_comm_finalize()
+    """)
+
+
+def _run(code, args, env, timeout=600):
+    p = subprocess.run([sys.executable, "-c", code] + [str(a) for a in args], env=env, timeout=timeout, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if p.returncode != 0:
+        print(p.stdout.decode()[-3000:])
+    assert p.returncode == 0
+    return p.stdout.decode()
+
+
+@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("bsr", 2), ("sell", 2), ("bsr", 3)])
+def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, case, world):
+    """xm_problem_t.n_gpus: ONE process, one host thread per rank, direct peer-write exchange fused into cg_step (here as `world`
+    virtual devices on the one GPU of the test box: own stream each, peer pointers are plain pointers).  Must reproduce the
+    `world`-process run over the shared-memory transport BIT FOR BIT (same partition, same arithmetic, same summation orders) --
+    R, s and the whole (loss, |g|, inner count, exit reason) trace -- with the fused exchange (2) and with the un-fused peer
+    all-gather between the launches (XM_EXCHANGE=1)."""
+    code = _team_worker_code()
+    env = dict(os.environ, XM_SHM_TIMEOUT="60", GPU_MAX_HW_QUEUES="8", XM_WATCHDOG_S="60")
+    if case == "sell":
+        env["XM_BSR_SELL"] = "1"
+    name = "/xm_t3_" + uuid.uuid4().hex[:12]
+    outs = [str(tmp_path / f"shm{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, "-c", code, f"shm{r}", str(world), outs[r], case, name], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    for p in procs:
+        o_, _ = p.communicate(timeout=600)
+        if p.returncode != 0:
+            print(o_.decode()[-2000:])
+        assert p.returncode == 0
+    ref = np.load(outs[0])
+    for ex in ("2", "1"):
+        out = str(tmp_path / f"team{ex}.npz")
+        _run(code, ["team", world, out, case], dict(env, XM_EXCHANGE=ex))
+        t = np.load(out)
+        assert int(t["n_gpus"]) == world and int(t["exchange"]) == (2 if ex == "2" else 1)
+        assert int(t["rank"]) == int(ref["rank"]) and int(t["status"]) == int(ref["status"]) == 1 and int(t["tcg"]) == int(ref["tcg"])
+        assert np.array_equal(t["trace"], ref["trace"])
+        assert np.array_equal(t["R"], ref["R"]) and np.array_equal(t["s"], ref["s"])
+
+
+def test_single_process_multi_gpu_viewgraph_hubs_and_xm2(xmamd, tmp_path):
+    """view-graph storage on 2 and 3 virtual devices with HUB cameras (3 cameras see 30 % of the others): the partition is balanced
+    by stored blocks, so the ranges are unequal and every replicated vector is addressed through the padded numbering; the
+    quaternion-compressed sliced ELL is forced on.  The certified optimum equals the single-GPU one, and so does the XM^2 round
+    (residuals, re-weighting, warm re-solve) that fans out to the ranks."""
+    code = _team_worker_code()
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", XM_BSR_SELL="1", XM_WATCHDOG_S="60")
+    one = str(tmp_path / "one.npz")
+    _run(code, ["single", 1, one, "vg"], env)
+    a = np.load(one)
+    H = tl.gen_vg_hubs(600, 8, 3, 0.3, 0.1, seed=8)
+    rp, ci, bl = tl.vg_from_edges(600, H["ei"], H["ej"], H["w"], H["M"])
+    for world in (2, 3):
+        c = [np.zeros(1, dtype=np.int64) for _ in range(2)]
+        cuts = []
+        for r in range(world):
+            c0, c1 = xmamd.C.c_int64(), xmamd.C.c_int64()
+            xmamd._chk(xmamd.lib().xm_partition_blocks(600, rp.ctypes.data_as(xmamd.C.c_void_p), world, r, xmamd.C.byref(c0), xmamd.C.byref(c1)))
+            cuts.append((c0.value, c1.value))
+        sizes = [b - a_ for a_, b in cuts]
+        assert max(sizes) > min(sizes) + 5, sizes                      # the hubs really make the ranges unequal
+        out = str(tmp_path / f"team{world}.npz")
+        _run(code, ["team", world, out, "vg"], env)
+        t = np.load(out)
+        assert int(t["rank"]) == int(a["rank"]) and int(t["status"]) == int(a["status"]) == 1
+        assert float(t["primal"]) == pytest.approx(float(a["primal"]), rel=1e-9)
+        assert tl.rotation_parity(t["R"], t["s"], a["R"], a["s"]) < 1e-6
+        assert np.allclose(t["res"], a["res"], rtol=1e-6, atol=1e-9)
+        assert float(t["primal2"]) == pytest.approx(float(a["primal2"]), rel=1e-8)
+        assert tl.rotation_parity(t["R2"], t["s2"], a["R2"], a["s2"]) < 1e-6
+
+
+def test_file_surface_on_two_virtual_gpus(xmamd, tmp_path):
+    """the reference's own call, XM.solve(path, ...) from a single-process script (1_test_solve.py:42), on two GPUs: XM_GPUS=2"""
+    d = tmp_path / "ds"; d.mkdir()
+    Q = tl.load_bin(os.path.join(G, "simple1", "Q.bin"))
+    tl.save_bin(str(d / "Q.bin"), Q)
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {os.path.join(ROOT, 'xm-code_amd', 'build')!r})
+        import XM
+        XM.solve({str(d)!r}, 3, 1e-16, 0.0, 1000)
+    """)
+    out = _run(code, [], dict(os.environ, XM_GPUS="2", XM_GPU_MAP="1", GPU_MAX_HW_QUEUES="8", XM_WATCHDOG_S="60"))
+    assert "BM finished with rank 3" in out or "Terminate" in out
+    R = tl.load_bin(str(d / "R.bin")); s = tl.load_bin(str(d / "s.bin")).reshape(-1)
+    exp = json.load(open(os.path.join(G, "simple1", "expected.json")))
+    rot, _ = tl.recover_rotations(R, s)
+    assert tl.rel_fro(rot, np.load(os.path.join(G, "simple1", "rot_anchor.npy"))) < 1e-6
+    sR = tl.scale_rows(R, s)
+    assert float(np.sum(sR * (Q @ sR))) == pytest.approx(exp["f_star"], rel=1e-9)
+
+
+def test_a_dead_peer_becomes_an_error_not_a_hang(xmamd, tmp_path):
+    """every device-side wait of the peer exchange is bounded: with the group's spin limit at 2 s and one rank made to skip its push
+    (XM_DEBUG_PEER_MUTE=1) the solve must come back with XM_ERR_COMM, promptly, and the GPU must still work afterwards"""
+    code = textwrap.dedent(f"""
+        import sys, os, time
+        sys.path.insert(0, {os.path.join(ROOT, 'xm-code_amd')!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+        import numpy as np, xmamd, xm_testlib as tl
+        P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
+        ctx = xmamd.Context(Q=P["Q"], n_gpus=2, gpu_map=1)
+        t0 = time.time()
+        try:
+            ctx.solve(6, 1e-9, 3.0)
+            print("NO ERROR")
+        except xmamd.XmError as e:
+            print("ERR", time.time() - t0, e)
+        ctx.close()
+        R, s, info = xmamd.solve_dense(P["Q"], 6, 1e-9, 3.0)
+        print("AFTER", info["status"])
+    """)
+    out = _run(code, [], dict(os.environ, GPU_MAX_HW_QUEUES="8", XM_WATCHDOG_S="2", XM_DEBUG_PEER_MUTE="1"), timeout=300)
+    err = [l for l in out.splitlines() if l.startswith("ERR")]
+    assert err and "-4" in err[0] and float(err[0].split()[1]) < 60.0, out[-800:]
+    assert "AFTER 1" in out
+
+
+# ---------------------------------------------------------------------------------------------- the 13.5 GB dense path
+def test_rome13682_dense_storage_vs_recorded_oracle(xmamd):
+    """the Final-13682-size Q in the reference's own DENSE storage (13.5 GB, expanded on the device) through the half-traffic
+    vertical-sweep symmetric product at its real plan: asserts what only bench.py touched before -- sym_product == 1, the oracle's
+    recorded optimum to 1e-9, rotations within 1e-6"""
+    c = json.load(open(os.path.join(G, "synth", "rome13682_oracle.json")))
+    P = tl.gen_vg(c["n"], deg=c["deg"], sigma=c["sigma"], seed=c["n"], dense=False)
+    ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True)
+    R, s, info = ctx.solve(5, c["tol"], c["lam"])
+    ctx.close()
+    assert info["sym_product"] == 1 and info["rank"] == 3 and info["status"] == 1
+    assert info["qw_stream_bytes"] == 4 * (3 * c["n"]) ** 2            # half the matrix per product
+    assert info["primal"] == pytest.approx(c["f"], rel=1e-9)
+    rot, _ = tl.recover_rotations(R, s)
+    assert tl.rel_fro(rot, np.load(os.path.join(G, "synth", "rome13682_oracle_rot.npy"))) < 1e-6

@@ -128,10 +128,55 @@ def gen_vg(n, deg=20, sigma=0.05, seed=None, dense=True):
     np.add.at(rowptr, rows + 1, 1)
     rowptr = np.cumsum(rowptr)
     out = dict(n=n, rowptr=rowptr, colidx=cols.astype(np.int32), blocks=np.ascontiguousarray(blocks), R_star=Rs,
-               edges=edges)
+               edges=edges, M=np.ascontiguousarray(Mij), w=w)
     if dense:
         out["Q"] = bsr_to_dense(n, rowptr, out["colidx"], blocks)
     return out
+
+
+def vg_from_edges(n, ei, ej, w, M):
+    """3x3-block CSR of Q = sum_e w_e G_e (Q_ii += w I, Q_jj += w I, Q_ij = -w M, Q_ji = Q_ij^T): the numpy statement of what
+    XM_STORAGE_VIEWGRAPH builds from an edge list (diagonal sums in edge order)"""
+    ei = np.asarray(ei); ej = np.asarray(ej); w = np.asarray(w, dtype=np.float64); M = np.asarray(M, dtype=np.float64).reshape(-1, 3, 3)
+    degw = np.zeros(n)
+    for e in range(ei.size):
+        degw[ei[e]] += w[e]; degw[ej[e]] += w[e]
+    rows = np.concatenate([np.arange(n), ei, ej]); cols = np.concatenate([np.arange(n), ej, ei])
+    blocks = np.concatenate([degw[:, None, None] * np.eye(3)[None], -w[:, None, None] * M, -w[:, None, None] * np.transpose(M, (0, 2, 1))], axis=0)
+    order = np.lexsort((cols, rows))
+    rows, cols, blocks = rows[order], cols[order], blocks[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    return np.cumsum(rowptr), cols.astype(np.int32), np.ascontiguousarray(blocks)
+
+
+def gen_vg_hubs(n, deg, hubs, frac, sigma, seed):
+    """view graph with HUB cameras: the Erdos-Renyi graph of gen_vg plus `hubs` cameras that see a fraction `frac` of all others
+    (rows of ~frac*n blocks among rows of ~deg).  Returns the edge list with consistent noisy rotations, unit weights."""
+    edges, rng = gen_vg_edges(n, deg, seed)
+    extra = []
+    for h in range(hubs):
+        hub = int(rng.integers(0, n))
+        others = rng.choice(n, size=int(frac * n), replace=False)
+        extra += [(min(hub, int(c)), max(hub, int(c))) for c in others if int(c) != hub]
+    e = np.concatenate([edges, np.array(extra, dtype=edges.dtype).reshape(-1, 2)], axis=0)
+    key = e[:, 0].astype(np.int64) * n + e[:, 1]
+    _, idx = np.unique(key, return_index=True)
+    e = e[np.sort(idx)]
+    Rs = haar_so3(rng, n)
+    xi = rng.standard_normal((e.shape[0], 3)) * sigma
+    M = Rs[e[:, 0]] @ so3_exp(xi) @ np.transpose(Rs[e[:, 1]], (0, 2, 1))
+    return dict(n=n, ei=e[:, 0].astype(np.int32), ej=e[:, 1].astype(np.int32), w=np.ones(e.shape[0]), M=np.ascontiguousarray(M), R_star=Rs)
+
+
+def xm2_error_numpy(cam, lm, p, w, R_real, s_real, t_est, p_est):
+    """weighted squared residual per observation of a recovered solution: w * | s_i R_i p + t_i - P_l |^2 (what the reference's XM^2
+    loop thresholds, 3_test_colmap_glomap.py:305-316).  R_real: 3 x 3N (block i = columns 3i..3i+2), t_est 3 x N, p_est 3 x M."""
+    N = np.asarray(s_real).size
+    Rm = np.asarray(R_real).reshape(3, N, 3).transpose(1, 0, 2)
+    x = np.asarray(s_real).reshape(-1)[cam, None] * np.einsum("nij,nj->ni", Rm[cam], np.asarray(p)) + np.asarray(t_est)[:, cam].T
+    d = np.asarray(p_est)[:, lm].T - x
+    return np.asarray(w).reshape(-1) * np.sum(d * d, axis=1)
 
 
 def bsr_to_dense(n, rowptr, colidx, blocks):

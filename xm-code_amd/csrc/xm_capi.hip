@@ -11,7 +11,8 @@
 #include "xm_solver.h"
 
 struct xm_ctx {
-    std::unique_ptr<xm::Context> impl;
+    std::unique_ptr<xm::Context> impl;   // one GPU (or one rank of a multi-process run)
+    std::unique_ptr<xm::Team> team;      // n_gpus > 1: single-process multi-GPU
 };
 
 namespace {
@@ -25,6 +26,24 @@ int fail(const std::exception &e) { g_err = e.what(); return XM_ERR_HIP; }
     catch (const xm::Error &e) { return fail(e); }                     \
     catch (const std::bad_alloc &) { g_err = "out of host memory"; return XM_ERR_NOMEM; } \
     catch (const std::exception &e) { return fail(e); }
+
+// Revision-3 structs start with the caller's sizeof: copy what the caller has, zero the rest (include/xm_amd.h, XM_ABI_REVISION)
+template <class T>
+T take_struct(const T *p, const char *what) {
+    T out;
+    std::memset(&out, 0, sizeof(T));
+    if (!p) throw xm::Error(XM_ERR_ARG, std::string(what) + ": null");
+    const uint32_t sz = p->struct_size;
+    if (sz < 16 || sz > 4096) throw xm::Error(XM_ERR_ARG, std::string(what) + ": struct_size is not set (ABI revision 3: the first field of the struct is sizeof(struct))");
+    std::memcpy(&out, p, std::min<size_t>(sz, sizeof(T)));
+    out.struct_size = (uint32_t)sizeof(T);
+    return out;
+}
+void give_result(xm_result_t *dst, const xm_result_t &src, uint32_t caller_size) {
+    xm_result_t tmp = src;
+    tmp.struct_size = caller_size;
+    std::memcpy(dst, &tmp, std::min<size_t>(caller_size, sizeof(xm_result_t)));
+}
 
 void require_device() {
     int cnt = 0;
@@ -110,7 +129,8 @@ int solve_path(const char *dataset_path, unsigned max_rank, double tol, double l
     const std::string base(dataset_path);
     std::vector<double> Q, sini;
     int64_t rows = 0, cols = 0, skip = 0;
-    const xm::Comm &cm = xm::global_comm();
+    const std::shared_ptr<xm::Comm> cmp = xm::default_comm();
+    const xm::Comm &cm = *cmp;
     const bool strip = cm.world > 1;                    // row-partitioned run: this rank needs only the rows of its cameras
     if (strip) peek_bin(base + "/Q.bin", rows, cols, skip);
     else read_bin(base + "/Q.bin", Q, rows, cols);      // XM_main.cu:185
@@ -128,7 +148,11 @@ int solve_path(const char *dataset_path, unsigned max_rank, double tol, double l
     }
     xm_problem_t prob;
     std::memset(&prob, 0, sizeof(prob));
+    prob.struct_size = sizeof(prob);
     prob.n = n; prob.storage = XM_STORAGE_DENSE; prob.q = Q.data(); prob.ldq = rows;
+    // XM_GPUS=N: the reference's own single-process call on N GPUs of this node (XM_GPU_MAP=1: N virtual ranks on device 0)
+    const int n_gpus = (int)std::max(1L, std::min(8L, std::getenv("XM_GPUS") ? std::atol(std::getenv("XM_GPUS")) : 1L));
+    const int gpu_map = std::getenv("XM_GPU_MAP") ? std::atoi(std::getenv("XM_GPU_MAP")) : 0;
     if (strip) {
         const int64_t per = (n + cm.world - 1) / cm.world;                       // same partition as xm_partition / Context
         const int64_t c0 = std::min<int64_t>(n, (int64_t)cm.rank * per), c1 = std::min<int64_t>(n, (int64_t)(cm.rank + 1) * per);
@@ -136,20 +160,25 @@ int solve_path(const char *dataset_path, unsigned max_rank, double tol, double l
         prob.q = Q.data(); prob.ldq = 3 * (c1 - c0); prob.q_row0 = 3 * c0;
         if (c1 == c0) { Q.assign(1, 0.0); prob.q = Q.data(); prob.ldq = 0; prob.q_row0 = 3 * c0; }
     }
-    xm::Context ctx(prob);
+    std::unique_ptr<xm::Context> ctx;
+    std::unique_ptr<xm::Team> team;
+    if (!strip && n_gpus > 1) team.reset(new xm::Team(prob, n_gpus, gpu_map));
+    else ctx.reset(new xm::Context(prob));
     std::vector<double>().swap(Q);
     const unsigned rmax = std::max(3u, max_rank);
     std::vector<double> R((size_t)rows * (rmax + 1), 0.0), s((size_t)n, 1.0);
     xm_options_t opt;
     std::memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt);
     opt.max_rank = max_rank; opt.tol = tol; opt.lam = lam; opt.max_time = max_time; opt.mode = mode;
     opt.flags = verbose ? XM_FLAG_VERBOSE : 0;
     opt.s_ini = sini.empty() ? nullptr : sini.data();
+    if (const char *e = std::getenv("XM_RETRACTION")) opt.retraction = (*e == 'p' || *e == 'P' || *e == '1') ? XM_RETRACT_POLAR : XM_RETRACT_QR;
     xm_result_t res;
     std::memset(&res, 0, sizeof(res));
     res.R = R.data(); res.s = s.data();
-    ctx.solve(opt, res);
-    if (xm::global_comm().rank == 0) {
+    if (team) team->solve(opt, res); else ctx->solve(opt, res);
+    if (cm.rank == 0) {
         write_bin(base + "/R.bin", R.data(), (int32_t)rows, res.rank);   // XM_main.cu:284-294
         if (verbose) printf("saved R\n");
         write_bin(base + "/s.bin", s.data(), (int32_t)n, 1);             // XM_main.cu:298-305
@@ -162,7 +191,8 @@ int solve_path(const char *dataset_path, unsigned max_rank, double tol, double l
 extern "C" {
 
 const char *xm_last_error(void) { return g_err.c_str(); }
-const char *xm_version(void) { return "xm-amd 0.1 (gfx950)"; }
+const char *xm_version(void) { return "xm-amd 0.3 (gfx950)"; }
+int xm_abi_revision(void) { return XM_ABI_REVISION; }
 
 int xm_solve(const char *p, unsigned int max_rank, double tol, double lam, double max_time) {
     XM_TRY return solve_path(p, max_rank, tol, lam, max_time, XM_MODE_SOLVE, nullptr); XM_CATCH
@@ -178,8 +208,16 @@ int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out) {
     XM_TRY
     if (!prob || !out) throw xm::Error(XM_ERR_ARG, "null argument");
     require_device();
+    const xm_problem_t pr = take_struct(prob, "xm_problem_t");
     auto *c = new xm_ctx;
-    try { c->impl.reset(new xm::Context(*prob)); } catch (...) { delete c; throw; }
+    try {
+        if (pr.n_gpus > 1) {
+            if (xm::default_comm()->world > 1) throw xm::Error(XM_ERR_ARG, "n_gpus > 1 inside a multi-process run (xm_comm_init): use one or the other");
+            c->team.reset(new xm::Team(pr, pr.n_gpus, pr.gpu_map));
+        } else {
+            c->impl.reset(new xm::Context(pr));
+        }
+    } catch (...) { delete c; throw; }
     *out = c;
     return XM_OK;
     XM_CATCH
@@ -187,7 +225,11 @@ int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out) {
 int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res) {
     XM_TRY
     if (!ctx || !opt || !res) throw xm::Error(XM_ERR_ARG, "null argument");
-    ctx->impl->solve(*opt, *res);
+    const xm_options_t op = take_struct(opt, "xm_options_t");
+    xm_result_t rs = take_struct(res, "xm_result_t");
+    const uint32_t caller = res->struct_size;
+    if (ctx->team) ctx->team->solve(op, rs); else ctx->impl->solve(op, rs);
+    give_result(res, rs, caller);
     return XM_OK;
     XM_CATCH
 }
@@ -195,6 +237,7 @@ void xm_ctx_destroy(xm_ctx_t *ctx) { delete ctx; }
 int xm_ctx_qw(xm_ctx_t *ctx, int o, const double *W, double *out, double alpha) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
+    if (!ctx->impl) throw xm::Error(XM_ERR_ARG, "xm_ctx_qw: single-GPU contexts only");
     ctx->impl->apply(o, W, out, alpha);
     return XM_OK;
     XM_CATCH
@@ -202,20 +245,21 @@ int xm_ctx_qw(xm_ctx_t *ctx, int o, const double *W, double *out, double alpha) 
 int xm_ctx_attach_edges(xm_ctx_t *ctx, int64_t ne, const int32_t *ei, const int32_t *ej, const double *M) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
-    ctx->impl->attach_edges(ne, ei, ej, M);
+    if (ctx->team) ctx->team->attach_edges(ne, ei, ej, M); else ctx->impl->attach_edges(ne, ei, ej, M);
     return XM_OK;
     XM_CATCH
 }
 int xm_ctx_edge_residuals(xm_ctx_t *ctx, double *res) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
-    ctx->impl->edge_residuals(res);
+    if (ctx->team) ctx->team->edge_residuals(res); else ctx->impl->edge_residuals(res);
     return XM_OK;
     XM_CATCH
 }
 int xm_ctx_recover_tp(xm_ctx_t *ctx, const double *rot, const double *scale, double *t, double *p) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
+    if (!ctx->impl) throw xm::Error(XM_ERR_ARG, "xm_ctx_recover_tp: single-GPU contexts only");
     ctx->impl->recover_tp(rot, scale, t, p);
     return XM_OK;
     XM_CATCH
@@ -223,7 +267,7 @@ int xm_ctx_recover_tp(xm_ctx_t *ctx, const double *rot, const double *scale, dou
 int xm_ctx_set_edge_weights(xm_ctx_t *ctx, const double *w) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
-    ctx->impl->set_edge_weights(w);
+    if (ctx->team) ctx->team->set_edge_weights(w); else ctx->impl->set_edge_weights(w);
     return XM_OK;
     XM_CATCH
 }
@@ -340,6 +384,13 @@ int xm_retract(int64_t n, int o, const double *dR, const double *ds, const doubl
     return XM_OK;
     XM_CATCH
 }
+int xm_retract_polar(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t, double *dRout,
+                     double *dsout, void *stream) {
+    XM_TRY
+    xm::launch_retract(o, (int)n, 0, dR, ds, dD, dds, t, dRout, dsout, nullptr, (hipStream_t)stream, 1);
+    return XM_OK;
+    XM_CATCH
+}
 int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
     XM_TRY
     hipEvent_t e0, e1;
@@ -426,6 +477,22 @@ int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *b
     require_device();
     if (!rowptr || !handle || n < 1) throw xm::Error(XM_ERR_ARG, "bad argument");
     *handle = new xm::SellMatrix(rowptr, colidx, blocks, n, ncols, slabs, lmax, nullptr);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_sell_create2(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
+                    int codec, int64_t row0, void **handle) {
+    XM_TRY
+    require_device();
+    if (!rowptr || !handle || n < 1 || row0 < 0) throw xm::Error(XM_ERR_ARG, "bad argument");
+    *handle = new xm::SellMatrix(rowptr, colidx, blocks, n, ncols, slabs, lmax, nullptr, codec, row0);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]) {
+    XM_TRY
+    if (!block || !quat || !rebuilt) throw xm::Error(XM_ERR_ARG, "null argument");
+    xm::sell_quat_roundtrip(block, quat, rebuilt);
     return XM_OK;
     XM_CATCH
 }
@@ -547,6 +614,16 @@ int xm_partition(int64_t n, int world, int rank, int64_t *c0, int64_t *c1) {
     *c0 = std::min<int64_t>(n, (int64_t)rank * per);
     *c1 = std::min<int64_t>(n, (int64_t)(rank + 1) * per);
     return XM_OK;
+}
+
+int xm_partition_blocks(int64_t n, const int64_t *rowptr, int world, int rank, int64_t *c0, int64_t *c1) {
+    XM_TRY
+    if (n < 0 || !rowptr || world < 1 || rank < 0 || rank >= world || !c0 || !c1) throw xm::Error(XM_ERR_ARG, "bad argument");
+    std::vector<int64_t> cuts;
+    xm::partition_cuts(n, world, rowptr, cuts);
+    *c0 = cuts[(size_t)rank]; *c1 = cuts[(size_t)rank + 1];
+    return XM_OK;
+    XM_CATCH
 }
 
 }  // extern "C"

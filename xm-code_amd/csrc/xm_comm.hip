@@ -1,11 +1,13 @@
-// xm_comm.hip — row-partition communicator: RCCL over xGMI, one process per GPU.
+// xm_comm.hip — row-partition communicators (the reference is single-GPU: memory.h:54 gpu_id == 0, no NCCL anywhere).
 //
-// The reference is single-GPU (memory.h:54 gpu_id == 0, no NCCL anywhere), so this is new design:
-// cameras are split in contiguous equal ranges; per Q*W product one in-place all-gather of the product input W
-// (3*nloc*OP doubles per rank) and, per tCG iteration, two all-gathers of a few hundred partial sums — gathered rather
-// than all-reduced so that every rank adds them in the same fixed order and takes bit-identical branch decisions.
-// RCCL is dlopen()ed at run time (torch bundles its own librccl.so with the same soname; whichever the process already
-// loaded is reused, otherwise /opt/rocm/lib/librccl.so).  No link-time dependency, no collective unless world > 1.
+// Cameras are split in contiguous ranges; per Q*W product outside the truncated CG one in-place all-gather of the product input W
+// (3*nloc*OP doubles per rank) and, per tCG iteration, ONE exchange of [rows of the image of Hp | a few hundred partial sums] —
+// gathered rather than all-reduced so that every rank adds them in the same fixed order and takes bit-identical branch decisions.
+// Three transports behind one interface (xm_solver.h: Comm), each owned by the Context that uses it:
+//   RcclComm  one process per GPU; RCCL is dlopen()ed at run time (torch bundles its own librccl.so with the same soname; whichever
+//             the process already loaded is reused, otherwise /opt/rocm/lib/librccl.so).  No link-time dependency.
+//   ShmComm   TEST transport: the same calls staged through a POSIX shared-memory segment, so several ranks can share ONE GPU.
+//   PeerComm  direct peer writes (this file, bottom): single process, one host thread per GPU, no library call per collective.
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -13,6 +15,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include <cstdlib>
@@ -22,86 +26,78 @@
 
 namespace xm {
 
+using clk = std::chrono::steady_clock;
+static double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// settings: caller's xm_tuning_t, else the XM_* environment (experiments), else the defaults.  Read once per context.
+// ------------------------------------------------------------------------------------------------------------------
+static bool env_has(const char *k) { const char *e = std::getenv(k); return e && *e; }
+static long long env_ll(const char *k, long long d) { const char *e = std::getenv(k); return (e && *e) ? std::atoll(e) : d; }
+static double env_f(const char *k, double d) { const char *e = std::getenv(k); return (e && *e) ? std::atof(e) : d; }
+
+Settings Settings::resolve(const xm_tuning_t *t) {
+    Settings s;
+    xm_tuning_t z;
+    std::memset(&z, 0, sizeof(z));
+    if (t) z = *t;
+    // tri-state switches: field != 0 wins, else the environment (XM_X=1 force, XM_X=0 off), else auto
+    auto tri = [](int field, const char *env) { if (field != 0) return field > 0 ? 1 : -1; if (!env_has(env)) return 0; return env_ll(env, 0) != 0 ? 1 : -1; };
+    s.sym = tri(z.sym, "XM_SYM");
+    s.sym_min_rows = z.sym_min_rows > 0 ? z.sym_min_rows : env_ll("XM_SYM_MIN_ROWS", 6144);
+    s.sell = tri(z.sell, "XM_BSR_SELL");
+    s.sell_slabs = z.sell_slabs > 0 ? z.sell_slabs : (int)env_ll("XM_SELL_SLABS", 4);
+    s.sell_lmax = z.sell_lmax > 0 ? z.sell_lmax : (int)env_ll("XM_SELL_LMAX", 64);
+    s.sell_gather = z.sell_gather > 0 ? 0 : (int)env_ll("XM_SELL_GATHER", 1);
+    s.sell_codec = z.sell_codec > 0 ? z.sell_codec : (int)env_ll("XM_SELL_CODEC", 0);
+    s.overlap = (z.overlap < 0) ? -1 : ((env_has("XM_OVERLAP") && env_ll("XM_OVERLAP", 1) == 0) ? -1 : 0);
+    s.overlap_min_mb = z.overlap_min_mb > 0 ? (double)z.overlap_min_mb : env_f("XM_OVERLAP_MIN_MB", 64.0);
+    s.cert_dense_rows = z.cert_dense_rows > 0 ? z.cert_dense_rows : env_ll("XM_CERT_DENSE_ROWS", 384);
+    s.lanczos_mmax = z.lanczos_mmax > 0 ? z.lanczos_mmax : (int)env_ll("XM_LANCZOS_MMAX", 400);
+    s.lanczos_restarts = z.lanczos_restarts > 0 ? z.lanczos_restarts : (int)env_ll("XM_LANCZOS_RESTARTS", 12);
+    s.watchdog_s = z.watchdog_s > 0 ? (double)z.watchdog_s : env_f("XM_WATCHDOG_S", 600.0);
+    s.balance = z.balance != 0 ? z.balance : (int)env_ll("XM_BALANCE", 0);
+    s.exchange = z.exchange != 0 ? z.exchange : (int)env_ll("XM_EXCHANGE", 0);
+    s.debug_drop_finalize = env_ll("XM_DEBUG_DROP_FINALIZE", -1);
+    s.debug_peer_mute = (int)env_ll("XM_DEBUG_PEER_MUTE", 0);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// base class
+// ------------------------------------------------------------------------------------------------------------------
+Comm::~Comm() { if (trace_) std::fclose(trace_); }
+
+// XM_COMM_TRACE=<prefix>: every collective / marker is appended to <prefix>.<rank> (debugging aid for rank divergence)
+void Comm::note(const char *what, double a, double b) {
+    if (!trace_tried_) {
+        trace_tried_ = true;
+        const char *e = std::getenv("XM_COMM_TRACE");
+        if (e && *e) trace_ = std::fopen((std::string(e) + "." + std::to_string(rank)).c_str(), "w");
+    }
+    if (trace_) { std::fprintf(trace_, "%s %.17g %.17g\n", what, a, b); std::fflush(trace_); }
+}
+
 namespace {
+// ------------------------------------------------------------------------------------------------------------------
+// RCCL
+// ------------------------------------------------------------------------------------------------------------------
 typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef int ncclResult_t;
 constexpr int kNcclFloat64 = 8;  // rccl.h: ncclFloat64 = 8
 
-struct Rccl {
+struct Rccl {   // the library (process-wide: a dlopen handle and its entry points, no communicator state)
     void *handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    ncclComm_t comm = nullptr;
 };
 Rccl g_rccl;
-Comm g_comm;
-
-// Test transport: the same collectives through a POSIX shared-memory segment (device -> host -> shm -> host -> device), so
-// that several ranks can share ONE GPU on a 1-GPU box and the whole row-partitioned solver (partition, padding cameras,
-// identical collective counts on every rank) can be exercised there.  Never used when RCCL is initialised.
-struct ShmHeader {
-    std::atomic<unsigned long long> arrive;   // monotonically increasing barrier counter
-};
-struct Shm {
-    void *base = nullptr;
-    size_t bytes = 0;
-    unsigned long long barriers = 0;           // barriers completed by this rank
-    std::string name;
-    std::vector<double> host;
-    bool async = false;                        // XM_SHM_ASYNC=1: stream-ordered exchange (host functions on the stream)
-    double *stage = nullptr;                   // pinned staging buffer of the stream-ordered variant
-    std::atomic<int> err{0};                   // set by a host function that timed out (it cannot throw)
-    bool active() const { return base != nullptr; }
-};
-Shm g_shm;
-
-void shm_barrier(int world) {
-    ShmHeader *h = static_cast<ShmHeader *>(g_shm.base);
-    h->arrive.fetch_add(1, std::memory_order_acq_rel);
-    g_shm.barriers++;
-    const unsigned long long target = g_shm.barriers * (unsigned long long)world;
-    const auto t0 = std::chrono::steady_clock::now();
-    while (h->arrive.load(std::memory_order_acquire) < target) {
-        static const double limit = [] { const char *e = std::getenv("XM_SHM_TIMEOUT"); return e ? std::atof(e) : 120.0; }();
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
-            throw Error(XM_ERR_COMM, "shared-memory communicator: rank " + std::to_string(g_comm.rank) + " waited too long in barrier #" +
-                                         std::to_string(g_shm.barriers) + " (arrived " + std::to_string(h->arrive.load()) +
-                                         "): ranks issued different collectives?");
-    }
-}
-
-// barrier for code that must not throw (host functions executed by the stream); false on timeout
-bool shm_barrier_nothrow(int world) {
-    ShmHeader *h = static_cast<ShmHeader *>(g_shm.base);
-    h->arrive.fetch_add(1, std::memory_order_acq_rel);
-    g_shm.barriers++;
-    const unsigned long long target = g_shm.barriers * (unsigned long long)world;
-    static const double limit = [] { const char *e = std::getenv("XM_SHM_TIMEOUT"); return e ? std::atof(e) : 120.0; }();
-    const auto t0 = std::chrono::steady_clock::now();
-    while (h->arrive.load(std::memory_order_acquire) < target)
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return false;
-    return true;
-}
-// Stream-ordered variant of the test transport (XM_SHM_ASYNC=1): the exchange runs inside a host function that the STREAM
-// executes between the device-to-host and host-to-device copies, so the calling thread never blocks — exactly like an RCCL
-// collective.  The solver's enqueue-ahead logic is then exercised for real: a rank that enqueues a different number of
-// collectives than its peers leaves a barrier unmatched (time-out -> error flag -> XM_ERR_COMM at the next collective).
-struct ShmOp { size_t count; };
-void shm_exchange_cb(void *p) {
-    ShmOp *op = static_cast<ShmOp *>(p);
-    const size_t count = op->count;
-    delete op;
-    if (g_shm.err.load()) return;
-    double *data = reinterpret_cast<double *>(static_cast<char *>(g_shm.base) + sizeof(ShmHeader) + 64);
-    std::memcpy(data + (size_t)g_comm.rank * count, g_shm.stage + (size_t)g_comm.rank * count, count * sizeof(double));
-    if (!shm_barrier_nothrow(g_comm.world)) { g_shm.err.store(1); return; }
-    std::memcpy(g_shm.stage, data, count * (size_t)g_comm.world * sizeof(double));
-    if (!shm_barrier_nothrow(g_comm.world)) g_shm.err.store(1);
-}
+std::mutex g_mu;
+std::shared_ptr<Comm> g_default;   // installed by xm_comm_init / xm_comm_init_shm for the multi-PROCESS launch (one rank per process)
 
 void load_rccl(const char *path) {
     if (g_rccl.handle) return;
@@ -126,25 +122,121 @@ void load_rccl(const char *path) {
 void check(ncclResult_t r, const char *what) {
     if (r != 0) throw Error(XM_ERR_COMM, std::string("RCCL ") + what + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
 }
+
+struct RcclComm : Comm {
+    ncclComm_t comm = nullptr;
+    ~RcclComm() override { if (comm) g_rccl.CommDestroy(comm); }
+    int kind() const override { return 1; }
+    void allgather(double *buf, size_t count, hipStream_t st) override {
+        note("allgather", (double)count, 0.0);
+        if (!comm) return;
+        check(g_rccl.AllGather(buf + (size_t)rank * count, buf, count, kNcclFloat64, comm, st), "ncclAllGather");
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Test transport: the same collectives through a POSIX shared-memory segment (device -> host -> shm -> host -> device), so
+// that several ranks can share ONE GPU on a 1-GPU box and the whole row-partitioned solver (partition, padding cameras,
+// identical collective counts on every rank) can be exercised there.
+// Invariant: every collective of a ShmComm goes through ONE stream (the owning Context's st_).  The stream-ordered variant keeps a
+// single pinned staging buffer and a plain barrier counter that only the stream's host functions touch; they execute in stream
+// order, so there is never more than one in flight.  finalize() drains the device before the buffer is freed.
+// ------------------------------------------------------------------------------------------------------------------
+struct ShmHeader {
+    std::atomic<unsigned long long> arrive;   // monotonically increasing barrier counter
+};
+struct ShmComm;
+struct ShmOp { ShmComm *c; size_t count; };
+struct ShmComm : Comm {
+    void *base = nullptr;
+    size_t bytes = 0;
+    std::atomic<unsigned long long> barriers{0};   // barriers completed by this rank (host thread or stream callbacks, never both at once)
+    std::string name;
+    bool async = false;                        // XM_SHM_ASYNC=1: stream-ordered exchange (host functions on the stream)
+    double *stage = nullptr;                   // pinned staging buffer of the stream-ordered variant
+    std::atomic<int> err{0};                   // set by a host function that timed out (it cannot throw)
+    double limit = 120.0;
+    hipStream_t bound = nullptr;               // the one stream this communicator is used on (asserted)
+    bool bound_set = false;
+    int kind() const override { return 2; }
+    ~ShmComm() override {
+        if (base) {
+            (void)hipDeviceSynchronize();      // no host function may still be pending when the staging buffer goes away
+            munmap(base, bytes);
+            if (rank == 0) shm_unlink(name.c_str());
+            if (stage) (void)hipHostFree(stage);
+        }
+    }
+    bool barrier_nothrow() {
+        ShmHeader *h = static_cast<ShmHeader *>(base);
+        h->arrive.fetch_add(1, std::memory_order_acq_rel);
+        const unsigned long long target = (barriers.fetch_add(1) + 1) * (unsigned long long)world;
+        const auto t0 = clk::now();
+        while (h->arrive.load(std::memory_order_acquire) < target)
+            if (since(t0) > limit) return false;
+        return true;
+    }
+    void barrier() {
+        if (!barrier_nothrow()) {
+            ShmHeader *h = static_cast<ShmHeader *>(base);
+            throw Error(XM_ERR_COMM, "shared-memory communicator: rank " + std::to_string(rank) + " waited too long in barrier #" +
+                                         std::to_string(barriers.load()) + " (arrived " + std::to_string(h->arrive.load()) +
+                                         "): ranks issued different collectives?");
+        }
+    }
+    double *data() const { return reinterpret_cast<double *>(static_cast<char *>(base) + sizeof(ShmHeader) + 64); }
+    // Stream-ordered variant (XM_SHM_ASYNC=1): the exchange runs inside a host function that the STREAM executes between the
+    // device-to-host and host-to-device copies, so the calling thread never blocks — exactly like an RCCL collective.  The solver's
+    // enqueue-ahead logic is then exercised for real: a rank that enqueues a different number of collectives than its peers
+    // leaves a barrier unmatched (time-out -> error flag -> XM_ERR_COMM at the next collective).
+    static void exchange_cb(void *p) {
+        ShmOp *op = static_cast<ShmOp *>(p);
+        ShmComm *c = op->c;
+        const size_t count = op->count;
+        delete op;
+        if (c->err.load()) return;
+        double *d = c->data();
+        std::memcpy(d + (size_t)c->rank * count, c->stage + (size_t)c->rank * count, count * sizeof(double));
+        if (!c->barrier_nothrow()) { c->err.store(1); return; }
+        std::memcpy(c->stage, d, count * (size_t)c->world * sizeof(double));
+        if (!c->barrier_nothrow()) c->err.store(1);
+    }
+    void allgather(double *buf, size_t count, hipStream_t st) override {
+        note("allgather", (double)count, 0.0);
+        if (!bound_set) { bound = st; bound_set = true; }
+        if (st != bound) {   // a new context took over the communicator: nothing of the previous stream may still be pending
+            XM_HIP_CHECK(hipDeviceSynchronize());
+            bound = st;
+        }
+        const size_t cap = (bytes - sizeof(ShmHeader) - 64) / sizeof(double);
+        if (count * (size_t)world > cap) throw Error(XM_ERR_COMM, "shared-memory communicator: message too large");
+        if (err.load()) throw Error(XM_ERR_COMM, "shared-memory communicator: a stream-ordered exchange timed out (ranks issued different collectives?)");
+        if (async) {
+            XM_HIP_CHECK(hipMemcpyAsync(stage + (size_t)rank * count, buf + (size_t)rank * count, count * sizeof(double), hipMemcpyDeviceToHost, st));
+            XM_HIP_CHECK(hipLaunchHostFunc(st, exchange_cb, new ShmOp{this, count}));
+            XM_HIP_CHECK(hipMemcpyAsync(buf, stage, count * (size_t)world * sizeof(double), hipMemcpyHostToDevice, st));
+            return;
+        }
+        double *d = data();
+        XM_HIP_CHECK(hipMemcpyAsync(d + (size_t)rank * count, buf + (size_t)rank * count, count * sizeof(double), hipMemcpyDeviceToHost, st));
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        barrier();                                // every chunk is in the segment
+        XM_HIP_CHECK(hipMemcpyAsync(buf, d, count * (size_t)world * sizeof(double), hipMemcpyHostToDevice, st));
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        barrier();                                // everybody has read it; the segment may be overwritten
+    }
+    void host_barrier() override { if (!async) barrier(); }
+};
 }  // namespace
 
-Comm &global_comm() { return g_comm; }
-
-// XM_COMM_TRACE=<prefix>: every collective / marker is appended to <prefix>.<rank> (debugging aid for rank divergence)
-static FILE *g_trace = nullptr;
-static void trace_open() {
-    static bool tried = false;
-    if (tried) return;
-    tried = true;
-    const char *e = std::getenv("XM_COMM_TRACE");
-    if (e && *e) g_trace = std::fopen((std::string(e) + "." + std::to_string(g_comm.rank)).c_str(), "w");
-}
-void Comm::note(const char *what, double a, double b) {
-    trace_open();
-    if (g_trace) { std::fprintf(g_trace, "%s %.17g %.17g\n", what, a, b); std::fflush(g_trace); }
+std::shared_ptr<Comm> default_comm() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_default) return g_default;
+    return std::make_shared<Comm>();
 }
 
 void comm_unique_id(unsigned char id[128]) {
+    std::lock_guard<std::mutex> lk(g_mu);
     load_rccl(nullptr);
     ncclUniqueId u;
     check(g_rccl.GetUniqueId(&u), "ncclGetUniqueId");
@@ -154,18 +246,21 @@ void comm_unique_id(unsigned char id[128]) {
 void comm_init(int rank, int world, int device, const unsigned char id[128], const char *lib_path) {
     if (world < 1 || rank < 0 || rank >= world) throw Error(XM_ERR_ARG, "bad rank/world");
     XM_HIP_CHECK(hipSetDevice(device));
-    if (g_rccl.comm) comm_finalize();
+    comm_finalize();
     if (world > 1 && id == nullptr) throw Error(XM_ERR_ARG, "xm_comm_init: world > 1 needs the 128-byte unique id of rank 0");
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto c = std::make_shared<RcclComm>();
     if (world > 1 || id != nullptr) {
         load_rccl(lib_path);
         ncclUniqueId u;
         std::memcpy(u.internal, id, 128);
-        check(g_rccl.CommInitRank(&g_rccl.comm, world, u, rank), "ncclCommInitRank");
+        check(g_rccl.CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank");
     }
-    g_comm.rank = rank;
-    g_comm.world = world;
+    c->rank = rank;
+    c->world = world;
     const char *f = std::getenv("XM_FORCE_COMM");
-    g_comm.forced = (f && *f == '1' && g_rccl.comm != nullptr);
+    c->forced = (f && *f == '1' && c->comm != nullptr);
+    g_default = c;
 }
 
 void comm_init_shm(int rank, int world, int device, const char *name, size_t bytes) {
@@ -179,52 +274,270 @@ void comm_init_shm(int rank, int world, int device, const char *name, size_t byt
     void *p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) throw Error(XM_ERR_COMM, "mmap failed");
-    g_shm.base = p; g_shm.bytes = total; g_shm.barriers = 0; g_shm.name = name;
-    g_shm.err.store(0);
+    auto c = std::make_shared<ShmComm>();
+    c->base = p; c->bytes = total; c->name = name;
+    { const char *e = std::getenv("XM_SHM_TIMEOUT"); c->limit = e ? std::atof(e) : 120.0; }
     const char *as = std::getenv("XM_SHM_ASYNC");
-    g_shm.async = (as && *as == '1');
-    if (g_shm.async) XM_HIP_CHECK(hipHostMalloc((void **)&g_shm.stage, bytes, hipHostMallocDefault));
-    g_comm.rank = rank; g_comm.world = world; g_comm.forced = true;
-    shm_barrier(world);   // everybody has the segment mapped (a fresh segment is zero-filled)
+    c->async = (as && *as == '1');
+    if (c->async) XM_HIP_CHECK(hipHostMalloc((void **)&c->stage, bytes, hipHostMallocDefault));
+    c->rank = rank; c->world = world; c->forced = true;
+    c->barrier();   // everybody has the segment mapped (a fresh segment is zero-filled)
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_default = c;
 }
 
 void comm_finalize() {
-    if (g_shm.base) {
-        munmap(g_shm.base, g_shm.bytes);
-        if (g_comm.rank == 0) shm_unlink(g_shm.name.c_str());
-        if (g_shm.stage) (void)hipHostFree(g_shm.stage);
-        g_shm.base = nullptr; g_shm.bytes = 0; g_shm.barriers = 0; g_shm.name.clear(); g_shm.async = false; g_shm.stage = nullptr;
-        g_shm.err.store(0);
+    std::shared_ptr<Comm> old;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        old.swap(g_default);
     }
-    if (g_rccl.comm) { g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
-    g_comm.rank = 0;
-    g_comm.world = 1;
-    g_comm.forced = false;
+    old.reset();   // contexts that still hold it keep it alive; the process default is a single-rank Comm again
 }
 
-void Comm::allgather(double *buf, size_t count, hipStream_t st) {
-    note("allgather", (double)count, 0.0);
-    if (g_shm.active()) {
-        const size_t cap = (g_shm.bytes - sizeof(ShmHeader) - 64) / sizeof(double);
-        if (count * (size_t)world > cap) throw Error(XM_ERR_COMM, "shared-memory communicator: message too large");
-        if (g_shm.err.load()) throw Error(XM_ERR_COMM, "shared-memory communicator: a stream-ordered exchange timed out (ranks issued different collectives?)");
-        if (g_shm.async) {
-            XM_HIP_CHECK(hipMemcpyAsync(g_shm.stage + (size_t)rank * count, buf + (size_t)rank * count, count * sizeof(double), hipMemcpyDeviceToHost, st));
-            XM_HIP_CHECK(hipLaunchHostFunc(st, shm_exchange_cb, new ShmOp{count}));
-            XM_HIP_CHECK(hipMemcpyAsync(buf, g_shm.stage, count * (size_t)world * sizeof(double), hipMemcpyHostToDevice, st));
-            return;
+// ==================================================================================================================
+// PeerComm: direct peer writes.
+//
+// Every rank owns an ARENA in fine-grained memory of its own device (hipExtMallocWithFlags(hipDeviceMallocFinegrained): remote
+// stores and system-scope atomics are coherent without cache maintenance on either side) that every rank of the group can address:
+//     flags   2 slots x kMaxPeers epoch words for the generic all-gather + 2 x kMaxPeers for the fused tCG exchange
+//     ticket  local arrival counters (which workgroup of a pushing launch finished last)
+//     stage   2 slots x capacity doubles: landing zone of the generic all-gather
+// all-gather(buf, count) = push kernel (each workgroup copies a slice of the rank's chunk into slot s of EVERY peer's stage,
+// system-scope fence, local ticket; the last workgroup stores the epoch into flags[s][me] of every peer) + wait kernel (bounded
+// spin on the world-1 epoch words of slot s, then copies the peers' chunks from the own stage into buf).  Slots alternate; a rank
+// can be at most one collective ahead of its slowest peer (it cannot pass a wait the peer has not pushed for), so two suffice.
+// No host rendezvous, no library: 2 short launches per collective.  The truncated CG does not even pay those: cg_step_kernel pushes
+// the rank's [rows of B | partial sums] chunk into the peers' exchange buffers and waits for theirs inside the launch it needs
+// anyway (xm_kernels.hip, PeerXchg).
+// Every device-side wait is bounded (spin_ticks of the 100 MHz wall clock): a dead or diverged peer turns into an error word that the
+// host reports as XM_ERR_COMM instead of a hung GPU.
+// ==================================================================================================================
+struct PeerGroup {
+    int world = 1;
+    int device[kMaxPeers] = {};
+    double spin_seconds = 20.0;
+    // published by each rank's PeerComm constructor
+    char *arena[kMaxPeers] = {};
+    size_t stage_cap[kMaxPeers] = {};      // doubles per slot
+    double *xbuf[kMaxPeers] = {};          // current tCG exchange buffers
+    std::atomic<int> aborted{0};
+    // reusable host barrier (sense counting)
+    std::mutex mu;
+    std::atomic<unsigned long long> arrive{0};
+    void barrier(unsigned long long &mine, const char *what) {
+        arrive.fetch_add(1, std::memory_order_acq_rel);
+        const unsigned long long target = (++mine) * (unsigned long long)world;
+        const auto t0 = clk::now();
+        while (arrive.load(std::memory_order_acquire) < target) {
+            if (aborted.load()) throw Error(XM_ERR_COMM, std::string("peer group aborted while waiting in ") + what);
+            if (since(t0) > 120.0) throw Error(XM_ERR_COMM, std::string("peer group: a rank did not reach ") + what);
+            std::this_thread::yield();
         }
-        double *data = reinterpret_cast<double *>(static_cast<char *>(g_shm.base) + sizeof(ShmHeader) + 64);
-        XM_HIP_CHECK(hipMemcpyAsync(data + (size_t)rank * count, buf + (size_t)rank * count, count * sizeof(double), hipMemcpyDeviceToHost, st));
-        XM_HIP_CHECK(hipStreamSynchronize(st));
-        shm_barrier(world);                       // every chunk is in the segment
-        XM_HIP_CHECK(hipMemcpyAsync(buf, data, count * (size_t)world * sizeof(double), hipMemcpyHostToDevice, st));
-        XM_HIP_CHECK(hipStreamSynchronize(st));
-        shm_barrier(world);                       // everybody has read it; the segment may be overwritten
-        return;
     }
-    if (!g_rccl.comm) return;
-    check(g_rccl.AllGather(buf + (size_t)rank * count, buf, count, kNcclFloat64, g_rccl.comm, st), "ncclAllGather");
+};
+
+namespace {
+constexpr size_t kFlagWords = 4 * kMaxPeers;                        // [gen slot0 | gen slot1 | tcg par0 | tcg par1]
+constexpr size_t kArenaHead = (kFlagWords + 8) * sizeof(unsigned long long) + 64;   // flags, 4 tickets, error word, pad
+
+struct PeerPtrs {   // by value into the kernels
+    double *stage[kMaxPeers];
+    unsigned long long *flags[kMaxPeers];
+    int world, rank;
+};
+
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+// chunk -> slot of every peer's stage; last workgroup publishes the epoch
+__global__ __launch_bounds__(256) void peer_push_kernel(PeerPtrs pp, const double *__restrict__ chunk, size_t count, size_t slot_off,
+                                                         int fslot, unsigned long long epoch, unsigned long long *ticket) {
+    __shared__ int last;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (int p = 0; p < pp.world; ++p) {
+        if (p == pp.rank) continue;
+        double *dst = pp.stage[p] + slot_off + (size_t)pp.rank * count;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) dst[i] = chunk[i];
+    }
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t + 1 == gridDim.x);
+        if (last) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one pushing launch at a time (stream order)
+    }
+    __syncthreads();
+    if (last && threadIdx.x < pp.world && (int)threadIdx.x != pp.rank) {
+        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(pp.flags[threadIdx.x] + fslot * kMaxPeers + pp.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// wait for the world-1 epochs of the slot, then stage -> buf for the peers' chunks
+__global__ __launch_bounds__(256) void peer_wait_kernel(PeerPtrs pp, double *__restrict__ buf, size_t count, size_t slot_off, int fslot,
+                                                         unsigned long long epoch, long long spin_ticks, unsigned long long *err) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        int good = 1;
+        const long long t0 = wall_clock64();
+        const unsigned long long *f = pp.flags[pp.rank] + fslot * kMaxPeers;
+        for (int p = 0; p < pp.world && good; ++p) {
+            if (p == pp.rank) continue;
+            while (ld_sys(f + p) < epoch) {
+                if (wall_clock64() - t0 > spin_ticks) { good = 0; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (!good) __hip_atomic_store(err, epoch | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ok = good;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: the peers' payload stores precede their flag
+    }
+    __syncthreads();
+    if (!ok) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    const double *src = pp.stage[pp.rank] + slot_off;
+    const size_t total = count * (size_t)pp.world, stride = (size_t)gridDim.x * 256;
+    const size_t own0 = (size_t)pp.rank * count, own1 = own0 + count;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride)
+        if (i < own0 || i >= own1) buf[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct PeerComm : Comm {
+    std::shared_ptr<PeerGroup> g;
+    char *arena = nullptr;
+    size_t cap = 0;                    // doubles per stage slot
+    unsigned long long seq = 0;        // collectives issued (identical on every rank)
+    unsigned long long hb = 0;         // host barriers passed
+    unsigned long long *herr = nullptr;   // host-mapped error word
+    unsigned long long *herr_dev = nullptr;
+    double *xbuf = nullptr;
+    int kind() const override { return 3; }
+    bool peer() const override { return true; }
+    unsigned long long *flags_of(int r) const { return reinterpret_cast<unsigned long long *>(g->arena[r]); }
+    unsigned long long *tickets() const { return reinterpret_cast<unsigned long long *>(arena) + kFlagWords; }
+    double *stage_of(int r) const { return reinterpret_cast<double *>(g->arena[r] + kArenaHead); }
+    long long spin_ticks() const { return (long long)(g->spin_seconds * 1e8); }
+
+    PeerComm(const std::shared_ptr<PeerGroup> &grp, int r) : g(grp) {
+        rank = r; world = grp->world; forced = true;
+        XM_HIP_CHECK(hipHostMalloc((void **)&herr, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(herr, 0, 64);
+        XM_HIP_CHECK(hipHostGetDevicePointer((void **)&herr_dev, herr, 0));
+        if (world > 1) {   // peer access between distinct devices (no-op for virtual devices)
+            for (int p = 0; p < world; ++p) {
+                if (g->device[p] == g->device[rank]) continue;
+                int can = 0;
+                XM_HIP_CHECK(hipDeviceCanAccessPeer(&can, g->device[rank], g->device[p]));
+                if (!can) throw Error(XM_ERR_COMM, "peer communicator: device " + std::to_string(g->device[rank]) + " cannot address device " + std::to_string(g->device[p]));
+                const hipError_t e = hipDeviceEnablePeerAccess(g->device[p], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) XM_HIP_CHECK(e);
+                (void)hipGetLastError();
+            }
+        }
+        alloc_arena(1 << 16);
+    }
+    ~PeerComm() override {
+        (void)hipDeviceSynchronize();
+        if (arena) (void)hipFree(arena);
+        if (xbuf) (void)hipFree(xbuf);
+        if (herr) (void)hipHostFree(herr);
+    }
+    static void *fine_alloc(size_t bytes) {
+        void *p = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) { (void)hipGetLastError(); XM_HIP_CHECK(hipMalloc(&p, bytes)); }   // single-device use does not need it
+        XM_HIP_CHECK(hipMemset(p, 0, bytes));
+        XM_HIP_CHECK(hipDeviceSynchronize());
+        return p;
+    }
+    // collective: every rank (re)allocates its arena with `doubles` per stage slot; nobody may be inside a collective
+    void alloc_arena(size_t doubles) {
+        if (arena) {
+            XM_HIP_CHECK(hipDeviceSynchronize());
+            g->barrier(hb, "arena re-allocation (drain)");   // every rank has drained: no remote store into the old arenas is in flight
+            (void)hipFree(arena);
+        }
+        cap = doubles;
+        arena = static_cast<char *>(fine_alloc(kArenaHead + 2 * cap * sizeof(double)));
+        g->arena[rank] = arena;
+        g->stage_cap[rank] = cap;
+        seq = 0;   // fresh flag words everywhere
+        g->barrier(hb, "arena allocation");
+        for (int p = 0; p < world; ++p)
+            if (g->stage_cap[p] != cap) throw Error(XM_ERR_COMM, "peer communicator: ranks reserved different staging sizes");
+    }
+    void reserve(size_t doubles) override {
+        if (doubles <= cap) { g->barrier(hb, "reserve"); return; }   // same decision on every rank (same argument)
+        alloc_arena(doubles + 1024);
+    }
+    void host_barrier() override { g->barrier(hb, "barrier"); }
+    void check_device_error() override {
+        if (g->aborted.load()) throw Error(XM_ERR_COMM, "peer group aborted (another rank failed)");
+        const unsigned long long e = *reinterpret_cast<volatile unsigned long long *>(herr);
+        if (e != 0) {
+            g->aborted.store(1);
+            throw Error(XM_ERR_COMM, "peer exchange: rank " + std::to_string(rank) + " waited more than " + std::to_string(g->spin_seconds) +
+                                         " s for a peer (epoch " + std::to_string(e & ~(1ull << 63)) + "): peer failed, or the ranks diverged");
+        }
+    }
+    PeerPtrs ptrs() const {
+        PeerPtrs pp;
+        std::memset(&pp, 0, sizeof(pp));
+        pp.world = world; pp.rank = rank;
+        for (int p = 0; p < world; ++p) { pp.stage[p] = stage_of(p); pp.flags[p] = flags_of(p); }
+        return pp;
+    }
+    void allgather(double *buf, size_t count, hipStream_t st) override {
+        note("allgather", (double)count, 0.0);
+        check_device_error();
+        if (count * (size_t)world > cap) throw Error(XM_ERR_COMM, "peer communicator: message larger than the reserved staging area");
+        if (count == 0) return;
+        ++seq;
+        const int slot = (int)(seq & 1);
+        const size_t slot_off = (size_t)slot * cap;
+        const PeerPtrs pp = ptrs();
+        if (world > 1) {
+            const int grid = (int)std::min<size_t>(64, (count + 2047) / 2048);
+            hipLaunchKernelGGL(peer_push_kernel, dim3(grid), dim3(256), 0, st, pp, buf + (size_t)rank * count, count, slot_off, slot, seq, tickets() + slot);
+            const int wgrid = (int)std::min<size_t>(128, (count * world + 2047) / 2048);
+            hipLaunchKernelGGL(peer_wait_kernel, dim3(wgrid), dim3(256), 0, st, pp, buf, count, slot_off, slot, seq, spin_ticks(), herr_dev);
+            check_launch("peer_allgather");
+        }
+    }
+    // collective (host-synchronised): fresh tCG exchange buffer
+    void xchg_setup(size_t doubles, PeerXchg &out) override {
+        XM_HIP_CHECK(hipDeviceSynchronize());
+        g->barrier(hb, "exchange buffer (drain)");
+        if (xbuf) (void)hipFree(xbuf);
+        xbuf = static_cast<double *>(fine_alloc(std::max<size_t>(doubles, 8) * sizeof(double)));
+        g->xbuf[rank] = xbuf;
+        // the tCG flag words restart from zero with every buffer: epochs are (run << 12 | iteration + 1), compared with >=
+        XM_HIP_CHECK(hipMemset(flags_of(rank) + 2 * kMaxPeers, 0, 2 * kMaxPeers * sizeof(unsigned long long)));
+        XM_HIP_CHECK(hipDeviceSynchronize());
+        g->barrier(hb, "exchange buffer");
+        out = PeerXchg();
+        out.world = world; out.rank = rank;
+        for (int p = 0; p < world; ++p) { out.buf[p] = g->xbuf[p]; out.flag[p] = flags_of(p) + 2 * kMaxPeers; }
+        out.ticket = tickets() + 2;
+        out.err = herr_dev;
+        out.spin_ticks = spin_ticks();
+    }
+};
+}  // namespace
+
+std::shared_ptr<PeerGroup> peer_group_create(int world, const int *devices, double spin_seconds) {
+    if (world < 1 || world > kMaxPeers) throw Error(XM_ERR_ARG, "n_gpus must be 1.." + std::to_string(kMaxPeers));
+    auto g = std::make_shared<PeerGroup>();
+    g->world = world;
+    for (int r = 0; r < world; ++r) g->device[r] = devices[r];
+    if (spin_seconds > 0) g->spin_seconds = spin_seconds;
+    return g;
+}
+std::shared_ptr<Comm> peer_comm_create(const std::shared_ptr<PeerGroup> &g, int rank) { return std::make_shared<PeerComm>(g, rank); }
+void peer_group_abort(const std::shared_ptr<PeerGroup> &g) { if (g) g->aborted.store(1); }
 
 }  // namespace xm

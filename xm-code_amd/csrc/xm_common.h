@@ -88,6 +88,20 @@ struct CamArgs {
 
 enum Epilogue { EPI_PLAIN = 0, EPI_GRAD = 1, EPI_HESS = 2, EPI_CERT = 3 };
 
+// Direct peer-write exchange of the truncated CG (peer communicators, xm_comm.hip): device-visible description, by value into
+// cg_step_kernel.  world == 0: no exchange (single GPU, or a communicator that gathers between the launches).
+constexpr int kMaxPeers = 8;
+struct PeerXchg {
+    int world = 0, rank = 0;
+    double *buf[kMaxPeers] = {};                // every rank's exchange buffer (2 parities x world chunks); [rank] = this rank's own
+    unsigned long long *flag[kMaxPeers] = {};   // every rank's tCG flag words: flag[r][parity * kMaxPeers + source]
+    unsigned long long *ticket = nullptr;       // this rank's arrival counters (one per parity)
+    unsigned long long *err = nullptr;          // this rank's error word (a bounded spin expired), host-mapped
+    long long spin_ticks = 0;                   // bound of every device-side wait, in wall_clock64() ticks (100 MHz)
+    unsigned long long epoch_base = 0;          // epochs of this tCG run are epoch_base + iteration + 1 (identical on all ranks)
+    int mute = 0;                               // tests: this rank never publishes its epoch (a dead peer)
+};
+
 // ---- launchers implemented in xm_kernels.hip -------------------------------------------------------------------
 // Q*W products.  grid = ceil(nloc / kQwWaves).  Q rows are the local cameras' rows; W has `ld` rows (all cameras).
 void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a,
@@ -124,13 +138,14 @@ void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next
                     const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
                     double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat, double *Afull,
-                    double *Wfull, hipStream_t st);
+                    double *Wfull, int grouping, const struct PeerXchg &xchg, hipStream_t st);
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs,
                         const double *rgR, const double *rgs, const double *s, double *parts, hipStream_t st);
 void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,
-                           unsigned long long seq, hipStream_t st);
+                           unsigned long long seq, int grouping, hipStream_t st);
+// polar != 0: polar retraction (XM_RETRACT_POLAR) instead of the reference's Gram-Schmidt retraction
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
-                    double *Rout, double *sout, double *Wloc, hipStream_t st);
+                    double *Rout, double *sout, double *Wloc, hipStream_t st, int polar = 0);
 void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *QsR, const double *R, const double *s,
                          double *Lam, double *dz, double *parts, hipStream_t st);
 // solution recovery
@@ -156,6 +171,11 @@ void launch_edge_write(bool dense, int64_t ne, const int32_t *ei, const int32_t 
                        double *blocks, double *Q, int64_t ld, hipStream_t st);
 void launch_edge_residual(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M, const double *Y, int o, int OP, double *res,
                           hipStream_t st);
+
+// XM^2 outlier filter (weighted residuals, radix select of an order statistic, weight filter)
+void launch_xm2_error(int64_t n, const double *w, const double *res, double *err, hipStream_t st);
+void launch_radix_hist(int64_t n, const double *x, int shift, unsigned long long prefix, unsigned int *hist, hipStream_t st);
+void launch_xm2_filter(int64_t n, const double *err, const double *w, double thr, double *wout, unsigned int *removed, hipStream_t st);
 
 // ---- host-side launch helpers shared by the kernel translation units ---------------------------------------------
 #define XM_DISPATCH_O(o, CALL)                                                         \

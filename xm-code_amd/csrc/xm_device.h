@@ -57,20 +57,27 @@ __device__ __forceinline__ double block_sum256(double v, double *sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// Order in which a list of per-workgroup partial sums is added (xm_options_t.sum_grouping): 0 ascending, 1 descending, 2 even
+// entries then odd entries.  Each is a fixed order (bit-reproducible runs); they differ in the last bits of the sums.
+__device__ __forceinline__ int sum_perm(int i, int count, int grp) {
+    if (grp == 1) return count - 1 - i;
+    if (grp == 2) { const int h = (count + 1) >> 1; return (i < h) ? 2 * i : 2 * (i - h) + 1; }
+    return i;
+}
 // fixed-order sum of an array of partials by one 256-thread block (identical in every kernel that needs it)
-__device__ __forceinline__ double sum_partials256(const double *p, int count, double *sh) {
+__device__ __forceinline__ double sum_partials256(const double *p, int count, double *sh, int grp = 0) {
     double v = 0.0;
-    for (int i = threadIdx.x; i < count; i += 256) v += p[i];
+    for (int i = threadIdx.x; i < count; i += 256) v += p[sum_perm(i, count, grp)];
     return block_sum256(v, sh);
 }
 
 // four such sums with ONE pair of barriers and all loads in flight together (each sum keeps exactly the summation tree of
 // sum_partials256, so results are bit-identical); the fourth array may have its own length (0 = skip)
 __device__ __forceinline__ void sum_partials256_x4(const double *p0, const double *p1, const double *p2, int count, const double *p3,
-                                                   int count3, double *sh16, double (&out)[4]) {
+                                                   int count3, double *sh16, double (&out)[4], int grp = 0) {
     double v[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < count; i += 256) { v[0] += p0[i]; v[1] += p1[i]; v[2] += p2[i]; }
-    for (int i = threadIdx.x; i < count3; i += 256) v[3] += p3[i];
+    for (int i = threadIdx.x; i < count; i += 256) { const int j = sum_perm(i, count, grp); v[0] += p0[j]; v[1] += p1[j]; v[2] += p2[j]; }
+    for (int i = threadIdx.x; i < count3; i += 256) v[3] += p3[sum_perm(i, count3, grp)];
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
     __syncthreads();

@@ -21,6 +21,7 @@
 //
 // No MFMA on this path (no dense contraction with reuse); everything is float64 like the reference
 // (Optimization/optimization.h:9).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -930,10 +931,11 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
                                                        double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR,
                                                        const double *__restrict__ rs_cur, double *rs_next, double *Wloc,
                                                        double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat,
-                                                       double *Afull, double *Wfull) {
+                                                       double *Afull, double *Wfull, int grp, PeerXchg x) {
     constexpr int OP = pitch_of(O);
     __shared__ double sh[4];
     __shared__ double sh16[16];
+    __shared__ int sh_flag;
     const int64_t total = (int64_t)nloc * 3 * OP;
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -950,6 +952,64 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
         if (lead) *scal_next = sc0;
         return;
     }
+    if (x.world > 1) {
+        // DIRECT PEER EXCHANGE fused into this launch (peer communicators, xm_comm.hip): `parts` is this rank's exchange buffer for the
+        // parity of this iteration; its own chunk [rows of B | 3 nA sums of this iteration's Hessian epilogue | nB sums of the previous
+        // cg_step] is complete (earlier launches of this stream).  Every workgroup stores a slice of it into the SAME place of every
+        // peer's buffer, fences at system scope and takes a ticket; the last one publishes the epoch to the peers' flag words.  Then
+        // everybody waits (bounded) for the peers' epochs and goes on with identical data on every rank.  Launches that find the tCG
+        // finished returned above without touching the exchange, so ranks may enqueue ahead freely.
+        const int par = sc0.iter & 1;
+        const size_t chunk_d = (size_t)b_off + 3 * (size_t)nA_loc + nB_loc;
+        const size_t off = ((size_t)par * x.world + x.rank) * chunk_d;
+        const unsigned long long epoch = x.epoch_base + (unsigned long long)sc0.iter + 1ull;
+        const double *src = x.buf[x.rank] + off;
+        for (int p = 0; p < x.world; ++p) {
+            if (p == x.rank) continue;
+            double *dst = x.buf[p] + off;
+            for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < chunk_d; j += (size_t)stride) dst[j] = src[j];
+        }
+        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t = __hip_atomic_fetch_add(x.ticket + par, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            sh_flag = (t + 1 == gridDim.x);
+            if (sh_flag) __hip_atomic_store(x.ticket + par, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (sh_flag && !x.mute && threadIdx.x < x.world && (int)threadIdx.x != x.rank) {
+            __threadfence_system();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(x.flag[threadIdx.x] + par * kMaxPeers + x.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int good = 1;
+            const long long t0 = wall_clock64();
+            const unsigned long long *f = x.flag[x.rank] + par * kMaxPeers;
+            for (int p = 0; p < x.world && good; ++p) {
+                if (p == x.rank) continue;
+                while (__hip_atomic_load(f + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+                    if (wall_clock64() - t0 > x.spin_ticks) { good = 0; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (!good) __hip_atomic_store(x.err, epoch | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sh_flag = good;
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        __syncthreads();
+        if (!sh_flag) {   // a peer never arrived: end the tCG with an error status (the host reports XM_ERR_COMM)
+            if (lead) {
+                TcgScal nx = sc0; nx.status = 7;
+                *scal_next = nx;
+                publish_host(hstat, pack_stat(nx.iter, nx.status));
+            }
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
     // `parts` = the gathered per-rank chunks [ <p,Hp> | <r,Hp> | <Hp,Hp> (nA_loc each, from this iteration's Hessian epilogue)
     //                                          | |r|^2 partials of the PREVIOUS iteration's cg_step (nB_loc) ]
     // (multi-rank: each chunk starts with b_off doubles = that rank's rows of the image of Hp, see below)
@@ -958,7 +1018,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
     for (int r = 0; r < world; ++r) {
         const double *pa = parts + (size_t)r * chunk + b_off;
         double t[4];
-        sum_partials256_x4(pa, pa + nA_loc, pa + 2 * nA_loc, nA_loc, pa + 3 * nA_loc, (sc0.iter > 0) ? nB_loc : 0, sh16, t);
+        sum_partials256_x4(pa, pa + nA_loc, pa + 2 * nA_loc, nA_loc, pa + 3 * nA_loc, (sc0.iter > 0) ? nB_loc : 0, sh16, t, grp);
         pHp += t[0]; rHp += t[1]; HpHp += t[2];
         if (sc0.iter > 0) rr_prev += t[3];
     }
@@ -1092,14 +1152,14 @@ __global__ __launch_bounds__(256) void model_value_kernel(int nloc, const double
 // is written last.  Replaces three device-to-host copies and a stream synchronisation per outer iteration.
 __global__ __launch_bounds__(256) void outer_finalize_kernel(const double *__restrict__ partsA, int nA_loc, int world,
                                                               const double *__restrict__ partsM, int nM,
-                                                              const TcgScal *__restrict__ scal, double *hres, unsigned long long seq) {
+                                                              const TcgScal *__restrict__ scal, double *hres, unsigned long long seq, int grp) {
     __shared__ double sh[4];
     double f = 0.0, rr = 0.0;
     for (int r = 0; r < world; ++r) {   // same grouping as the host-side summation it replaces: rank by rank
-        f += sum_partials256(partsA + (size_t)r * 2 * nA_loc, nA_loc, sh);
-        rr += sum_partials256(partsA + (size_t)r * 2 * nA_loc + nA_loc, nA_loc, sh);
+        f += sum_partials256(partsA + (size_t)r * 2 * nA_loc, nA_loc, sh, grp);
+        rr += sum_partials256(partsA + (size_t)r * 2 * nA_loc + nA_loc, nA_loc, sh, grp);
     }
-    const double m = sum_partials256(partsM, nM, sh);
+    const double m = sum_partials256(partsM, nM, sh, grp);
     if (threadIdx.x == 0) {
         const TcgScal sc = *scal;
         __hip_atomic_store(hres + 0, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1118,7 +1178,53 @@ __global__ __launch_bounds__(256) void outer_finalize_kernel(const double *__res
 // ----------------------------------------------------------------------------------------------------------------
 // Rout_i = MGS_rows(R_i + t D_i)  (Dense/batchedQR.h:42-67),  sout = s exp(t ds / s)  (trustregion.h:19-24),
 // Wloc_i = sout_i * Rout_i  (the next product's input, trustregion.h:677).  The anchor's scale stays untouched.
+__device__ __forceinline__ double det3(const double (&M)[3][3]);
+// Polar retraction (XM_RETRACT_POLAR): the orthogonal factor U = (M M^T)^{-1/2} M of the 3 x O block M = R_i + t D_i -- the closest point
+// of St(3, O) -- by the scaled Newton iteration X <- (g X + (X X^T)^{-1} X / g) / 2 on the 3 x O block itself (every step needs only
+// the 3x3 Gram matrix and its cofactors; quadratically convergent; g = (|(X X^T)^{-1} X|_F / |X|_F)^(1/2) removes the slow start of
+// a long step).  The reference uses this projection only after the solve (utils/recoversolution.py:65-86, via SVD).
 template <int O>
+__device__ __forceinline__ void polar_rows(double (&X)[3][O]) {
+    for (int it = 0; it < 40; ++it) {
+        double G[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = a; b < 3; ++b) {
+                double tt = 0.0;
+#pragma unroll
+                for (int k = 0; k < O; ++k) tt += X[a][k] * X[b][k];
+                G[a][b] = tt; G[b][a] = tt;
+            }
+        const double d = det3(G);
+        if (!(d > 0.0)) return;   // rank-deficient block: leave it (the caller's MGS would divide by zero as well)
+        double C[3][3];           // adjugate of the symmetric G: G^{-1} = C / d
+        C[0][0] = G[1][1] * G[2][2] - G[1][2] * G[2][1]; C[0][1] = G[0][2] * G[2][1] - G[0][1] * G[2][2]; C[0][2] = G[0][1] * G[1][2] - G[0][2] * G[1][1];
+        C[1][1] = G[0][0] * G[2][2] - G[0][2] * G[2][0]; C[1][2] = G[0][2] * G[1][0] - G[0][0] * G[1][2]; C[2][2] = G[0][0] * G[1][1] - G[0][1] * G[1][0];
+        C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
+        double Y[3][O], nx = 0.0, ny = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                const double y = (C[a][0] * X[0][k] + C[a][1] * X[1][k] + C[a][2] * X[2][k]) / d;
+                Y[a][k] = y; nx += X[a][k] * X[a][k]; ny += y * y;
+            }
+        const double g = sqrt(sqrt(ny / nx));
+        double delta = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                const double z = 0.5 * (g * X[a][k] + Y[a][k] / g);
+                delta += (z - X[a][k]) * (z - X[a][k]);
+                X[a][k] = z;
+            }
+        if (delta < 1e-31) return;
+    }
+}
+
+template <int O, int POLAR>
 __global__ __launch_bounds__(256) void retract_kernel(int nloc, int cam0, const double *__restrict__ R, const double *__restrict__ s,
                                                        const double *__restrict__ D, const double *__restrict__ ds, double t,
                                                        double *Rout, double *sout, double *Wloc) {
@@ -1131,21 +1237,25 @@ __global__ __launch_bounds__(256) void retract_kernel(int nloc, int cam0, const 
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < O; ++k) q[r][k] = R[base + r * OP + k] + t * D[base + r * OP + k];
+    if constexpr (POLAR) {
+        polar_rows<O>(q);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double qq = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            double qq = 0.0;
 #pragma unroll
-        for (int k = 0; k < O; ++k) qq += q[i][k] * q[i][k];
-        qq = sqrt(qq);
+            for (int k = 0; k < O; ++k) qq += q[i][k] * q[i][k];
+            qq = sqrt(qq);
 #pragma unroll
-        for (int k = 0; k < O; ++k) q[i][k] /= qq;
+            for (int k = 0; k < O; ++k) q[i][k] /= qq;
 #pragma unroll
-        for (int j = i + 1; j < 3; ++j) {
-            double uu = 0.0;
+            for (int j = i + 1; j < 3; ++j) {
+                double uu = 0.0;
 #pragma unroll
-            for (int k = 0; k < O; ++k) uu += q[i][k] * q[j][k];
+                for (int k = 0; k < O; ++k) uu += q[i][k] * q[j][k];
 #pragma unroll
-            for (int k = 0; k < O; ++k) q[j][k] -= uu * q[i][k];
+                for (int k = 0; k < O; ++k) q[j][k] -= uu * q[i][k];
+            }
         }
     }
     const double so = s[cam];
@@ -1521,9 +1631,47 @@ __global__ __launch_bounds__(256) void edge_residual_kernel(int64_t ne, const in
     res[e] = acc;
 }
 
+// ---- XM^2 outlier filter on the device (reference: np.percentile(error, 90) and the index filter, 3_test_colmap_glomap.py:316-324) ----
+// err = w .* res
+__global__ __launch_bounds__(256) void xm2_error_kernel(int64_t n, const double *__restrict__ w, const double *__restrict__ res, double *__restrict__ err) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) err[e] = w[e] * res[e];
+}
+// One pass of a most-significant-digit radix SELECT over non-negative doubles (their bit patterns order like unsigned integers):
+// histogram of the 16 bits at `shift` over the elements whose higher bits equal `prefix`.  Integer atomics: exact and order-free.
+__global__ __launch_bounds__(256) void radix_hist_kernel(int64_t n, const double *__restrict__ x, int shift, unsigned long long prefix,
+                                                          unsigned int *__restrict__ hist) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const unsigned long long k = (unsigned long long)__double_as_longlong(x[e]);
+        if (shift + 16 < 64 && (k >> (shift + 16)) != prefix) continue;
+        atomicAdd(hist + ((k >> shift) & 0xffffull), 1u);
+    }
+}
+// wout = err > thr ? 0 : w ; per-block counts of the removed entries (integers)
+__global__ __launch_bounds__(256) void xm2_filter_kernel(int64_t n, const double *__restrict__ err, const double *__restrict__ w, double thr,
+                                                          double *__restrict__ wout, unsigned int *__restrict__ removed) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const bool rm = err[e] > thr;
+    wout[e] = rm ? 0.0 : w[e];
+    if (rm && w[e] != 0.0) atomicAdd(removed, 1u);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // launchers (dispatch on the rank o)
 // ----------------------------------------------------------------------------------------------------------------
+void launch_xm2_error(int64_t n, const double *w, const double *res, double *err, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(xm2_error_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w, res, err);
+    check_launch("xm2_error");
+}
+void launch_radix_hist(int64_t n, const double *x, int shift, unsigned long long prefix, unsigned int *hist, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, st, n, x, shift, prefix, hist);
+    check_launch("radix_hist");
+}
+void launch_xm2_filter(int64_t n, const double *err, const double *w, double thr, double *wout, unsigned int *removed, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(xm2_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, err, w, thr, wout, removed);
+    check_launch("xm2_filter");
+}
 int qw_grid(int nloc) { return (nloc + kQwWaves - 1) / kQwWaves; }
 int bsr_grid(int nloc) { return (nloc + kBsrRows - 1) / kBsrRows; }
 int flat_grid(int64_t elems) {
@@ -1796,10 +1944,10 @@ void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next
                     const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
                     double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat, double *Afull,
-                    double *Wfull, hipStream_t st) {
+                    double *Wfull, int grouping, const PeerXchg &xchg, hipStream_t st) {
     XM_DISPATCH_O(o, hipLaunchKernelGGL((cg_step_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st, nloc,
                                         scal_cur, scal_next, parts, nA_loc, nB_loc, world, HpR, Hps, R, s, pR, ps_cur, ps_next, vR,
-                                        vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat, b_off, mat, Afull, Wfull));
+                                        vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat, b_off, mat, Afull, Wfull, grouping, xchg));
     check_launch("cg_step");
 }
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs, const double *rgR,
@@ -1809,14 +1957,19 @@ void launch_model_value(int o, int nloc, const double *vR, const double *vs, con
     check_launch("model_value");
 }
 void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,
-                           unsigned long long seq, hipStream_t st) {
-    hipLaunchKernelGGL(outer_finalize_kernel, dim3(1), dim3(256), 0, st, partsA, nA_loc, world, partsM, nM, scal, hres, seq);
+                           unsigned long long seq, int grouping, hipStream_t st) {
+    hipLaunchKernelGGL(outer_finalize_kernel, dim3(1), dim3(256), 0, st, partsA, nA_loc, world, partsM, nM, scal, hres, seq, grouping);
     check_launch("outer_finalize");
 }
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
-                    double *Rout, double *sout, double *Wloc, hipStream_t st) {
-    XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_>), dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, R, s, D, ds, t,
-                                        Rout, sout, Wloc));
+                    double *Rout, double *sout, double *Wloc, hipStream_t st, int polar) {
+    if (polar) {
+        XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 1>), dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, R, s, D, ds, t,
+                                            Rout, sout, Wloc));
+    } else {
+        XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 0>), dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, R, s, D, ds, t,
+                                            Rout, sout, Wloc));
+    }
     check_launch("retract");
 }
 void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *QsR, const double *R, const double *s, double *Lam,

@@ -41,6 +41,7 @@ public:
     void product(int o, int epi, const double *W, double alpha, const CamArgs &a, hipStream_t st);
     // XM^2 loop on the reference's own Q: per-observation residuals at U = s.*R (input order of the observations) and new weights
     void residuals(int o, const double *U, double *res_host, const CamArgs &a, hipStream_t st);
+    const double *residuals_device(int o, const double *U, const CamArgs &a, hipStream_t st);   // the same, left on the device
     void set_weights(const double *w, hipStream_t st);
     // translations t (3 x n column-major, camera 0 at the origin) and landmarks p (3 x m column-major) of a rank-3 solution given as
     // anchored rotations rot (3 x 3n column-major) and scales (n): the eliminated variables of the chain at U = (s.*R)^T, negated

@@ -414,14 +414,18 @@ __global__ __launch_bounds__(256) void schur_obs_residual_kernel(int64_t nobs, c
     res[e] = acc;
 }
 
-void SchurOp::residuals(int o, const double *U, double *res_host, const CamArgs &a, hipStream_t st) {
+const double *SchurOp::residuals_device(int o, const double *U, const CamArgs &a, hipStream_t st) {
     // the chain with the plain epilogue leaves x_cam / x_l of this U in the scratch buffers
     product(o, EPI_PLAIN, U, 1.0, a, st);
-    res_.alloc((size_t)nobs_, false);
+    if (res_.count < (size_t)nobs_) res_.alloc((size_t)nobs_, false);
     XM_DISPATCH_O(o, hipLaunchKernelGGL((schur_obs_residual_kernel<O_>), dim3((unsigned)((nobs_ + 255) / 256)), dim3(256), 0, st, nobs_, obs_cam_.p,
                                         obs_lm_.p, obs_p_.p, U, xc_.p, xl_.p, res_.p));
     check_launch("schur_obs_residual");
-    XM_HIP_CHECK(hipMemcpyAsync(res_host, res_.p, (size_t)nobs_ * sizeof(double), hipMemcpyDeviceToHost, st));
+    return res_.p;
+}
+void SchurOp::residuals(int o, const double *U, double *res_host, const CamArgs &a, hipStream_t st) {
+    const double *r = residuals_device(o, U, a, st);
+    XM_HIP_CHECK(hipMemcpyAsync(res_host, r, (size_t)nobs_ * sizeof(double), hipMemcpyDeviceToHost, st));
     XM_HIP_CHECK(hipStreamSynchronize(st));
 }
 

@@ -39,17 +39,33 @@ struct SellHost {
     std::vector<int32_t> pslot;       // nslices * 64: where (slice, lane) stores its partial result, -1 = padding lane
     std::vector<int32_t> ridx;        // nparts: storage index of the k-th listed partial result (see pptr)
     std::vector<int64_t> pptr;        // nloc + 1: the partial results of camera r are ridx[pptr[r] .. pptr[r+1])
+    std::vector<int64_t> diag_src;    // view-graph codec only (diag_row0 >= 0): CSR position of row r's diagonal block (-1: none); those
+                                      // blocks are NOT in the slices (they are d * I, applied by the second launch from one double)
 };
 
 // rowptr: nloc + 1 offsets (rowptr[0] may be non-zero: offsets into colidx); colidx: global columns in [0, ncols).
 // Throws Error(XM_ERR_ARG) on a malformed description (non-monotone rowptr, column out of range).
-void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc, int64_t ncols, int S, int lmax, SellHost &out);
+// diag_row0 >= 0: local row r is global camera diag_row0 + r and its diagonal block (column diag_row0 + r) is left out of the slices.
+void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc, int64_t ncols, int S, int lmax, SellHost &out,
+                     int64_t diag_row0 = -1);
+
+// Block codecs of the slices.
+//   SELL_CODEC_FULL  9 doubles per block (any 3x3 block): 76 bytes per stored block with its column index.
+//   SELL_CODEC_QUAT  view-graph matrices (the north_star workload: Q = sum_e w_e G_e over view-graph edges, off-diagonal blocks
+//                    -w_e M_e with M_e a rotation, diagonal blocks (sum of incident weights) * I): an off-diagonal block is stored as
+//                    the quaternion of M_e scaled by sqrt(2 w_e) -- 4 doubles, the block is rebuilt in registers as -R(q) (R is
+//                    quadratic in q, so the scale carries the weight; 23 flops) -- and a diagonal block as ONE double per camera.
+//                    36 bytes per stored block instead of 76: the HBM stream of the product is 0.47x.  w_e = 0 (an edge removed by
+//                    the XM^2 filter) is the zero quaternion.
+enum { SELL_CODEC_FULL = 0, SELL_CODEC_QUAT = 1 };
 
 struct SellArgs {   // what the kernels see
     const int64_t *slice_off;
     const int32_t *slab_start;
     const int32_t *cols;    // step unit = 64 ints: pair [lane][2] over two units, single [lane]
-    const double *blk;      // step unit = 576 doubles: pair [e][lane][2] over two units, single [e][lane]
+    const double *blk;      // step unit = 64 * NQ doubles (NQ = 9 | 4 by codec): pair [e][lane][2] over two units, single [e][lane]
+    const double *diag;     // quaternion codec: diagonal scalar per local camera (else nullptr)
+    int64_t row0;           // global camera index of local row 0 (the diagonal term reads W at row0 + cam)
     const int32_t *pslot;
     const int64_t *pptr;
     const int32_t *ridx;
@@ -61,8 +77,12 @@ struct SellArgs {   // what the kernels see
 class SellMatrix {
 public:
     // blocks: host, 9 doubles per block (row-major 3x3), indexed like colidx
+    // codec SELL_CODEC_QUAT: throws Error(XM_ERR_ARG) unless every off-diagonal block is -w * rotation and every diagonal block d * I
+    // (relative 1e-9); row0 = global camera index of local row 0
     SellMatrix(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t nloc, int64_t ncols, int S, int lmax,
-               hipStream_t st);
+               hipStream_t st, int codec = SELL_CODEC_FULL, int64_t row0 = 0);
+    int codec() const { return codec_; }
+    int64_t stream_bytes() const;   // bytes of block + index stream one product reads
     SellArgs args() const;
     void refill(const int32_t *d_colidx, const double *d_blocks, hipStream_t st);   // values changed on the device (XM^2 re-weighting)
     double *parts(int o);
@@ -89,6 +109,10 @@ private:
     DevBuf<uint8_t> kind_;
     int64_t b0_ = 0;
     int parts_o_ = 0;
+    int codec_ = SELL_CODEC_FULL;
+    int64_t row0_ = 0;
+    DevBuf<double> diag_;
+    DevBuf<int64_t> diag_src_;
 };
 
 // product = two launches: partial results per virtual row, then per-camera sum + fused epilogue (same CamArgs contract and
@@ -96,5 +120,6 @@ private:
 // 1 = records fetched element-per-lane and transposed through LDS.
 void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st);
 bool sell_supports(int o);
+void sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]);   // host: the codec's two maps
 
 }  // namespace xm

@@ -16,7 +16,8 @@ namespace xm {
 // ------------------------------------------------------------------------------------------------------------------
 // host: build the layout description
 // ------------------------------------------------------------------------------------------------------------------
-void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc, int64_t ncols, int S, int lmax, SellHost &out) {
+void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc, int64_t ncols, int S, int lmax, SellHost &out,
+                     int64_t diag_row0) {
     if (!(S == 1 || S == 2 || S == 4 || S == 8)) throw Error(XM_ERR_ARG, "SELL: slabs must be 1, 2, 4 or 8");
     if (lmax < 2) throw Error(XM_ERR_ARG, "SELL: lmax must be >= 2");
     if (nloc < 0 || ncols < 1 || !rowptr) throw Error(XM_ERR_ARG, "SELL: bad sizes");
@@ -25,20 +26,31 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
     const int64_t b0 = rowptr[0], nb = rowptr[nloc] - b0;
     if (nb < 0) throw Error(XM_ERR_ARG, "BSR3: rowptr is not monotone");
     if (nb > 0 && !colidx) throw Error(XM_ERR_ARG, "BSR3: colidx missing");
-    // order[i]: i-th block of the matrix with every row in ascending column order (identity when the rows are sorted already)
-    std::vector<int64_t> order((size_t)nb);
-    std::iota(order.begin(), order.end(), b0);
+    // order[i]: i-th kept block of the matrix with every row in ascending column order (identity when the rows are sorted already and
+    // nothing is left out); row r owns order[ro[r] .. ro[r+1])
+    std::vector<int64_t> order;
+    order.reserve((size_t)nb);
+    std::vector<int64_t> ro((size_t)nloc + 1, 0);
+    if (diag_row0 >= 0) out.diag_src.assign((size_t)nloc, -1);
     for (int64_t r = 0; r < nloc; ++r) {
         const int64_t a = rowptr[r], e = rowptr[r + 1];
         if (e < a) throw Error(XM_ERR_ARG, "BSR3: rowptr is not monotone");
         bool sorted = true;
+        const size_t first = order.size();
         for (int64_t q = a; q < e; ++q) {
             const int32_t c = colidx[q];
             if (c < 0 || (int64_t)c >= ncols) throw Error(XM_ERR_ARG, "BSR3: column index out of range");
-            if (q > a && colidx[q - 1] > c) sorted = false;
+            if (diag_row0 >= 0 && (int64_t)c == diag_row0 + r) {
+                if (out.diag_src[(size_t)r] >= 0) throw Error(XM_ERR_ARG, "SELL: duplicate diagonal block");
+                out.diag_src[(size_t)r] = q;
+                continue;
+            }
+            if (order.size() > first && colidx[order.back()] > c) sorted = false;
+            order.push_back(q);
         }
         if (!sorted)
-            std::stable_sort(order.begin() + (a - b0), order.begin() + (e - b0), [&](int64_t x, int64_t y) { return colidx[x] < colidx[y]; });
+            std::stable_sort(order.begin() + (int64_t)first, order.end(), [&](int64_t x, int64_t y) { return colidx[x] < colidx[y]; });
+        ro[(size_t)r + 1] = (int64_t)order.size();
     }
     auto slab_of = [&](int32_t c) { return (int)(((int64_t)c * S) / ncols); };
     struct VRow { int64_t start; int32_t len; int32_t slot; };   // start: position in `order`
@@ -50,8 +62,8 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
     int64_t slot = 0;
     for (int64_t r = 0; r < nloc; ++r) {
         out.pptr[(size_t)r] = slot;
-        int64_t q = rowptr[r] - b0;
-        const int64_t e = rowptr[r + 1] - b0;
+        int64_t q = ro[(size_t)r];
+        const int64_t e = ro[(size_t)r + 1];
         while (q < e) {
             const int s = slab_of(colidx[order[(size_t)q]]);
             int64_t q2 = q;
@@ -111,6 +123,46 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
 // ------------------------------------------------------------------------------------------------------------------
 // device: fill the interleaved arrays from the CSR arrays (one thread per (step, lane))
 // ------------------------------------------------------------------------------------------------------------------
+// block -w * M (M a rotation, row-major) -> quaternion of M scaled by sqrt(2 w): (a; b, c, d) with a the scalar part.  The product
+// kernel rebuilds the block as -R(q) from products of pairs (qw_sell_body).  Shepperd's branch selection keeps the divisor >= 1.
+__host__ __device__ inline void block_to_quat(const double (&b)[9], double (&q)[4]) {
+    double ss = 0.0;
+    for (int e = 0; e < 9; ++e) ss += b[e] * b[e];
+    const double w = sqrt(ss / 3.0);
+    if (!(w > 0.0)) { q[0] = q[1] = q[2] = q[3] = 0.0; return; }
+    double M[9];
+    for (int e = 0; e < 9; ++e) M[e] = -b[e] / w;
+    const double tr = M[0] + M[4] + M[8];
+    double a, x, y, z;
+    if (tr > 0.0) {
+        const double S = sqrt(tr + 1.0) * 2.0;
+        a = 0.25 * S; x = (M[7] - M[5]) / S; y = (M[2] - M[6]) / S; z = (M[3] - M[1]) / S;
+    } else if (M[0] > M[4] && M[0] > M[8]) {
+        const double S = sqrt(1.0 + M[0] - M[4] - M[8]) * 2.0;
+        a = (M[7] - M[5]) / S; x = 0.25 * S; y = (M[1] + M[3]) / S; z = (M[2] + M[6]) / S;
+    } else if (M[4] > M[8]) {
+        const double S = sqrt(1.0 + M[4] - M[0] - M[8]) * 2.0;
+        a = (M[2] - M[6]) / S; x = (M[1] + M[3]) / S; y = 0.25 * S; z = (M[5] + M[7]) / S;
+    } else {
+        const double S = sqrt(1.0 + M[8] - M[0] - M[4]) * 2.0;
+        a = (M[3] - M[1]) / S; x = (M[2] + M[6]) / S; y = (M[5] + M[7]) / S; z = 0.25 * S;
+    }
+    const double nrm = sqrt((a * a + x * x) + (y * y + z * z));
+    const double sc = sqrt(2.0 * w) / nrm;
+    q[0] = a * sc; q[1] = x * sc; q[2] = y * sc; q[3] = z * sc;
+}
+// the block the product kernel works with, rebuilt from the stored quaternion (same expression tree as qw_sell_body)
+__host__ __device__ inline void quat_to_block(double a, double b, double c, double d, double (&q)[9]) {
+    const double aa = a * a, bb = b * b, cc = c * c, dd = d * d;
+    const double n2 = 0.5 * ((aa + bb) + (cc + dd));
+    const double ad = a * d, ac = a * c, ab = a * b;
+    q[0] = n2 - (aa + bb); q[4] = n2 - (aa + cc); q[8] = n2 - (aa + dd);
+    q[1] = fma(-b, c, ad);  q[3] = -fma(b, c, ad);
+    q[2] = -fma(b, d, ac);  q[6] = fma(-b, d, ac);
+    q[5] = fma(-c, d, ab);  q[7] = -fma(c, d, ab);
+}
+
+template <int NQ>
 __global__ __launch_bounds__(256) void sell_fill_kernel(int64_t nsteps, const int64_t *__restrict__ src, const uint8_t *__restrict__ kind,
                                                          const int32_t *__restrict__ colidx, const double *__restrict__ blocks, int64_t b0,
                                                          int32_t *__restrict__ cols, double *__restrict__ blk) {
@@ -124,22 +176,72 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(int64_t nsteps, const in
     double q[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) q[e] = (s < 0) ? 0.0 : blocks[(s - b0) * 9 + e];
+    double v[NQ];
+    if constexpr (NQ == 4) {
+        double qq[4];
+        block_to_quat(q, qq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = qq[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) v[e] = q[e];
+    }
+    constexpr int U = 64 * NQ;
     if (kd == 2) {
         cols[g * 64 + lane] = c;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) blk[g * 576 + e * 64 + lane] = q[e];
+        for (int e = 0; e < NQ; ++e) blk[g * U + e * 64 + lane] = v[e];
     } else {
         const int64_t gb = g - kd;   // first unit of the pair
         cols[gb * 64 + lane * 2 + kd] = c;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) blk[gb * 576 + e * 128 + lane * 2 + kd] = q[e];
+        for (int e = 0; e < NQ; ++e) blk[gb * U + e * 128 + lane * 2 + kd] = v[e];
     }
+}
+__global__ __launch_bounds__(256) void sell_diag_kernel(int64_t nloc, const int64_t *__restrict__ diag_src, const double *__restrict__ blocks, int64_t b0,
+                                                         double *__restrict__ diag) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nloc) return;
+    const int64_t s = diag_src[r];
+    diag[r] = (s < 0) ? 0.0 : blocks[(s - b0) * 9];
+}
+
+// host check of the view-graph structure the quaternion codec relies on (O(nb))
+static void check_viewgraph_blocks(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t nloc, int64_t row0) {
+    for (int64_t r = 0; r < nloc; ++r)
+        for (int64_t q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+            const double *b = blocks + q * 9;
+            double ss = 0.0;
+            for (int e = 0; e < 9; ++e) ss += b[e] * b[e];
+            if (!(ss == ss)) throw Error(XM_ERR_ARG, "view-graph codec: NaN block");
+            if ((int64_t)colidx[q] == row0 + r) {
+                const double d = b[0];
+                const double off = std::fabs(b[1]) + std::fabs(b[2]) + std::fabs(b[3]) + std::fabs(b[5]) + std::fabs(b[6]) + std::fabs(b[7]) +
+                                   std::fabs(b[4] - d) + std::fabs(b[8] - d);
+                if (off > 1e-9 * std::fabs(d)) throw Error(XM_ERR_ARG, "view-graph codec: a diagonal block is not a multiple of the identity");
+                continue;
+            }
+            if (ss == 0.0) continue;
+            const double w2 = ss / 3.0;
+            double dev = 0.0;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    const double g = b[3 * i] * b[3 * j] + b[3 * i + 1] * b[3 * j + 1] + b[3 * i + 2] * b[3 * j + 2] - (i == j ? w2 : 0.0);
+                    dev += g * g;
+                }
+            const double det = b[0] * (b[4] * b[8] - b[5] * b[7]) - b[1] * (b[3] * b[8] - b[5] * b[6]) + b[2] * (b[3] * b[7] - b[4] * b[6]);
+            if (std::sqrt(dev) > 1e-9 * w2 || !(det < 0.0))   // det(-w M) = -w^3
+                throw Error(XM_ERR_ARG, "view-graph codec: an off-diagonal block is not -w * rotation");
+        }
 }
 
 SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t nloc, int64_t ncols, int S, int lmax,
-                       hipStream_t st) {
+                       hipStream_t st, int codec, int64_t row0) {
+    if (codec != SELL_CODEC_FULL && codec != SELL_CODEC_QUAT) throw Error(XM_ERR_ARG, "SELL: unknown codec");
+    codec_ = codec; row0_ = row0;
+    if (codec == SELL_CODEC_QUAT) check_viewgraph_blocks(rowptr, colidx, blocks, nloc, row0);
     SellHost h;
-    sell_build_host(rowptr, colidx, nloc, ncols, S, lmax, h);
+    sell_build_host(rowptr, colidx, nloc, ncols, S, lmax, h, codec == SELL_CODEC_QUAT ? row0 : -1);
     ncols_ = ncols;
     max_list_ = 0;
     for (int64_t r = 0; r < nloc; ++r) max_list_ = std::max<int64_t>(max_list_, h.pptr[(size_t)r + 1] - h.pptr[(size_t)r]);
@@ -156,18 +258,25 @@ SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const doubl
     ridx_.alloc(h.ridx.size(), false);
     XM_HIP_CHECK(hipMemcpy(ridx_.p, h.ridx.data(), h.ridx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     cols_.alloc((size_t)std::max<int64_t>(nsteps_, 1) * 64, false);
-    blk_.alloc((size_t)std::max<int64_t>(nsteps_, 1) * 576, false);
+    blk_.alloc((size_t)std::max<int64_t>(nsteps_, 1) * 64 * (codec_ == SELL_CODEC_QUAT ? 4 : 9), false);
+    if (codec_ == SELL_CODEC_QUAT) {
+        diag_.alloc((size_t)std::max<int64_t>(nloc, 1));
+        diag_src_.alloc((size_t)std::max<int64_t>(nloc, 1), false);
+        if (nloc > 0) XM_HIP_CHECK(hipMemcpy(diag_src_.p, h.diag_src.data(), (size_t)nloc * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
     XM_HIP_CHECK(hipMemcpy(slice_off_.p, h.slice_off.data(), h.slice_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     XM_HIP_CHECK(hipMemcpy(slab_start_.p, h.slab_start.data(), h.slab_start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!h.pslot.empty()) XM_HIP_CHECK(hipMemcpy(pslot_.p, h.pslot.data(), h.pslot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     XM_HIP_CHECK(hipMemcpy(pptr_.p, h.pptr.data(), h.pptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     b0_ = b0;
-    if (nsteps_ > 0) {
+    if (nsteps_ > 0 || (codec_ == SELL_CODEC_QUAT && nb > 0)) {
         DevBuf<int32_t> dci; DevBuf<double> dbl;
-        src_.alloc(h.src.size(), false); kind_.alloc(h.kind.size(), false);   // kept: refill() after a device-side update of the values
+        if (nsteps_ > 0) {
+            src_.alloc(h.src.size(), false); kind_.alloc(h.kind.size(), false);   // kept: refill() after a device-side update of the values
+            XM_HIP_CHECK(hipMemcpy(src_.p, h.src.data(), h.src.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+            XM_HIP_CHECK(hipMemcpy(kind_.p, h.kind.data(), h.kind.size(), hipMemcpyHostToDevice));
+        }
         dci.alloc((size_t)std::max<int64_t>(nb, 1), false); dbl.alloc((size_t)std::max<int64_t>(nb, 1) * 9, false);
-        XM_HIP_CHECK(hipMemcpy(src_.p, h.src.data(), h.src.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-        XM_HIP_CHECK(hipMemcpy(kind_.p, h.kind.data(), h.kind.size(), hipMemcpyHostToDevice));
         XM_HIP_CHECK(hipMemcpy(dci.p, colidx + b0, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice));
         XM_HIP_CHECK(hipMemcpy(dbl.p, blocks + b0 * 9, (size_t)nb * 9 * sizeof(double), hipMemcpyHostToDevice));
         refill(dci.p, dbl.p, st);
@@ -186,17 +295,28 @@ SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const doubl
 
 // (re)build the interleaved arrays from block-CSR arrays on the device (colidx / blocks indexed from the first local block)
 void SellMatrix::refill(const int32_t *d_colidx, const double *d_blocks, hipStream_t st) {
+    if (codec_ == SELL_CODEC_QUAT && nloc_ > 0) {
+        hipLaunchKernelGGL(sell_diag_kernel, dim3((unsigned)((nloc_ + 255) / 256)), dim3(256), 0, st, nloc_, diag_src_.p, d_blocks, b0_, diag_.p);
+        check_launch("sell_diag");
+    }
     if (nsteps_ <= 0) return;
     const int64_t threads = nsteps_ * 64;
-    hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, nsteps_, src_.p, kind_.p, d_colidx, d_blocks,
-                       b0_, cols_.p, blk_.p);
+    if (codec_ == SELL_CODEC_QUAT)
+        hipLaunchKernelGGL(sell_fill_kernel<4>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, nsteps_, src_.p, kind_.p, d_colidx, d_blocks,
+                           b0_, cols_.p, blk_.p);
+    else
+        hipLaunchKernelGGL(sell_fill_kernel<9>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, nsteps_, src_.p, kind_.p, d_colidx, d_blocks,
+                           b0_, cols_.p, blk_.p);
     check_launch("sell_fill");
 }
+int64_t SellMatrix::stream_bytes() const { return nsteps_ * 64 * (4 + 8 * (int64_t)(codec_ == SELL_CODEC_QUAT ? 4 : 9)) + (codec_ == SELL_CODEC_QUAT ? 8 * nloc_ : 0); }
 
 SellArgs SellMatrix::args() const {
     SellArgs a;
     a.slice_off = slice_off_.p; a.slab_start = slab_start_.p; a.cols = cols_.p; a.blk = blk_.p; a.pslot = pslot_.p; a.pptr = pptr_.p; a.ridx = ridx_.p;
     a.S = S_;
+    a.diag = (codec_ == SELL_CODEC_QUAT) ? diag_.p : nullptr;
+    a.row0 = row0_;
     a.wstride = 0;   // set per rank by the launcher (wstride(o))
     a.coalesced_store = coalesced_ ? 1 : 0;
     return a;
@@ -243,18 +363,19 @@ typedef double d2a __attribute__((ext_vector_type(2)));               // 16-byte
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));   // pair at 8-byte alignment (records of W)
 typedef int i2a __attribute__((ext_vector_type(2)));
 
-template <int O, int GM>
+template <int O, int GM, int NQ = 9>
 struct SellBuf {   // one pipeline stage: two steps of blocks and the two gathered records of W
     static constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2;
-    d2a q[9];
+    d2a q[NQ];
     double w[2][(GM == 0) ? REC : 1];
     d2u raw[2][(GM == 1) ? NPR : 1];
 };
 
-template <int O, int GM, int ABL = 0, int PIPE = 0>   // PIPE 1: block loads run one pair ahead.  ABL: ablation bits for timing experiments (1 no block loads, 2 no gather, 4 no partial store)
+template <int O, int GM, int ABL = 0, int PIPE = 0, int CODEC = 0>   // PIPE 1: block loads run one pair ahead.  ABL: ablation bits for timing experiments (1 no block loads, 2 no gather, 4 no partial store).  CODEC: SELL_CODEC_*
 __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
                                              double *__restrict__ parts) {
     constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2, RECP = (REC + 1) & ~1;
+    constexpr int NQ = (CODEC == SELL_CODEC_QUAT) ? 4 : 9;   // doubles per stored block
     if (scal != nullptr) {
         if (scal->status != 0) return;
     }
@@ -270,7 +391,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     const int np = w >> 1;
     const bool tail = (w & 1) != 0;
     const int32_t *cb = m.cols + off * 64;
-    const double *bb = m.blk + off * 576;
+    const double *bb = m.blk + off * (64 * NQ);
     double *L = lds + ((GM == 1) ? wave * 2 * 64 * RECP : 0);
 
     double acc[3][O];
@@ -280,12 +401,22 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
 
     auto load_cols = [&](int p) -> i2a { return __builtin_nontemporal_load(reinterpret_cast<const i2a *>(cb) + (size_t)p * 64 + lane); };
-    auto load_blk = [&](int p, d2a (&q)[9]) {
-        const d2a *b = reinterpret_cast<const d2a *>(bb) + (size_t)p * 576 + lane;
+    auto load_blk = [&](int p, d2a (&q)[NQ]) {
+        const d2a *b = reinterpret_cast<const d2a *>(bb) + (size_t)p * (64 * NQ) + lane;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) {
+        for (int e = 0; e < NQ; ++e) {
             if constexpr (ABL & 1) { q[e] = d2a{(double)(lane + e), (double)(p - e)}; asm volatile("" : "+v"(q[e])); }
             else q[e] = __builtin_nontemporal_load(b + e * 64);
+        }
+    };
+    // stored planes of one pair -> the two 3x3 blocks (codec 0: the planes ARE the blocks; quaternion codec: -R(q), 23 flops each)
+    auto expand = [&](const d2a (&q)[NQ], double (&q0)[9], double (&q1)[9]) {
+        if constexpr (CODEC == SELL_CODEC_QUAT) {
+            quat_to_block(q[0].x, q[1].x, q[2].x, q[3].x, q0);
+            quat_to_block(q[0].y, q[1].y, q[2].y, q[3].y, q1);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { q0[e] = q[e].x; q1[e] = q[e].y; }
         }
     };
     // GM 0: every lane reads its own record (REC doubles at 8-byte alignment)
@@ -336,7 +467,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             for (int k = 0; k < O; ++k)
                 acc[r][k] = fma(q[3 * r + 2], wv[2 * OP + k], fma(q[3 * r + 1], wv[OP + k], fma(q[3 * r], wv[k], acc[r][k])));
     };
-    auto gather_pair = [&](const i2a j, SellBuf<O, GM> &B) {
+    auto gather_pair = [&](const i2a j, SellBuf<O, GM, NQ> &B) {
         if constexpr (ABL & 2) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -355,13 +486,13 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     // One pair of steps per iteration, single-buffered: the memory-level parallelism comes from the resident wavefronts (each has
     // ~20 KB of loads in flight), not from a per-wave software pipeline, which would double the register footprint and halve
     // the occupancy.  Only the column indices run one pair ahead (they head the dependent chain index -> gathered record).
-    SellBuf<O, GM> A;
+    SellBuf<O, GM, NQ> A;
     if constexpr (PIPE == 1) {
         // PIPE 1: the block stream (HBM latency) runs one pair ahead of the gathers (L2 latency), the column indices two pairs
         // ahead; only the blocks are double-buffered (the gathered records would cost another 36-40 registers).
-        d2a qA[9], qB[9];
+        d2a qA[NQ], qB[NQ];
         i2a jc = {0, 0}, jn = {0, 0};
-        auto body = [&](int p, d2a (&cur)[9], d2a (&nxt)[9], auto pf) {
+        auto body = [&](int p, d2a (&cur)[NQ], d2a (&nxt)[NQ], auto pf) {
             constexpr bool PF = decltype(pf)::value;
             i2a jnn = jn;
             if constexpr (PF) {
@@ -371,8 +502,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             gather_pair(jc, A);
             __builtin_amdgcn_sched_barrier(0);
             double q0[9], q1[9];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) { q0[e] = cur[e].x; q1[e] = cur[e].y; }
+            expand(cur, q0, q1);
             if constexpr (GM == 0) {
                 fma_step(q0, A.w[0]);
                 fma_step(q1, A.w[1]);
@@ -412,8 +542,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             __builtin_amdgcn_sched_barrier(0);   // every load of the pair is in flight before the first FMA (the scheduler would
                                                  // otherwise trickle them to save registers: 4-5 dependent round trips per pair)
             double q0[9], q1[9];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) { q0[e] = A.q[e].x; q1[e] = A.q[e].y; }
+            expand(A.q, q0, q1);
             if constexpr (GM == 0) {
                 fma_step(q0, A.w[0]);
                 fma_step(q1, A.w[1]);
@@ -433,9 +562,16 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     if (tail) {
         const int jt = __builtin_nontemporal_load(cb + (size_t)np * 128 + lane);
         double qt[9];
-        const double *b = bb + (size_t)np * 1152 + lane;
+        const double *b = bb + (size_t)np * (128 * NQ) + lane;
+        if constexpr (CODEC == SELL_CODEC_QUAT) {
+            double t4[4];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) qt[e] = __builtin_nontemporal_load(b + e * 64);
+            for (int e = 0; e < 4; ++e) t4[e] = __builtin_nontemporal_load(b + e * 64);
+            quat_to_block(t4[0], t4[1], t4[2], t4[3], qt);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) qt[e] = __builtin_nontemporal_load(b + e * 64);
+        }
         if constexpr (GM == 0) {
             double wt[REC];
             gather0(jt, wt);
@@ -487,10 +623,17 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     }
 }
 
-template <int O, int GM, int ABL = 0, int PIPE = 0>
+template <int O, int GM, int ABL = 0, int PIPE = 0, int CODEC = 0>
 __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
                                                        double *__restrict__ parts) {
-    qw_sell_body<O, GM, ABL, PIPE>(m, W, scal, parts);
+    qw_sell_body<O, GM, ABL, PIPE, CODEC>(m, W, scal, parts);
+}
+// quaternion codec compiled for FOUR wavefronts per SIMD (the blocks of a pair are 16 registers instead of 36)
+template <int O, int GM, int PIPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void qw_sell_kernel_q_occ4(SellArgs m, const double *__restrict__ W,
+                                                                                                      const TcgScal *__restrict__ scal,
+                                                                                                      double *__restrict__ parts) {
+    qw_sell_body<O, GM, 0, PIPE, SELL_CODEC_QUAT>(m, W, scal, parts);
 }
 // the same body compiled for FOUR wavefronts per SIMD (<= 128 VGPRs; XM_SELL_PIPE=2): the product is bound by the bytes a CU keeps
 // in flight (PMC: 64 % of the wave cycles wait on memory, ~6 wavefronts resident per CU), not by issue slots
@@ -512,7 +655,8 @@ int SellMatrix::reduce_grid(int o, int nloc) const { const int per = 256 / reduc
 
 template <int O, int EPI, int GW>
 __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restrict__ pptr, const int32_t *__restrict__ ridx, const double *__restrict__ parts,
-                                                           double alpha, CamArgs a) {
+                                                           double alpha, CamArgs a, const double *__restrict__ diag, const double *__restrict__ W,
+                                                           int64_t row0, int wstride) {
     constexpr int NSLOT = 256 / GW;
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
@@ -537,11 +681,28 @@ __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restr
 #pragma unroll
                 for (int k = 0; k < O; ++k) acc[r][k] += v[r * O + k];
         }
+        if (diag != nullptr && gl == GW - 1) {   // quaternion codec: the diagonal block d * I was left out of the slices (last lane: it has the fewest list entries)
+            constexpr int OPW = pitch_of(O);
+            const double d = diag[cam];
+            const double *w = W + (size_t)(row0 + cam) * wstride;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc[r][k] = fma(d, w[r * OPW + k], acc[r][k]);
+        }
     }
     qw_finish<O, EPI, GW, NSLOT>(cam, gl, slot, active, acc, alpha, a, eops, red);
 }
 
 bool sell_supports(int o) { return o == 1 || (o >= 3 && o <= 5); }
+void sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]) {
+    double b[9], q[4], r[9];
+    for (int e = 0; e < 9; ++e) b[e] = block[e];
+    block_to_quat(b, q);
+    quat_to_block(q[0], q[1], q[2], q[3], r);
+    for (int e = 0; e < 4; ++e) quat[e] = q[e];
+    for (int e = 0; e < 9; ++e) rebuilt[e] = r[e];
+}
 
 template <int O>
 static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st) {
@@ -549,23 +710,46 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
     double *parts = m.parts(O);
     SellArgs sa = m.args();
     sa.wstride = m.wstride(O);
+    const bool quat = m.codec() == SELL_CODEC_QUAT;
     if (m.grid() > 0) {
         W = m.pack_w(O, W, st);
         const dim3 g(m.grid()), b(256);
         static const int abl = [] { const char *e = std::getenv("XM_SELL_ABLATE"); return (e && *e) ? std::atoi(e) : 0; }();   // timing experiments only
         if constexpr (O == 3) {
-            if (abl != 0) {
+            if (abl != 0 && !quat) {
 #define XM_ABL_CASE(G, A) if (gm == G && abl == A) hipLaunchKernelGGL((qw_sell_kernel<3, G, A>), g, b, 0, st, sa, W, sc, parts);
                 XM_ABL_CASE(0, 1) XM_ABL_CASE(0, 2) XM_ABL_CASE(0, 3) XM_ABL_CASE(0, 4) XM_ABL_CASE(0, 6) XM_ABL_CASE(0, 7)
                 XM_ABL_CASE(1, 1) XM_ABL_CASE(1, 2) XM_ABL_CASE(1, 4)
 #undef XM_ABL_CASE
             }
+            if (abl != 0 && quat) {
+#define XM_ABL_CASE(G, A) if (gm == G && abl == A) hipLaunchKernelGGL((qw_sell_kernel<3, G, A, 0, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
+                XM_ABL_CASE(1, 1) XM_ABL_CASE(1, 2) XM_ABL_CASE(1, 4) XM_ABL_CASE(1, 6)
+#undef XM_ABL_CASE
+            }
         }
-        // block loads one pair ahead: worth 2-3 us at o = 3; beyond that the second block buffer costs the occupancy (o = 5: 256 VGPRs)
+        // block loads one pair ahead: worth 2-3 us at o = 3 with full blocks; beyond that the second block buffer costs the occupancy
+        // (o = 5: 256 VGPRs).  Quaternion codec: a pair of blocks is 16 registers, the second buffer is cheap at every rank.
         static const int pipe_env = [] { const char *e = std::getenv("XM_SELL_PIPE"); return (e && *e) ? std::atoi(e) : -1; }();
-        const int pipe = (pipe_env >= 0) ? pipe_env : (O == 3 ? 1 : 0);
+        // measured at 100 k cameras, o = 3 (profiles/r03_kbench_sell.txt): full blocks 111.4 / 111.3 / 110.5 us for pipe 0 / 1 / 2; quaternion
+        // codec 82.4 / 84.2 / 204.8 (spills) / 81.9 us for pipe 0 / 1 / 2 / 3 -> 3 (four wavefronts per SIMD, no software pipeline)
+        const int pipe = (pipe_env >= 0) ? pipe_env : (quat ? (O == 3 ? 3 : 0) : (O == 3 ? 1 : 0));
         if (abl == 0 || O != 3) {
-            if (pipe == 2 && O == 3) {
+            if (quat) {
+                if (pipe == 2) {          // four wavefronts per SIMD, block loads one pair ahead
+                    if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<O, 1, 1>), g, b, 0, st, sa, W, sc, parts);
+                    else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<O, 0, 1>), g, b, 0, st, sa, W, sc, parts);
+                } else if (pipe == 3) {   // four wavefronts per SIMD, no software pipeline
+                    if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<O, 1, 0>), g, b, 0, st, sa, W, sc, parts);
+                    else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<O, 0, 0>), g, b, 0, st, sa, W, sc, parts);
+                } else if (pipe == 1) {
+                    if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, 0, 1, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
+                    else hipLaunchKernelGGL((qw_sell_kernel<O, 0, 0, 1, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
+                } else {
+                    if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, 0, 0, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
+                    else hipLaunchKernelGGL((qw_sell_kernel<O, 0, 0, 0, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
+                }
+            } else if (pipe == 2 && O == 3) {
                 if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_occ4<3, 1>), g, b, 0, st, sa, W, sc, parts);
                 else hipLaunchKernelGGL((qw_sell_kernel_occ4<3, 0>), g, b, 0, st, sa, W, sc, parts);
             } else if (pipe == 1) {
@@ -580,9 +764,9 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
     const dim3 g(m.reduce_grid(O, a.nloc)), b(256);
 #define XM_SELL_REDUCE(GW_)                                                                                                                          \
     switch (epi) {                                                                                                                                  \
-        case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;          \
-        case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;            \
-        case EPI_HESS: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_HESS, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a); break;            \
+        case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride); break; \
+        case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride); break;   \
+        case EPI_HESS: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_HESS, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride); break;   \
         default: throw Error(XM_ERR_ARG, "bad epilogue");                                                                                           \
     }
     if (m.reduce_gw(O) == 4) { XM_SELL_REDUCE(4) } else { XM_SELL_REDUCE(16) }
@@ -596,9 +780,12 @@ void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha
         double *parts = m.parts(1);
         SellArgs sa = m.args();
         sa.wstride = 3;
-        if (m.grid() > 0) hipLaunchKernelGGL((qw_sell_kernel<1, 0>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
-        if (m.reduce_gw(1) == 4) hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT, 4>), dim3(m.reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a);
-        else hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT, 16>), dim3(m.reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a);
+        if (m.grid() > 0) {
+            if (m.codec() == SELL_CODEC_QUAT) hipLaunchKernelGGL((qw_sell_kernel<1, 0, 0, 0, SELL_CODEC_QUAT>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
+            else hipLaunchKernelGGL((qw_sell_kernel<1, 0>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
+        }
+        if (m.reduce_gw(1) == 4) hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT, 4>), dim3(m.reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride);
+        else hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT, 16>), dim3(m.reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride);
     } else {
         switch (o) {
             case 1: qw_sell_o<1>(epi, m, W, alpha, a, 0, st); break;

@@ -3,6 +3,7 @@
 
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <memory>
 #include <string>
 #include <vector>
@@ -12,20 +13,65 @@
 
 namespace xm {
 
-// ---- communicator (row partition over the GPUs of one node; RCCL loaded at run time) -----------------------------
+// ---- settings resolved ONCE at context creation (xm_tuning_t of the caller, else the XM_* environment, else the defaults) ----------------
+struct Settings {
+    int sym = 0;                 // 0 auto | 1 force | -1 off
+    int64_t sym_min_rows = 6144;
+    int sell = 0;                // 0 auto | 1 force | -1 off
+    int sell_slabs = 4, sell_lmax = 64, sell_gather = 1;   // sell_gather: kernel gather mode (1 = LDS-transposed)
+    int sell_codec = 0;          // 0 auto | 1 full | 2 quaternion
+    int overlap = 0;             // 0 auto | -1 off
+    double overlap_min_mb = 64.0;
+    int64_t cert_dense_rows = 384;
+    int lanczos_mmax = 400, lanczos_restarts = 12;
+    double watchdog_s = 600.0;
+    int balance = 0;             // 0 by stored blocks | 1 equal camera ranges
+    int exchange = 0;            // 0 auto | 1 RCCL | 2 peer writes
+    long long debug_drop_finalize = -1;   // XM_DEBUG_DROP_FINALIZE (tests)
+    int debug_peer_mute = 0;              // XM_DEBUG_PEER_MUTE=1 (tests): rank 1 never publishes its tCG epoch -> the peers' bounded wait must expire
+    static Settings resolve(const xm_tuning_t *t);
+};
+
+// ---- communicators (row partition over the GPUs of one node) ---------------------------------------------------------------------
+// A Context holds a shared_ptr to ITS communicator (no process-global state inside the solver).  Kinds:
+//   none   single GPU
+//   RCCL   one process per GPU, ncclAllGather (xm_comm_init)
+//   shm    test transport: the same calls staged through a POSIX shared-memory segment (several ranks on one GPU)
+//   peer   DIRECT PEER WRITES: every rank owns a fine-grained arena on its device that all ranks of the group can address (same
+//          process: peer access; "virtual devices": the same device); a collective is a copy kernel that stores the rank's chunk
+//          straight into the peers' memory, a system-scope release, an epoch flag per (source, slot), and a bounded spin on the
+//          consumer side.  No library call, no host rendezvous, ~1 hop of xGMI latency.  The truncated CG fuses push and wait into
+//          cg_step_kernel (PeerXchg below).
 struct Comm {
     int rank = 0, world = 1;
-    bool forced = false;   // XM_FORCE_COMM=1: issue the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
+    bool forced = false;   // issue the collectives even with one rank (exercises the path on a 1-GPU box)
+    virtual ~Comm();
     bool active() const { return world > 1 || forced; }
+    virtual int kind() const { return 0; }                    // 0 none | 1 RCCL | 2 shm | 3 peer
     // in-place all-gather on `stream`: every rank contributes `count` doubles located at buf + rank*count
-    void allgather(double *buf, size_t count, hipStream_t st);
+    virtual void allgather(double *buf, size_t count, hipStream_t st) { (void)buf; (void)count; (void)st; }
+    // ---- direct exchange (kind 3 only) ----
+    virtual bool peer() const { return false; }
+    // collective: (re)allocate this rank's tCG exchange buffer of `doubles` doubles in peer-addressable memory and learn the peers'
+    virtual void xchg_setup(size_t doubles, PeerXchg &out) { (void)doubles; (void)out; }
+    virtual void reserve(size_t doubles) { (void)doubles; }   // collective: staging capacity of allgather (per rank chunk * world)
+    virtual void check_device_error() {}                      // throws XM_ERR_COMM when a device-side wait expired
+    virtual void host_barrier() {}
     void note(const char *what, double a, double b);   // XM_COMM_TRACE debugging aid
+private:
+    FILE *trace_ = nullptr;
+    bool trace_tried_ = false;
 };
-Comm &global_comm();
+std::shared_ptr<Comm> default_comm();          // what xm_comm_init / xm_comm_init_shm installed for this process (else a single-rank Comm)
 void comm_unique_id(unsigned char id[128]);
 void comm_init(int rank, int world, int device, const unsigned char id[128], const char *lib_path);
 void comm_init_shm(int rank, int world, int device, const char *name, size_t bytes);
 void comm_finalize();
+// single-process group of `world` ranks (one host thread each); devices[r] = HIP device of rank r (all equal = virtual devices)
+struct PeerGroup;
+std::shared_ptr<PeerGroup> peer_group_create(int world, const int *devices, double spin_seconds);
+std::shared_ptr<Comm> peer_comm_create(const std::shared_ptr<PeerGroup> &g, int rank);   // call on rank's own thread, device current
+void peer_group_abort(const std::shared_ptr<PeerGroup> &g);                               // wakes every host-side wait with an error
 
 template <class T>
 struct DevBuf {
@@ -54,6 +100,8 @@ struct DevBuf {
     }
 };
 
+void partition_cuts(int64_t n, int world, const int64_t *weights, std::vector<int64_t> &cuts);   // xm_solver.hip
+
 class SellMatrix;   // xm_sell.h
 class SchurOp;      // xm_schur.h
 
@@ -76,7 +124,12 @@ struct CertResult {
 
 class Context {
 public:
-    explicit Context(const xm_problem_t &prob);
+    // comm: the communicator of THIS context (nullptr = default_comm()); the HIP device current on the calling thread is the rank's
+    explicit Context(const xm_problem_t &prob, std::shared_ptr<Comm> comm = nullptr);
+    int rank() const { return comm_->rank; }
+    int world() const { return comm_->world; }
+    int64_t cameras() const { return n_; }
+    int64_t edges() const { return ne_; }
     ~Context();
     void solve(const xm_options_t &opt, xm_result_t &res);
     void apply(int o, const double *W_host, double *out_host, double alpha);   // out = alpha Q W (host, column-major)
@@ -91,7 +144,9 @@ private:
     // ---- problem ------------------------------------------------------------------------------------------------
     int64_t n_ = 0;        // true cameras
     int nloc_ = 0;         // cameras owned by this GPU (padded so that every rank owns the same number)
-    int cam0_ = 0;         // global index of the first local camera
+    int cam0_ = 0;         // position of the first local camera in the padded numbering (rank * nloc_)
+    int64_t g0_ = 0;       // global index of the first local camera (cam_cut_[rank])
+    int64_t true_loc_ = 0; // real (non-padding) cameras on this rank
     int64_t ntot_ = 0;     // padded total = world * nloc
     int64_t ld_ = 0;       // rows of every product input W (>= 3*ntot, multiple of 128)
     int storage_ = XM_STORAGE_DENSE;
@@ -116,7 +171,13 @@ private:
     hipEvent_t ev_w_ = nullptr, ev_p_ = nullptr;
     DevBuf<double> Pstrip_;              // raw row sums of the local column strip
     bool w_pending_ = false;             // gather_W() was deferred into the next product()
-    Comm *comm_ = nullptr;
+    std::shared_ptr<Comm> comm_;
+    Settings cfg_;
+    PeerXchg xchg_;                      // direct tCG exchange (peer communicators): partsB lives in peer-addressable memory
+    double *partsB_peer_ = nullptr;
+    unsigned long long tcg_runs_ = 0;    // epoch base of the peer exchange (identical on every rank)
+    std::vector<int64_t> cam_cut_;       // world + 1 camera offsets of the partition (balanced by stored blocks for block-sparse Q)
+    int retraction_ = 0, grouping_ = 0;
 
     // ---- per-rank workspace -------------------------------------------------------------------------------------
     int o_ = 0, OP_ = 0;
@@ -148,6 +209,11 @@ private:
     std::vector<float> qw_samples_;
 
     void init(const xm_problem_t &prob);
+    void to_host(void *dst, const void *src_dev, size_t bytes);   // through the pinned staging buffer; synchronises st_
+    void to_dev(void *dst_dev, const void *src, size_t bytes);
+    void ensure_pinned(size_t doubles);
+    DevBuf<double> lzV_, lzc_, lzw_, lzc2_, lzab_, lzscr_;      // Lanczos workspace (grow-only)
+    int64_t pos_of(int64_t g) const;   // global camera -> position in the padded numbering of the replicated vectors
     void release_raw();   // frees the raw (non-RAII) resources: dQ_, stream, mapped / pinned host memory, events
     void setup_rank(int o);
     void upload_point(const std::vector<double> &R_cm, int o, const std::vector<double> &s_ex);
@@ -170,6 +236,24 @@ private:
     CertResult certificate(int o, double primal, std::vector<double> &v_out);
     int lanczos_min(std::vector<double> &x_out, double &theta, int &iters, double &resid);   // 0 converged, 1 not
     void log(const char *fmt, ...) const;
+};
+
+// single-process multi-GPU driver (xm_team.hip): `n_gpus` Contexts, one host thread and one device each, joined by a peer group
+class Team {
+public:
+    Team(const xm_problem_t &prob, int n_gpus, int gpu_map);
+    ~Team();
+    Team(const Team &) = delete;
+    Team &operator=(const Team &) = delete;
+    int world() const;
+    void solve(const xm_options_t &opt, xm_result_t &res);
+    void attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
+    void edge_residuals(double *res);
+    void set_edge_weights(const double *w);
+private:
+    struct Impl;
+    std::unique_ptr<Impl> p_;
+    void shutdown();
 };
 
 }  // namespace xm

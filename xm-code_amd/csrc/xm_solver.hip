@@ -35,10 +35,49 @@ void Context::log(const char *fmt, ...) const {
     fflush(stdout);
 }
 
+// Host <-> device transfers of the solve path go through the context's PINNED staging buffer: a copy from / to pageable memory makes
+// the runtime wait for the stream while it holds its staging lock, and with several ranks in one process (peer communicators) a
+// rank that waits like that for a peer's push can keep exactly that peer from enqueuing it (seen on the virtual-device runs: both
+// ranks inside download_point, one in a pageable copy behind its wait kernel, the other on the lock).  Pinned copies are plain
+// enqueues; the only blocking call is hipStreamSynchronize on the context's own stream.
+void Context::to_host(void *dst, const void *src_dev, size_t bytes) {
+    char *d = static_cast<char *>(dst);
+    const char *s = static_cast<const char *>(src_dev);
+    const size_t cap = hpin_count_ * sizeof(double);
+    if (cap == 0) throw Error(XM_ERR_HIP, "staging buffer missing");
+    for (size_t off = 0; off < bytes; off += cap) {
+        const size_t n = std::min(cap, bytes - off);
+        XM_HIP_CHECK(hipMemcpyAsync(hpin_, s + off, n, hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        std::memcpy(d + off, hpin_, n);
+    }
+}
+void Context::to_dev(void *dst_dev, const void *src, size_t bytes) {
+    char *d = static_cast<char *>(dst_dev);
+    const char *s = static_cast<const char *>(src);
+    const size_t cap = hpin_count_ * sizeof(double);
+    if (cap == 0) throw Error(XM_ERR_HIP, "staging buffer missing");
+    for (size_t off = 0; off < bytes; off += cap) {
+        const size_t n = std::min(cap, bytes - off);
+        std::memcpy(hpin_, s + off, n);
+        XM_HIP_CHECK(hipMemcpyAsync(d + off, hpin_, n, hipMemcpyHostToDevice, st_));
+        XM_HIP_CHECK(hipStreamSynchronize(st_));   // the staging buffer is reused by the next transfer
+    }
+}
+void Context::ensure_pinned(size_t doubles) {
+    if (doubles <= hpin_count_) return;
+    if (hpin_) (void)hipHostFree(hpin_);
+    hpin_ = nullptr; hpin_count_ = 0;
+    XM_HIP_CHECK(hipHostMalloc((void **)&hpin_, doubles * sizeof(double), hipHostMallocDefault));
+    hpin_count_ = doubles;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // construction: lay Q out on the device
 // ------------------------------------------------------------------------------------------------------------------
-Context::Context(const xm_problem_t &prob) {
+Context::Context(const xm_problem_t &prob, std::shared_ptr<Comm> comm) {
+    comm_ = comm ? std::move(comm) : default_comm();
+    cfg_ = Settings::resolve(prob.tuning);
     try {
         init(prob);
     } catch (...) {   // a later allocation failed (e.g. the 13.5 GB slab): release what the destructor would have released
@@ -77,19 +116,126 @@ static void validate_bsr(const xm_problem_t &prob) {
         if (prob.colidx[q] < 0 || (int64_t)prob.colidx[q] >= prob.n) throw Error(XM_ERR_ARG, "BSR3: column index out of range");
 }
 
-void Context::init(const xm_problem_t &prob) {
-    comm_ = &global_comm();
+// edge list validation shared by the view-graph storage and attach_edges: in range, no self edge, no unordered pair twice (two edges
+// on one pair would write the same off-diagonal block from two threads while the diagonal sums count both)
+static void validate_edges(int64_t n, int64_t ne, const int32_t *ei, const int32_t *ej, const char *who) {
+    if (ne < 0 || (ne > 0 && (!ei || !ej))) throw Error(XM_ERR_ARG, std::string(who) + ": bad edge arrays");
+    std::vector<int64_t> key((size_t)ne);
+    for (int64_t e = 0; e < ne; ++e) {
+        if (ei[e] < 0 || ej[e] < 0 || ei[e] >= n || ej[e] >= n || ei[e] == ej[e]) throw Error(XM_ERR_ARG, std::string(who) + ": bad edge (out of range or i == j)");
+        const int64_t a = std::min(ei[e], ej[e]), b = std::max(ei[e], ej[e]);
+        key[(size_t)e] = a * n + b;
+    }
+    std::sort(key.begin(), key.end());
+    for (int64_t e = 1; e < ne; ++e)
+        if (key[(size_t)e] == key[(size_t)e - 1]) throw Error(XM_ERR_ARG, std::string(who) + ": the same pair of cameras is listed twice (as (i,j) or (j,i))");
+}
+
+// Q = sum_e w_e G_e as 3x3-block CSR, rows sorted by column, a diagonal block for every camera (XM_STORAGE_VIEWGRAPH)
+static void build_viewgraph_csr(int64_t n, int64_t ne, const int32_t *ei, const int32_t *ej, const double *w, const double *M,
+                                std::vector<int64_t> &rowptr, std::vector<int32_t> &colidx, std::vector<double> &blocks) {
+    if (ne > 0 && (!w || !M)) throw Error(XM_ERR_ARG, "view-graph storage needs edge_w and edge_M");
+    validate_edges(n, ne, ei, ej, "view-graph storage");
+    rowptr.assign((size_t)n + 1, 0);
+    for (int64_t e = 0; e < ne; ++e) { rowptr[(size_t)ei[e] + 1]++; rowptr[(size_t)ej[e] + 1]++; }
+    for (int64_t c = 0; c < n; ++c) rowptr[(size_t)c + 1] += rowptr[(size_t)c] + 1;   // + the diagonal block
+    const int64_t nb = rowptr[(size_t)n];
+    colidx.assign((size_t)nb, 0);
+    blocks.assign((size_t)nb * 9, 0.0);
+    std::vector<int64_t> fill(rowptr.begin(), rowptr.end() - 1), eidx((size_t)nb, -1);
+    std::vector<uint8_t> etr((size_t)nb, 0);
+    std::vector<double> dsum((size_t)n, 0.0);
+    for (int64_t e = 0; e < ne; ++e) {
+        const int64_t a = fill[(size_t)ei[e]]++, b = fill[(size_t)ej[e]]++;
+        colidx[(size_t)a] = ej[e]; eidx[(size_t)a] = e; etr[(size_t)a] = 0;
+        colidx[(size_t)b] = ei[e]; eidx[(size_t)b] = e; etr[(size_t)b] = 1;
+        dsum[(size_t)ei[e]] += w[e]; dsum[(size_t)ej[e]] += w[e];   // EDGE order: what diag_write_kernel does after a re-weighting
+    }
+    for (int64_t c = 0; c < n; ++c) colidx[(size_t)fill[(size_t)c]] = (int32_t)c;   // the diagonal entry, sorted into place below
+    std::vector<int64_t> perm;
+    std::vector<int32_t> cc;
+    std::vector<int64_t> ee;
+    std::vector<uint8_t> tt;
+    for (int64_t c = 0; c < n; ++c) {
+        const int64_t a = rowptr[(size_t)c], len = rowptr[(size_t)c + 1] - a;
+        perm.resize((size_t)len); cc.resize((size_t)len); ee.resize((size_t)len); tt.resize((size_t)len);
+        for (int64_t k = 0; k < len; ++k) perm[(size_t)k] = a + k;
+        std::sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) { return colidx[(size_t)x] < colidx[(size_t)y]; });
+        for (int64_t k = 0; k < len; ++k) { cc[(size_t)k] = colidx[(size_t)perm[(size_t)k]]; ee[(size_t)k] = eidx[(size_t)perm[(size_t)k]]; tt[(size_t)k] = etr[(size_t)perm[(size_t)k]]; }
+        for (int64_t k = 0; k < len; ++k) {
+            const int64_t q = a + k;
+            colidx[(size_t)q] = cc[(size_t)k];
+            double *bl = blocks.data() + (size_t)q * 9;
+            if (ee[(size_t)k] < 0) { bl[0] = bl[4] = bl[8] = dsum[(size_t)c]; continue; }
+            const double *m = M + (size_t)ee[(size_t)k] * 9;
+            const double we = w[ee[(size_t)k]];
+            for (int r = 0; r < 3; ++r)
+                for (int k2 = 0; k2 < 3; ++k2) bl[r * 3 + k2] = -we * (tt[(size_t)k] ? m[k2 * 3 + r] : m[r * 3 + k2]);   // Q_ij = -w M, Q_ji = Q_ij^T
+        }
+    }
+}
+
+// Contiguous camera ranges of a row partition: cuts[r] .. cuts[r+1] belongs to rank r.  weights == nullptr: equal ranges of
+// ceil(n / world) cameras (dense rows).  weights = the rowptr of a 3x3-block CSR matrix: ranges balanced by STORED BLOCKS -- rank r
+// starts at the first camera whose rowptr reaches r/world of all blocks.
+void partition_cuts(int64_t n, int world, const int64_t *weights, std::vector<int64_t> &cuts) {
+    cuts.assign((size_t)world + 1, 0);
+    const int64_t per = (n + world - 1) / world;
+    for (int r = 0; r <= world; ++r) cuts[(size_t)r] = std::min<int64_t>(n, (int64_t)r * per);
+    if (weights && world > 1) {
+        const int64_t nb = weights[n] - weights[0];
+        int64_t c = 0;
+        for (int r = 1; r < world; ++r) {
+            const int64_t target = weights[0] + (nb * r) / world;
+            while (c < n && weights[c] < target) ++c;
+            cuts[(size_t)r] = c;
+        }
+        cuts[(size_t)world] = n;
+    }
+}
+
+// position of global camera g in the padded numbering (rank r's cameras start at r * nloc_)
+int64_t Context::pos_of(int64_t g) const {
+    int r = (int)std::min<int64_t>((int64_t)cam_cut_.size() - 2, g / std::max<int64_t>(1, nloc_));
+    while (r > 0 && cam_cut_[(size_t)r] > g) --r;
+    while (r + 2 < (int)cam_cut_.size() && cam_cut_[(size_t)r + 1] <= g) ++r;
+    return (int64_t)r * nloc_ + (g - cam_cut_[(size_t)r]);
+}
+
+void Context::init(const xm_problem_t &prob_in) {
     const int world = comm_->world, rank = comm_->rank;
+    xm_problem_t prob = prob_in;
     if (prob.n < 1) throw Error(XM_ERR_ARG, "n must be >= 1");
     if (3 * prob.n > 2000000000LL) throw Error(XM_ERR_ARG, "n too large");
     n_ = prob.n;
-    nloc_ = (int)((n_ + world - 1) / world);
-    cam0_ = rank * nloc_;
-    ntot_ = (int64_t)nloc_ * world;
-    ld_ = dense_ld(ntot_);
     storage_ = prob.storage;
     XM_HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-    const int64_t true_loc = std::max<int64_t>(0, std::min<int64_t>(n_ - cam0_, nloc_));  // real cameras on this rank
+
+    // view-graph storage: the edge list becomes 3x3-block CSR on the host (and is attached for the XM^2 calls further down)
+    std::vector<int64_t> vg_rp; std::vector<int32_t> vg_ci; std::vector<double> vg_bl;
+    const bool viewgraph = (storage_ == XM_STORAGE_VIEWGRAPH);
+    if (viewgraph) {
+        build_viewgraph_csr(n_, prob.ne, prob.edge_i, prob.edge_j, prob.edge_w, prob.edge_M, vg_rp, vg_ci, vg_bl);
+        prob.rowptr = vg_rp.data(); prob.colidx = vg_ci.data(); prob.blocks = vg_bl.data(); prob.nb = vg_rp[(size_t)n_];
+        storage_ = XM_STORAGE_BSR3;
+    }
+    if (storage_ == XM_STORAGE_BSR3 || storage_ == XM_STORAGE_BSR3_DENSE) validate_bsr(prob);
+
+    // ---- row partition: contiguous camera ranges.  Dense rows: equal ranges.  Block-sparse: ranges balanced by STORED BLOCKS
+    //  unless Settings.balance == 1 -- a hub-camera graph would otherwise land most of the matrix on one rank.  Every rank
+    // is padded to the longest range with inert cameras (zero rows of Q, R = [I 0], s = 1: exact zeros in every sum), so all ranks
+    // exchange equal chunks; a camera's record sits at position rank * nloc_ + (g - cut[rank]) of every replicated vector.
+    partition_cuts(n_, world, (storage_ == XM_STORAGE_BSR3 && cfg_.balance == 0) ? prob.rowptr : nullptr, cam_cut_);
+    int64_t longest = 1;
+    for (int r = 0; r < world; ++r) longest = std::max(longest, cam_cut_[(size_t)r + 1] - cam_cut_[(size_t)r]);
+    nloc_ = (int)longest;
+    cam0_ = rank * nloc_;
+    g0_ = cam_cut_[(size_t)rank];
+    ntot_ = (int64_t)nloc_ * world;
+    ld_ = dense_ld(ntot_);
+    const int64_t true_loc = cam_cut_[(size_t)rank + 1] - g0_;  // real cameras on this rank
+    true_loc_ = true_loc;
+    comm_->reserve((size_t)ld_ * (kMaxRank + 1) + 4096);   // staging of the largest all-gather (W at the top rank); collective
 
     if (storage_ == XM_STORAGE_DENSE) {
         if (prob.q_on_device) {
@@ -97,7 +243,7 @@ void Context::init(const xm_problem_t &prob) {
             ownQ_ = false;
         } else {
             // q may hold the whole matrix (q_row0 == 0, ldq >= 3n) or just a row strip that covers this rank's cameras
-            const int64_t need0 = 3 * (int64_t)cam0_, need1 = 3 * ((int64_t)cam0_ + true_loc);
+            const int64_t need0 = 3 * g0_, need1 = 3 * (g0_ + true_loc);
             if (!prob.q || prob.q_row0 < 0 || (true_loc > 0 && (prob.q_row0 > need0 || prob.q_row0 + prob.ldq < need1)))
                 throw Error(XM_ERR_ARG, "dense Q needs q with the rows of this rank's cameras (ldq >= 3n for the whole matrix)");
             const size_t rows = (size_t)3 * nloc_;
@@ -105,12 +251,12 @@ void Context::init(const xm_problem_t &prob) {
             ownQ_ = true;
             XM_HIP_CHECK(hipMemsetAsync(dQ_, 0, rows * (size_t)ld_ * sizeof(double), st_));
             if (true_loc > 0) {
-                // rows [3 cam0, 3 cam0 + 3 true_loc) of the column-major host matrix, all 3n columns -> device slab
+                // rows [3 g0, 3 g0 + 3 true_loc) of the column-major host matrix, all 3n columns -> device slab
                 // (column-major, leading dim = local rows), then an LDS-tiled transpose into the padded row-major layout.
                 const int64_t lr = 3 * true_loc, cols = 3 * n_;
                 DevBuf<double> slab;
                 slab.alloc((size_t)lr * cols, false);
-                XM_HIP_CHECK(hipMemcpy2D(slab.p, (size_t)lr * sizeof(double), prob.q + (3 * (int64_t)cam0_ - prob.q_row0), (size_t)prob.ldq * sizeof(double),
+                XM_HIP_CHECK(hipMemcpy2D(slab.p, (size_t)lr * sizeof(double), prob.q + (3 * g0_ - prob.q_row0), (size_t)prob.ldq * sizeof(double),
                                          (size_t)lr * sizeof(double), (size_t)cols, hipMemcpyHostToDevice));
                 launch_transpose_pad(slab.p, lr, lr, cols, dQ_, ld_, st_);
                 XM_HIP_CHECK(hipStreamSynchronize(st_));
@@ -119,15 +265,14 @@ void Context::init(const xm_problem_t &prob) {
     } else if (storage_ == XM_STORAGE_BSR3_DENSE) {
         // described as 3x3-block CSR on the host, stored dense (the reference's format) on the device: every rank expands
         // only its own camera rows, so a 13.5 GB Q never exists on the host or on one GPU of a multi-GPU run
-        validate_bsr(prob);
         const size_t rows = (size_t)3 * nloc_;
         XM_HIP_CHECK(hipMalloc((void **)&dQ_, rows * (size_t)ld_ * sizeof(double)));
         ownQ_ = true;
         XM_HIP_CHECK(hipMemsetAsync(dQ_, 0, rows * (size_t)ld_ * sizeof(double), st_));
         if (true_loc > 0) {
-            const int64_t b0 = prob.rowptr[cam0_], b1 = prob.rowptr[cam0_ + true_loc];
+            const int64_t b0 = prob.rowptr[g0_], b1 = prob.rowptr[g0_ + true_loc];
             std::vector<int64_t> rp((size_t)true_loc + 1);
-            for (int64_t i = 0; i <= true_loc; ++i) rp[(size_t)i] = prob.rowptr[cam0_ + i] - b0;
+            for (int64_t i = 0; i <= true_loc; ++i) rp[(size_t)i] = prob.rowptr[g0_ + i] - b0;
             DevBuf<int64_t> drp; DevBuf<int32_t> dci; DevBuf<double> dbl;
             drp.alloc(rp.size(), false); dci.alloc((size_t)std::max<int64_t>(b1 - b0, 1), false); dbl.alloc((size_t)std::max<int64_t>(b1 - b0, 1) * 9, false);
             XM_HIP_CHECK(hipMemcpy(drp.p, rp.data(), rp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -140,33 +285,29 @@ void Context::init(const xm_problem_t &prob) {
         XM_HIP_CHECK(hipStreamSynchronize(st_));
         storage_ = XM_STORAGE_DENSE;
     } else if (storage_ == XM_STORAGE_BSR3) {
-        validate_bsr(prob);
         std::vector<int64_t> rp((size_t)nloc_ + 1, 0);
-        const int64_t b0 = (true_loc > 0) ? prob.rowptr[cam0_] : 0;
-        for (int64_t i = 0; i <= nloc_; ++i) {
-            const int64_t g = std::min<int64_t>(cam0_ + i, n_);
-            rp[(size_t)i] = ((true_loc > 0) ? prob.rowptr[std::max<int64_t>(g, cam0_)] : 0) - b0;
-        }
+        const int64_t b0 = (true_loc > 0) ? prob.rowptr[g0_] : 0;
+        for (int64_t i = 0; i <= nloc_; ++i) rp[(size_t)i] = ((true_loc > 0) ? prob.rowptr[g0_ + std::min<int64_t>(i, true_loc)] : 0) - b0;
         nb_loc_ = rp[(size_t)nloc_];
+        // column indices in the padded numbering (identity for equal ranges, whose only padding is at the end)
+        std::vector<int32_t> ci((size_t)std::max<int64_t>(nb_loc_, 1), 0);
+        for (int64_t q = 0; q < nb_loc_; ++q) ci[(size_t)q] = (int32_t)pos_of(prob.colidx[b0 + q]);
         rowptr_.alloc((size_t)nloc_ + 1);
         colidx_.alloc((size_t)std::max<int64_t>(nb_loc_, 1));
         blocks_.alloc((size_t)std::max<int64_t>(nb_loc_, 1) * 9);
         XM_HIP_CHECK(hipMemcpy(rowptr_.p, rp.data(), rp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         if (nb_loc_ > 0) {
-            XM_HIP_CHECK(hipMemcpy(colidx_.p, prob.colidx + b0, (size_t)nb_loc_ * sizeof(int32_t), hipMemcpyHostToDevice));
+            XM_HIP_CHECK(hipMemcpy(colidx_.p, ci.data(), (size_t)nb_loc_ * sizeof(int32_t), hipMemcpyHostToDevice));
             XM_HIP_CHECK(hipMemcpy(blocks_.p, prob.blocks + b0 * 9, (size_t)nb_loc_ * 9 * sizeof(double), hipMemcpyHostToDevice));
         }
         // Large problems: sliced-ELL over per-XCD column slabs (xm_sell.h).  Below ~1M blocks per GPU the product is in the
-        // launch-latency regime (13 us at 13682 cameras) and the one-launch CSR kernel stays.  XM_BSR_SELL=1|0 forces / disables,
-        // XM_SELL_SLABS (1,2,4,8), XM_SELL_LMAX, XM_SELL_GATHER (0|1) tune it.
-        {
-            auto env_int = [](const char *k, int dflt) { const char *e = std::getenv(k); return (e && *e) ? std::atoi(e) : dflt; };
-            const int mode = env_int("XM_BSR_SELL", -1);
-            if (mode == 1 || (mode != 0 && nb_loc_ >= 1000000)) {
-                sell_gm_ = env_int("XM_SELL_GATHER", 1);
-                sell_.reset(new SellMatrix(rp.data(), prob.colidx + b0, prob.blocks + b0 * 9, nloc_, ntot_, env_int("XM_SELL_SLABS", 4),
-                                           env_int("XM_SELL_LMAX", 64), st_));
-            }
+        // launch-latency regime (13 us at 13682 cameras) and the one-launch CSR kernel stays.  View-graph storage compresses the
+        // stream with the quaternion codec (36 instead of 76 bytes per stored block).  Settings: sell, sell_slabs, sell_lmax,
+        // sell_gather, sell_codec (XM_BSR_SELL, XM_SELL_SLABS, XM_SELL_LMAX, XM_SELL_GATHER, XM_SELL_CODEC).
+        if (cfg_.sell == 1 || (cfg_.sell == 0 && nb_loc_ >= 1000000)) {
+            sell_gm_ = cfg_.sell_gather;
+            const int codec = (cfg_.sell_codec == 2 || (cfg_.sell_codec == 0 && viewgraph)) ? SELL_CODEC_QUAT : SELL_CODEC_FULL;
+            sell_.reset(new SellMatrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_lmax, st_, codec, cam0_));
         }
     } else if (storage_ == XM_STORAGE_SCHUR) {
         if (world != 1) throw Error(XM_ERR_ARG, "matrix-free storage is single-GPU in this version");
@@ -174,18 +315,16 @@ void Context::init(const xm_problem_t &prob) {
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
     }
-    // Symmetric half-traffic product: single GPU, dense, Q exactly symmetric.  It pays when the product is truly HBM
-    // bound (measured: 13682 cameras 2215 -> 1667 us at o = 3) and not at Venice size, where the per-tile column-sum exchange
-    // costs what the halved traffic saves (34.1 vs 33.8 us).  Default: on for 3n >= 12288 and o <= 4; XM_SYM=1 forces it for
-    // every size (o <= 5), XM_SYM=0 disables it.
-    auto sym_min_rows = [] { const char *e = std::getenv("XM_SYM_MIN_ROWS"); return (e && *e) ? (int64_t)std::atoll(e) : (int64_t)6144; };
+    // Symmetric half-traffic product: dense, Q exactly symmetric.  It pays when the product is truly HBM bound (measured: 13682
+    // cameras 2017 -> 1147 us at o = 3) and not at Venice size.  Settings.sym: auto = on for 3n >= sym_min_rows and o <= 4; 1 forces
+    // it for every size (o <= 5, 1e-9 relative asymmetry accepted); -1 disables it.  Single rank only: the kernel sweeps the upper
+    // triangle of the WHOLE matrix (a rank's row strip is a rectangle).
     sym_ok_ = false;
     sym_max_o_ = 4;
     {
-        const char *e = std::getenv("XM_SYM");
-        const bool force = (e && *e == '1'), off = (e && *e == '0');
+        const bool force = cfg_.sym == 1, off = cfg_.sym == -1;
         if (force) sym_max_o_ = 5;
-        if (storage_ == XM_STORAGE_DENSE && world == 1 && !off && (force || 3 * n_ >= sym_min_rows())) {
+        if (storage_ == XM_STORAGE_DENSE && world == 1 && !off && (force || 3 * n_ >= cfg_.sym_min_rows)) {
             const int grid = 2048;
             DevBuf<double> d;
             d.alloc((size_t)2 * grid);
@@ -204,13 +343,15 @@ void Context::init(const xm_problem_t &prob) {
             q_asym_ = da; q_max_ = mx;
             // The lower triangle is never read on this path, so by default it is taken only for an EXACTLY symmetric matrix (what
             // utils/creatematrix.py:326-328 writes): round-off asymmetry in a Q.bin is honoured like cublasDgemm does, at every
-            // size.  XM_SYM=1 accepts |Q - Q^T| <= 1e-9 |Q| (results then differ from the general path by that much).
+            // size.  sym = 1 accepts |Q - Q^T| <= 1e-9 |Q| (results then differ from the general path by that much).
             sym_ok_ = force ? (da <= 1e-9 * mx) : (da == 0.0);
         }
     }
     XM_HIP_CHECK(hipHostMalloc((void **)&hstat_, 256, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(hstat_, 0, 256);
     XM_HIP_CHECK(hipHostGetDevicePointer((void **)&hstat_dev_, hstat_, 0));
+    ensure_pinned((size_t)1 << 17);   // 1 MB to start with; setup_rank sizes it for the solve
+    if (viewgraph) attach_edges(prob.ne, prob.edge_i, prob.edge_j, prob.edge_M);
 }
 
 Context::~Context() { release_raw(); }
@@ -219,6 +360,10 @@ Context::~Context() { release_raw(); }
 // per-rank workspace
 // ------------------------------------------------------------------------------------------------------------------
 void Context::setup_rank(int o) {
+    // (Re)allocation frees device memory, and hipFree synchronises the WHOLE device.  With several ranks of one process on one device
+    // (virtual devices) that would wait for a peer's wait kernel, which in turn waits for a push this rank has not enqueued yet: the
+    // host barrier makes sure every rank has enqueued everything up to here before anybody frees (no-op for other communicators).
+    if (comm_->active()) comm_->host_barrier();
     o_ = o;
     OP_ = pitch_of(o);
     const size_t mat = (size_t)nloc_ * 3 * OP_, vec = (size_t)nloc_;
@@ -236,7 +381,18 @@ void Context::setup_rank(int o) {
     partsA_.alloc((size_t)3 * nA_);
     // tCG exchange buffers: two parity buffers of world chunks [rows of the image of Hp (multi-rank only) | 3*nA_loc | nB_loc]
     const size_t b_off = comm_->active() ? mat : 0;
-    partsB_.alloc((size_t)2 * (b_off * world + 3 * nA_ + nB_));
+    const size_t pb = (size_t)2 * (b_off * world + 3 * nA_ + nB_);
+    if (comm_->peer() && world > 1 && cfg_.exchange != 1) {
+        // direct peer exchange: the buffers live in memory every rank of the group can store into (collective, host-synchronised)
+        partsB_.release();
+        comm_->xchg_setup(pb, xchg_);
+        partsB_peer_ = xchg_.buf[comm_->rank];
+        xchg_.mute = (cfg_.debug_peer_mute && comm_->rank == 1) ? 1 : 0;
+    } else {
+        xchg_ = PeerXchg();
+        partsB_peer_ = nullptr;
+        partsB_.alloc(pb);
+    }
     if (comm_->active()) Afull_.alloc(mat * world); else Afull_.release();
     partsM_.alloc((size_t)std::max(nB_, 2 * ((nloc_ + 255) / 256) * world));
     if (sym_ok_ && o >= 3 && o <= sym_max_o_) {
@@ -254,12 +410,9 @@ void Context::setup_rank(int o) {
         Pstrip_.alloc(mat);
     }
     scal_.alloc(2);
-    const size_t need = (size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64;
-    if (need > hpin_count_) {
-        if (hpin_) (void)hipHostFree(hpin_);
-        XM_HIP_CHECK(hipHostMalloc((void **)&hpin_, need * sizeof(double), hipHostMallocDefault));
-        hpin_count_ = need;
-    }
+    // pinned staging: partial sums, a whole replicated point (download_point) and a Lanczos vector
+    ensure_pinned(std::max<size_t>((size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64, (size_t)ld_ * OP_ + (size_t)ntot_ + 1024));
+    if (comm_->active()) comm_->host_barrier();   // nobody enqueues the next collective while somebody is still freeing
 }
 
 // host column-major (true n) -> device row-major (pitch OP) rows of the local cameras; padding cameras get [I 0]
@@ -267,16 +420,16 @@ void Context::upload_point(const std::vector<double> &R_cm, int o, const std::ve
     const size_t m = (size_t)3 * n_;
     std::vector<double> Rr((size_t)nloc_ * 3 * OP_, 0.0), sl((size_t)nloc_, 1.0);
     for (int c = 0; c < nloc_; ++c) {
-        const int64_t g = (int64_t)cam0_ + c;
+        const bool real = c < true_loc_;
+        const int64_t g = g0_ + c;
         for (int a = 0; a < 3; ++a)
             for (int k = 0; k < o; ++k)
-                Rr[((size_t)c * 3 + a) * OP_ + k] = (g < n_) ? R_cm[(size_t)(3 * g + a) + (size_t)k * m] : (a == k ? 1.0 : 0.0);
-        if (g < n_) sl[(size_t)c] = s_ex[(size_t)g];
+                Rr[((size_t)c * 3 + a) * OP_ + k] = real ? R_cm[(size_t)(3 * g + a) + (size_t)k * m] : (a == k ? 1.0 : 0.0);
+        if (real) sl[(size_t)c] = s_ex[(size_t)g];
     }
     if (cam0_ == 0) sl[0] = 1.0;  // the anchor's scale is 1 inside the solver (trustregion.h:125-127)
-    XM_HIP_CHECK(hipMemcpyAsync(R_.p, Rr.data(), Rr.size() * sizeof(double), hipMemcpyHostToDevice, st_));
-    XM_HIP_CHECK(hipMemcpyAsync(s_.p, sl.data(), sl.size() * sizeof(double), hipMemcpyHostToDevice, st_));
-    XM_HIP_CHECK(hipStreamSynchronize(st_));
+    to_dev(R_.p, Rr.data(), Rr.size() * sizeof(double));
+    to_dev(s_.p, sl.data(), sl.size() * sizeof(double));
 }
 
 // device -> host column-major for ALL cameras (gathers across ranks through the W buffer)
@@ -285,19 +438,18 @@ void Context::download_point(std::vector<double> &R_cm, std::vector<double> &s_e
     std::vector<double> full((size_t)ntot_ * 3 * OP_), sf((size_t)ntot_);
     XM_HIP_CHECK(hipMemcpyAsync(W_.p + (size_t)comm_->rank * mat, R_.p, mat * sizeof(double), hipMemcpyDeviceToDevice, st_));
     if (comm_->active()) comm_->allgather(W_.p, mat, st_);
-    XM_HIP_CHECK(hipMemcpyAsync(full.data(), W_.p, full.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
-    XM_HIP_CHECK(hipStreamSynchronize(st_));
+    to_host(full.data(), W_.p, full.size() * sizeof(double));
     XM_HIP_CHECK(hipMemcpyAsync(W_.p + (size_t)comm_->rank * nloc_, s_.p, (size_t)nloc_ * sizeof(double), hipMemcpyDeviceToDevice, st_));
     if (comm_->active()) comm_->allgather(W_.p, (size_t)nloc_, st_);
-    XM_HIP_CHECK(hipMemcpyAsync(sf.data(), W_.p, sf.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
-    XM_HIP_CHECK(hipStreamSynchronize(st_));
+    to_host(sf.data(), W_.p, sf.size() * sizeof(double));
     XM_HIP_CHECK(hipMemsetAsync(W_.p, 0, W_.count * sizeof(double), st_));
     R_cm.assign(m * (size_t)o_, 0.0);
     s_ex.assign((size_t)n_, 1.0);
     for (int64_t g = 0; g < n_; ++g) {
+        const size_t q = (size_t)pos_of(g);
         for (int a = 0; a < 3; ++a)
-            for (int k = 0; k < o_; ++k) R_cm[(size_t)(3 * g + a) + (size_t)k * m] = full[((size_t)g * 3 + a) * OP_ + k];
-        s_ex[(size_t)g] = sf[(size_t)g];
+            for (int k = 0; k < o_; ++k) R_cm[(size_t)(3 * g + a) + (size_t)k * m] = full[(q * 3 + a) * OP_ + k];
+        s_ex[(size_t)g] = sf[q];
     }
 }
 
@@ -368,10 +520,8 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
 // side) — inside the tCG the product input comes from replicated data and there is no gather to hide.  It costs
 // an extra launch, so it is used only when the per-rank matrix is large (XM_OVERLAP_MIN_MB, default 64; XM_OVERLAP=0 disables).
 bool Context::overlap_applies() const {
-    static const int mode = [] { const char *e = std::getenv("XM_OVERLAP"); return (e && *e) ? std::atoi(e) : 1; }();
-    static const double min_mb = [] { const char *e = std::getenv("XM_OVERLAP_MIN_MB"); return (e && *e) ? std::atof(e) : 64.0; }();
-    if (mode == 0 || !comm_->active() || storage_ != XM_STORAGE_DENSE || sym_ok_) return false;
-    if ((double)nloc_ * 3.0 * (double)ld_ * 8.0 < min_mb * 1048576.0) return false;
+    if (cfg_.overlap < 0 || !comm_->active() || storage_ != XM_STORAGE_DENSE || sym_ok_) return false;
+    if ((double)nloc_ * 3.0 * (double)ld_ * 8.0 < cfg_.overlap_min_mb * 1048576.0) return false;
     const int tc = qw_dense_tile_cols();
     const int64_t c0 = 3 * (int64_t)cam0_, c1 = 3 * ((int64_t)cam0_ + nloc_);
     return (c1 / tc) > ((c0 + tc - 1) / tc);
@@ -408,7 +558,7 @@ void Context::eval_point(int state, const double *Rp, const double *sp, double &
     product(EPI_GRAD, o_, 2.0, a);
     if (comm_->active()) comm_->allgather(partsA_.p, (size_t)2 * nA_loc, st_);
     launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, 0, scal_.p, reinterpret_cast<double *>(hstat_dev_) + 8,
-                          ++outer_seq_, st_);
+                          ++outer_seq_, grouping_, st_);
     volatile double *hres = wait_outer_result();
     f = hres[0];
     rr = hres[1];
@@ -420,7 +570,7 @@ bool Context::agree_any(bool local) {
     if (!comm_->active()) return local;
     const int world = comm_->world;
     double v = local ? 1.0 : 0.0;
-    XM_HIP_CHECK(hipMemcpyAsync(partsM_.p + comm_->rank, &v, sizeof(double), hipMemcpyHostToDevice, st_));
+    to_dev(partsM_.p + comm_->rank, &v, sizeof(double));
     comm_->allgather(partsM_.p, 1, st_);
     XM_HIP_CHECK(hipMemcpyAsync(hpin_, partsM_.p, (size_t)world * sizeof(double), hipMemcpyDeviceToHost, st_));
     XM_HIP_CHECK(hipStreamSynchronize(st_));
@@ -433,7 +583,8 @@ bool Context::agree_any(bool local) {
 // neither hipSuccess nor hipErrorNotReady and must end the wait with XM_ERR_HIP instead of spinning for ever; so must a wait that
 // exceeds the watchdog (XM_WATCHDOG_S seconds, default 600: a dead peer inside an RCCL collective never completes the stream).
 bool Context::stream_idle(clk::time_point t_wait, const char *what) {
-    static const double limit = [] { const char *e = std::getenv("XM_WATCHDOG_S"); return (e && *e) ? std::atof(e) : 600.0; }();
+    const double limit = cfg_.watchdog_s;
+    comm_->check_device_error();   // a bounded device-side wait of the peer exchange expired -> XM_ERR_COMM
     const hipError_t q = hipStreamQuery(st_);
     if (q == hipSuccess) return true;
     if (q != hipErrorNotReady) {
@@ -505,7 +656,12 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     // enqueued only once iteration j-2 is confirmed (so nobody can be past T+1 when the tCG ends in iteration T) and every
     // rank tops its queue up to exactly T+2 iterations after it has seen the end (identical scalar state on all ranks =>
     // identical T).  One iteration is always queued behind the running one, so the host round trip is hidden.
-    const int run_ahead = comm_->active() ? 2 : 3;
+    // With the DIRECT PEER EXCHANGE (xchg_.world > 1) the exchange lives inside cg_step_kernel and launches past the end of the tCG
+    // skip it, so there is nothing to keep in lockstep: the loop is the single-GPU loop.
+    const bool fused = xchg_.world > 1;
+    if (fused) xchg_.epoch_base = (++tcg_runs_) << 12;
+    const bool lockstep = comm_->active() && !fused;
+    const int run_ahead = lockstep ? 2 : 3;
     int fin_status = 0, fin_iter = 0;
     int it = 0;  // iterations enqueued
     auto enqueue = [&](int i) {
@@ -521,7 +677,8 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
         const size_t mat = (size_t)nloc_ * 3 * OP_;
         const size_t b_off = comm_->active() ? mat : 0;
         const size_t chunk = b_off + (size_t)3 * nA_loc + nB_loc;
-        double *pcur = partsB_.p + (size_t)par * chunk * comm_->world, *pnext = partsB_.p + (size_t)(par ^ 1) * chunk * comm_->world;
+        double *pB = fused ? partsB_peer_ : partsB_.p;
+        double *pcur = pB + (size_t)par * chunk * comm_->world, *pnext = pB + (size_t)(par ^ 1) * chunk * comm_->world;
         a.partials = pcur + (size_t)rank * chunk + b_off;
         a.Bout = comm_->active() ? pcur + (size_t)rank * chunk : nullptr;
         const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
@@ -529,16 +686,15 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
         product(EPI_HESS, o_, 2.0, a);
         if (timed) { XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].second, st_)); ev_used_++; }
         hess_launches_++;
-        if (comm_->active()) comm_->allgather(pcur, chunk, st_);
+        if (lockstep) comm_->allgather(pcur, chunk, st_);
         launch_cg_step(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), pcur, nA_loc, nB_loc, comm_->world, HpR_.p, Hps_.p, R_.p,
                        s_.p, pR_.p, par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, rR_.p,
                        par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pnext + (size_t)rank * chunk + b_off + 3 * nA_loc, hstat_dev_,
-                       (int)b_off, (int64_t)mat, comm_->active() ? Afull_.p : nullptr, W_.p, st_);
+                       (int)b_off, (int64_t)mat, comm_->active() ? Afull_.p : nullptr, W_.p, grouping_, xchg_, st_);
     };
     auto read_scal = [&](int par) {
         TcgScal sc;
-        XM_HIP_CHECK(hipMemcpyAsync(&sc, scal_.p + par, sizeof(TcgScal), hipMemcpyDeviceToHost, st_));
-        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        to_host(&sc, scal_.p + par, sizeof(TcgScal));
         return sc;
     };
     if (stepped) {
@@ -576,7 +732,8 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
         }
     }
     if (comm_->active()) comm_->note("tcg_end_before_topup", (double)it, (double)(fin_iter * 16 + fin_status));
-    if (comm_->active() && !stepped) {
+    if (fin_status == 7) { comm_->check_device_error(); throw Error(XM_ERR_COMM, "peer exchange: a rank did not arrive inside the truncated CG"); }
+    if (lockstep && !stepped) {
         const int T = (fin_status == 6) ? fin_iter - 1 : fin_iter;   // iteration in which the tCG ended
         while (it < std::min(kMaxInner, T + 2)) enqueue(it++);      // no-ops, but the same collectives on every rank
     }
@@ -604,14 +761,14 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         double alpha = linesearch_step;
         // direction: v in the new last column only
         std::vector<double> D((size_t)nloc_ * 3 * OP_, 0.0);
-        for (int c = 0; c < nloc_; ++c) {
-            const int64_t g = (int64_t)cam0_ + c;
-            if (g < n_) for (int a = 0; a < 3; ++a) D[((size_t)c * 3 + a) * OP_ + (o - 1)] = v_dir[(size_t)(3 * g + a)];
+        for (int c = 0; c < (int)true_loc_; ++c) {
+            const int64_t g = g0_ + c;
+            for (int a = 0; a < 3; ++a) D[((size_t)c * 3 + a) * OP_ + (o - 1)] = v_dir[(size_t)(3 * g + a)];
         }
-        XM_HIP_CHECK(hipMemcpyAsync(D_.p, D.data(), D.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+        to_dev(D_.p, D.data(), D.size() * sizeof(double));
         double fn;
         for (;;) {
-            launch_retract(o, nloc_, cam0_, R_.p, s_.p, D_.p, nullptr, -alpha, Rc_.p, nullptr, Wloc, st_);
+            launch_retract(o, nloc_, cam0_, R_.p, s_.p, D_.p, nullptr, -alpha, Rc_.p, nullptr, Wloc, st_, retraction_);
             gather_W();
             eval_point(cur_ ^ 1, Rc_.p, s_.p, fn, tmp);
             if (!(fn > f0)) break;
@@ -678,7 +835,7 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         const PointState &P = ps_[cur_];
         launch_model_value(o, nloc_, vR_.p, vs_.p, HvR_.p, Hvs_.p, P.rgR.p, P.rgs.p, s_.p, partsM_.p + (size_t)comm_->rank * nB_loc, st_);
         if (comm_->active()) comm_->allgather(partsM_.p, (size_t)nB_loc, st_);
-        launch_retract(o, nloc_, cam0_, R_.p, s_.p, vR_.p, vs_.p, 1.0, Rc_.p, sc_.p, Wloc, st_);
+        launch_retract(o, nloc_, cam0_, R_.p, s_.p, vR_.p, vs_.p, 1.0, Rc_.p, sc_.p, Wloc, st_, retraction_);
         gather_W();
         {
             CamArgs a = cam_args(cur_ ^ 1);
@@ -690,15 +847,16 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         }
         // XM_DEBUG_DROP_FINALIZE=k (tests): the k-th outer iteration "loses" its result kernel, as a failed launch would: the host
         // must come back with XM_ERR_HIP from wait_outer_result() instead of spinning on a sequence word that never arrives
-        static const long long drop_at = [] { const char *e = std::getenv("XM_DEBUG_DROP_FINALIZE"); return (e && *e) ? std::atoll(e) : -1LL; }();
+        const long long drop_at = cfg_.debug_drop_finalize;
         if (drop_at >= 0 && (long long)outer_seq_ + 1 == drop_at) ++outer_seq_;
         else
         launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, nB_, scal_.p + (enq & 1),
-                              reinterpret_cast<double *>(hstat_dev_) + 8, ++outer_seq_, st_);
+                              reinterpret_cast<double *>(hstat_dev_) + 8, ++outer_seq_, grouping_, st_);
         volatile double *hres = wait_outer_result();
         double f_new = hres[0], rr_new = hres[1], loss_qu = hres[2];
         fin.status = (int)hres[3];
         fin.iter = (int)hres[4];
+        if (fin.status == 7) { comm_->check_device_error(); throw Error(XM_ERR_COMM, "peer exchange: a rank did not arrive inside the truncated CG"); }
         if (fin.status == 0) fin.status = 6;  // ran out of iterations
         endreason = fin.status;
         inner_print = fin.iter + 1;
@@ -823,30 +981,40 @@ static void tridiag_min(const std::vector<double> &a, const std::vector<double> 
 int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &iters_out, double &resid_out) {
     const int64_t len = ld_;           // vectors are replicated, full length, zero beyond 3n
     const int64_t m3 = 3 * n_;
-    // XM_LANCZOS_MMAX / XM_LANCZOS_RESTARTS: debugging aids (the tests use them to force a non-converged run)
-    static const int env_mmax = [] { const char *e = std::getenv("XM_LANCZOS_MMAX"); return (e && *e) ? std::atoi(e) : 400; }();
-    static const int env_restarts = [] { const char *e = std::getenv("XM_LANCZOS_RESTARTS"); return (e && *e) ? std::atoi(e) : 12; }();
+    const int env_mmax = cfg_.lanczos_mmax, env_restarts = cfg_.lanczos_restarts;   // small values: debugging aids (the tests force a non-converged run)
     const int mmax = (int)std::min<int64_t>(m3, std::max(2, env_mmax));
     // Small problems take the DENSE route of the reference (cusolverDnDsyevd on S, Dense/eig.h:35-73): Householder-free, the same
     // three-term recurrence with full re-orthogonalisation IS the reduction of S to tridiagonal form when it runs all 3n steps, and
     // the QL sweep on T then returns the smallest eigenvalue of S itself (no convergence test, Ritz residual = round-off).
-    static const int64_t dense_rows = [] { const char *e = std::getenv("XM_CERT_DENSE_ROWS"); return (e && *e) ? (int64_t)std::atoll(e) : (int64_t)384; }();
-    const bool exact = m3 <= dense_rows && m3 <= mmax;
-    eig_exact_ = exact;
-    DevBuf<double> V, c, w;
-    V.alloc((size_t)len * (mmax + 1));
-    c.alloc((size_t)mmax + 2);
-    w.alloc((size_t)len);
+    const bool exact = m3 <= cfg_.cert_dense_rows && m3 <= mmax;
+    eig_exact_ = false;   // set after the run: only when the Krylov space was really exhausted
+    // Lanczos workspace: owned by the context and grow-only, so that no device memory is freed between two collectives of a solve
+    // (see setup_rank); the host barrier covers the (re)allocation
+    DevBuf<double> &V = lzV_, &c = lzc_, &w = lzw_, &c2 = lzc2_, &ab = lzab_, &dscr = lzscr_;
+    const size_t nscr = (size_t)(mmax + 1) * (size_t)dots_multi_segments(len);
+    if (V.count < (size_t)len * (mmax + 1) || c.count < (size_t)mmax + 2 || w.count < (size_t)len || dscr.count < nscr) {
+        if (comm_->active()) comm_->host_barrier();
+        V.alloc((size_t)len * (mmax + 1));
+        c.alloc((size_t)mmax + 2);
+        w.alloc((size_t)len);
+        c2.alloc((size_t)mmax + 2);
+        dscr.alloc(nscr);
+        ab.alloc((size_t)2 * (mmax + 1));
+        if (comm_->active()) comm_->host_barrier();
+    }
     std::vector<double> x((size_t)len, 0.0);
     unsigned long long lcg = 0x9E3779B97F4A7C15ull;
     double nrm = 0;
-    for (int64_t i = 0; i < m3; ++i) {
+    std::vector<int64_t> posv((size_t)n_);   // global camera -> position (identity unless the partition is balanced by blocks)
+    for (int64_t g = 0; g < n_; ++g) posv[(size_t)g] = pos_of(g);
+    for (int64_t i = 0; i < m3; ++i) {   // drawn in GLOBAL order: the start vector does not depend on the partition
         lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
-        x[(size_t)i] = ((double)(lcg >> 11) / 9007199254740992.0) - 0.5;
-        nrm += x[(size_t)i] * x[(size_t)i];
+        const double v = ((double)(lcg >> 11) / 9007199254740992.0) - 0.5;
+        x[(size_t)(3 * posv[(size_t)(i / 3)] + i % 3)] = v;
+        nrm += v * v;
     }
     nrm = std::sqrt(nrm);
-    for (int64_t i = 0; i < m3; ++i) x[(size_t)i] /= nrm;
+    for (int64_t i = 0; i < len; ++i) x[(size_t)i] /= nrm;
 
     CamArgs a = cam_args(cur_);
     a.Lam = ps_[cur_ ^ 1].S0.p;
@@ -855,14 +1023,11 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
     std::vector<double> al, be, y;
     int total = 0;
     // device-side bookkeeping: c1 / c2 = Gram-Schmidt coefficients of the two passes, ab = [alpha_0.. | beta_0..]
-    DevBuf<double> c2, ab, dscr;
-    c2.alloc((size_t)mmax + 2);
-    dscr.alloc((size_t)(mmax + 1) * (size_t)dots_multi_segments(len));   // segment sums of the Gram-Schmidt dot products (long vectors)
-    ab.alloc((size_t)2 * (mmax + 1));
+    XM_HIP_CHECK(hipMemsetAsync(ab.p, 0, ab.count * sizeof(double), st_));
     std::vector<double> hab((size_t)2 * (mmax + 1));
     const int batch = 8;   // Lanczos steps enqueued between two host checks
     for (int restart = 0; restart < std::max(1, env_restarts); ++restart) {
-        XM_HIP_CHECK(hipMemcpyAsync(V.p, x.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, st_));
+        to_dev(V.p, x.data(), (size_t)len * sizeof(double));
         al.clear(); be.clear();
         bool done = false;
         int m_use = 0;
@@ -890,8 +1055,7 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 launch_lz_next(V.p + (size_t)(j + 1) * len, w.p, c.p + mmax + 1, ab.p + (mmax + 1) + j, len, st_);
                 total++;
             }
-            XM_HIP_CHECK(hipMemcpyAsync(hab.data(), ab.p, hab.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
-            XM_HIP_CHECK(hipStreamSynchronize(st_));
+            to_host(hab.data(), ab.p, hab.size() * sizeof(double));
             for (int j = j0; j < j1; ++j) {
                 al.push_back(hab[(size_t)j]);
                 const double beta = hab[(size_t)(mmax + 1) + j];
@@ -899,23 +1063,25 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 tridiag_min(al, be, m, theta, y, tmax);
                 resid = std::fabs(beta * y[(size_t)m - 1]);
                 m_use = m;
-                if ((!exact && resid <= 1e-9 * std::max(1.0, tmax)) || beta < 1e-13 * std::max(1.0, tmax) || m == (int)m3 || !std::isfinite(beta)) { done = true; break; }
+                const bool exhausted = (m == (int)m3) || (beta < 1e-13 * std::max(1.0, tmax));   // full space, or an invariant subspace under full re-orthogonalisation
+                if (exact && exhausted && std::isfinite(beta)) eig_exact_ = true;
+                if ((!exact && resid <= 1e-9 * std::max(1.0, tmax)) || exhausted || !std::isfinite(beta)) { done = true; break; }
                 be.push_back(beta);
             }
         }
         // Ritz vector x = V(:,0..m_use-1) y
         if ((int)y.size() != m_use) tridiag_min(al, be, m_use, theta, y, tmax);
-        XM_HIP_CHECK(hipMemcpyAsync(c.p, y.data(), (size_t)m_use * sizeof(double), hipMemcpyHostToDevice, st_));
+        to_dev(c.p, y.data(), (size_t)m_use * sizeof(double));
         launch_gemv_n(w.p, V.p, len, c.p, m_use, len, st_);
-        XM_HIP_CHECK(hipMemcpyAsync(x.data(), w.p, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, st_));
-        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        to_host(x.data(), w.p, (size_t)len * sizeof(double));
         double nn = 0;
         for (int64_t i = 0; i < len; ++i) nn += x[(size_t)i] * x[(size_t)i];
         nn = std::sqrt(nn);
         if (nn > 0) for (int64_t i = 0; i < len; ++i) x[(size_t)i] /= nn;
         if (done) break;
     }
-    x_out.assign(x.begin(), x.begin() + m3);
+    x_out.assign((size_t)m3, 0.0);
+    for (int64_t i = 0; i < m3; ++i) x_out[(size_t)i] = x[(size_t)(3 * posv[(size_t)(i / 3)] + i % 3)];
     theta_out = theta;
     iters_out = total;
     resid_out = resid;
@@ -1002,11 +1168,14 @@ void Context::apply(int o, const double *Wh, double *out, double alpha) {
 // ------------------------------------------------------------------------------------------------------------------
 void Context::attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M) {
     if (ne < 0 || (ne > 0 && (!ei || !ej || !M))) throw Error(XM_ERR_ARG, "attach_edges: bad argument");
+    validate_edges(n_, ne, ei, ej, "attach_edges");
+    // the kernels address cameras by their position in the padded numbering (== the global index unless the row partition is
+    // balanced by stored blocks)
+    std::vector<int32_t> pi((size_t)std::max<int64_t>(ne, 1)), pj((size_t)std::max<int64_t>(ne, 1));
+    for (int64_t e = 0; e < ne; ++e) { pi[(size_t)e] = (int32_t)pos_of(ei[e]); pj[(size_t)e] = (int32_t)pos_of(ej[e]); }
+    ei = pi.data(); ej = pj.data();
     std::vector<int64_t> inc((size_t)ntot_ + 1, 0);
-    for (int64_t e = 0; e < ne; ++e) {
-        if (ei[e] < 0 || ej[e] < 0 || ei[e] >= n_ || ej[e] >= n_ || ei[e] == ej[e]) throw Error(XM_ERR_ARG, "attach_edges: bad edge");
-        inc[(size_t)ei[e] + 1]++; inc[(size_t)ej[e] + 1]++;
-    }
+    for (int64_t e = 0; e < ne; ++e) { inc[(size_t)ei[e] + 1]++; inc[(size_t)ej[e] + 1]++; }
     for (int64_t c = 0; c < ntot_; ++c) inc[(size_t)c + 1] += inc[(size_t)c];
     std::vector<int32_t> ie((size_t)std::max<int64_t>(2 * ne, 1));
     {   // incidence lists in edge order (fixed -> the diagonal sums are bit-reproducible)
@@ -1034,8 +1203,7 @@ void Context::attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, con
         XM_HIP_CHECK(hipStreamSynchronize(st_));
         for (int64_t e = 0; e < ne; ++e)
             if (a[(size_t)e] == -2 || b[(size_t)e] == -2) { ne_ = 0; throw Error(XM_ERR_ARG, "attach_edges: an edge has no stored block in the BSR3 pattern"); }
-        const int64_t true_loc = std::max<int64_t>(0, std::min<int64_t>(n_ - cam0_, nloc_));
-        for (int64_t c = 0; c < true_loc; ++c)
+        for (int64_t c = 0; c < true_loc_; ++c)
             if (d[(size_t)c] < 0 && inc[(size_t)(cam0_ + c) + 1] > inc[(size_t)(cam0_ + c)]) { ne_ = 0; throw Error(XM_ERR_ARG, "attach_edges: a camera with edges has no stored diagonal block"); }
     }
 }
@@ -1064,7 +1232,7 @@ void Context::edge_residuals(double *res) {
     gather_W();
     flush_gather();
     launch_edge_residual(ne_, ei_.p, ej_.p, eM_.p, W_.p, o_, OP_, eres_.p, st_);
-    if (ne_ > 0) XM_HIP_CHECK(hipMemcpyAsync(res, eres_.p, (size_t)ne_ * sizeof(double), hipMemcpyDeviceToHost, st_));
+    if (ne_ > 0) to_host(res, eres_.p, (size_t)ne_ * sizeof(double));
     XM_HIP_CHECK(hipMemsetAsync(W_.p, 0, W_.count * sizeof(double), st_));
     XM_HIP_CHECK(hipStreamSynchronize(st_));
 }
@@ -1079,7 +1247,7 @@ void Context::set_edge_weights(const double *w) {
     if (storage_ == XM_STORAGE_SCHUR) { schur_->set_weights(w, st_); return; }
     if (!ei_.p) throw Error(XM_ERR_ARG, "set_edge_weights: no edges attached");
     if (ne_ > 0 && !w) throw Error(XM_ERR_ARG, "set_edge_weights: null weights");
-    if (ne_ > 0) XM_HIP_CHECK(hipMemcpyAsync(ew_.p, w, (size_t)ne_ * sizeof(double), hipMemcpyHostToDevice, st_));
+    if (ne_ > 0) to_dev(ew_.p, w, (size_t)ne_ * sizeof(double));
     const bool dense = (storage_ == XM_STORAGE_DENSE);
     launch_edge_write(dense, ne_, ei_.p, ej_.p, eM_.p, ew_.p, cam0_, nloc_, inc_ptr_.p, inc_edge_.p, pos_ij_.p, pos_ji_.p, pos_d_.p,
                       dense ? nullptr : blocks_.p, dense ? dQ_ : nullptr, ld_, st_);
@@ -1094,6 +1262,10 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     opt_ = &opt;
     res_ = &res;
     verbose_ = (opt.flags & XM_FLAG_VERBOSE) != 0;
+    if (opt.retraction != XM_RETRACT_QR && opt.retraction != XM_RETRACT_POLAR) throw Error(XM_ERR_ARG, "unknown retraction");
+    if (opt.sum_grouping < 0 || opt.sum_grouping > 2) throw Error(XM_ERR_ARG, "sum_grouping must be 0, 1 or 2");
+    retraction_ = opt.retraction;
+    grouping_ = opt.sum_grouping;
     double *Rout = res.R, *sout = res.s;
     std::memset(&res, 0, sizeof(res));
     res.R = Rout; res.s = sout;
@@ -1136,12 +1308,15 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
             setup_rank((int)o);
             if (o == 3) {
                 identity_stack();
-                const bool warm = opt.mode == XM_MODE_REBUTTLE && (opt.flags & XM_FLAG_WARM_R) && opt.R_ini;
+                // XM_FLAG_WARM_R is honoured in EVERY staircase mode (solve and solve_rebuttle differ only in s_ini): a caller who hands
+                // over R_ini wants the warm start, and silently starting from the identity would only cost iterations
+                if ((opt.flags & XM_FLAG_WARM_R) && !opt.R_ini) throw Error(XM_ERR_ARG, "XM_FLAG_WARM_R without R_ini");
+                const bool warm = (opt.flags & XM_FLAG_WARM_R) && opt.R_ini;
                 if (warm) std::memcpy(R0.data(), opt.R_ini, m * 3 * sizeof(double));
                 upload_point(R0, 3, s0);
                 if (warm) {   // rows of a previous solution truncated to rank 3 are re-orthonormalised (MGS of R + 0 * D)
                     XM_HIP_CHECK(hipMemsetAsync(D_.p, 0, D_.count * sizeof(double), st_));
-                    launch_retract(3, nloc_, cam0_, R_.p, s_.p, D_.p, nullptr, 0.0, Rc_.p, nullptr, nullptr, st_);
+                    launch_retract(3, nloc_, cam0_, R_.p, s_.p, D_.p, nullptr, 0.0, Rc_.p, nullptr, nullptr, st_, 0);
                     std::swap(R_.p, Rc_.p);
                 }
                 tr = trust_region(3, gradtol, 0.0, v, opt.max_time);
@@ -1184,6 +1359,10 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     if (storage_ == XM_STORAGE_DENSE) res.qw_bytes = 8LL * (3 * n_) * (3 * n_) + 2LL * 8 * 3 * n_ * of;
     else if (storage_ == XM_STORAGE_SCHUR) res.qw_bytes = schur_->bytes_per_product(of);
     else res.qw_bytes = 76LL * nb_loc_ + 4LL * (n_ + 1) + 2LL * 8 * 3 * n_ * of;
+    res.qw_stream_bytes = (storage_ == XM_STORAGE_DENSE) ? (res.sym_product ? 4LL : 8LL) * (3 * n_) * (3 * n_)
+                          : (storage_ == XM_STORAGE_BSR3) ? ((sell_ && sell_supports(of)) ? sell_->stream_bytes() : 76LL * nb_loc_) : 0;
+    res.n_gpus = comm_->world;
+    res.exchange = !comm_->active() ? 0 : (xchg_.world > 1 ? 2 : 1);
     res.seconds = secs_since(t0);
     // leave the end point resident at its final rank for edge_residuals(): R_/s_ hold the last trust-region point already,
     // unless the staircase escalated past it (then the last stage's buffers still describe the returned point)

@@ -15,6 +15,8 @@ MODULE_DIR = os.path.join(_HERE, "build")      # holds XM.cpython-*.so (the refe
 STORAGE_DENSE, STORAGE_BSR3 = 0, 1
 STORAGE_BSR3_DENSE = 2   # BSR3 on the host, expanded to the dense layout on the device (each rank: its own rows)
 STORAGE_SCHUR = 3        # matrix-free: the observation list of the reference's create_matrix (cam, lm, p, w)
+STORAGE_VIEWGRAPH = 4    # the view-graph edge list (ei, ej, w, M): block CSR + quaternion-compressed sliced ELL on the device
+RETRACT_QR, RETRACT_POLAR = 0, 1
 MODE_SOLVE, MODE_RANK3, MODE_REBUTTLE = 0, 1, 2
 FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 CERT_EIG_NOT_CONVERGED = 1
@@ -22,11 +24,11 @@ CERT_EIG_EXACT = 2           # small problem: the certificate's tridiagonalisati
 FLAG_WARM_R = 16
 
 EXPORTS = [
-    "xm_last_error", "xm_version", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
+    "xm_last_error", "xm_version", "xm_abi_revision", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
-    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
-    "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition",
-    "xm_symv_plan", "xm_sell_layout", "xm_sell_create", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
+    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
+    "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition", "xm_partition_blocks",
+    "xm_symv_plan", "xm_sell_layout", "xm_sell_create", "xm_sell_create2", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
     "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse",
 ]
 
@@ -35,27 +37,36 @@ class XmError(RuntimeError):
     pass
 
 
+class Tuning(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("sym", "sym_min_rows", "sell", "sell_slabs", "sell_lmax", "sell_gather", "sell_codec", "overlap",
+                                         "overlap_min_mb", "cert_dense_rows", "lanczos_mmax", "lanczos_restarts", "watchdog_s", "balance",
+                                         "exchange")] + [("reserved", C.c_int32 * 5)]
+
+
 class Problem(C.Structure):
-    _fields_ = [("n", C.c_int64), ("storage", C.c_int32), ("q_on_device", C.c_int32), ("q", C.c_void_p),
+    _fields_ = [("struct_size", C.c_uint32), ("n", C.c_int64), ("storage", C.c_int32), ("q_on_device", C.c_int32), ("q", C.c_void_p),
                 ("ldq", C.c_int64), ("nb", C.c_int64), ("rowptr", C.c_void_p), ("colidx", C.c_void_p),
                 ("blocks", C.c_void_p), ("nobs", C.c_int64), ("n_landmarks", C.c_int64), ("obs_cam", C.c_void_p), ("obs_lm", C.c_void_p),
-                ("obs_p", C.c_void_p), ("obs_w", C.c_void_p), ("q_row0", C.c_int64)]
+                ("obs_p", C.c_void_p), ("obs_w", C.c_void_p), ("q_row0", C.c_int64),
+                ("ne", C.c_int64), ("edge_i", C.c_void_p), ("edge_j", C.c_void_p), ("edge_w", C.c_void_p), ("edge_M", C.c_void_p),
+                ("n_gpus", C.c_int32), ("gpu_map", C.c_int32), ("tuning", C.POINTER(Tuning))]
 
 
 class Options(C.Structure):
-    _fields_ = [("max_rank", C.c_uint32), ("tol", C.c_double), ("lam", C.c_double), ("max_time", C.c_double),
+    _fields_ = [("struct_size", C.c_uint32), ("max_rank", C.c_uint32), ("tol", C.c_double), ("lam", C.c_double), ("max_time", C.c_double),
                 ("mode", C.c_int32), ("flags", C.c_uint32), ("s_ini", C.c_void_p), ("trace_cap", C.c_int32),
-                ("trace", C.c_void_p), ("R_ini", C.c_void_p)]
+                ("trace", C.c_void_p), ("R_ini", C.c_void_p), ("retraction", C.c_int32), ("sum_grouping", C.c_int32)]
 
 
 class Result(C.Structure):
-    _fields_ = [("R", C.c_void_p), ("s", C.c_void_p), ("rank", C.c_int32), ("status", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("R", C.c_void_p), ("s", C.c_void_p), ("rank", C.c_int32), ("status", C.c_int32),
                 ("primal", C.c_double), ("dual", C.c_double), ("min_eig", C.c_double), ("gap", C.c_double),
                 ("tcg_iters", C.c_int64), ("outer_iters", C.c_int64), ("qw_products", C.c_int64),
                 ("lanczos_iters", C.c_int64), ("seconds", C.c_double), ("tr_seconds", C.c_double),
                 ("cert_seconds", C.c_double), ("qw_ms_sum", C.c_double), ("qw_ms_count", C.c_int64),
                 ("qw_bytes", C.c_int64), ("trace_len", C.c_int32), ("last_stop_reason", C.c_int32),
-                ("sym_product", C.c_int32), ("cert_flags", C.c_int32), ("eig_residual", C.c_double)]
+                ("sym_product", C.c_int32), ("cert_flags", C.c_int32), ("eig_residual", C.c_double),
+                ("n_gpus", C.c_int32), ("exchange", C.c_int32), ("qw_stream_bytes", C.c_int64)]
 
 
 _lib = None
@@ -100,6 +111,7 @@ def lib():
                                  C.c_double, C.c_void_p]
         L.xm_retract.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        L.xm_retract_polar.argtypes = L.xm_retract.argtypes
         L.xm_qw_dense_time.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.POINTER(C.c_double)]
         L.xm_qw_bsr3_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -109,8 +121,11 @@ def lib():
         L.xm_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.xm_comm_init_shm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
         L.xm_partition.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.xm_partition_blocks.argtypes = [C.c_int64, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.xm_sell_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p] + [C.c_void_p] * 7
         L.xm_sell_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.xm_sell_create2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]
+        L.xm_sell_quat_roundtrip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_sell_destroy.argtypes = [C.c_void_p]
         L.xm_sell_destroy.restype = None
         L.xm_qw_sell.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
@@ -250,6 +265,14 @@ def spd_inverse(A):
     return np.ascontiguousarray(A)
 
 
+def quat_roundtrip(block):
+    """host-only: (stored quaternion, block rebuilt by the product kernel) of a 3x3 block -w * rotation"""
+    b = np.ascontiguousarray(block, dtype=np.float64).reshape(9)
+    q = np.zeros(4); r = np.zeros(9)
+    _chk(lib().xm_sell_quat_roundtrip(b.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p)))
+    return q, r.reshape(3, 3)
+
+
 def sell_layout(rowptr, colidx, ncols=None, slabs=4, lmax=64):
     """host-side description of the sliced-ELL layout (xm_sell.h) -- no GPU involved; used by the CPU tests"""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
@@ -271,14 +294,15 @@ def sell_layout(rowptr, colidx, ncols=None, slabs=4, lmax=64):
 class SellMatrix:
     """3x3-block sparse Q in the sliced-ELL device layout (xm_sell_create); product through xm_qw_sell"""
 
-    def __init__(self, rowptr, colidx, blocks, ncols=None, slabs=4, lmax=64):
+    def __init__(self, rowptr, colidx, blocks, ncols=None, slabs=4, lmax=64, codec=0, row0=0):
+        """codec 1 = view-graph codec (quaternion per off-diagonal block, scalar per diagonal block)"""
         require_gpu()
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
         blocks = np.ascontiguousarray(blocks, dtype=np.float64)
         self.n = rowptr.size - 1
         self.h = C.c_void_p()
-        _chk(lib().xm_sell_create(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
-                                  self.n, self.n if ncols is None else ncols, slabs, lmax, C.byref(self.h)))
+        _chk(lib().xm_sell_create2(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
+                                   self.n, self.n if ncols is None else ncols, slabs, lmax, codec, row0, C.byref(self.h)))
 
     def qw(self, W, alpha=1.0, gather=0):
         W = np.asarray(W, dtype=np.float64)
@@ -302,15 +326,15 @@ class SellMatrix:
             pass
 
 
-def retract(R, s, D, ds, t):
-    """(MGS_rows(R + t D), s*exp(t ds/s)) through xm_retract."""
+def retract(R, s, D, ds, t, polar=False):
+    """(MGS_rows(R + t D), s*exp(t ds/s)) through xm_retract; polar=True: the polar retraction (xm_retract_polar)."""
     require_gpu()
     R = np.asarray(R, dtype=np.float64)
     n, o = R.shape[0] // 3, R.shape[1]
     dR = DevArray(to_rm(R)); dD = DevArray(to_rm(D)); dsv = DevArray(np.asarray(s, dtype=np.float64))
     dds = DevArray(np.asarray(ds, dtype=np.float64))
     dRo = DevArray(nbytes=dR.nbytes); dso = DevArray(nbytes=dsv.nbytes)
-    _chk(lib().xm_retract(n, o, dR.ptr, dsv.ptr, dD.ptr, dds.ptr, t, dRo.ptr, dso.ptr, None))
+    _chk((lib().xm_retract_polar if polar else lib().xm_retract)(n, o, dR.ptr, dsv.ptr, dD.ptr, dds.ptr, t, dRo.ptr, dso.ptr, None))
     _chk(lib().xm_dev_sync())
     out = from_rm(dRo.get(), 3 * n, o), dso.get()
     for b in (dR, dD, dsv, dds, dRo, dso):
@@ -333,11 +357,31 @@ def recover_rotations(R, s):
 class Context:
     """Q resident in HBM; solve() == the reference's staircase (XM_main.cu:180 / :312 / :35)."""
 
-    def __init__(self, Q=None, bsr=None, dq=None, n=None, densify=False, obs=None):
+    def __init__(self, Q=None, bsr=None, dq=None, n=None, densify=False, obs=None, vg=None, n_gpus=1, gpu_map=0, tuning=None):
+        """vg = (ei, ej, w, M): view-graph edge list (STORAGE_VIEWGRAPH).  n_gpus > 1: single-process row partition over that many GPUs
+        (gpu_map=1: all ranks on device 0).  tuning: dict of xm_tuning_t fields."""
         require_gpu()
         self._keep = []
         p = Problem()
-        if obs is not None:                     # matrix-free: (cam, lm, p, w) = (edges[:, 0] - 1, edges[:, 1] - 1, landmarks, weight)
+        p.struct_size = C.sizeof(Problem)
+        p.n_gpus, p.gpu_map = int(n_gpus), int(gpu_map)
+        if tuning:
+            tn = Tuning()
+            for k, v in tuning.items():
+                setattr(tn, k, int(v))
+            p.tuning = C.pointer(tn)
+            self._keep.append(tn)
+        if vg is not None:
+            ei, ej, w, M = vg
+            ei = np.ascontiguousarray(ei, dtype=np.int32); ej = np.ascontiguousarray(ej, dtype=np.int32)
+            w = np.ascontiguousarray(w, dtype=np.float64).reshape(-1); M = np.ascontiguousarray(M, dtype=np.float64).reshape(-1, 9)
+            assert ei.size == ej.size == w.size == M.shape[0]
+            self.n = int(max(ei.max(), ej.max())) + 1 if n is None else int(n)
+            p.n, p.storage, p.ne = self.n, STORAGE_VIEWGRAPH, ei.size
+            p.edge_i, p.edge_j, p.edge_w, p.edge_M = (a.ctypes.data_as(C.c_void_p) for a in (ei, ej, w, M))
+            self._keep += [ei, ej, w, M]
+            self.ne = ei.size
+        elif obs is not None:                     # matrix-free: (cam, lm, p, w) = (edges[:, 0] - 1, edges[:, 1] - 1, landmarks, weight)
             cam, lm, pts, w = obs
             cam = np.ascontiguousarray(cam, dtype=np.int32); lm = np.ascontiguousarray(lm, dtype=np.int32)
             pts = np.ascontiguousarray(pts, dtype=np.float64); w = np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
@@ -402,11 +446,14 @@ class Context:
         assert w.size == self.ne
         _chk(lib().xm_ctx_set_edge_weights(self.h, w.ctypes.data_as(C.c_void_p)))
 
-    def solve(self, max_rank, tol, lam, max_time=1000.0, mode=MODE_SOLVE, flags=0, s_ini=None, trace=0, R_ini=None):
+    def solve(self, max_rank, tol, lam, max_time=1000.0, mode=MODE_SOLVE, flags=0, s_ini=None, trace=0, R_ini=None, retraction=RETRACT_QR,
+              grouping=0):
         n = self.n
         rmax = max(int(max_rank), 3)
         R = np.zeros((3 * n, rmax + 1), order="F"); s = np.zeros(n)
         opt = Options(); res = Result()
+        opt.struct_size, res.struct_size = C.sizeof(Options), C.sizeof(Result)
+        opt.retraction, opt.sum_grouping = int(retraction), int(grouping)
         opt.max_rank, opt.tol, opt.lam, opt.max_time, opt.mode, opt.flags = int(max_rank), tol, lam, max_time, mode, flags
         si = None
         if s_ini is not None:
@@ -421,7 +468,7 @@ class Context:
             tr = np.zeros((trace, 6)); opt.trace_cap = trace; opt.trace = tr.ctypes.data_as(C.c_void_p)
         res.R = R.ctypes.data_as(C.c_void_p); res.s = s.ctypes.data_as(C.c_void_p)
         _chk(lib().xm_ctx_solve(self.h, C.byref(opt), C.byref(res)))
-        info = {k: getattr(res, k) for k, _ in Result._fields_ if k not in ("R", "s")}
+        info = {k: getattr(res, k) for k, _ in Result._fields_ if k not in ("R", "s", "struct_size")}
         if tr is not None:
             info["trace"] = tr[: res.trace_len].copy()
         return np.ascontiguousarray(R[:, : res.rank]), s, info
