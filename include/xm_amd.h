@@ -227,6 +227,36 @@ int64_t xm_dense_ld(int64_t n);                                       /* padded 
 int xm_ctx_attach_edges(xm_ctx_t *ctx, int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
 int xm_ctx_edge_residuals(xm_ctx_t *ctx, double *res);
 int xm_ctx_set_edge_weights(xm_ctx_t *ctx, const double *w);
+/* ---- the same loop with the REFERENCE's residual definition and sequencing (3_test_colmap_glomap.py:299-351).
+ *   residuals_recovered: res[e] = squared distance of edge / observation e for the RECOVERED solution -- rot: 3 x 3n column-major anchored
+ *              rotations and scale: n, as xm_recover_rotations returns them (the reference's R_real / s_real, :295-316).  Matrix-free
+ *              contexts: |s_i R_i p + t_i - P_l|^2 with t, P eliminated (== the reference's landmarks_transformed vs p_est); view-graph
+ *              contexts: |s_i R_i - M_e s_j R_j|_F^2.  Host array, input order.  Single-GPU contexts.
+ *   xm2_filter: error = w .* res on the device, threshold = np.percentile(error, pct) (linear interpolation between two order
+ *              statistics found by a device radix select, :321), weights of everything above it set to 0 and Q rebuilt (:323-338,
+ *              without the reference's re-indexing of emptied landmarks / cameras: checklandmarks is upstream data cleaning).
+ *   xm2_round: filter at `percentile` (0 -> 90), then the reference's second pass (:339-351): solve_rank3 at lam = 0, statistics of its
+ *              scales; |mean(s[1:]) - 1| > 2 std(s[1:]) or more than 10 scales < 0.1  ->  lam = kept edges / n, else lam = 0; final solve
+ *              with opt->max_rank / tol / max_time / flags (XM_FLAG_WARM_R in opt->flags: start it from the rank-3 result instead of the
+ *              reference's cold start).  R (3n x r column-major), s (n): the solution the round starts from (what the first solve
+ *              returned).  res: the final solve's result. */
+typedef struct {
+    uint32_t struct_size;
+    double percentile;         /* in: 0 = the reference's 90 */
+    double threshold;          /* out */
+    int64_t removed;           /* out: edges newly removed by this round */
+    double s_avg, s_std;       /* out: mean / standard deviation of the rank-3 scales s[1:] (:343-344) */
+    int64_t n_small;           /* out: scales < 0.1 */
+    int32_t regularised;       /* out: 1 = the final solve ran with lam = kept / n */
+    int32_t rank3_status;
+    double lam_used;
+    int64_t rank3_tcg_iters;
+} xm_xm2_info_t;
+int xm_ctx_edge_residuals_recovered(xm_ctx_t *ctx, const double *rot, const double *scale, double *res);
+int xm_ctx_xm2_filter(xm_ctx_t *ctx, const double *rot, const double *scale, double percentile, double *threshold, int64_t *removed,
+                      double *w_out /* optional: the new weights */);
+int xm_ctx_xm2_round(xm_ctx_t *ctx, const double *R, const double *s, int r, const xm_options_t *opt, xm_xm2_info_t *info,
+                     xm_result_t *res);
 /* Translations and landmarks of a solution: the last step of utils/recoversolution.py:recover_XM (lines 77-86,
  * ybar_est = Abar @ sR_real.T; t_est = [0 | first N-1 columns], p_est = the rest) for an XM_STORAGE_SCHUR context.  The reference
  * needs the dense (N-1+M) x 3N matrix Abar.bin that create_matrix writes (creatematrix.py:283-311; 80 GB at Final-13682 with 800 k
@@ -297,6 +327,12 @@ int xm_retract_polar(int64_t n, int o, const double *dR, const double *ds, const
                      double *dRout, double *dsout, void *stream);
 /* timing helper for bench.py: average milliseconds of `reps` back-to-back xm_qw_dense launches (HIP events) */
 int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
+/* the same for a ROW STRIP of nloc cameras of an n-camera matrix (what one rank of an N-GPU row partition multiplies: dq = 3 nloc rows x
+ * xm_dense_ld(n)); used to state the expected per-iteration time of the partitioned solve from measured pieces */
+int xm_qw_dense_strip_time(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
+/* micro-benchmark of the direct peer-write all-gather (xm-code_amd/csrc/xm_comm.hip): `world` ranks (one host thread each; gpu_map 1 = all
+ * on device 0) gather `count` doubles per rank `reps` times; us_avg = average time per collective on rank 0, stream time */
+int xm_peer_allgather_bench(int world, int gpu_map, int64_t count, int reps, double *us_avg);
 int xm_qw_bsr3_time(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o, const double *dW,
                     double *dOut, int reps, double *ms_avg);
 

@@ -8,6 +8,8 @@
     vg100k       vg100k_oracle.json + vg100k_oracle_rot_every8.npy       rank-3 trust region of the 100k-camera view-graph Q through
                  the oracle's test-only block-CSR product: ~2 minutes on 8 cores
     medium       recorded_oracle_medium.json                             600- / 2000-camera view graphs in the hard regime: hours at n = 2000
+    mid700       mid700_oracle.json + mid700_oracle_rot.npy              700-camera dense instance that needs rank 4 (two O(n^3) certificates
+                 of a 2100 x 2100 matrix): ~5 minutes
 
     python scripts/record_oracle_large.py vg100k [rome13682 venice1778 medium] [--out DIR]
 
@@ -35,6 +37,24 @@ def venice1778(out):
                    f=float(info["trace"][-1, 0]), tcg=int(info["tcg_iters"]), outer=int(info["outer_iters"]), min_eig=c["min_eig"],
                    gap=c["gap"], seconds=el, threads=xo.num_threads(), s_min=float(s.min()), s_max=float(s.max())),
               open(os.path.join(out, "venice1778_oracle.json"), "w"), indent=1)
+
+
+def mid700(out):
+    n = 700
+    Q = tl.gen_dense(n, seed=n)["Q"]
+    t0 = time.time()
+    R, s, info = xo.solve(Q, 5, 1e-9, 0.0, 1e9, trace=4000)
+    el = time.time() - t0
+    rot, _ = tl.recover_rotations(R, s)
+    np.save(os.path.join(out, "mid700_oracle_rot.npy"), rot)
+    sR = tl.scale_rows(R, s)
+    idx = tl.gram_sample_index(sR.shape[0])
+    np.save(os.path.join(out, "mid700_oracle_gram_sample.npy"), (sR[idx[:, 0]] * sR[idx[:, 1]]).sum(axis=1))
+    c = info["cert"]
+    json.dump(dict(n=n, seed=n, max_rank=5, tol=1e-9, lam=0.0, rank=int(info["rank"]), status=int(info["status"]),
+                   f=float(info["trace"][-1, 0]), tcg=int(info["tcg_iters"]), outer=int(info["outer_iters"]), min_eig=c["min_eig"],
+                   gap=c["gap"], seconds=el, threads=xo.num_threads()),
+              open(os.path.join(out, "mid700_oracle.json"), "w"), indent=1)
 
 
 def _vg_tr(out, name, n, deg, lam, sub, bsr):
@@ -73,7 +93,7 @@ def medium(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", nargs="+", choices=["venice1778", "rome13682", "vg100k", "medium"])
+    ap.add_argument("which", nargs="+", choices=["venice1778", "rome13682", "vg100k", "medium", "mid700"])
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "synth"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -85,6 +105,8 @@ if __name__ == "__main__":
             venice1778(a.out)
         elif w == "rome13682":
             _vg_tr(a.out, "rome13682", 13682, 30, 1000.0, 1, bsr=False)
+        elif w == "mid700":
+            mid700(a.out)
         elif w == "vg100k":
             _vg_tr(a.out, "vg100k", 100000, 50, 1000.0, 8, bsr=True)
         else:

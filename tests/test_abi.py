@@ -28,12 +28,64 @@ def test_header_symbols_exported(xmamd):
 def test_struct_layout_matches_header(xmamd):
     # POD structs cross the ABI by pointer: sizes must match what a C compiler produces for the header
     import subprocess, tempfile
-    src = '#include "xm_amd.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n",sizeof(xm_problem_t),sizeof(xm_options_t),sizeof(xm_result_t));return 0;}\n'
+    src = ('#include "xm_amd.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n",sizeof(xm_problem_t),sizeof(xm_options_t),'
+           'sizeof(xm_result_t),sizeof(xm_tuning_t),sizeof(xm_xm2_info_t));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
-        a, b, c = map(int, subprocess.check_output([os.path.join(d, "t")]).split())
-    assert (a, b, c) == (ctypes.sizeof(xmamd.Problem), ctypes.sizeof(xmamd.Options), ctypes.sizeof(xmamd.Result))
+        sizes = tuple(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
+    assert sizes == tuple(ctypes.sizeof(t) for t in (xmamd.Problem, xmamd.Options, xmamd.Result, xmamd.Tuning, xmamd.Xm2Info))
+    assert xmamd.lib().xm_abi_revision() == 3
+
+
+def test_block_balanced_partition(xmamd):
+    """xm_partition_blocks: contiguous ranges that cover all cameras with (nearly) equal STORED BLOCKS per rank -- a hub-camera graph
+    must not land most of the matrix on one rank"""
+    L = xmamd.lib()
+    H = tl.gen_vg_hubs(2000, 8, 5, 0.3, 0.1, seed=3)
+    rp, ci, bl = tl.vg_from_edges(2000, H["ei"], H["ej"], H["w"], H["M"])
+    for world in (1, 2, 3, 8):
+        prev, loads, sizes = 0, [], []
+        for r in range(world):
+            c0, c1 = ctypes.c_int64(), ctypes.c_int64()
+            assert L.xm_partition_blocks(2000, rp.ctypes.data_as(ctypes.c_void_p), world, r, ctypes.byref(c0), ctypes.byref(c1)) == 0
+            assert c0.value == prev and c1.value >= c0.value
+            prev = c1.value
+            loads.append(int(rp[c1.value] - rp[c0.value])); sizes.append(c1.value - c0.value)
+        assert prev == 2000
+        heaviest_row = int(np.diff(rp).max())
+        assert max(loads) <= rp[-1] / world + heaviest_row                 # within one row of the ideal share
+        eq = [int(rp[min(2000, (r + 1) * -(-2000 // world))] - rp[min(2000, r * -(-2000 // world))]) for r in range(world)]
+        assert max(loads) <= max(eq)                                        # never worse than equal camera ranges
+
+
+def test_view_graph_codec_round_trip(xmamd):
+    """host statement of the quaternion codec of the sliced-ELL product (xm_sell_quat_roundtrip): -w * rotation -> 4 doubles -> the
+    block the kernel rebuilds, for every branch of the quaternion extraction (rotation angles up to pi about each axis), weights
+    over six decades and the removed edge (w = 0)"""
+    from scipy.spatial.transform import Rotation as Rt
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for t in range(3000):
+        M = (Rt.from_rotvec(np.pi * np.eye(3)[t % 3] * (1 - 1e-9 * (t // 3))) if t < 60 else Rt.random(random_state=int(rng.integers(1 << 31)))).as_matrix()
+        w = 10.0 ** rng.uniform(-3, 3)
+        q, r = xmamd.quat_roundtrip(-w * M)
+        worst = max(worst, np.abs(r + w * M).max() / w)
+        assert abs(q @ q - 2 * w) < 1e-12 * w
+    assert worst < 5e-15
+    q, r = xmamd.quat_roundtrip(np.zeros((3, 3)))
+    assert not q.any() and not r.any()
+
+
+def test_xm2_reference_fixture(xmamd):
+    """tests/golden/simple2/xm2.npz was produced by EXECUTING the reference's XM^2 lines (3_test_colmap_glomap.py:303-323) on its own
+    pipeline's variables (make_simple2_xm2.py); the numpy statement used by the GPU tests reproduces it, and so does np.percentile"""
+    G = os.path.join(ROOT, "tests", "golden", "simple2")
+    x = np.load(os.path.join(G, "xm2.npz")); tp = np.load(os.path.join(G, "tp.npz")); obs = np.load(os.path.join(G, "obs.npz"))
+    err = tl.xm2_error_numpy(obs["cam"], obs["lm"], obs["p"], obs["w"], tp["R_real"], tp["s_real"], tp["t_est"], tp["p_est"])
+    assert np.abs(err - x["error"]).max() <= 1e-12 * x["error"].max()
+    assert float(np.percentile(err, 90)) == pytest.approx(float(x["threshold"]), rel=1e-12)
+    assert np.array_equal(np.where(err > float(x["threshold"]))[0], x["removed"]) and x["removed"].size == 6455
 
 
 def test_partition_is_contiguous_and_covers(xmamd):

@@ -358,6 +358,63 @@ def test_a_dead_peer_becomes_an_error_not_a_hang(xmamd, tmp_path):
     assert "AFTER 1" in out
 
 
+# ---------------------------------------------------------------------------------------------- XM^2 with the reference's definitions
+def test_xm2_residuals_and_filter_match_the_reference_fixture(xmamd):
+    """tests/golden/simple2/xm2.npz holds `error`, `threshold` and the removed indices of the reference's own XM^2 lines
+    (3_test_colmap_glomap.py:303-323, executed on its pipeline's R_real / s_real / t_est / p_est by make_simple2_xm2.py).  The
+    matrix-free context built from the same observation list must reproduce them from (R_real, s_real) ALONE -- translations and
+    landmarks are eliminated on the device: residuals to 1e-9, the device percentile (radix select + numpy's interpolation) to
+    1e-9, and exactly the same 6455 observations removed."""
+    d = os.path.join(G, "simple2")
+    x = np.load(os.path.join(d, "xm2.npz")); tp = np.load(os.path.join(d, "tp.npz")); obs = np.load(os.path.join(d, "obs.npz"))
+    ctx = xmamd.Context(obs=(obs["cam"], obs["lm"], obs["p"], obs["w"]))
+    ctx.solve(5, 1e-6, 0.0)                                     # any solve: allocates the workspace the chain uses
+    res = ctx.edge_residuals_recovered(tp["R_real"], tp["s_real"])
+    err = obs["w"].reshape(-1) * res
+    assert np.abs(err - x["error"]).max() <= 1e-9 * x["error"].max()
+    thr, removed, w_new = ctx.xm2_filter(tp["R_real"], tp["s_real"], 90.0)
+    assert thr == pytest.approx(float(x["threshold"]), rel=1e-9)
+    assert removed == x["removed"].size and np.array_equal(np.where(w_new == 0.0)[0], x["removed"])
+    # Q now is the matrix of the filtered list: the product equals the one of a fresh context created with the new weights
+    W = np.random.default_rng(2).standard_normal((3 * ctx.n, 3))
+    fresh = xmamd.Context(obs=(obs["cam"], obs["lm"], obs["p"], w_new))
+    assert tl.rel_fro(ctx.qw(W), fresh.qw(W)) < 1e-10
+    fresh.close()
+    ctx.close()
+
+
+def test_xm2_round_follows_the_reference_sequence(xmamd):
+    """xm_ctx_xm2_round on SIMPLE2 (matrix-free): filter at the 90th percentile, solve_rank3 at lam = 0, the lam decision from the
+    rank-3 scales (3_test_colmap_glomap.py:339-351), final solve -- every step checked against the same steps done by hand through
+    the separate calls"""
+    d = os.path.join(G, "simple2")
+    obs = np.load(os.path.join(d, "obs.npz"))
+    cam, lm, p, w = obs["cam"], obs["lm"], obs["p"], obs["w"].reshape(-1)
+    ctx = xmamd.Context(obs=(cam, lm, p, w))
+    R, s, info = ctx.solve(5, 1e-6, 0.0)
+    R2, s2, i2, x2 = ctx.xm2_round(R, s, 5, 1e-6)
+    ctx.close()
+    # by hand
+    c2 = xmamd.Context(obs=(cam, lm, p, w))
+    Rh, sh, ih = c2.solve(5, 1e-6, 0.0)
+    rot, scale, _ = xmamd.recover_rotations(Rh, sh)
+    err = w * c2.edge_residuals_recovered(rot, scale)
+    thr = float(np.percentile(err, 90))
+    wn = np.where(err > thr, 0.0, w)
+    c2.set_edge_weights(wn)
+    R3, s3, i3 = c2.solve(3, 1e-6, 0.0, mode=xmamd.MODE_RANK3)
+    avg, std, small = float(np.mean(s3[1:])), float(np.std(s3[1:])), int(np.sum(s3 < 0.1))
+    reg = abs(avg - 1) > 2 * std or small > 10
+    lam = (wn != 0).sum() / c2.n if reg else 0.0
+    Rf, sf, i_f = c2.solve(5, 1e-6, lam)
+    c2.close()
+    assert x2["threshold"] == pytest.approx(thr, rel=1e-9) and x2["removed"] == int((wn == 0).sum())
+    assert x2["s_avg"] == pytest.approx(avg, rel=1e-9) and x2["s_std"] == pytest.approx(std, rel=1e-6) and x2["n_small"] == small
+    assert bool(x2["regularised"]) == bool(reg) and x2["lam_used"] == pytest.approx(lam)
+    assert i2["status"] == i_f["status"] and i2["rank"] == i_f["rank"] and i2["primal"] == pytest.approx(i_f["primal"], rel=1e-9)
+    assert tl.rotation_parity(R2, s2, Rf, sf) < 1e-6
+
+
 # ---------------------------------------------------------------------------------------------- the 13.5 GB dense path
 def test_rome13682_dense_storage_vs_recorded_oracle(xmamd):
     """the Final-13682-size Q in the reference's own DENSE storage (13.5 GB, expanded on the device) through the half-traffic

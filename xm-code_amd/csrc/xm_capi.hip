@@ -410,6 +410,32 @@ int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, doubl
     XM_CATCH
 }
 
+int xm_qw_dense_strip_time(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
+    XM_TRY
+    if (nloc < 1 || nloc > n) throw xm::Error(XM_ERR_ARG, "bad strip");
+    hipEvent_t e0, e1;
+    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+    const xm::CamArgs a = plain_args(nloc, dOut);
+    const int64_t ld = xm::dense_ld(n);
+    for (int i = 0; i < 3; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr);
+    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+    XM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_avg) *ms_avg = (double)ms / reps;
+    return XM_OK;
+    XM_CATCH
+}
+int xm_peer_allgather_bench(int world, int gpu_map, int64_t count, int reps, double *us_avg) {
+    XM_TRY
+    require_device();
+    if (us_avg) *us_avg = xm::peer_allgather_bench(world, gpu_map, count, reps);
+    return XM_OK;
+    XM_CATCH
+}
 int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int64_t n, int o, const double *dW, double *dOut, int reps,
                     double *ms_avg) {
     XM_TRY
@@ -596,6 +622,71 @@ int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, dou
     XM_HIP_CHECK(hipMemcpy(rot, drot.p, (size_t)9 * n * sizeof(double), hipMemcpyDeviceToHost));
     XM_HIP_CHECK(hipMemcpy(scale, dscale.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (n_negative_det) *n_negative_det = neg;
+    return XM_OK;
+    XM_CATCH
+}
+
+int xm_ctx_edge_residuals_recovered(xm_ctx_t *ctx, const double *rot, const double *scale, double *res) {
+    XM_TRY
+    if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
+    if (!ctx->impl) throw xm::Error(XM_ERR_ARG, "xm_ctx_edge_residuals_recovered: single-GPU contexts only");
+    ctx->impl->edge_residuals_recovered(rot, scale, res);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_ctx_xm2_filter(xm_ctx_t *ctx, const double *rot, const double *scale, double percentile, double *threshold, int64_t *removed, double *w_out) {
+    XM_TRY
+    if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
+    if (!ctx->impl) throw xm::Error(XM_ERR_ARG, "xm_ctx_xm2_filter: single-GPU contexts only");
+    const double thr = ctx->impl->xm2_filter(rot, scale, percentile, removed, w_out);
+    if (threshold) *threshold = thr;
+    return XM_OK;
+    XM_CATCH
+}
+int xm_ctx_xm2_round(xm_ctx_t *ctx, const double *R, const double *s, int r, const xm_options_t *opt, xm_xm2_info_t *info, xm_result_t *res) {
+    XM_TRY
+    if (!ctx || !R || !s || !opt || !info || !res) throw xm::Error(XM_ERR_ARG, "null argument");
+    if (!ctx->impl) throw xm::Error(XM_ERR_ARG, "xm_ctx_xm2_round: single-GPU contexts only");
+    xm_options_t op = take_struct(opt, "xm_options_t");
+    xm_result_t rs = take_struct(res, "xm_result_t");
+    xm_xm2_info_t inf = take_struct(info, "xm_xm2_info_t");
+    const uint32_t caller_res = res->struct_size, caller_inf = info->struct_size;
+    const int64_t n = ctx->impl->cameras();
+    // recover_XM's rotations and scales of the starting solution (utils/recoversolution.py:12-86)
+    std::vector<double> rot((size_t)9 * n), scale((size_t)n);
+    int neg = 0;
+    if (xm_recover_rotations(n, r, R, s, rot.data(), scale.data(), &neg) != XM_OK) throw xm::Error(XM_ERR_HIP, g_err);
+    const double pct = (inf.percentile > 0.0) ? inf.percentile : 90.0;
+    inf.threshold = ctx->impl->xm2_filter(rot.data(), scale.data(), pct, &inf.removed, nullptr);
+    int64_t kept = 0;
+    for (double w : ctx->impl->weights()) kept += (w != 0.0);
+    // second pass: rank-3 solve without regulariser, then decide on lam from the spread of its scales (3_test_colmap_glomap.py:339-351)
+    std::vector<double> R3((size_t)3 * n * 4, 0.0), s3((size_t)n, 1.0);
+    xm_options_t o3 = op;
+    o3.mode = XM_MODE_RANK3; o3.lam = 0.0; o3.max_rank = 3; o3.flags &= ~XM_FLAG_WARM_R; o3.R_ini = nullptr; o3.s_ini = nullptr; o3.trace = nullptr; o3.trace_cap = 0;
+    xm_result_t r3;
+    std::memset(&r3, 0, sizeof(r3));
+    r3.R = R3.data(); r3.s = s3.data();
+    ctx->impl->solve(o3, r3);
+    inf.rank3_status = r3.status; inf.rank3_tcg_iters = r3.tcg_iters;
+    double mean = 0.0, var = 0.0;
+    int64_t small = 0;
+    for (int64_t i = 1; i < n; ++i) mean += s3[(size_t)i];
+    mean = (n > 1) ? mean / (double)(n - 1) : 1.0;
+    for (int64_t i = 1; i < n; ++i) var += (s3[(size_t)i] - mean) * (s3[(size_t)i] - mean);
+    const double sd = (n > 1) ? std::sqrt(var / (double)(n - 1)) : 0.0;   // numpy.std: population standard deviation
+    for (int64_t i = 0; i < n; ++i) small += (s3[(size_t)i] < 0.1);
+    inf.s_avg = mean; inf.s_std = sd; inf.n_small = small;
+    inf.regularised = (std::fabs(mean - 1.0) > 2.0 * sd || small > 10) ? 1 : 0;
+    inf.lam_used = inf.regularised ? (double)kept / (double)n : 0.0;
+    xm_options_t of = op;
+    of.lam = inf.lam_used;
+    if (op.flags & XM_FLAG_WARM_R) { of.mode = XM_MODE_REBUTTLE; of.R_ini = R3.data(); of.s_ini = s3.data(); }
+    else { of.mode = XM_MODE_SOLVE; of.R_ini = nullptr; of.s_ini = nullptr; }
+    ctx->impl->solve(of, rs);
+    give_result(res, rs, caller_res);
+    inf.struct_size = caller_inf;
+    std::memcpy(info, &inf, std::min<size_t>(caller_inf, sizeof(inf)));
     return XM_OK;
     XM_CATCH
 }

@@ -71,7 +71,8 @@ void comm_finalize();
 struct PeerGroup;
 std::shared_ptr<PeerGroup> peer_group_create(int world, const int *devices, double spin_seconds);
 std::shared_ptr<Comm> peer_comm_create(const std::shared_ptr<PeerGroup> &g, int rank);   // call on rank's own thread, device current
-void peer_group_abort(const std::shared_ptr<PeerGroup> &g);                               // wakes every host-side wait with an error
+void peer_group_abort(const std::shared_ptr<PeerGroup> &g);
+double peer_allgather_bench(int world, int gpu_map, int64_t count, int reps);   // microseconds per collective (xm_team.hip)                               // wakes every host-side wait with an error
 
 template <class T>
 struct DevBuf {
@@ -138,6 +139,14 @@ public:
     void edge_residuals(double *res);
     void set_edge_weights(const double *w);
     void recover_tp(const double *rot, const double *scale, double *t, double *p);   // matrix-free storage only
+    // XM^2 with the reference's residual definition (3_test_colmap_glomap.py:305-316): squared distance per edge / observation of the
+    // RECOVERED solution (anchored rotations rot 3 x 3n column-major, scales) -- res: host, input order
+    void edge_residuals_recovered(const double *rot, const double *scale, double *res);
+    // the reference's filter (:316-324) on the device: error = w .* residual, threshold = its `pct` percentile (numpy's linear
+    // interpolation between the two order statistics, found by a radix select), every edge above it gets weight 0 and Q is rebuilt.
+    // Returns the threshold; *removed = edges newly removed; w_out (optional, host) = the new weights
+    double xm2_filter(const double *rot, const double *scale, double pct, int64_t *removed, double *w_out);
+    const std::vector<double> &weights() const { return w_cur_; }
     int64_t n_landmarks() const;
 
 private:
@@ -166,6 +175,9 @@ private:
     DevBuf<int64_t> inc_ptr_, pos_ij_, pos_ji_, pos_d_;
     DevBuf<double> eM_, ew_, eres_;
     bool solved_ = false;   // R_/s_ hold the end point of a solve
+    std::vector<double> w_cur_;          // current edge / observation weights (host mirror; empty: unknown, e.g. edges attached to a given Q)
+    DevBuf<double> eerr_;                // XM^2 filter: weighted residuals
+    const double *residuals_recovered_device(const double *rot, const double *scale);
     hipStream_t st_ = nullptr;
     hipStream_t st2_ = nullptr;          // local-strip product running beside the all-gather of W (multi-rank, dense)
     hipEvent_t ev_w_ = nullptr, ev_p_ = nullptr;

@@ -312,6 +312,7 @@ void Context::init(const xm_problem_t &prob_in) {
     } else if (storage_ == XM_STORAGE_SCHUR) {
         if (world != 1) throw Error(XM_ERR_ARG, "matrix-free storage is single-GPU in this version");
         schur_.reset(new SchurOp(n_, prob.n_landmarks, prob.nobs, prob.obs_cam, prob.obs_lm, prob.obs_p, prob.obs_w, st_));
+        w_cur_.assign(prob.obs_w, prob.obs_w + prob.nobs);
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
     }
@@ -351,7 +352,10 @@ void Context::init(const xm_problem_t &prob_in) {
     std::memset(hstat_, 0, 256);
     XM_HIP_CHECK(hipHostGetDevicePointer((void **)&hstat_dev_, hstat_, 0));
     ensure_pinned((size_t)1 << 17);   // 1 MB to start with; setup_rank sizes it for the solve
-    if (viewgraph) attach_edges(prob.ne, prob.edge_i, prob.edge_j, prob.edge_M);
+    if (viewgraph) {
+        attach_edges(prob.ne, prob.edge_i, prob.edge_j, prob.edge_M);
+        w_cur_.assign(prob.edge_w, prob.edge_w + prob.ne);
+    }
 }
 
 Context::~Context() { release_raw(); }
@@ -1237,6 +1241,100 @@ void Context::edge_residuals(double *res) {
     XM_HIP_CHECK(hipStreamSynchronize(st_));
 }
 
+// residuals of a RECOVERED rank-3 solution on the device: the product input is W_i = s_i * R_i^T (camera i's 3 x 3 record)
+const double *Context::residuals_recovered_device(const double *rot, const double *scale) {
+    if (!rot || !scale) throw Error(XM_ERR_ARG, "edge_residuals_recovered: null argument");
+    if (comm_->active()) throw Error(XM_ERR_ARG, "edge_residuals_recovered: single-GPU contexts only");
+    if (storage_ != XM_STORAGE_SCHUR && !ei_.p) throw Error(XM_ERR_ARG, "edge_residuals_recovered: no edges attached");
+    constexpr int OP = pitch_of(3);
+    if (o_ < 3 || W_.count < (size_t)ld_ * OP + 2) setup_rank(3);
+    std::vector<double> hW((size_t)ld_ * OP + 2, 0.0);
+    for (int64_t i = 0; i < n_; ++i)
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < 3; ++k) hW[((size_t)i * 3 + a) * OP + k] = scale[i] * rot[(size_t)k + 3 * ((size_t)3 * i + a)];
+    DevBuf<double> &dW = lzw_;   // any scratch of >= ld * 3 doubles that no product touches: the Lanczos vector buffer
+    if (dW.count < hW.size()) dW.alloc(hW.size());
+    to_dev(dW.p, hW.data(), hW.size() * sizeof(double));
+    if (storage_ == XM_STORAGE_SCHUR) {
+        xm_options_t opt;
+        std::memset(&opt, 0, sizeof(opt));
+        const xm_options_t *keep = opt_;
+        opt_ = &opt;
+        const int o_keep = o_, OP_keep = OP_;
+        o_ = 3; OP_ = OP;
+        CamArgs a = cam_args(cur_);
+        a.out = HpR_.p;
+        const double *r = schur_->residuals_device(3, dW.p, a, st_);
+        o_ = o_keep; OP_ = OP_keep;
+        opt_ = keep;
+        return r;
+    }
+    launch_edge_residual(ne_, ei_.p, ej_.p, eM_.p, dW.p, 3, OP, eres_.p, st_);
+    return eres_.p;
+}
+void Context::edge_residuals_recovered(const double *rot, const double *scale, double *res) {
+    if (!res) throw Error(XM_ERR_ARG, "edge_residuals_recovered: null output");
+    const double *r = residuals_recovered_device(rot, scale);
+    const int64_t ne = (storage_ == XM_STORAGE_SCHUR) ? schur_->nobs() : ne_;
+    if (ne > 0) to_host(res, r, (size_t)ne * sizeof(double));
+    XM_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+// k-th smallest (0-based) of n non-negative doubles on the device: most-significant-digit radix select, 4 passes of 16 bits
+static double radix_select(const double *x, int64_t n, int64_t k, unsigned int *dhist, hipStream_t st) {
+    unsigned long long prefix = 0;
+    std::vector<unsigned int> h(65536);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 48 - 16 * pass;
+        XM_HIP_CHECK(hipMemsetAsync(dhist, 0, 65536 * sizeof(unsigned int), st));
+        launch_radix_hist(n, x, shift, prefix, dhist, st);
+        XM_HIP_CHECK(hipMemcpyAsync(h.data(), dhist, 65536 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        int64_t acc = 0;
+        int bin = 65535;
+        for (int b = 0; b < 65536; ++b) {
+            if (acc + (int64_t)h[(size_t)b] > k) { bin = b; break; }
+            acc += h[(size_t)b];
+        }
+        k -= acc;
+        prefix = (prefix << 16) | (unsigned long long)bin;
+    }
+    double v;
+    std::memcpy(&v, &prefix, sizeof(double));
+    return v;
+}
+
+double Context::xm2_filter(const double *rot, const double *scale, double pct, int64_t *removed, double *w_out) {
+    if (!(pct >= 0.0 && pct <= 100.0)) throw Error(XM_ERR_ARG, "xm2_filter: percentile must be in [0, 100]");
+    const int64_t ne = (storage_ == XM_STORAGE_SCHUR) ? schur_->nobs() : ne_;
+    if ((int64_t)w_cur_.size() != ne || ne < 1) throw Error(XM_ERR_ARG, "xm2_filter: the context does not know its edge weights (view-graph / matrix-free storage, or call xm_ctx_set_edge_weights first)");
+    const double *res = residuals_recovered_device(rot, scale);
+    if (ew_.count < (size_t)ne) ew_.alloc((size_t)ne);
+    if (eerr_.count < (size_t)ne) eerr_.alloc((size_t)ne);
+    to_dev(ew_.p, w_cur_.data(), (size_t)ne * sizeof(double));
+    launch_xm2_error(ne, ew_.p, res, eerr_.p, st_);
+    DevBuf<unsigned int> hist;
+    hist.alloc(65536 + 1);
+    // numpy.percentile, method "linear": h = (n - 1) q; x[floor h] + (h - floor h) (x[floor h + 1] - x[floor h])
+    const double hq = (double)(ne - 1) * pct / 100.0;
+    const int64_t k0 = (int64_t)std::floor(hq), k1 = std::min<int64_t>(k0 + 1, ne - 1);
+    const double x0 = radix_select(eerr_.p, ne, k0, hist.p, st_);
+    const double x1 = (k1 == k0) ? x0 : radix_select(eerr_.p, ne, k1, hist.p, st_);
+    const double thr = x0 + (hq - (double)k0) * (x1 - x0);
+    XM_HIP_CHECK(hipMemsetAsync(hist.p + 65536, 0, sizeof(unsigned int), st_));
+    DevBuf<double> wn;
+    wn.alloc((size_t)ne, false);
+    launch_xm2_filter(ne, eerr_.p, ew_.p, thr, wn.p, hist.p + 65536, st_);
+    unsigned int rm = 0;
+    std::vector<double> w2((size_t)ne);
+    to_host(w2.data(), wn.p, (size_t)ne * sizeof(double));
+    to_host(&rm, hist.p + 65536, sizeof(unsigned int));
+    if (removed) *removed = (int64_t)rm;
+    set_edge_weights(w2.data());
+    if (w_out) std::memcpy(w_out, w2.data(), (size_t)ne * sizeof(double));
+    return thr;
+}
+
 void Context::recover_tp(const double *rot, const double *scale, double *t, double *p) {
     if (storage_ != XM_STORAGE_SCHUR || !schur_) throw Error(XM_ERR_ARG, "recover_tp: needs a matrix-free context (XM_STORAGE_SCHUR): the translations and landmarks are functions of the observations");
     schur_->recover_tp(rot, scale, t, p, st_);
@@ -1244,9 +1342,14 @@ void Context::recover_tp(const double *rot, const double *scale, double *t, doub
 int64_t Context::n_landmarks() const { return schur_ ? schur_->n_landmarks() : 0; }
 
 void Context::set_edge_weights(const double *w) {
-    if (storage_ == XM_STORAGE_SCHUR) { schur_->set_weights(w, st_); return; }
+    if (storage_ == XM_STORAGE_SCHUR) {
+        schur_->set_weights(w, st_);
+        w_cur_.assign(w, w + schur_->nobs());
+        return;
+    }
     if (!ei_.p) throw Error(XM_ERR_ARG, "set_edge_weights: no edges attached");
     if (ne_ > 0 && !w) throw Error(XM_ERR_ARG, "set_edge_weights: null weights");
+    w_cur_.assign(w, w + ne_);
     if (ne_ > 0) to_dev(ew_.p, w, (size_t)ne_ * sizeof(double));
     const bool dense = (storage_ == XM_STORAGE_DENSE);
     launch_edge_write(dense, ne_, ei_.p, ej_.p, eM_.p, ew_.p, cam0_, nloc_, inc_ptr_.p, inc_edge_.p, pos_ij_.p, pos_ji_.p, pos_d_.p,

@@ -181,4 +181,52 @@ void Team::set_edge_weights(const double *w) {
     p_->run([&](int r) { p_->ctx[(size_t)r]->set_edge_weights(w); });
 }
 
+// micro-benchmark of the peer all-gather: `world` threads, each with its own stream and communicator, `reps` collectives back to back
+double peer_allgather_bench(int world, int gpu_map, int64_t count, int reps) {
+    if (world < 2 || world > kMaxPeers || count < 1 || reps < 1) throw Error(XM_ERR_ARG, "peer_allgather_bench: bad argument");
+    int ndev = 0;
+    XM_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (gpu_map == 0 && world > ndev) throw Error(XM_ERR_ARG, "peer_allgather_bench: not enough devices (gpu_map 1 = virtual devices)");
+    std::vector<int> dev((size_t)world);
+    for (int r = 0; r < world; ++r) dev[(size_t)r] = gpu_map == 1 ? 0 : r;
+    auto group = peer_group_create(world, dev.data(), 20.0);
+    std::vector<double> us((size_t)world, 0.0);
+    std::vector<std::exception_ptr> err((size_t)world);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r)
+        th.emplace_back([&, r] {
+            try {
+                XM_HIP_CHECK(hipSetDevice(dev[(size_t)r]));
+                auto comm = peer_comm_create(group, r);
+                comm->reserve((size_t)count * world + 64);
+                hipStream_t st;
+                XM_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                DevBuf<double> buf;
+                buf.alloc((size_t)count * world);
+                hipEvent_t e0, e1;
+                XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+                for (int i = 0; i < 5; ++i) comm->allgather(buf.p, (size_t)count, st);
+                XM_HIP_CHECK(hipStreamSynchronize(st));
+                comm->host_barrier();
+                XM_HIP_CHECK(hipEventRecord(e0, st));
+                for (int i = 0; i < reps; ++i) comm->allgather(buf.p, (size_t)count, st);
+                XM_HIP_CHECK(hipEventRecord(e1, st));
+                XM_HIP_CHECK(hipEventSynchronize(e1));
+                float ms = 0;
+                XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                us[(size_t)r] = (double)ms * 1e3 / reps;
+                comm->check_device_error();
+                comm->host_barrier();
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                (void)hipStreamDestroy(st);
+            } catch (...) {
+                err[(size_t)r] = std::current_exception();
+                peer_group_abort(group);
+            }
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+    return us[0];
+}
+
 }  // namespace xm

@@ -26,10 +26,10 @@ FLAG_WARM_R = 16
 EXPORTS = [
     "xm_last_error", "xm_version", "xm_abi_revision", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
-    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_qw_dense_time", "xm_qw_bsr3_time", "xm_recover_rotations",
+    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_qw_dense_time", "xm_qw_dense_strip_time", "xm_peer_allgather_bench", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition", "xm_partition_blocks",
     "xm_symv_plan", "xm_sell_layout", "xm_sell_create", "xm_sell_create2", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
-    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse",
+    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse",
 ]
 
 
@@ -69,6 +69,12 @@ class Result(C.Structure):
                 ("n_gpus", C.c_int32), ("exchange", C.c_int32), ("qw_stream_bytes", C.c_int64)]
 
 
+class Xm2Info(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("percentile", C.c_double), ("threshold", C.c_double), ("removed", C.c_int64),
+                ("s_avg", C.c_double), ("s_std", C.c_double), ("n_small", C.c_int64), ("regularised", C.c_int32), ("rank3_status", C.c_int32),
+                ("lam_used", C.c_double), ("rank3_tcg_iters", C.c_int64)]
+
+
 _lib = None
 
 
@@ -96,6 +102,9 @@ def lib():
         L.xm_ctx_attach_edges.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_ctx_edge_residuals.argtypes = [C.c_void_p, C.c_void_p]
         L.xm_ctx_set_edge_weights.argtypes = [C.c_void_p, C.c_void_p]
+        L.xm_ctx_edge_residuals_recovered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.xm_ctx_xm2_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p]
+        L.xm_ctx_xm2_round.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Options), C.POINTER(Xm2Info), C.POINTER(Result)]
         L.xm_ctx_recover_tp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_dev_count.argtypes = [C.POINTER(C.c_int)]
         L.xm_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
@@ -114,6 +123,8 @@ def lib():
         L.xm_retract_polar.argtypes = L.xm_retract.argtypes
         L.xm_qw_dense_time.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.POINTER(C.c_double)]
+        L.xm_qw_dense_strip_time.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.xm_peer_allgather_bench.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)]
         L.xm_qw_bsr3_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                       C.POINTER(C.c_double)]
         L.xm_recover_rotations.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -440,6 +451,37 @@ class Context:
         _chk(lib().xm_ctx_recover_tp(self.h, rot.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p),
                                      t.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p)))
         return np.ascontiguousarray(t), np.ascontiguousarray(p)
+
+    def edge_residuals_recovered(self, rot, scale):
+        """squared distance per edge / observation of a RECOVERED solution (rot 3 x 3n, scale n): the reference's XM^2 residual"""
+        rot = np.asfortranarray(np.asarray(rot, dtype=np.float64)); scale = np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(-1))
+        res = np.zeros(self.ne)
+        _chk(lib().xm_ctx_edge_residuals_recovered(self.h, rot.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p)))
+        return res
+
+    def xm2_filter(self, rot, scale, percentile=90.0):
+        """the reference's percentile filter on the device -> (threshold, newly removed, new weights); Q is rebuilt"""
+        rot = np.asfortranarray(np.asarray(rot, dtype=np.float64)); scale = np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(-1))
+        thr = C.c_double(); rm = C.c_int64(); w = np.zeros(self.ne)
+        _chk(lib().xm_ctx_xm2_filter(self.h, rot.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p), percentile, C.byref(thr), C.byref(rm),
+                                     w.ctypes.data_as(C.c_void_p)))
+        return thr.value, rm.value, w
+
+    def xm2_round(self, R, s, max_rank, tol, max_time=1000.0, percentile=90.0, flags=0):
+        """one round of the reference's XM^2 loop starting from the solution (R, s): filter, solve_rank3 at lam 0, lam decision, final solve"""
+        n = self.n
+        R = np.asfortranarray(np.asarray(R, dtype=np.float64)); s = np.ascontiguousarray(np.asarray(s, dtype=np.float64).reshape(-1))
+        rmax = max(int(max_rank), 3)
+        Ro = np.zeros((3 * n, rmax + 1), order="F"); so = np.zeros(n)
+        opt = Options(); res = Result(); inf = Xm2Info()
+        opt.struct_size, res.struct_size, inf.struct_size = C.sizeof(Options), C.sizeof(Result), C.sizeof(Xm2Info)
+        opt.max_rank, opt.tol, opt.max_time, opt.flags = int(max_rank), tol, max_time, flags
+        inf.percentile = percentile
+        res.R = Ro.ctypes.data_as(C.c_void_p); res.s = so.ctypes.data_as(C.c_void_p)
+        _chk(lib().xm_ctx_xm2_round(self.h, R.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), R.shape[1], C.byref(opt), C.byref(inf), C.byref(res)))
+        info = {k: getattr(res, k) for k, _ in Result._fields_ if k not in ("R", "s", "struct_size")}
+        x2 = {k: getattr(inf, k) for k, _ in Xm2Info._fields_ if k != "struct_size"}
+        return np.ascontiguousarray(Ro[:, : res.rank]), so, info, x2
 
     def set_edge_weights(self, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
