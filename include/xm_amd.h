@@ -99,7 +99,9 @@ typedef struct {
     int32_t balance;           /* row partition of block-sparse storage: 0 = by stored blocks, 1 = equal camera ranges */
     int32_t exchange;          /* multi-GPU tCG exchange: 0 auto (direct peer writes when the ranks share this process or IPC is set up, else RCCL),
                                   1 RCCL all-gather, 2 direct peer writes */
-    int32_t reserved[5];
+    int32_t split_k;           /* dense product of a SMALL row strip with its columns split over several workgroups per camera group: 0 auto
+                                  (multi-GPU runs whose strip has fewer than ~1.5 workgroups per CU), -1 off, 2..8 forced (also on one GPU) */
+    int32_t reserved[4];
 } xm_tuning_t;
 
 typedef struct {
@@ -330,6 +332,10 @@ int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, doubl
 /* the same for a ROW STRIP of nloc cameras of an n-camera matrix (what one rank of an N-GPU row partition multiplies: dq = 3 nloc rows x
  * xm_dense_ld(n)); used to state the expected per-iteration time of the partitioned solve from measured pieces */
 int xm_qw_dense_strip_time(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
+/* the strip product with its COLUMNS split over `ks` workgroups per camera group (ks = 0: the small-strip policy picks; 1: no split):
+ * out = alpha * Q_strip * W; with reps > 0 also the average launch time */
+int xm_qw_dense_strip_ks(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, double alpha, int ks, int reps,
+                         double *ms_avg, int *ks_used);
 /* micro-benchmark of the direct peer-write all-gather (xm-code_amd/csrc/xm_comm.hip): `world` ranks (one host thread each; gpu_map 1 = all
  * on device 0) gather `count` doubles per rank `reps` times; us_avg = average time per collective on rank 0, stream time */
 int xm_peer_allgather_bench(int world, int gpu_map, int64_t count, int reps, double *us_avg);

@@ -27,7 +27,15 @@ for o in a.o:
         ms = C.c_double()
         xmamd._chk(L.xm_qw_dense_strip_time(dq.ptr, nloc, n, o, dW.ptr, dO.ptr, a.reps, C.byref(ms)))
         by = 8.0 * 3 * nloc * 3 * n
-        print(f"strip product n={n} o={o} N={N}: {nloc} cameras / rank, {by/1e6:7.1f} MB of Q: {ms.value*1e3:7.1f} us  ({by/ms.value/1e6:7.0f} GB/s)", flush=True)
+        line = f"strip product n={n} o={o} N={N}: {nloc} cameras / rank, {by/1e6:7.1f} MB of Q: {ms.value*1e3:7.1f} us  ({by/ms.value/1e6:7.0f} GB/s)"
+        used = C.c_int()
+        xmamd._chk(L.xm_qw_dense_strip_ks(dq.ptr, nloc, n, o, dW.ptr, dO.ptr, 1.0, 0, a.reps, C.byref(ms), C.byref(used)))
+        line += f"   | columns split x{used.value} (policy): {ms.value*1e3:6.1f} us"
+        for ks in (2, 3, 4, 6, 8):
+            if N > 1 and ks != used.value:
+                xmamd._chk(L.xm_qw_dense_strip_ks(dq.ptr, nloc, n, o, dW.ptr, dO.ptr, 1.0, ks, a.reps, C.byref(ms), C.byref(used)))
+                line += f"  x{ks}: {ms.value*1e3:5.1f}"
+        print(line, flush=True)
         dq.free(); dO.free()
     dW.free()
 for world in (2, 4, 8):

@@ -201,6 +201,37 @@ def test_abi_struct_size_is_checked(xmamd):
     ctx.close()
 
 
+# ---------------------------------------------------------------------------------------------- column-split strip product
+@pytest.mark.parametrize("nloc,n,o,ks", [(223, 1778, 3, 0), (223, 1778, 5, 4), (445, 1778, 3, 2), (45, 356, 4, 0), (7, 400, 3, 8), (223, 1778, 1, 4),
+                                          (300, 700, 10, 2), (889, 1778, 3, 0)])
+def test_column_split_strip_product_matches_oracle(xmamd, oracle, nloc, n, o, ks):
+    """qw_dense_ks_kernel: the product of a rank's ROW STRIP with the columns split over `ks` workgroups per camera group (partial sums
+    per slice, arrival counter, the last slice adds them in slice order): equals the oracle's product of the same non-symmetric rows to
+    1e-13 and is bit-reproducible from launch to launch (whichever slice finishes last)"""
+    rng = np.random.default_rng(nloc + 7 * o)
+    Qfull = np.zeros((3 * n, 3 * n)); Qfull[: 3 * nloc] = rng.standard_normal((3 * nloc, 3 * n))
+    W = rng.standard_normal((3 * n, o))
+    ref = oracle.qw(Qfull, W, 2.0)[: 3 * nloc]
+    got, used, _ = xmamd.qw_dense_strip(Qfull[: 3 * nloc], n, W, 2.0, ks=ks)
+    assert used >= 1 and (ks == 0 or used == ks)
+    assert tl.rel_fro(got, ref) < 1e-13
+    for _ in range(3):
+        again, _, _ = xmamd.qw_dense_strip(Qfull[: 3 * nloc], n, W, 2.0, ks=ks)
+        assert np.array_equal(again, got)
+
+
+def test_split_k_solve_equals_plain_solve(xmamd, monkeypatch):
+    """the whole solver through the column-split product (forced on one GPU with XM_SPLIT_K; on its own it switches on for the small
+    strips of a multi-GPU run): gradient / Hessian / certificate epilogues run by the finishing slice -- same certified optimum"""
+    P = tl.gen_vg(301, deg=10, sigma=0.2, seed=5)
+    R0, s0, i0 = xmamd.solve_dense(P["Q"], 5, 1e-9, 10.0)
+    monkeypatch.setenv("XM_SPLIT_K", "3")
+    R1, s1, i1 = xmamd.solve_dense(P["Q"], 5, 1e-9, 10.0)
+    assert i0["rank"] == i1["rank"] and i0["status"] == i1["status"] == 1
+    assert i1["primal"] == pytest.approx(i0["primal"], rel=1e-11)
+    assert tl.rotation_parity(R1, s1, R0, s0) < 1e-8
+
+
 # ---------------------------------------------------------------------------------------------- single-process multi-GPU
 def _team_worker_code():
     return textwrap.dedent(f"""

@@ -429,6 +429,38 @@ int xm_qw_dense_strip_time(const double *dq, int64_t nloc, int64_t n, int o, con
     return XM_OK;
     XM_CATCH
 }
+int xm_qw_dense_strip_ks(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, double alpha, int ks, int reps,
+                         double *ms_avg, int *ks_used) {
+    XM_TRY
+    if (nloc < 1 || nloc > n || ks < 0 || ks > 8) throw xm::Error(XM_ERR_ARG, "bad argument");
+    const int64_t ld = xm::dense_ld(n);
+    if (ks == 0) ks = xm::qw_dense_split_k((int)nloc, ld);
+    if (ks_used) *ks_used = ks;
+    xm::CamArgs a = plain_args(nloc, dOut);
+    xm::DevBuf<double> ksum;
+    xm::DevBuf<unsigned int> kcount;
+    if (ks > 1) {
+        ksum.alloc((size_t)ks * nloc * 3 * xm::pitch_of(o));
+        kcount.alloc((size_t)xm::qw_grid((int)nloc));
+        a.ks = ks; a.ksum = ksum.p; a.kcount = kcount.p;
+    }
+    xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, alpha, a, nullptr);
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    if (reps > 0) {
+        hipEvent_t e0, e1;
+        XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+        XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, alpha, a, nullptr);
+        XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+        XM_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (ms_avg) *ms_avg = (double)ms / reps;
+    }
+    return XM_OK;
+    XM_CATCH
+}
 int xm_peer_allgather_bench(int world, int gpu_map, int64_t count, int reps, double *us_avg) {
     XM_TRY
     require_device();

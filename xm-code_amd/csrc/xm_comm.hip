@@ -58,6 +58,7 @@ Settings Settings::resolve(const xm_tuning_t *t) {
     s.watchdog_s = z.watchdog_s > 0 ? (double)z.watchdog_s : env_f("XM_WATCHDOG_S", 600.0);
     s.balance = z.balance != 0 ? z.balance : (int)env_ll("XM_BALANCE", 0);
     s.exchange = z.exchange != 0 ? z.exchange : (int)env_ll("XM_EXCHANGE", 0);
+    s.split_k = z.split_k != 0 ? z.split_k : (int)env_ll("XM_SPLIT_K", 0);
     s.debug_drop_finalize = env_ll("XM_DEBUG_DROP_FINALIZE", -1);
     s.debug_peer_mute = (int)env_ll("XM_DEBUG_PEER_MUTE", 0);
     return s;

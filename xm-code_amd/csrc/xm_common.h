@@ -84,6 +84,12 @@ struct CamArgs {
     int range_mode;      // 0 whole matrix | 1 only the column tiles [t_lo, t_hi) | 2 all tiles except [t_lo, t_hi)
     int t_lo, t_hi;
     const double *addend; // range_mode 2: raw row sums of the tiles done earlier (3*nloc x OP, pitch OP), added before the epilogue
+    // dense product with the COLUMNS split over `ks` workgroups per camera group (small row strips of a multi-GPU run: 223 cameras
+    // per rank = 56 workgroups on 256 CUs otherwise): raw partial sums per (slice, camera) + an arrival counter per camera group; the
+    // last slice to arrive adds them in slice order and runs the epilogue (one launch, no atomics on data, bit-reproducible)
+    int ks;               // 0 / 1: off
+    double *ksum;         // ks x nloc x 3 x OP
+    unsigned int *kcount; // one per camera group, zero between launches
 };
 
 enum Epilogue { EPI_PLAIN = 0, EPI_GRAD = 1, EPI_HESS = 2, EPI_CERT = 3 };
@@ -112,6 +118,7 @@ int qw_grid(int nloc);
 // the same product restricted to a range of column tiles (CamArgs.range_mode / t_lo / t_hi / addend); plain or gradient epilogue
 void launch_qw_dense_split(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st);
 int qw_dense_tile_cols();
+int qw_dense_split_k(int nloc, int64_t ld);   // column split the small-strip policy picks for `nloc` cameras (1 = none)
 int bsr_grid(int nloc);   // workgroups (= partial sums per epilogue slot) of the BSR3 kernels
 int sym_groups(int nloc);
 int sym_variant();   // 1: vertical sweep (also instantiated for the rank-1 certificate operator)

@@ -249,20 +249,11 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
 // ----------------------------------------------------------------------------------------------------------------
 // common tail of the Q*W kernels: wave reduction of the 3 x O accumulators, epilogue, per-workgroup partial sums
 // ----------------------------------------------------------------------------------------------------------------
+// tail shared by every product kernel: h = this camera's 3 x O block of alpha * Q * W, column k in lane k of the camera's lane group
 template <int O, int EPI, int GW, int NSLOT>
-__device__ __forceinline__ void qw_finish(int cam, int lane, int slot, bool active, double (&acc)[3][O], double alpha,
-                                          const CamArgs &a, const EpiOps &e, double (*red)[3]) {
+__device__ __forceinline__ void qw_tail(int cam, int lane, int slot, bool active, Col3 h, const CamArgs &a, const EpiOps &e, double (*red)[3]) {
     // `lane` = position inside the camera's lane group (0..GW-1), `slot` = index of that group inside the workgroup
     constexpr int OP = pitch_of(O);
-    Col3 h;
-    h.v[0] = h.v[1] = h.v[2] = 0.0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int k = 0; k < O; ++k) {
-            const double t = alpha * group_sum<GW>(acc[r][k]);
-            if (lane == k) h.v[r] = t;
-        }
     double p0 = 0.0, p1 = 0.0, p2 = 0.0;
     if (active) {  // uniform across the group
         if (EPI == EPI_PLAIN) {
@@ -294,6 +285,24 @@ __device__ __forceinline__ void qw_finish(int cam, int lane, int slot, bool acti
             if (EPI == EPI_HESS) a.partials[2 * gridDim.x + blockIdx.x] = t2;
         }
     }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// common tail of the Q*W kernels: wave reduction of the 3 x O accumulators, epilogue, per-workgroup partial sums
+// ----------------------------------------------------------------------------------------------------------------
+template <int O, int EPI, int GW, int NSLOT>
+__device__ __forceinline__ void qw_finish(int cam, int lane, int slot, bool active, double (&acc)[3][O], double alpha,
+                                          const CamArgs &a, const EpiOps &e, double (*red)[3]) {
+    Col3 h;
+    h.v[0] = h.v[1] = h.v[2] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            const double t = alpha * group_sum<GW>(acc[r][k]);
+            if (lane == k) h.v[r] = t;
+        }
+    qw_tail<O, EPI, GW, NSLOT>(cam, lane, slot, active, h, a, e, red);
 }
 
 }  // namespace xm

@@ -168,6 +168,145 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
     qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }
 
+// Column-split variant for SMALL ROW STRIPS (a rank of a multi-GPU run: Venice-1778 over 8 GPUs leaves 223 cameras = 56 workgroups for
+// 256 CUs, each walking all 21 column tiles serially: 18.7 us for 28 MB, profiles/r03_kbench_multi.txt).  grid = (camera groups, KS):
+// workgroup (b, y) multiplies the tiles of slice y only and stores its wavefronts' raw 3 x O sums; an arrival counter per camera group
+// tells the last slice to arrive, which adds the KS partial results IN SLICE ORDER (fixed, so the result does not depend on who
+// finishes) and runs the fused epilogue.  Same pipelined body as qw_dense_kernel.
+template <int O, int EPI>
+__global__ __launch_bounds__(256) void qw_dense_ks_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, double alpha, CamArgs a) {
+    constexpr int OP = pitch_of(O);
+    constexpr int NSUB = 2, TILE = NSUB * 128, TILE2 = TILE * OP / 2, NST = (TILE2 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) double wt[2][TILE * OP];
+    __shared__ double red[kQwWaves][3];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cam = blockIdx.x * kQwWaves + wave;
+    const bool active = cam < a.nloc;
+    const double *q0 = Q + (size_t)(active ? cam : 0) * 3 * (size_t)ld + 2 * lane;
+    const int ntiles_all = (int)((ld + TILE - 1) / TILE);
+    const int KS = a.ks, y = blockIdx.y;
+    const int t_lo = (int)((int64_t)ntiles_all * y / KS), t_hi = (int)((int64_t)ntiles_all * (y + 1) / KS);
+    const int ntiles = t_hi - t_lo;
+    if (EPI == EPI_HESS) {
+        if (a.scal->status != 0) return;
+    }
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+    double2 qn[NSUB][3];
+    double2 ws[NST];
+    auto load_q = [&](int t) {
+        const int64_t c0 = (int64_t)t * TILE;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            const int64_t c = c0 + u * 128;
+            if (active && c < ld) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) qn[u][r] = *reinterpret_cast<const double2 *>(q0 + (size_t)r * ld + c);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) qn[u][r] = make_double2(0.0, 0.0);
+            }
+        }
+    };
+    auto load_w = [&](int t) {
+        const int64_t c0 = (int64_t)t * TILE;
+        const int64_t cols = (ld - c0 < TILE) ? (ld - c0) : TILE;
+        const int n2 = (int)(cols * OP / 2);
+        const double2 *src = reinterpret_cast<const double2 *>(W + (size_t)c0 * OP);
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            ws[j] = (idx < n2) ? src[idx] : make_double2(0.0, 0.0);
+        }
+    };
+    auto store_w = [&](int buf) {
+        double2 *dst = reinterpret_cast<double2 *>(wt[buf]);
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            if (idx < TILE2) dst[idx] = ws[j];
+        }
+    };
+    if (ntiles > 0) {
+        load_q(t_lo);
+        load_w(t_lo);
+        store_w(0);
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            double2 q[NSUB][3];
+#pragma unroll
+            for (int u = 0; u < NSUB; ++u)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) q[u][r] = qn[u][r];
+            const bool more = (t + 1 < ntiles);
+            if (more) { load_q(t_lo + t + 1); load_w(t_lo + t + 1); }
+            const double2 *wbase = reinterpret_cast<const double2 *>(wt[t & 1]);
+#pragma unroll
+            for (int u = 0; u < NSUB; ++u) {
+                const double2 *wp = wbase + (size_t)(u * 64 + lane) * OP;
+                double wv[2 * OP];
+#pragma unroll
+                for (int j = 0; j < OP; ++j) {
+                    const double2 tt = wp[j];
+                    wv[2 * j] = tt.x;
+                    wv[2 * j + 1] = tt.y;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < O; ++k) acc[r][k] += q[u][r].x * wv[k] + q[u][r].y * wv[OP + k];
+            }
+            if (more) store_w((t + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // raw sums of this slice: column k of the camera's block in lane k
+    Col3 h;
+    h.v[0] = h.v[1] = h.v[2] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            const double t = wave_sum(acc[r][k]);
+            if (lane == k) h.v[r] = t;
+        }
+    // hand-off without cache-wide fences (a release fence writes back the whole L2 of the XCD and the acquire invalidates it: measured
+    // 39 us instead of 22 for the N = 4 strip): the partial sums are agent-scope (write-through) stores, drained with s_waitcnt before
+    // the arrival is counted, and the finisher reads them with agent-scope loads (MI355X_MICROARCH: "sc1 stores AND sc1 loads")
+    if (active && lane < O) {
+        double *ps = a.ksum + ((size_t)y * a.nloc + cam) * 3 * OP + lane;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) __hip_atomic_store(ps + r * OP, h.v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(a.kcount + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old + 1 == (unsigned int)KS);
+        if (s_last) __hip_atomic_store(a.kcount + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    EpiOps eops;
+    epi_prefetch<O, EPI>(eops, cam, lane, active, a);
+    h.v[0] = h.v[1] = h.v[2] = 0.0;
+    if (active && lane < O) {
+        for (int s = 0; s < KS; ++s) {   // slice order: the sum does not depend on which slice arrived last
+            const double *ps = a.ksum + ((size_t)s * a.nloc + cam) * 3 * OP + lane;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) h.v[r] += __hip_atomic_load(ps + r * OP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) h.v[r] *= alpha;
+    }
+    // the partial sums of the epilogue are indexed by the camera group, as in the unsplit kernel (gridDim.x = camera groups)
+    qw_tail<O, EPI, 64, kQwWaves>(cam, lane, wave, active, h, a, eops, red);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // Half-traffic product for SYMMETRIC dense Q (single GPU, o <= 5).  Only the upper block triangle is read: a workgroup of 8
 // wavefronts owns 8 consecutive cameras (24 rows) and sweeps the column tiles from its diagonal block to the right.  Every Q
@@ -1730,8 +1869,33 @@ void launch_qw_dense_split(int o, int epi, const double *Q, int64_t ld, const do
 }
 int qw_dense_tile_cols() { return 2 * 128; }   // column tile of the split launches
 
+// Small-strip policy: split the columns so that about two workgroups per CU exist, every slice keeping at least two tiles
+// (measured at Venice size, profiles/r03_kbench_multi.txt: 223 cameras x6 9.3 us against 19.0 unsplit, 445 cameras x3 14.2 against 22.0)
+int qw_dense_split_k(int nloc, int64_t ld) {
+    const int g = qw_grid(nloc), ntiles = (int)((ld + 255) / 256);
+    int ks = 512 / (g > 0 ? g : 1);
+    if (ks > 8) ks = 8;
+    if (ks > ntiles / 2) ks = ntiles / 2;
+    return ks < 2 ? 1 : ks;
+}
+template <int O>
+static void qw_dense_ks_o(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
+    const dim3 g(qw_grid(a.nloc), a.ks), b(256);
+    switch (epi) {
+        case EPI_PLAIN: hipLaunchKernelGGL((qw_dense_ks_kernel<O, EPI_PLAIN>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((qw_dense_ks_kernel<O, EPI_GRAD>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((qw_dense_ks_kernel<O, EPI_HESS>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_CERT: if constexpr (O == 1) { hipLaunchKernelGGL((qw_dense_ks_kernel<1, EPI_CERT>), g, b, 0, st, Q, ld, W, alpha, a); break; }
+        default: throw Error(-2, "bad epilogue");
+    }
+}
 void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
     if (a.nloc <= 0) return;
+    if (a.ks > 1 && a.ksum && a.kcount) {
+        XM_DISPATCH_O(o, (qw_dense_ks_o<O_>(epi, Q, ld, W, alpha, a, st)));
+        check_launch("qw_dense_ks");
+        return;
+    }
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
         if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2, true>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);

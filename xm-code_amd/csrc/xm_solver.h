@@ -27,6 +27,7 @@ struct Settings {
     double watchdog_s = 600.0;
     int balance = 0;             // 0 by stored blocks | 1 equal camera ranges
     int exchange = 0;            // 0 auto | 1 RCCL | 2 peer writes
+    int split_k = 0;             // 0 auto (multi-rank small strips) | -1 off | 2..8 forced
     long long debug_drop_finalize = -1;   // XM_DEBUG_DROP_FINALIZE (tests)
     int debug_peer_mute = 0;              // XM_DEBUG_PEER_MUTE=1 (tests): rank 1 never publishes its tCG epoch -> the peers' bounded wait must expire
     static Settings resolve(const xm_tuning_t *t);
@@ -199,6 +200,9 @@ private:
     DevBuf<double> rR_, rs_, rsB_, pR_, psA_, psB_, vR_, vs_, HvR_, Hvs_, HpR_, Hps_;
     DevBuf<double> partsA_, partsB_, partsM_;
     DevBuf<double> Prow_, Pcol_;               // symmetric product: row results and per-workgroup column partials
+    DevBuf<double> ksum_;                      // column-split dense product of a small strip: partial sums per (slice, camera)
+    DevBuf<unsigned int> kcount_;              //   arrival counters per camera group
+    int ks_ = 1;
     bool sym_ok_ = false;
     int sym_max_o_ = 4;
     bool eig_exact_ = false;                   // the last certificate ran the tridiagonalisation to completion (small n)

@@ -405,6 +405,16 @@ void Context::setup_rank(int o) {
     } else {
         Prow_.release(); Pcol_.release();
     }
+    // column-split product for small strips (xm_kernels.hip:qw_dense_ks_kernel): multi-rank dense storage by default
+    ks_ = 1;
+    if (storage_ == XM_STORAGE_DENSE && !sym_ok_ && cfg_.split_k >= 0) {
+        if (cfg_.split_k >= 2) ks_ = std::min(cfg_.split_k, std::max(1, (int)((ld_ + 255) / 256)));
+        else if (comm_->active()) ks_ = qw_dense_split_k(nloc_, ld_);
+    }
+    if (ks_ > 1) {
+        ksum_.alloc((size_t)ks_ * mat);
+        kcount_.alloc((size_t)qw_grid(nloc_));
+    }
     if (overlap_applies()) {
         if (!st2_) {
             XM_HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
@@ -478,6 +488,7 @@ CamArgs Context::cam_args(int state) const {
     a.out = HpR_.p;
     a.partials = partsA_.p;
     a.scal = scal_.p;
+    if (ks_ > 1) { a.ks = ks_; a.ksum = ksum_.p; a.kcount = kcount_.p; }
     return a;
 }
 

@@ -26,7 +26,7 @@ FLAG_WARM_R = 16
 EXPORTS = [
     "xm_last_error", "xm_version", "xm_abi_revision", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
-    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_qw_dense_time", "xm_qw_dense_strip_time", "xm_peer_allgather_bench", "xm_qw_bsr3_time", "xm_recover_rotations",
+    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_qw_dense_time", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_peer_allgather_bench", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_finalize", "xm_partition", "xm_partition_blocks",
     "xm_symv_plan", "xm_sell_layout", "xm_sell_create", "xm_sell_create2", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
     "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse",
@@ -40,7 +40,7 @@ class XmError(RuntimeError):
 class Tuning(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("sym", "sym_min_rows", "sell", "sell_slabs", "sell_lmax", "sell_gather", "sell_codec", "overlap",
                                          "overlap_min_mb", "cert_dense_rows", "lanczos_mmax", "lanczos_restarts", "watchdog_s", "balance",
-                                         "exchange")] + [("reserved", C.c_int32 * 5)]
+                                         "exchange", "split_k")] + [("reserved", C.c_int32 * 4)]
 
 
 class Problem(C.Structure):
@@ -124,6 +124,8 @@ def lib():
         L.xm_qw_dense_time.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.POINTER(C.c_double)]
         L.xm_qw_dense_strip_time.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.xm_qw_dense_strip_ks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_int)]
         L.xm_peer_allgather_bench.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)]
         L.xm_qw_bsr3_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                       C.POINTER(C.c_double)]
@@ -251,6 +253,22 @@ def qw_dense(Q, W, alpha=1.0, dq=None, sym=False):
     for b in (dW, dO) + ((dq,) if own else ()):
         b.free()
     return out
+
+
+def qw_dense_strip(Qs, n, W, alpha=1.0, ks=0, reps=0):
+    """alpha * Qs @ W for a ROW STRIP Qs (3 nloc x 3n, the rows one rank of a row partition owns) through the column-split kernel
+    (ks workgroups per camera group; 0 = policy).  Returns (product, ks used, average ms when reps > 0)."""
+    require_gpu()
+    Qs = np.asarray(Qs, dtype=np.float64); W = np.asarray(W, dtype=np.float64)
+    nloc, o, ld = Qs.shape[0] // 3, W.shape[1], dense_ld(n)
+    Qp = np.zeros((3 * nloc, ld)); Qp[:, :3 * n] = Qs
+    dq = DevArray(Qp); dW = DevArray(to_rm(W, rows=ld)); dO = DevArray(nbytes=3 * nloc * pitch_of(o) * 8)
+    ms = C.c_double(); used = C.c_int()
+    _chk(lib().xm_qw_dense_strip_ks(dq.ptr, nloc, n, o, dW.ptr, dO.ptr, alpha, ks, reps, C.byref(ms), C.byref(used)))
+    out = from_rm(dO.get(), 3 * nloc, o)
+    for b in (dq, dW, dO):
+        b.free()
+    return out, used.value, ms.value
 
 
 def qw_bsr3(rowptr, colidx, blocks, W, alpha=1.0):
