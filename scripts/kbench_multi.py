@@ -32,7 +32,7 @@ for o in a.o:
         xmamd._chk(L.xm_qw_dense_strip_ks(dq.ptr, nloc, n, o, dW.ptr, dO.ptr, 1.0, 0, a.reps, C.byref(ms), C.byref(used)))
         line += f"   | columns split x{used.value} (policy): {ms.value*1e3:6.1f} us"
         for ks in (2, 3, 4, 6, 8):
-            if N > 1 and ks != used.value:
+            if ks != used.value:
                 xmamd._chk(L.xm_qw_dense_strip_ks(dq.ptr, nloc, n, o, dW.ptr, dO.ptr, 1.0, ks, a.reps, C.byref(ms), C.byref(used)))
                 line += f"  x{ks}: {ms.value*1e3:5.1f}"
         print(line, flush=True)
