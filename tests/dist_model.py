@@ -16,17 +16,28 @@ def _sym(M):
 
 
 class RankModel:
-    def __init__(self, Q, o, lam, rank, world, allgather, overlap=False):
+    def __init__(self, Q, o, lam, rank, world, allgather, overlap=False, cuts=None):
+        # cuts: world + 1 camera offsets of an UNEQUAL partition (block-sparse storage is balanced by stored blocks, Context::init /
+        # partition_cuts); every rank is padded to the longest range and a camera's record sits at position rank * nloc + (g - cuts[rank])
+        # of every replicated vector (Context::pos_of).  None: equal ranges (positions == global indices).
         # overlap: the products outside the tCG multiply the rank's OWN column strip before the all-gather of W is awaited and add
         # the other columns afterwards (Context::product with a pending gather); `events` records the order
         self.overlap, self.events = overlap, []
         n = Q.shape[0] // 3
         self.n, self.o, self.lam, self.rank, self.world, self.ag = n, o, lam, rank, world, allgather
-        self.nloc = -(-n // world)
-        self.cam0 = rank * self.nloc
+        if cuts is None:
+            per = -(-n // world)
+            cuts = [min(n, r * per) for r in range(world + 1)]
+        assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == n and all(b >= a for a, b in zip(cuts, cuts[1:]))
+        self.cuts = list(cuts)
+        self.nloc = max(1, max(b - a for a, b in zip(cuts, cuts[1:])))
+        self.cam0 = rank * self.nloc                                          # first position of this rank in the padded numbering
+        self.g0, self.real = cuts[rank], cuts[rank + 1] - cuts[rank]            # first global camera, real cameras
         self.ntot = self.nloc * world
+        self.pos = np.concatenate([r * self.nloc + np.arange(cuts[r + 1] - cuts[r]) for r in range(world)]).astype(np.int64)   # global -> position
+        idx3 = (3 * self.pos[:, None] + np.arange(3)[None, :]).ravel()
         Qp = np.zeros((3 * self.ntot, 3 * self.ntot))
-        Qp[:3 * n, :3 * n] = Q
+        Qp[np.ix_(idx3, idx3)] = Q
         self.Qloc = Qp[3 * self.cam0:3 * (self.cam0 + self.nloc)]          # this rank's rows only
         self.anchor = np.zeros(self.nloc, dtype=bool)
         if self.cam0 == 0:
@@ -113,9 +124,9 @@ class RankModel:
         n, o = self.n, self.o
         R = np.zeros((self.nloc, 3, o)); R[:, :, :3] = np.eye(3)
         s = np.ones(self.nloc)
-        real = max(0, min(n - self.cam0, self.nloc))
-        R[:real] = R0.reshape(n, 3, o)[self.cam0:self.cam0 + real]
-        s[:real] = s0[self.cam0:self.cam0 + real]
+        real = self.real
+        R[:real] = R0.reshape(n, 3, o)[self.g0:self.g0 + real]
+        s[:real] = s0[self.g0:self.g0 + real]
         delta_bar = np.sqrt(n * (3 * o - 6) + n - 1)
         delta = delta_bar / 8
         st = self.eval_point(R, s)
@@ -172,6 +183,6 @@ class RankModel:
             if not (stc["f"] > loss or rou < 0.1):
                 R, s, st, loss, rr = Rc, sc, stc, stc["f"], stc["rr"]
         # assemble the full solution on every rank
-        Rfull = self.ag(R.reshape(-1)).reshape(self.ntot * 3, o)[:3 * n]
-        sfull = self.ag(s)[:n]
+        Rfull = self.ag(R.reshape(-1)).reshape(self.ntot, 3, o)[self.pos].reshape(3 * n, o)   # padded numbering -> global order
+        sfull = self.ag(s)[self.pos]
         return Rfull, sfull, dict(primal=loss, tcg_iters=total, outer=len(trace) - 1, trace=np.array(trace))
