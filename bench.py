@@ -33,7 +33,7 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:   # torchrun pins OMP_NUM_THREADS
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")              # control-plane rendezvous on loopback (hostname may not resolve)
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")              # RCCL bootstrap of the single-node communicator likewise
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (multi-process runs)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # virtual devices (N ranks on one GPU) need a hardware queue per rank's stream
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")           # virtual devices (N ranks on one GPU) need a hardware queue per rank's stream (8 ranks: 16 queues)
 os.environ.setdefault("OMP_PROC_BIND", "close")            # cpu_baseline: threads stay where they first touched their share of Q
 os.environ.setdefault("OMP_PLACES", "cores")
 

@@ -4,7 +4,7 @@ cg_step launch, and the direct peer-write all-gather on `world` virtual devices 
 import argparse, ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "xm-code_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np, xmamd
 
 ap = argparse.ArgumentParser()

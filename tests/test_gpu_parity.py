@@ -287,11 +287,11 @@ def test_bsr_solve_equals_dense_solve(xmamd):
     assert tl.rel_fro(rot, ref) < 0.2
 
 
-def test_file_surface_XM_module(xmamd, tmp_path):
+def test_file_surface_XM_module(xmamd, tmp_path, monkeypatch):
     """the reference's own entry point: XM.solve(path, ...) reading Q.bin, writing R.bin / s.bin (1_test_solve.py:42)"""
     Q, exp, d = _case("simple1")
     tl.save_bin(tmp_path / "Q.bin", Q)
-    os.environ["XM_QUIET"] = "1"
+    monkeypatch.setenv("XM_QUIET", "1")
     XM = xmamd.import_XM()
     assert XM.solve(str(tmp_path) + "/", 3, 1e-16, 0.0, 1000) is None
     R = tl.load_bin(tmp_path / "R.bin"); s = tl.load_bin(tmp_path / "s.bin")
@@ -309,11 +309,11 @@ def test_file_surface_XM_module(xmamd, tmp_path):
         XM.solve(str(tmp_path / "missing"), 3, 1e-6, 0.0, 10)
 
 
-def test_in_memory_XM_surface_and_bin_v2(xmamd, tmp_path):
+def test_in_memory_XM_surface_and_bin_v2(xmamd, tmp_path, monkeypatch):
     """XM.solve_array / XM.solve_bsr return what the file surface writes (bit for bit), and Q.bin with the
     8-byte header fields of utils/io.py:24-26 (`byte = 8`, which the reference's own C++ loader cannot read) is accepted"""
     Q, exp, d = _case("simple2")
-    os.environ["XM_QUIET"] = "1"
+    monkeypatch.setenv("XM_QUIET", "1")
     XM = xmamd.import_XM()
     R, s, info = XM.solve_array(Q, 3, 1e-12, 0.0, 1000.0)
     assert R.shape == (3 * exp["n"], info["rank"]) and R.flags.f_contiguous and s.shape == (exp["n"],) and info["status"] == 1

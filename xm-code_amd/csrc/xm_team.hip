@@ -104,8 +104,9 @@ Team::Team(const xm_problem_t &prob, int n_gpus, int gpu_map) : p_(new Impl) {
     t.device.resize((size_t)n_gpus);
     for (int r = 0; r < n_gpus; ++r) t.device[(size_t)r] = (gpu_map == 1) ? 0 : r;
     const Settings cfg = Settings::resolve(prob.tuning);
-    // device-side waits give up after min(watchdog, 30 s): long enough for a peer that is still uploading, short enough not to look hung
-    t.group = peer_group_create(n_gpus, t.device.data(), std::min(30.0, cfg.watchdog_s));
+    // device-side waits give up after min(watchdog / 3, 30 s): long enough for a peer that lags, short enough not to look hung, and well
+    // before the host-side watchdog of the rank that waits (so that the failure is reported as what it is: XM_ERR_COMM)
+    t.group = peer_group_create(n_gpus, t.device.data(), std::min(30.0, cfg.watchdog_s / 3.0));
     t.ctx.resize((size_t)n_gpus);
     t.comm.resize((size_t)n_gpus);
     t.err.resize((size_t)n_gpus);
