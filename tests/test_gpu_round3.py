@@ -94,6 +94,28 @@ def test_viewgraph_storage_equals_bsr_storage(xmamd, monkeypatch):
     cv.close()
 
 
+def test_vg100k_viewgraph_storage_vs_recorded_oracle(xmamd):
+    """BASELINE config 'synthetic 100k-camera Erdos-Renyi view-graph Q' handed over as its EDGE LIST (XM_STORAGE_VIEWGRAPH): the products
+    stream the quaternion-compressed sliced ELL (181 MB instead of 387 MB per product).  Same recorded CPU-oracle run as
+    test_vg100k_vs_recorded_oracle: optimum to 1e-9, every 8th camera's anchored rotation within 1e-6."""
+    fj = os.path.join(G, "synth", "vg100k_oracle.json")
+    if not os.path.exists(fj):
+        pytest.skip("recorded oracle run not present")
+    c = json.load(open(fj))
+    P = tl.gen_vg(c["n"], deg=c["deg"], sigma=c["sigma"], seed=c["n"], dense=False)
+    e = P["edges"]
+    ctx = xmamd.Context(vg=(e[:, 0], e[:, 1], P["w"], P["M"]), n=c["n"])
+    R, s, i = ctx.solve(5, c["tol"], c["lam"])
+    ctx.close()
+    assert i["rank"] == 3 and i["status"] == 1
+    assert i["qw_stream_bytes"] < 0.5 * 76 * P["colidx"].size            # the compressed copy is what the products read
+    assert i["primal"] == pytest.approx(c["f"], rel=1e-9)
+    rot, _ = tl.recover_rotations(R, s)
+    sub = rot.reshape(3, c["n"], 3)[:, ::8, :]
+    assert tl.rel_fro(sub, np.load(os.path.join(G, "synth", "vg100k_oracle_rot_every8.npy"))) < 1e-6
+    assert abs(i["tcg_iters"] - c["tcg"]) <= 0.2 * c["tcg"]
+
+
 def test_viewgraph_rejects_duplicate_pairs_and_attach_too(xmamd):
     """the same unordered pair listed twice would race on one off-diagonal block while the diagonal counts both"""
     P = tl.gen_vg(30, deg=4, sigma=0.1, seed=2)

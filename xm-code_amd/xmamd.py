@@ -85,6 +85,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise XmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
+        # "virtual devices" (several ranks of a single-process multi-GPU context on one GPU) need a hardware queue per rank's stream; the
+        # HIP runtime reads this when it initialises, i.e. at the first call into the library
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         L = C.CDLL(LIB_PATH)
         L.xm_last_error.restype = C.c_char_p
         L.xm_version.restype = C.c_char_p
