@@ -268,16 +268,21 @@ def _team_worker_code():
         elif mode.startswith("shm"):
             rank = int(mode[3:])
             xmamd._chk(xmamd.lib().xm_comm_init_shm(rank, world, 0, sys.argv[5].encode(), 64 << 20))
+        skw = {{}}
         if case == "dense":
             P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)         # odd camera count (padding camera), needs rank escalation
             ctx = xmamd.Context(Q=P["Q"], **kw); args = (6, 1e-9, 3.0)
+        elif case == "dense_opts":                                # the solve options travel to every rank: polar retraction, a summation
+            P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)         # grouping, host-stepped tCG (a synchronisation per iteration)
+            ctx = xmamd.Context(Q=P["Q"], **kw); args = (6, 1e-9, 3.0)
+            skw = dict(retraction=xmamd.RETRACT_POLAR, grouping=2, flags=xmamd.FLAG_HOST_STEPPED)
         elif case == "bsr" or case == "sell":
             P = tl.gen_vg(301, deg=10, sigma=0.1, seed=5)
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), **kw); args = (5, 1e-10, 10.0)
         elif case == "vg":                                        # view-graph storage, quaternion codec forced on, hub cameras
             H = tl.gen_vg_hubs(600, 8, 3, 0.3, 0.1, seed=8)
             ctx = xmamd.Context(vg=(H["ei"], H["ej"], H["w"], H["M"]), n=600, **kw); args = (5, 1e-9, 20.0)
-        R, s, info = ctx.solve(*args, trace=4000)
+        R, s, info = ctx.solve(*args, trace=4000, **skw)
         extra = {{}}
         if case == "vg":                                          # XM^2 calls fan out to every rank
             res = ctx.edge_residuals()
@@ -302,7 +307,7 @@ def _run(code, args, env, timeout=600):
     return p.stdout.decode()
 
 
-@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("bsr", 2), ("sell", 2), ("bsr", 3)])
+@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("bsr", 2), ("sell", 2), ("bsr", 3), ("dense_opts", 2)])
 def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, case, world):
     """xm_problem_t.n_gpus: ONE process, one host thread per rank, direct peer-write exchange fused into cg_step (here as `world`
     virtual devices on the one GPU of the test box: own stream each, peer pointers are plain pointers).  Must reproduce the
