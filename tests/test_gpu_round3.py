@@ -53,6 +53,29 @@ def test_qw_sell_quaternion_codec_matches_dense(xmamd, oracle, n, deg, o, slabs,
     Mf.close()
 
 
+def test_round3_paths_are_bit_reproducible(xmamd, monkeypatch):
+    """fixed summation orders in the round-3 kernels too: the sliced-ELL product with the view-graph codec (blocks rebuilt in registers,
+    partial results added in list order, diagonal term by a fixed lane), a whole solve on view-graph storage, and a whole solve on two
+    virtual devices (peer exchange: whoever publishes first, the sums are added rank by rank) give the same bits on every run"""
+    P = _weighted_vg(3000, 16, seed=4)
+    W = np.random.default_rng(2).standard_normal((9000, 3))
+    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=4, codec=1)
+    a = M.qw(W, 1.0, gather=1)
+    for _ in range(3):
+        assert np.array_equal(M.qw(W, 1.0, gather=1), a)
+    M.close()
+    monkeypatch.setenv("XM_BSR_SELL", "1")
+    runs = []
+    for kw in ({}, {}, dict(n_gpus=2, gpu_map=1), dict(n_gpus=2, gpu_map=1)):
+        ctx = xmamd.Context(vg=(P["ei"], P["ej"], P["w"], P["M"]), n=3000, **kw)
+        runs.append(ctx.solve(5, 1e-8, 30.0))
+        ctx.close()
+    for a_, b_ in ((runs[0], runs[1]), (runs[2], runs[3])):
+        assert np.array_equal(a_[0], b_[0]) and np.array_equal(a_[1], b_[1]) and a_[2]["tcg_iters"] == b_[2]["tcg_iters"] and a_[2]["primal"] == b_[2]["primal"]
+    assert runs[0][2]["status"] == runs[2][2]["status"] == 1
+    assert tl.rotation_parity(runs[2][0], runs[2][1], runs[0][0], runs[0][1]) < 1e-6
+
+
 def test_quaternion_codec_rejects_general_blocks(xmamd):
     P = tl.gen_skewed(300, 10, seed=3)                      # random 3x3 blocks: not a view-graph matrix
     with pytest.raises(xmamd.XmError, match="view-graph codec"):
