@@ -65,10 +65,12 @@ def test_round3_paths_are_bit_reproducible(xmamd, monkeypatch):
         assert np.array_equal(M.qw(W, 1.0, gather=1), a)
     M.close()
     monkeypatch.setenv("XM_BSR_SELL", "1")
+    V = tl.gen_vg(3000, deg=16, sigma=0.2, seed=4, dense=False)      # unit weights, lam at their scale: certifies at rank 3
+    e = V["edges"]
     runs = []
     for kw in ({}, {}, dict(n_gpus=2, gpu_map=1), dict(n_gpus=2, gpu_map=1)):
-        ctx = xmamd.Context(vg=(P["ei"], P["ej"], P["w"], P["M"]), n=3000, **kw)
-        runs.append(ctx.solve(5, 1e-8, 30.0))
+        ctx = xmamd.Context(vg=(e[:, 0], e[:, 1], V["w"], V["M"]), n=3000, **kw)
+        runs.append(ctx.solve(5, 1e-8, 100.0))
         ctx.close()
     for a_, b_ in ((runs[0], runs[1]), (runs[2], runs[3])):
         assert np.array_equal(a_[0], b_[0]) and np.array_equal(a_[1], b_[1]) and a_[2]["tcg_iters"] == b_[2]["tcg_iters"] and a_[2]["primal"] == b_[2]["primal"]
@@ -299,6 +301,9 @@ def _team_worker_code():
             P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)         # grouping, host-stepped tCG (a synchronisation per iteration)
             ctx = xmamd.Context(Q=P["Q"], **kw); args = (6, 1e-9, 3.0)
             skw = dict(retraction=xmamd.RETRACT_POLAR, grouping=2, flags=xmamd.FLAG_HOST_STEPPED)
+        elif case == "sell_esc":                                  # block-sparse storage through the sliced ELL WITH rank escalation (certificate's
+            P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)         # o = 1 products, escape line search, o = 4, 5 products) on every rank
+            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), **kw); args = (6, 1e-9, 3.0)
         elif case == "bsr" or case == "sell":
             P = tl.gen_vg(301, deg=10, sigma=0.1, seed=5)
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), **kw); args = (5, 1e-10, 10.0)
@@ -330,7 +335,7 @@ def _run(code, args, env, timeout=600):
     return p.stdout.decode()
 
 
-@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("bsr", 2), ("sell", 2), ("bsr", 3), ("dense_opts", 2)])
+@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("bsr", 2), ("sell", 2), ("bsr", 3), ("dense_opts", 2), ("sell_esc", 2)])
 def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, case, world):
     """xm_problem_t.n_gpus: ONE process, one host thread per rank, direct peer-write exchange fused into cg_step (here as `world`
     virtual devices on the one GPU of the test box: own stream each, peer pointers are plain pointers).  Must reproduce the
@@ -339,7 +344,7 @@ def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, 
     all-gather between the launches (XM_EXCHANGE=1)."""
     code = _team_worker_code()
     env = dict(os.environ, XM_SHM_TIMEOUT="60", GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="60")
-    if case == "sell":
+    if case in ("sell", "sell_esc"):
         env["XM_BSR_SELL"] = "1"
     name = "/xm_t3_" + uuid.uuid4().hex[:12]
     outs = [str(tmp_path / f"shm{r}.npz") for r in range(world)]
