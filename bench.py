@@ -246,7 +246,9 @@ def main():
                    "retraction": args.retraction,
                    "summation_groupings": "step i uses xm_options_t.sum_grouping = i mod 3; tcg_iters_by_step lists what each drew",
                    "parallelism": ("single GPU" if ngp == 1 else
-                                   f"camera row partition x{world}, one process per GPU, RCCL all-gather per exchange" if team == 1 else
+                                   (f"camera row partition x{world}, one process per GPU, " +
+                                    ("direct peer-write exchange through IPC-mapped buffers fused into the tCG" if last.get("exchange") == 2
+                                     else "all-gather per exchange (RCCL; shm test transport on a shared device)")) if team == 1 else
                                    f"camera row partition x{team} inside ONE process (xm_problem_t.n_gpus), direct peer-write exchange fused into the tCG"),
                    **({"transport": "shared-memory TEST transport, all ranks on one GPU (functional dry run, not a scaling measurement)"}
                       if os.environ.get("XM_BENCH_SHM") == "1" else {}),

@@ -353,6 +353,13 @@ int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, dou
  * (bench.py does that with torch.distributed); every rank then calls xm_comm_init before xm_ctx_create. */
 int xm_comm_unique_id(unsigned char id[128]);
 int xm_comm_init(int rank, int world, int device, const unsigned char id[128], const char *rccl_path /* NULL = default search */);
+/* One process per GPU WITHOUT a collective library on the data path: every rank exports its exchange buffers as hipIpcMemHandle_t
+ * through the POSIX shared-memory segment `name` (same string on every rank of the node, unique per job), maps the peers' and uses
+ * the direct peer-write exchange of the single-process mode (fused into the tCG kernel).  xm_comm_init tries the same transport on
+ * its own (segment name derived from the unique id) and keeps RCCL when any rank cannot map a peer, the transport's self-test
+ * fails, the ranks span several nodes, or XM_COMM_PEER=0; this entry point has no fallback: XM_ERR_COMM instead.
+ * spin_seconds <= 0: default bound (20 s) of the device-side waits.  Two ranks may share one GPU (tests). */
+int xm_comm_init_ipc(int rank, int world, int device, const char *name, double spin_seconds);
 /* TEST transport: the same collectives through a POSIX shared-memory segment, so several ranks can share one GPU on a
  * 1-GPU box (tests/test_gpu_parity.py::test_two_ranks_one_gpu); `bytes` = capacity of the exchange area */
 int xm_comm_init_shm(int rank, int world, int device, const char *name, size_t bytes);

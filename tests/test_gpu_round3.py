@@ -293,6 +293,9 @@ def _team_worker_code():
         elif mode.startswith("shm"):
             rank = int(mode[3:])
             xmamd._chk(xmamd.lib().xm_comm_init_shm(rank, world, 0, sys.argv[5].encode(), 64 << 20))
+        elif mode.startswith("ipc"):                              # one process per rank, peer writes through hipIpcMemHandle mappings
+            rank = int(mode[3:])
+            xmamd._chk(xmamd.lib().xm_comm_init_ipc(rank, world, 0, sys.argv[5].encode(), 0.0))
         skw = {{}}
         if case == "dense":
             P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)         # odd camera count (padding camera), needs rank escalation
@@ -319,10 +322,10 @@ def _team_worker_code():
             R2, s2, i2 = ctx.solve(*args, R_ini=R, s_ini=s, mode=xmamd.MODE_REBUTTLE)
             extra = dict(res=res, R2=R2, s2=s2, primal2=i2["primal"], tcg2=i2["tcg_iters"])
         ctx.close()
-        if rank == 0 or mode.startswith("shm"):
+        if rank == 0 or mode.startswith("shm") or mode.startswith("ipc"):
             np.savez(out, R=R, s=s, primal=info["primal"], rank=info["rank"], status=info["status"], tcg=info["tcg_iters"],
                      min_eig=info["min_eig"], trace=info["trace"], n_gpus=info["n_gpus"], exchange=info["exchange"], **extra)
-        if mode.startswith("shm"):
+        if mode.startswith("shm") or mode.startswith("ipc"):
             xmamd.lib().xm_comm_finalize()
     """)
 
@@ -361,6 +364,36 @@ def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, 
         _run(code, ["team", world, out, case], dict(env, XM_EXCHANGE=ex))
         t = np.load(out)
         assert int(t["n_gpus"]) == world and int(t["exchange"]) == (2 if ex == "2" else 1)
+        assert int(t["rank"]) == int(ref["rank"]) and int(t["status"]) == int(ref["status"]) == 1 and int(t["tcg"]) == int(ref["tcg"])
+        assert np.array_equal(t["trace"], ref["trace"])
+        assert np.array_equal(t["R"], ref["R"]) and np.array_equal(t["s"], ref["s"])
+
+
+@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("sell_esc", 2), ("dense_opts", 2)])
+def test_one_process_per_gpu_over_ipc_handles_equals_the_single_process_team(xmamd, tmp_path, case, world):
+    """xm_comm_init_ipc: the cross-process form of the direct peer exchange -- every rank is its own PROCESS (what
+    `python -m torch.distributed.run` starts), exports its arena and tCG exchange buffer as hipIpcMemHandle_t through a shared-memory
+    directory, maps the peers' and runs the very kernels of the single-process team (push + epoch flag + bounded wait inside
+    cg_step).  Here `world` processes share the one GPU of the box.  Every rank must reproduce the team run bit for bit."""
+    code = _team_worker_code()
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="60")
+    if case == "sell_esc":
+        env["XM_BSR_SELL"] = "1"
+    ref_out = str(tmp_path / "team.npz")
+    _run(code, ["team", world, ref_out, case], env)
+    ref = np.load(ref_out)
+    name = "/xm_t3i_" + uuid.uuid4().hex[:12]
+    outs = [str(tmp_path / f"ipc{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, "-c", code, f"ipc{r}", str(world), outs[r], case, name], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    for p in procs:
+        o_, _ = p.communicate(timeout=600)
+        if p.returncode != 0:
+            print(o_.decode()[-2000:])
+        assert p.returncode == 0
+    for r in range(world):
+        t = np.load(outs[r])
+        assert int(t["exchange"]) == 2 and int(ref["exchange"]) == 2
         assert int(t["rank"]) == int(ref["rank"]) and int(t["status"]) == int(ref["status"]) == 1 and int(t["tcg"]) == int(ref["tcg"])
         assert np.array_equal(t["trace"], ref["trace"])
         assert np.array_equal(t["R"], ref["R"]) and np.array_equal(t["s"], ref["s"])
@@ -501,6 +534,60 @@ def test_xm2_round_follows_the_reference_sequence(xmamd):
     assert bool(x2["regularised"]) == bool(reg) and x2["lam_used"] == pytest.approx(lam)
     assert i2["status"] == i_f["status"] and i2["rank"] == i_f["rank"] and i2["primal"] == pytest.approx(i_f["primal"], rel=1e-9)
     assert tl.rotation_parity(R2, s2, Rf, sf) < 1e-6
+
+
+def test_xm2_round_on_two_virtual_gpus_equals_the_single_gpu_round_and_the_oracle(xmamd, oracle):
+    """the whole XM^2 round -- recovered-solution residuals, device percentile filter, solve_rank3 at lam 0, lam decision, final solve --
+    on a multi-GPU context: every rank evaluates the filter itself from the caller's recovered solution (identical numbers, no
+    exchange) and re-weights its own rows.  View graph with hub cameras (unequal camera ranges) and 8 % gross outlier edges; same
+    threshold, same edges removed, same decision, same certified optimum as the single-GPU round -- and as the same round done by
+    hand with numpy and the CPU oracle (dense Q re-assembled from the filtered list).
+    Regression: the recovered-solution residuals once borrowed the Lanczos work vector as scratch and left garbage in its padding
+    beyond 3n; the next certificate then saw lambda_min = -2.6 at a rank-3 optimum (oracle: -1e-14) and escalated."""
+    n = 400
+    H = tl.gen_vg_hubs(n, 8, 2, 0.3, 0.05, seed=12)
+    ei, ej, w, M = H["ei"], H["ej"], H["w"] * 0.2, H["M"].copy()
+    rng = np.random.default_rng(3)
+    for e in rng.choice(ei.size, size=int(ei.size * 0.08), replace=False):   # replace the measured rotation by a random one
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        M[e] = q * np.sign(np.linalg.det(q))
+    outs = []
+    for kw in (dict(), dict(n_gpus=2, gpu_map=1)):
+        ctx = xmamd.Context(vg=(ei, ej, w, M), n=n, **kw)
+        R, s, info = ctx.solve(5, 1e-8, 20.0)
+        R2, s2, i2, x2 = ctx.xm2_round(R, s, 5, 1e-8, percentile=90.0)
+        rot, scale, _ = xmamd.recover_rotations(R, s)
+        res = ctx.edge_residuals_recovered(rot, scale)
+        ctx.close()
+        outs.append((R2, s2, i2, x2, res, R, s))
+    (Ra, sa, ia, xa, resa, R0, s0), (Rb, sb, ib, xb, resb, _, _) = outs
+    assert ib["n_gpus"] == 2 and ia["n_gpus"] == 1
+    assert xb["removed"] == xa["removed"] > 0 and xb["threshold"] == pytest.approx(xa["threshold"], rel=1e-8)
+    assert xb["regularised"] == xa["regularised"] and xb["lam_used"] == pytest.approx(xa["lam_used"])
+    assert ia["status"] == ib["status"] == 1 and ia["rank"] == ib["rank"] == 3
+    assert ia["min_eig"] > -1e-9 and ib["min_eig"] > -1e-9
+    assert ib["primal"] == pytest.approx(ia["primal"], rel=1e-8)
+    assert tl.rotation_parity(Rb, sb, Ra, sa) < 1e-6
+    assert np.allclose(resb, resa, rtol=1e-7, atol=1e-10)
+    # by hand: numpy residuals / percentile on the recovered first solution, dense Q of the filtered list, CPU oracle
+    rot, scale = tl.recover_rotations(R0, s0)
+    Y = np.stack([scale[i] * rot[:, 3 * i:3 * i + 3].T for i in range(n)])
+    res = np.array([np.sum((Y[ei[e]] - M[e] @ Y[ej[e]]) ** 2) for e in range(ei.size)])
+    assert np.allclose(resa, res, rtol=1e-7, atol=1e-10)
+    err = w * res
+    thr = float(np.percentile(err, 90.0))
+    w2 = np.where(err > thr, 0.0, w)
+    assert xa["threshold"] == pytest.approx(thr, rel=1e-8) and xa["removed"] == int((w2 == 0).sum())
+    Q2 = tl.bsr_to_dense(n, *tl.vg_from_edges(n, ei, ej, w2, M))
+    R3, s3, _ = oracle.solve(Q2, 3, 1e-8, 0.0, 1000.0, mode=1)
+    avg, sd, small = float(s3[1:].mean()), float(s3[1:].std()), int((s3 < 0.1).sum())
+    reg = abs(avg - 1) > 2 * sd or small > 10
+    lam = (w2 != 0).sum() / n if reg else 0.0
+    assert xa["s_avg"] == pytest.approx(avg, rel=1e-6) and bool(xa["regularised"]) == bool(reg) and xa["lam_used"] == pytest.approx(lam)
+    Ro, so, io = oracle.solve(Q2, 5, 1e-8, lam, 1000.0)
+    assert io["status"] == 1 and io["rank"] == 3
+    assert ia["primal"] == pytest.approx(io["cert"]["dual"], rel=1e-7)
+    assert tl.rotation_parity(Ra, sa, Ro, so) < 1e-6
 
 
 def test_matrix_free_final_size_scene_certifies(xmamd):

@@ -661,16 +661,14 @@ int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, dou
 int xm_ctx_edge_residuals_recovered(xm_ctx_t *ctx, const double *rot, const double *scale, double *res) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
-    if (!ctx->impl) throw xm::Error(XM_ERR_ARG, "xm_ctx_edge_residuals_recovered: single-GPU contexts only");
-    ctx->impl->edge_residuals_recovered(rot, scale, res);
+    if (ctx->team) ctx->team->edge_residuals_recovered(rot, scale, res); else ctx->impl->edge_residuals_recovered(rot, scale, res);
     return XM_OK;
     XM_CATCH
 }
 int xm_ctx_xm2_filter(xm_ctx_t *ctx, const double *rot, const double *scale, double percentile, double *threshold, int64_t *removed, double *w_out) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");
-    if (!ctx->impl) throw xm::Error(XM_ERR_ARG, "xm_ctx_xm2_filter: single-GPU contexts only");
-    const double thr = ctx->impl->xm2_filter(rot, scale, percentile, removed, w_out);
+    const double thr = ctx->team ? ctx->team->xm2_filter(rot, scale, percentile, removed, w_out) : ctx->impl->xm2_filter(rot, scale, percentile, removed, w_out);
     if (threshold) *threshold = thr;
     return XM_OK;
     XM_CATCH
@@ -678,20 +676,22 @@ int xm_ctx_xm2_filter(xm_ctx_t *ctx, const double *rot, const double *scale, dou
 int xm_ctx_xm2_round(xm_ctx_t *ctx, const double *R, const double *s, int r, const xm_options_t *opt, xm_xm2_info_t *info, xm_result_t *res) {
     XM_TRY
     if (!ctx || !R || !s || !opt || !info || !res) throw xm::Error(XM_ERR_ARG, "null argument");
-    if (!ctx->impl) throw xm::Error(XM_ERR_ARG, "xm_ctx_xm2_round: single-GPU contexts only");
+    // a multi-GPU context fans every step out to its ranks (each evaluates the filter itself: identical numbers, no exchange)
+    auto solve_ctx = [&](const xm_options_t &o_, xm_result_t &r_) { if (ctx->team) ctx->team->solve(o_, r_); else ctx->impl->solve(o_, r_); };
     xm_options_t op = take_struct(opt, "xm_options_t");
     xm_result_t rs = take_struct(res, "xm_result_t");
     xm_xm2_info_t inf = take_struct(info, "xm_xm2_info_t");
     const uint32_t caller_res = res->struct_size, caller_inf = info->struct_size;
-    const int64_t n = ctx->impl->cameras();
+    const int64_t n = ctx->team ? ctx->team->cameras() : ctx->impl->cameras();
     // recover_XM's rotations and scales of the starting solution (utils/recoversolution.py:12-86)
     std::vector<double> rot((size_t)9 * n), scale((size_t)n);
     int neg = 0;
     if (xm_recover_rotations(n, r, R, s, rot.data(), scale.data(), &neg) != XM_OK) throw xm::Error(XM_ERR_HIP, g_err);
     const double pct = (inf.percentile > 0.0) ? inf.percentile : 90.0;
-    inf.threshold = ctx->impl->xm2_filter(rot.data(), scale.data(), pct, &inf.removed, nullptr);
+    inf.threshold = ctx->team ? ctx->team->xm2_filter(rot.data(), scale.data(), pct, &inf.removed, nullptr)
+                              : ctx->impl->xm2_filter(rot.data(), scale.data(), pct, &inf.removed, nullptr);
     int64_t kept = 0;
-    for (double w : ctx->impl->weights()) kept += (w != 0.0);
+    for (double w : (ctx->team ? ctx->team->weights() : ctx->impl->weights())) kept += (w != 0.0);
     // second pass: rank-3 solve without regulariser, then decide on lam from the spread of its scales (3_test_colmap_glomap.py:339-351)
     std::vector<double> R3((size_t)3 * n * 4, 0.0), s3((size_t)n, 1.0);
     xm_options_t o3 = op;
@@ -699,7 +699,7 @@ int xm_ctx_xm2_round(xm_ctx_t *ctx, const double *R, const double *s, int r, con
     xm_result_t r3;
     std::memset(&r3, 0, sizeof(r3));
     r3.R = R3.data(); r3.s = s3.data();
-    ctx->impl->solve(o3, r3);
+    solve_ctx(o3, r3);
     inf.rank3_status = r3.status; inf.rank3_tcg_iters = r3.tcg_iters;
     double mean = 0.0, var = 0.0;
     int64_t small = 0;
@@ -715,7 +715,7 @@ int xm_ctx_xm2_round(xm_ctx_t *ctx, const double *R, const double *s, int r, con
     of.lam = inf.lam_used;
     if (op.flags & XM_FLAG_WARM_R) { of.mode = XM_MODE_REBUTTLE; of.R_ini = R3.data(); of.s_ini = s3.data(); }
     else { of.mode = XM_MODE_SOLVE; of.R_ini = nullptr; of.s_ini = nullptr; }
-    ctx->impl->solve(of, rs);
+    solve_ctx(of, rs);
     give_result(res, rs, caller_res);
     inf.struct_size = caller_inf;
     std::memcpy(info, &inf, std::min<size_t>(caller_inf, sizeof(inf)));
@@ -729,6 +729,9 @@ int xm_comm_init(int rank, int world, int device, const unsigned char id[128], c
 }
 int xm_comm_init_shm(int rank, int world, int device, const char *name, size_t bytes) {
     XM_TRY require_device(); xm::comm_init_shm(rank, world, device, name, bytes); return XM_OK; XM_CATCH
+}
+int xm_comm_init_ipc(int rank, int world, int device, const char *name, double spin_seconds) {
+    XM_TRY require_device(); xm::comm_init_ipc(rank, world, device, name, spin_seconds); return XM_OK; XM_CATCH
 }
 int xm_comm_finalize(void) { XM_TRY xm::comm_finalize(); return XM_OK; XM_CATCH }
 int xm_partition(int64_t n, int world, int rank, int64_t *c0, int64_t *c1) {

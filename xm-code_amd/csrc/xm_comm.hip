@@ -244,6 +244,7 @@ void comm_unique_id(unsigned char id[128]) {
     std::memcpy(id, u.internal, 128);
 }
 
+static std::shared_ptr<Comm> ipc_upgrade(int rank, int world, int device, const unsigned char id[128], const std::shared_ptr<Comm> &keep);
 void comm_init(int rank, int world, int device, const unsigned char id[128], const char *lib_path) {
     if (world < 1 || rank < 0 || rank >= world) throw Error(XM_ERR_ARG, "bad rank/world");
     XM_HIP_CHECK(hipSetDevice(device));
@@ -262,6 +263,10 @@ void comm_init(int rank, int world, int device, const unsigned char id[128], con
     const char *f = std::getenv("XM_FORCE_COMM");
     c->forced = (f && *f == '1' && c->comm != nullptr);
     g_default = c;
+    // Ranks of ONE node: the direct peer exchange over IPC-mapped buffers replaces the library all-gather (2-4 x the partitioned
+    // product at Venice size) when every rank can map every peer and the transport passes its self-test; otherwise -- ranks on several
+    // nodes, no peer access, XM_COMM_PEER=0 -- all ranks keep the RCCL communicator (the decision is collective).
+    if (auto pc = ipc_upgrade(rank, world, device, id, c)) g_default = pc;
 }
 
 void comm_init_shm(int rank, int world, int device, const char *name, size_t bytes) {
@@ -314,29 +319,114 @@ void comm_finalize() {
 // Every device-side wait is bounded (spin_ticks of the 100 MHz wall clock): a dead or diverged peer turns into an error word that the
 // host reports as XM_ERR_COMM instead of a hung GPU.
 // ==================================================================================================================
-struct PeerGroup {
+struct PeerGroup {   // who the ranks of a peer communicator are and how they find each other's memory
     int world = 1;
     int device[kMaxPeers] = {};
     double spin_seconds = 20.0;
-    // published by each rank's PeerComm constructor
-    char *arena[kMaxPeers] = {};
-    size_t stage_cap[kMaxPeers] = {};      // doubles per slot
-    double *xbuf[kMaxPeers] = {};          // current tCG exchange buffers
-    std::atomic<int> aborted{0};
-    // reusable host barrier (sense counting)
-    std::mutex mu;
+    virtual ~PeerGroup() {}
+    virtual int kind() const = 0;                                             // 3 threads of one process | 4 processes (IPC handles)
+    virtual void barrier(unsigned long long &mine, const char *what) = 0;     // reusable host barrier of the group (counting)
+    virtual void abort() = 0;
+    virtual bool aborted() const = 0;
+    // collective: rank `me` publishes its allocation `p` under `key` (0 arena, 1 tCG exchange buffer) together with `meta`; on
+    // return addr[r] / metas[r] hold every rank's, addr[r] being an address THIS process can store through
+    virtual void share(int me, int key, void *p, size_t meta, void *addr[kMaxPeers], size_t metas[kMaxPeers], unsigned long long &hb) = 0;
+    // before a shared allocation is freed: drop this process's view of the peers' allocations under `key`; collective (ends with a
+    // barrier: the owner may free afterwards) unless `teardown`
+    virtual void unshare(int me, int key, unsigned long long &hb, bool teardown) = 0;
+};
+
+namespace {
+struct LocalPeerGroup : PeerGroup {   // single process, one host thread per rank: addresses are plain pointers
+    void *tab[2][kMaxPeers] = {};
+    size_t meta[2][kMaxPeers] = {};
+    std::atomic<int> aborted_{0};
     std::atomic<unsigned long long> arrive{0};
-    void barrier(unsigned long long &mine, const char *what) {
+    int kind() const override { return 3; }
+    void abort() override { aborted_.store(1); }
+    bool aborted() const override { return aborted_.load() != 0; }
+    void barrier(unsigned long long &mine, const char *what) override {
         arrive.fetch_add(1, std::memory_order_acq_rel);
         const unsigned long long target = (++mine) * (unsigned long long)world;
         const auto t0 = clk::now();
         while (arrive.load(std::memory_order_acquire) < target) {
-            if (aborted.load()) throw Error(XM_ERR_COMM, std::string("peer group aborted while waiting in ") + what);
+            if (aborted_.load()) throw Error(XM_ERR_COMM, std::string("peer group aborted while waiting in ") + what);
             if (since(t0) > 120.0) throw Error(XM_ERR_COMM, std::string("peer group: a rank did not reach ") + what);
             std::this_thread::yield();
         }
     }
+    void share(int me, int key, void *p, size_t m, void *addr[kMaxPeers], size_t metas[kMaxPeers], unsigned long long &hb) override {
+        tab[key][me] = p; meta[key][me] = m;
+        barrier(hb, "publication of a shared buffer");
+        for (int r = 0; r < world; ++r) { addr[r] = tab[key][r]; metas[r] = meta[key][r]; }
+    }
+    void unshare(int, int, unsigned long long &, bool) override {}
 };
+
+// One process per GPU: the directory lives in a POSIX shared-memory segment, allocations travel as hipIpcMemHandle_t (dmabuf export;
+// HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool) and are mapped into every peer process.  Same kernels, same protocol as the in-process
+// group -- the launch `python -m torch.distributed.run` gets the fused exchange instead of a library collective per tCG iteration.
+struct IpcShared {
+    std::atomic<unsigned long long> arrive;
+    std::atomic<int> aborted;
+    std::atomic<int> failed;      // a rank could not export or map: all ranks give the transport up together
+    struct Slot { hipIpcMemHandle_t h; unsigned long long meta; } slot[2][kMaxPeers];
+};
+struct IpcPeerGroup : PeerGroup {
+    IpcShared *sh = nullptr;
+    std::string name;
+    int me = 0;
+    double limit = 120.0;
+    void *mapped[2][kMaxPeers] = {};
+    int kind() const override { return 4; }
+    ~IpcPeerGroup() override {
+        for (int k = 0; k < 2; ++k)
+            for (int r = 0; r < kMaxPeers; ++r)
+                if (mapped[k][r]) (void)hipIpcCloseMemHandle(mapped[k][r]);
+        if (sh) munmap(sh, sizeof(IpcShared));
+    }
+    void abort() override { if (sh) sh->aborted.store(1); }
+    bool aborted() const override { return sh && sh->aborted.load() != 0; }
+    bool barrier_nothrow(unsigned long long &mine) {
+        sh->arrive.fetch_add(1, std::memory_order_acq_rel);
+        const unsigned long long target = (++mine) * (unsigned long long)world;
+        const auto t0 = clk::now();
+        while (sh->arrive.load(std::memory_order_acquire) < target) {
+            if (sh->aborted.load() || since(t0) > limit) return false;
+            std::this_thread::yield();
+        }
+        return true;
+    }
+    void barrier(unsigned long long &mine, const char *what) override {
+        if (!barrier_nothrow(mine))
+            throw Error(XM_ERR_COMM, std::string(sh->aborted.load() ? "peer group aborted while waiting in " : "peer group: a rank did not reach ") + what);
+    }
+    void share(int r0, int key, void *p, size_t m, void *addr[kMaxPeers], size_t metas[kMaxPeers], unsigned long long &hb) override {
+        IpcShared::Slot &mine = sh->slot[key][r0];
+        std::memset(&mine.h, 0, sizeof(mine.h));
+        if (hipIpcGetMemHandle(&mine.h, p) != hipSuccess) { (void)hipGetLastError(); sh->failed.store(1); }
+        mine.meta = m;
+        barrier(hb, "publication of a shared buffer");
+        for (int r = 0; r < world; ++r) {
+            metas[r] = (size_t)sh->slot[key][r].meta;
+            if (r == r0) { addr[r] = p; continue; }
+            addr[r] = nullptr;
+            if (sh->failed.load()) continue;
+            void *q = nullptr;
+            if (hipIpcOpenMemHandle(&q, sh->slot[key][r].h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); sh->failed.store(1); continue; }
+            mapped[key][r] = q;
+            addr[r] = q;
+        }
+        barrier(hb, "mapping of the peers' buffers");
+        if (sh->failed.load()) throw Error(XM_ERR_COMM, "peer communicator: a rank could not export or map a buffer through hipIpcMemHandle");
+    }
+    void unshare(int, int key, unsigned long long &hb, bool teardown) override {
+        for (int r = 0; r < world; ++r)
+            if (mapped[key][r]) { (void)hipIpcCloseMemHandle(mapped[key][r]); mapped[key][r] = nullptr; }
+        if (!teardown) barrier(hb, "release of the peers' buffers");
+    }
+};
+}  // namespace
 
 namespace {
 constexpr size_t kFlagWords = 4 * kMaxPeers;                        // [gen slot0 | gen slot1 | tcg par0 | tcg par1]
@@ -412,23 +502,27 @@ struct PeerComm : Comm {
     char *arena = nullptr;
     size_t cap = 0;                    // doubles per stage slot
     unsigned long long seq = 0;        // collectives issued (identical on every rank)
-    unsigned long long hb = 0;         // host barriers passed
+    unsigned long long hb;             // host barriers of the group this rank has passed
     unsigned long long *herr = nullptr;   // host-mapped error word
     unsigned long long *herr_dev = nullptr;
     double *xbuf = nullptr;
-    int kind() const override { return 3; }
+    size_t xcap = 0;                   // doubles of the tCG exchange buffer (grow-only)
+    void *parena[kMaxPeers] = {};      // every rank's arena / exchange buffer as THIS process addresses it
+    void *pxbuf[kMaxPeers] = {};
+    std::shared_ptr<Comm> keep;        // a library communicator created beside this one (xm_comm_init): destroyed with it
+    int kind() const override { return g->kind(); }
     bool peer() const override { return true; }
-    unsigned long long *flags_of(int r) const { return reinterpret_cast<unsigned long long *>(g->arena[r]); }
+    unsigned long long *flags_of(int r) const { return reinterpret_cast<unsigned long long *>(parena[r]); }
     unsigned long long *tickets() const { return reinterpret_cast<unsigned long long *>(arena) + kFlagWords; }
-    double *stage_of(int r) const { return reinterpret_cast<double *>(g->arena[r] + kArenaHead); }
+    double *stage_of(int r) const { return reinterpret_cast<double *>(static_cast<char *>(parena[r]) + kArenaHead); }
     long long spin_ticks() const { return (long long)(g->spin_seconds * 1e8); }
 
-    PeerComm(const std::shared_ptr<PeerGroup> &grp, int r) : g(grp) {
+    PeerComm(const std::shared_ptr<PeerGroup> &grp, int r, unsigned long long hb0 = 0) : g(grp), hb(hb0) {
         rank = r; world = grp->world; forced = true;
         XM_HIP_CHECK(hipHostMalloc((void **)&herr, 64, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(herr, 0, 64);
         XM_HIP_CHECK(hipHostGetDevicePointer((void **)&herr_dev, herr, 0));
-        if (world > 1) {   // peer access between distinct devices (no-op for virtual devices)
+        if (world > 1 && g->kind() == 3) {   // peer access between distinct devices of this process (no-op for virtual devices; IPC mappings enable it lazily)
             for (int p = 0; p < world; ++p) {
                 if (g->device[p] == g->device[rank]) continue;
                 int can = 0;
@@ -443,6 +537,8 @@ struct PeerComm : Comm {
     }
     ~PeerComm() override {
         (void)hipDeviceSynchronize();
+        g->unshare(rank, 0, hb, true);
+        g->unshare(rank, 1, hb, true);
         if (arena) (void)hipFree(arena);
         if (xbuf) (void)hipFree(xbuf);
         if (herr) (void)hipHostFree(herr);
@@ -460,16 +556,16 @@ struct PeerComm : Comm {
         if (arena) {
             XM_HIP_CHECK(hipDeviceSynchronize());
             g->barrier(hb, "arena re-allocation (drain)");   // every rank has drained: no remote store into the old arenas is in flight
+            g->unshare(rank, 0, hb, false);
             (void)hipFree(arena);
         }
         cap = doubles;
         arena = static_cast<char *>(fine_alloc(kArenaHead + 2 * cap * sizeof(double)));
-        g->arena[rank] = arena;
-        g->stage_cap[rank] = cap;
         seq = 0;   // fresh flag words everywhere
-        g->barrier(hb, "arena allocation");
+        size_t caps[kMaxPeers] = {};
+        g->share(rank, 0, arena, cap, parena, caps, hb);
         for (int p = 0; p < world; ++p)
-            if (g->stage_cap[p] != cap) throw Error(XM_ERR_COMM, "peer communicator: ranks reserved different staging sizes");
+            if (caps[p] != cap) throw Error(XM_ERR_COMM, "peer communicator: ranks reserved different staging sizes");
     }
     void reserve(size_t doubles) override {
         if (doubles <= cap) { g->barrier(hb, "reserve"); return; }   // same decision on every rank (same argument)
@@ -477,10 +573,10 @@ struct PeerComm : Comm {
     }
     void host_barrier() override { g->barrier(hb, "barrier"); }
     void check_device_error() override {
-        if (g->aborted.load()) throw Error(XM_ERR_COMM, "peer group aborted (another rank failed)");
+        if (g->aborted()) throw Error(XM_ERR_COMM, "peer group aborted (another rank failed)");
         const unsigned long long e = *reinterpret_cast<volatile unsigned long long *>(herr);
         if (e != 0) {
-            g->aborted.store(1);
+            g->abort();
             throw Error(XM_ERR_COMM, "peer exchange: rank " + std::to_string(rank) + " waited more than " + std::to_string(g->spin_seconds) +
                                          " s for a peer (epoch " + std::to_string(e & ~(1ull << 63)) + "): peer failed, or the ranks diverged");
         }
@@ -509,20 +605,26 @@ struct PeerComm : Comm {
             check_launch("peer_allgather");
         }
     }
-    // collective (host-synchronised): fresh tCG exchange buffer
+    // collective (host-synchronised): tCG exchange buffer of at least `doubles` (grow-only; the same argument on every rank) with
+    // fresh flag words
     void xchg_setup(size_t doubles, PeerXchg &out) override {
         XM_HIP_CHECK(hipDeviceSynchronize());
         g->barrier(hb, "exchange buffer (drain)");
-        if (xbuf) (void)hipFree(xbuf);
-        xbuf = static_cast<double *>(fine_alloc(std::max<size_t>(doubles, 8) * sizeof(double)));
-        g->xbuf[rank] = xbuf;
-        // the tCG flag words restart from zero with every buffer: epochs are (run << 12 | iteration + 1), compared with >=
+        const size_t want = std::max<size_t>(doubles, 8);
+        if (want > xcap) {
+            if (xbuf) { g->unshare(rank, 1, hb, false); (void)hipFree(xbuf); }
+            xcap = want + want / 4;
+            xbuf = static_cast<double *>(fine_alloc(xcap * sizeof(double)));
+            size_t caps[kMaxPeers] = {};
+            g->share(rank, 1, xbuf, xcap, pxbuf, caps, hb);
+        }
+        // the tCG flag words restart from zero with every set-up: epochs are (run << 12 | iteration + 1), compared with >=
         XM_HIP_CHECK(hipMemset(flags_of(rank) + 2 * kMaxPeers, 0, 2 * kMaxPeers * sizeof(unsigned long long)));
         XM_HIP_CHECK(hipDeviceSynchronize());
         g->barrier(hb, "exchange buffer");
         out = PeerXchg();
         out.world = world; out.rank = rank;
-        for (int p = 0; p < world; ++p) { out.buf[p] = g->xbuf[p]; out.flag[p] = flags_of(p) + 2 * kMaxPeers; }
+        for (int p = 0; p < world; ++p) { out.buf[p] = static_cast<double *>(pxbuf[p]); out.flag[p] = flags_of(p) + 2 * kMaxPeers; }
         out.ticket = tickets() + 2;
         out.err = herr_dev;
         out.spin_ticks = spin_ticks();
@@ -532,13 +634,123 @@ struct PeerComm : Comm {
 
 std::shared_ptr<PeerGroup> peer_group_create(int world, const int *devices, double spin_seconds) {
     if (world < 1 || world > kMaxPeers) throw Error(XM_ERR_ARG, "n_gpus must be 1.." + std::to_string(kMaxPeers));
-    auto g = std::make_shared<PeerGroup>();
+    auto g = std::make_shared<LocalPeerGroup>();
     g->world = world;
     for (int r = 0; r < world; ++r) g->device[r] = devices[r];
     if (spin_seconds > 0) g->spin_seconds = spin_seconds;
     return g;
 }
 std::shared_ptr<Comm> peer_comm_create(const std::shared_ptr<PeerGroup> &g, int rank) { return std::make_shared<PeerComm>(g, rank); }
-void peer_group_abort(const std::shared_ptr<PeerGroup> &g) { if (g) g->aborted.store(1); }
+void peer_group_abort(const std::shared_ptr<PeerGroup> &g) { if (g) g->abort(); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// one process per GPU over IPC handles (xm_comm_init_ipc; xm_comm_init tries it before it settles for the library all-gather)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+std::shared_ptr<IpcPeerGroup> ipc_group_open(int rank, int world, int device, const char *name, double limit, double spin_seconds) {
+    if (world > kMaxPeers) throw Error(XM_ERR_ARG, "direct peer exchange supports up to " + std::to_string(kMaxPeers) + " ranks");
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) throw Error(XM_ERR_COMM, "shm_open failed");
+    if (ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) { close(fd); throw Error(XM_ERR_COMM, "ftruncate failed"); }
+    void *p = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) throw Error(XM_ERR_COMM, "mmap failed");
+    auto g = std::make_shared<IpcPeerGroup>();
+    g->sh = static_cast<IpcShared *>(p);   // a fresh segment is zero-filled
+    g->name = name; g->me = rank; g->world = world; g->limit = limit;
+    for (int r = 0; r < world; ++r) g->device[r] = (r == rank) ? device : -1;
+    if (spin_seconds > 0) g->spin_seconds = spin_seconds;
+    return g;
+}
+
+// three all-gathers with known contents: the transport has to prove itself on this machine before the solver relies on it
+bool peer_selftest(PeerComm &c) {
+    const size_t cnt = 4096;
+    bool ok = true;
+    double *d = nullptr;
+    hipStream_t st = nullptr;
+    std::vector<double> h(cnt * (size_t)c.world);
+    try {
+        XM_HIP_CHECK(hipMalloc((void **)&d, h.size() * sizeof(double)));
+        XM_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (int it = 0; it < 3 && ok; ++it) {
+            std::fill(h.begin(), h.end(), -1.0);
+            for (size_t i = 0; i < cnt; ++i) h[(size_t)c.rank * cnt + i] = 1e6 * it + 1e4 * c.rank + (double)i;
+            XM_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+            c.allgather(d, cnt, st);
+            XM_HIP_CHECK(hipStreamSynchronize(st));
+            c.check_device_error();
+            XM_HIP_CHECK(hipMemcpy(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int r = 0; r < c.world && ok; ++r)
+                for (size_t i = 0; i < cnt; ++i)
+                    if (h[(size_t)r * cnt + i] != 1e6 * it + 1e4 * r + (double)i) { ok = false; break; }
+        }
+    } catch (const Error &) { ok = false; }
+    if (st) (void)hipStreamDestroy(st);
+    if (d) (void)hipFree(d);
+    return ok;
+}
+
+// all ranks return the same answer: a communicator that passed the self-test everywhere, or nullptr (why -> *why)
+std::shared_ptr<PeerComm> ipc_comm_try(int rank, int world, int device, const char *name, double limit, std::string *why) {
+    std::shared_ptr<IpcPeerGroup> g;
+    std::shared_ptr<PeerComm> c;
+    unsigned long long hb = 0;
+    try {
+        g = ipc_group_open(rank, world, device, name, limit, 5.0);   // short device-side waits while the transport is on probation
+        if (!g->barrier_nothrow(hb)) { if (why) *why = "not every rank reached the rendezvous segment (ranks on several nodes?)"; return nullptr; }
+        if (rank == 0) shm_unlink(name);   // everybody has it mapped
+        c = std::make_shared<PeerComm>(g, rank, hb);
+    } catch (const Error &e) {
+        if (why) *why = e.what();
+        if (g && g->sh) { g->sh->failed.store(1); g->sh->aborted.store(1); }
+        return nullptr;
+    }
+    bool ok = false;
+    try { ok = peer_selftest(*c); } catch (...) { ok = false; }
+    if (!ok) g->sh->failed.store(1);
+    if (!g->barrier_nothrow(c->hb) || g->sh->failed.load()) {
+        if (why) *why = ok ? "a peer failed the transport self-test" : "the transport self-test failed on this rank";
+        g->sh->aborted.store(1);
+        return nullptr;
+    }
+    g->limit = 120.0;   // ranks reach the solver's set-up barriers seconds apart (each uploads its own strip of Q first)
+    return c;
+}
+
+std::string ipc_name_of(const unsigned char id[128]) {   // every rank of a job derives the same segment name from rank 0's unique id
+    unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < 128; ++i) { h ^= id[i]; h *= 1099511628211ull; }
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "/xm_ipc_%016llx", h);
+    return buf;
+}
+}  // namespace
+
+static std::shared_ptr<Comm> ipc_upgrade(int rank, int world, int device, const unsigned char id[128], const std::shared_ptr<Comm> &keep) {
+    const char *pe = std::getenv("XM_COMM_PEER");
+    if (world <= 1 || world > kMaxPeers || id == nullptr || (pe && *pe == '0')) return nullptr;
+    std::string why;
+    auto pc = ipc_comm_try(rank, world, device, ipc_name_of(id).c_str(), 30.0, &why);
+    if (!pc) {
+        if (std::getenv("XM_COMM_TRACE")) std::fprintf(stderr, "xm_comm_init: rank %d keeps RCCL (%s)\n", rank, why.c_str());
+        return nullptr;
+    }
+    pc->g->spin_seconds = 20.0;
+    pc->keep = keep;
+    return pc;
+}
+
+void comm_init_ipc(int rank, int world, int device, const char *name, double spin_seconds) {
+    if (world < 1 || rank < 0 || rank >= world || !name) throw Error(XM_ERR_ARG, "bad rank/world/name");
+    XM_HIP_CHECK(hipSetDevice(device));
+    comm_finalize();
+    std::string why;
+    auto c = ipc_comm_try(rank, world, device, name, 120.0, &why);
+    if (!c) throw Error(XM_ERR_COMM, "direct peer exchange between processes is not available: " + why);
+    c->g->spin_seconds = spin_seconds > 0 ? spin_seconds : 20.0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_default = c;
+}
 
 }  // namespace xm

@@ -39,7 +39,7 @@ struct Settings {
 //   RCCL   one process per GPU, ncclAllGather (xm_comm_init)
 //   shm    test transport: the same calls staged through a POSIX shared-memory segment (several ranks on one GPU)
 //   peer   DIRECT PEER WRITES: every rank owns a fine-grained arena on its device that all ranks of the group can address (same
-//          process: peer access; "virtual devices": the same device); a collective is a copy kernel that stores the rank's chunk
+//          process: peer access; "virtual devices": the same device; one process per GPU: hipIpcMemHandle mappings); a collective is a copy kernel that stores the rank's chunk
 //          straight into the peers' memory, a system-scope release, an epoch flag per (source, slot), and a bounded spin on the
 //          consumer side.  No library call, no host rendezvous, ~1 hop of xGMI latency.  The truncated CG fuses push and wait into
 //          cg_step_kernel (PeerXchg below).
@@ -48,7 +48,7 @@ struct Comm {
     bool forced = false;   // issue the collectives even with one rank (exercises the path on a 1-GPU box)
     virtual ~Comm();
     bool active() const { return world > 1 || forced; }
-    virtual int kind() const { return 0; }                    // 0 none | 1 RCCL | 2 shm | 3 peer
+    virtual int kind() const { return 0; }                    // 0 none | 1 RCCL | 2 shm | 3 peer (threads) | 4 peer (processes, IPC)
     // in-place all-gather on `stream`: every rank contributes `count` doubles located at buf + rank*count
     virtual void allgather(double *buf, size_t count, hipStream_t st) { (void)buf; (void)count; (void)st; }
     // ---- direct exchange (kind 3 only) ----
@@ -67,6 +67,7 @@ std::shared_ptr<Comm> default_comm();          // what xm_comm_init / xm_comm_in
 void comm_unique_id(unsigned char id[128]);
 void comm_init(int rank, int world, int device, const unsigned char id[128], const char *lib_path);
 void comm_init_shm(int rank, int world, int device, const char *name, size_t bytes);
+void comm_init_ipc(int rank, int world, int device, const char *name, double spin_seconds);   // one process per GPU, peer writes through IPC-mapped buffers
 void comm_finalize();
 // single-process group of `world` ranks (one host thread each); devices[r] = HIP device of rank r (all equal = virtual devices)
 struct PeerGroup;
@@ -229,6 +230,8 @@ private:
     void to_dev(void *dst_dev, const void *src, size_t bytes);
     void ensure_pinned(size_t doubles);
     DevBuf<double> lzV_, lzc_, lzw_, lzc2_, lzab_, lzscr_;      // Lanczos workspace (grow-only)
+    DevBuf<double> recW_;                                       // product input built from a RECOVERED solution (XM^2 residuals); never a solver buffer:
+                                                                // the Lanczos vectors rely on their padding beyond 3n staying zero
     int64_t pos_of(int64_t g) const;   // global camera -> position in the padded numbering of the replicated vectors
     void release_raw();   // frees the raw (non-RAII) resources: dQ_, stream, mapped / pinned host memory, events
     void setup_rank(int o);
@@ -266,6 +269,10 @@ public:
     void attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
     void edge_residuals(double *res);
     void set_edge_weights(const double *w);
+    void edge_residuals_recovered(const double *rot, const double *scale, double *res);
+    double xm2_filter(const double *rot, const double *scale, double pct, int64_t *removed, double *w_out);
+    int64_t cameras() const;
+    std::vector<double> weights() const;
 private:
     struct Impl;
     std::unique_ptr<Impl> p_;

@@ -1255,15 +1255,18 @@ void Context::edge_residuals(double *res) {
 // residuals of a RECOVERED rank-3 solution on the device: the product input is W_i = s_i * R_i^T (camera i's 3 x 3 record)
 const double *Context::residuals_recovered_device(const double *rot, const double *scale) {
     if (!rot || !scale) throw Error(XM_ERR_ARG, "edge_residuals_recovered: null argument");
-    if (comm_->active()) throw Error(XM_ERR_ARG, "edge_residuals_recovered: single-GPU contexts only");
     if (storage_ != XM_STORAGE_SCHUR && !ei_.p) throw Error(XM_ERR_ARG, "edge_residuals_recovered: no edges attached");
+    // Under a row partition every rank holds the whole edge list and gets the whole recovered solution from the caller: each
+    // evaluates all residuals (and, in xm2_filter, the same order statistic) itself -- identical numbers everywhere, no exchange.
     constexpr int OP = pitch_of(3);
     if (o_ < 3 || W_.count < (size_t)ld_ * OP + 2) setup_rank(3);
     std::vector<double> hW((size_t)ld_ * OP + 2, 0.0);
-    for (int64_t i = 0; i < n_; ++i)
+    for (int64_t i = 0; i < n_; ++i) {
+        const size_t pi = (size_t)pos_of(i);   // the attached edges address cameras in the padded numbering
         for (int a = 0; a < 3; ++a)
-            for (int k = 0; k < 3; ++k) hW[((size_t)i * 3 + a) * OP + k] = scale[i] * rot[(size_t)k + 3 * ((size_t)3 * i + a)];
-    DevBuf<double> &dW = lzw_;   // any scratch of >= ld * 3 doubles that no product touches: the Lanczos vector buffer
+            for (int k = 0; k < 3; ++k) hW[(pi * 3 + a) * OP + k] = scale[i] * rot[(size_t)k + 3 * ((size_t)3 * i + a)];
+    }
+    DevBuf<double> &dW = recW_;
     if (dW.count < hW.size()) dW.alloc(hW.size());
     to_dev(dW.p, hW.data(), hW.size() * sizeof(double));
     if (storage_ == XM_STORAGE_SCHUR) {
@@ -1289,6 +1292,7 @@ void Context::edge_residuals_recovered(const double *rot, const double *scale, d
     const int64_t ne = (storage_ == XM_STORAGE_SCHUR) ? schur_->nobs() : ne_;
     if (ne > 0) to_host(res, r, (size_t)ne * sizeof(double));
     XM_HIP_CHECK(hipStreamSynchronize(st_));
+    if (comm_->active()) comm_->host_barrier();   // nobody runs ahead into a collective while a peer still (re)allocates here
 }
 
 // k-th smallest (0-based) of n non-negative doubles on the device: most-significant-digit radix select, 4 passes of 16 bits
@@ -1343,6 +1347,8 @@ double Context::xm2_filter(const double *rot, const double *scale, double pct, i
     if (removed) *removed = (int64_t)rm;
     set_edge_weights(w2.data());
     if (w_out) std::memcpy(w_out, w2.data(), (size_t)ne * sizeof(double));
+    hist.release(); wn.release();
+    if (comm_->active()) comm_->host_barrier();   // as above
     return thr;
 }
 

@@ -181,6 +181,29 @@ void Team::edge_residuals(double *res) {
 void Team::set_edge_weights(const double *w) {
     p_->run([&](int r) { p_->ctx[(size_t)r]->set_edge_weights(w); });
 }
+// every rank evaluates all residuals and the same order statistic from the caller's recovered solution; rank 0's outputs are returned
+void Team::edge_residuals_recovered(const double *rot, const double *scale, double *res) {
+    Impl &t = *p_;
+    std::vector<std::vector<double>> tmp((size_t)t.world);
+    const int64_t ne = t.ctx[0]->edges();
+    t.run([&](int r) {
+        double *out = res;
+        if (r != 0) { tmp[(size_t)r].assign((size_t)std::max<int64_t>(ne, 1), 0.0); out = tmp[(size_t)r].data(); }
+        t.ctx[(size_t)r]->edge_residuals_recovered(rot, scale, out);
+    });
+}
+double Team::xm2_filter(const double *rot, const double *scale, double pct, int64_t *removed, double *w_out) {
+    Impl &t = *p_;
+    std::vector<double> thr((size_t)t.world, 0.0);
+    std::vector<int64_t> rm((size_t)t.world, 0);
+    t.run([&](int r) { thr[(size_t)r] = t.ctx[(size_t)r]->xm2_filter(rot, scale, pct, &rm[(size_t)r], r == 0 ? w_out : nullptr); });
+    for (int r = 1; r < t.world; ++r)
+        if (thr[(size_t)r] != thr[0] || rm[(size_t)r] != rm[0]) throw Error(XM_ERR_COMM, "xm2_filter: the ranks disagree on the threshold");
+    if (removed) *removed = rm[0];
+    return thr[0];
+}
+int64_t Team::cameras() const { return p_->ctx[0]->cameras(); }
+std::vector<double> Team::weights() const { return p_->ctx[0]->weights(); }
 
 // micro-benchmark of the peer all-gather: `world` threads, each with its own stream and communicator, `reps` collectives back to back
 double peer_allgather_bench(int world, int gpu_map, int64_t count, int reps) {
