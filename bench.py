@@ -158,7 +158,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only (id exchange, barrier, max)
         uid = bytearray(128)
-        if rank == 0 and os.environ.get("XM_BENCH_SHM") != "1":
+        if rank == 0 and os.environ.get("XM_BENCH_SHM") != "1" and os.environ.get("XM_BENCH_IPC") != "1":
             buf = (xmamd.C.c_char * 128)()
             xmamd._chk(xmamd.lib().xm_comm_unique_id(buf))
             uid = bytearray(buf.raw)
@@ -166,8 +166,12 @@ def main():
         dist.broadcast_object_list(box, src=0)
         if os.environ.get("XM_BENCH_SHM") == "1":    # debugging aid: the library's shared-memory test transport instead of RCCL
             xmamd._chk(xmamd.lib().xm_comm_init_shm(rank, world, local, b"/xm_bench_%d" % int(os.environ.get("MASTER_PORT", "0")), 256 << 20))
+        elif os.environ.get("XM_BENCH_IPC") == "1":  # the direct peer exchange between processes WITHOUT RCCL beside it (two ranks may share a GPU)
+            xmamd._chk(xmamd.lib().xm_comm_init_ipc(rank, world, local, b"/xm_bench_ipc_%d" % int(os.environ.get("MASTER_PORT", "0")), 0.0))
         else:
-            xmamd._chk(xmamd.lib().xm_comm_init(rank, world, local, box[0], None))   # data plane: RCCL over xGMI inside the C++ solver
+            # data plane inside the C++ solver: direct peer writes through IPC-mapped buffers when every rank can map every peer and
+            # the transport's self-test passes (ranks of one node), else RCCL all-gathers over xGMI (XM_COMM_PEER=0 forces RCCL)
+            xmamd._chk(xmamd.lib().xm_comm_init(rank, world, local, box[0], None))
 
     wl = workload(args.workload)
     import xm_testlib as tl
@@ -252,6 +256,8 @@ def main():
                                    f"camera row partition x{team} inside ONE process (xm_problem_t.n_gpus), direct peer-write exchange fused into the tCG"),
                    **({"transport": "shared-memory TEST transport, all ranks on one GPU (functional dry run, not a scaling measurement)"}
                       if os.environ.get("XM_BENCH_SHM") == "1" else {}),
+                   **({"transport": "direct peer exchange between PROCESSES (xm_comm_init_ipc), all ranks on one GPU (functional dry run, not a scaling measurement)"}
+                      if os.environ.get("XM_BENCH_IPC") == "1" and os.environ.get("XM_BENCH_SINGLE_DEVICE") == "1" else {}),
                    **({"devices": "%d VIRTUAL devices on one GPU (gpu_map = 1): functional run of the %d-rank flow, not a scaling measurement" % (team, team)}
                       if gpu_map == 1 else {})},
         "solve": {"rank": last["rank"], "status": last["status"], "primal": last["primal"], "dual": last["dual"],

@@ -856,15 +856,18 @@ def test_vg100k_vs_recorded_oracle(xmamd):
     assert abs(i["tcg_iters"] - c["tcg"]) <= 0.2 * c["tcg"]
 
 
-def test_bench_two_ranks_flow(xmamd):
+@pytest.mark.parametrize("transport", ["shm", "ipc"])
+def test_bench_two_ranks_flow(xmamd, transport):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo control plane, per-rank on-device
-    expansion of the Rome-scale Q, replicas leg), with both ranks on the one GPU of the test box and the library's
-    shared-memory transport in place of RCCL: every leg must reach the certified optimum the single-GPU run reaches."""
+    expansion of the Rome-scale Q, replicas leg), with both ranks on the one GPU of the test box and, in place of RCCL (which
+    refuses two ranks on one device), (shm) the library's shared-memory test transport / (ipc) the direct peer exchange through
+    hipIpcMemHandle mappings -- the transport xm_comm_init switches to on a real node: every leg must reach the certified optimum
+    the single-GPU run reaches."""
     import socket, subprocess, sys
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, XM_BENCH_SHM="1", XM_BENCH_SINGLE_DEVICE="1")
+    env = dict(os.environ, XM_BENCH_SINGLE_DEVICE="1", GPU_MAX_HW_QUEUES="16", **({"XM_BENCH_SHM": "1"} if transport == "shm" else {"XM_BENCH_IPC": "1"}))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=900)
@@ -874,6 +877,8 @@ def test_bench_two_ranks_flow(xmamd):
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "strong" and d["value"] > 0
     assert d["solve"]["status"] == 1 and d["solve"]["primal"] == pytest.approx(0.2844696774, rel=1e-8)
+    assert d["solve"]["exchange"] == (2 if transport == "ipc" else 1)          # fused peer exchange / all-gather between the launches
+    assert ("IPC" in d["config"]["parallelism"]) == (transport == "ipc")
     for leg in ("rome_scale", "rome_scale_dense"):
         assert d[leg]["n_gpus"] == 2 and d[leg]["status"] == 1 and d[leg]["rank"] == 3
         assert d[leg]["primal"] == pytest.approx(2879.599460014564, rel=1e-10)
