@@ -343,8 +343,9 @@ def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, 
     """xm_problem_t.n_gpus: ONE process, one host thread per rank, direct peer-write exchange fused into cg_step (here as `world`
     virtual devices on the one GPU of the test box: own stream each, peer pointers are plain pointers).  Must reproduce the
     `world`-process run over the shared-memory transport BIT FOR BIT (same partition, same arithmetic, same summation orders) --
-    R, s and the whole (loss, |g|, inner count, exit reason) trace -- with the fused exchange (2) and with the un-fused peer
-    all-gather between the launches (XM_EXCHANGE=1)."""
+    R, s and the whole (loss, |g|, inner count, exit reason) trace -- with the fused exchange (2; payload through write-through
+    stores, and in its release-fence form XM_EXCHANGE_LITE=0) and with the un-fused peer all-gather between the launches
+    (XM_EXCHANGE=1)."""
     code = _team_worker_code()
     env = dict(os.environ, XM_SHM_TIMEOUT="60", GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="60")
     if case in ("sell", "sell_esc"):
@@ -359,9 +360,10 @@ def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, 
             print(o_.decode()[-2000:])
         assert p.returncode == 0
     ref = np.load(outs[0])
-    for ex in ("2", "1"):
-        out = str(tmp_path / f"team{ex}.npz")
-        _run(code, ["team", world, out, case], dict(env, XM_EXCHANGE=ex))
+    # fused exchange (write-through payload stores), un-fused peer all-gather, fused exchange in its release-fence form
+    for k, (ex, extra) in enumerate((("2", {}), ("1", {}), ("2", {"XM_EXCHANGE_LITE": "0"}))):
+        out = str(tmp_path / f"team{k}.npz")
+        _run(code, ["team", world, out, case], dict(env, XM_EXCHANGE=ex, **extra))
         t = np.load(out)
         assert int(t["n_gpus"]) == world and int(t["exchange"]) == (2 if ex == "2" else 1)
         assert int(t["rank"]) == int(ref["rank"]) and int(t["status"]) == int(ref["status"]) == 1 and int(t["tcg"]) == int(ref["tcg"])

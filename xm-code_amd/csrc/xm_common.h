@@ -106,6 +106,7 @@ struct PeerXchg {
     long long spin_ticks = 0;                   // bound of every device-side wait, in wall_clock64() ticks (100 MHz)
     unsigned long long epoch_base = 0;          // epochs of this tCG run are epoch_base + iteration + 1 (identical on all ranks)
     int mute = 0;                               // tests: this rank never publishes its epoch (a dead peer)
+    int lite = 0;                               // 1: payload through write-through (system-scope) stores + s_waitcnt instead of a release fence
 };
 
 // ---- launchers implemented in xm_kernels.hip -------------------------------------------------------------------

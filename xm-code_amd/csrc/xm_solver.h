@@ -30,6 +30,7 @@ struct Settings {
     int split_k = 0;             // 0 auto (multi-rank small strips) | -1 off | 2..8 forced
     long long debug_drop_finalize = -1;   // XM_DEBUG_DROP_FINALIZE (tests)
     int debug_peer_mute = 0;              // XM_DEBUG_PEER_MUTE=1 (tests): rank 1 never publishes its tCG epoch -> the peers' bounded wait must expire
+    int exchange_lite = 1;                // XM_EXCHANGE_LITE=0: the fused tCG exchange pushes with plain stores + a system-scope release fence instead of write-through stores
     static Settings resolve(const xm_tuning_t *t);
 };
 

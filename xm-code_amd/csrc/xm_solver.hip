@@ -392,6 +392,7 @@ void Context::setup_rank(int o) {
         comm_->xchg_setup(pb, xchg_);
         partsB_peer_ = xchg_.buf[comm_->rank];
         xchg_.mute = (cfg_.debug_peer_mute && comm_->rank == 1) ? 1 : 0;
+        xchg_.lite = cfg_.exchange_lite;
     } else {
         xchg_ = PeerXchg();
         partsB_peer_ = nullptr;
