@@ -479,8 +479,11 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PeerPtrs pp, const doubl
 }
 
 // wait for the world-1 epochs of the slot, then stage -> buf for the peers' chunks
+// plain != 0 (self-test only): the landed chunks are read with ordinary loads behind the acquire fence -- the way cg_step_kernel reads
+// its exchange buffer -- instead of system-scope loads, so that a platform on which that is not enough (stale lines of the rank's own
+// fine-grained buffer in its L2) fails the self-test instead of a solve
 __global__ __launch_bounds__(256) void peer_wait_kernel(PeerPtrs pp, double *__restrict__ buf, size_t count, size_t slot_off, int fslot,
-                                                         unsigned long long epoch, long long spin_ticks, unsigned long long *err) {
+                                                         unsigned long long epoch, long long spin_ticks, unsigned long long *err, int plain) {
     __shared__ int ok;
     if (threadIdx.x == 0) {
         int good = 1;
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(256) void peer_wait_kernel(PeerPtrs pp, double *__r
     const size_t total = count * (size_t)pp.world, stride = (size_t)gridDim.x * 256;
     const size_t own0 = (size_t)pp.rank * count, own1 = own0 + count;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride)
-        if (i < own0 || i >= own1) buf[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (i < own0 || i >= own1) buf[i] = plain ? src[i] : __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct PeerComm : Comm {
@@ -519,6 +522,7 @@ struct PeerComm : Comm {
     size_t xcap = 0;                   // doubles of the tCG exchange buffer (grow-only)
     void *parena[kMaxPeers] = {};      // every rank's arena / exchange buffer as THIS process addresses it
     void *pxbuf[kMaxPeers] = {};
+    int plain_reads = 0;               // self-test: see peer_wait_kernel
     int lite = 1;                      // write-through payload stores instead of a release fence (XM_EXCHANGE_LITE=0: fence form)
     std::shared_ptr<Comm> keep;        // a library communicator created beside this one (xm_comm_init): destroyed with it
     int kind() const override { return g->kind(); }
@@ -613,7 +617,7 @@ struct PeerComm : Comm {
             const int grid = (int)std::min<size_t>(64, (count + 2047) / 2048);
             hipLaunchKernelGGL(peer_push_kernel, dim3(grid), dim3(256), 0, st, pp, buf + (size_t)rank * count, count, slot_off, slot, seq, tickets() + slot);
             const int wgrid = (int)std::min<size_t>(128, (count * world + 2047) / 2048);
-            hipLaunchKernelGGL(peer_wait_kernel, dim3(wgrid), dim3(256), 0, st, pp, buf, count, slot_off, slot, seq, spin_ticks(), herr_dev);
+            hipLaunchKernelGGL(peer_wait_kernel, dim3(wgrid), dim3(256), 0, st, pp, buf, count, slot_off, slot, seq, spin_ticks(), herr_dev, plain_reads);
             check_launch("peer_allgather");
         }
     }
@@ -675,7 +679,9 @@ std::shared_ptr<IpcPeerGroup> ipc_group_open(int rank, int world, int device, co
     return g;
 }
 
-// three all-gathers with known contents: the transport has to prove itself on this machine before the solver relies on it
+// All-gathers with known contents that change from round to round at the same addresses: the transport has to prove itself on this
+// machine before the solver relies on it -- three rounds read through system-scope loads (what allgather does), six through ordinary
+// loads behind the acquire fence (what the fused tCG exchange does; a stale line of an earlier round would show up as a mismatch).
 bool peer_selftest(PeerComm &c) {
     const size_t cnt = 4096;
     bool ok = true;
@@ -685,7 +691,8 @@ bool peer_selftest(PeerComm &c) {
     try {
         XM_HIP_CHECK(hipMalloc((void **)&d, h.size() * sizeof(double)));
         XM_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        for (int it = 0; it < 3 && ok; ++it) {
+        for (int it = 0; it < 9 && ok; ++it) {
+            c.plain_reads = (it >= 3);
             std::fill(h.begin(), h.end(), -1.0);
             for (size_t i = 0; i < cnt; ++i) h[(size_t)c.rank * cnt + i] = 1e6 * it + 1e4 * c.rank + (double)i;
             XM_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -698,6 +705,7 @@ bool peer_selftest(PeerComm &c) {
                     if (h[(size_t)r * cnt + i] != 1e6 * it + 1e4 * r + (double)i) { ok = false; break; }
         }
     } catch (const Error &) { ok = false; }
+    c.plain_reads = 0;
     if (st) (void)hipStreamDestroy(st);
     if (d) (void)hipFree(d);
     return ok;
