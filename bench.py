@@ -28,13 +28,42 @@ for p in (ROOT, os.path.join(ROOT, "xm-code_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:   # torchrun pins OMP_NUM_THREADS=1; give each rank its share of the host cores
-    os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // int(os.environ["WORLD_SIZE"])))
+
+
+def host_cpu_budget():
+    """CPUs this process may really keep busy: physical cores, capped by the container's CPU quota (cgroup cpu.max).  The GPU boxes of
+    this pool show 256 logical CPUs and a quota of 16: 128 busy OpenMP threads are throttled to an eighth of their time (the host
+    product then takes 2.4 ms instead of 0.4 ms)."""
+    logical = os.cpu_count() or 8
+    budget = max(1, logical // 2)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        budget = max(1, min(budget, int(quota)))
+    return budget, quota, logical
+
+
+_HOST_BUDGET = host_cpu_budget()
+_WS = int(os.environ.get("WORLD_SIZE", "1"))
+if _WS > 1:   # torchrun pins OMP_NUM_THREADS=1; give each rank its share of the usable host cores
+    os.environ["OMP_NUM_THREADS"] = str(max(1, _HOST_BUDGET[0] // _WS))
+else:
+    os.environ.setdefault("OMP_NUM_THREADS", str(_HOST_BUDGET[0]))
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")              # control-plane rendezvous on loopback (hostname may not resolve)
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")              # RCCL bootstrap of the single-node communicator likewise
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (multi-process runs)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")           # virtual devices (N ranks on one GPU) need a hardware queue per rank's stream (8 ranks: 16 queues)
-os.environ.setdefault("OMP_PROC_BIND", "close")            # cpu_baseline: threads stay where they first touched their share of Q
+os.environ.setdefault("OMP_PROC_BIND", "spread")           # cpu_baseline: threads stay where they first touched their share of Q, spread over the L3 slices / memory controllers
 os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
@@ -114,6 +143,9 @@ def cpu_baseline(Q, wl, budget_s, bsr=None):
                        f"{its} tCG iters / {st['outer_iters']} outer in {st['seconds']:.1f}s (stop {st['stop_reason']}), "
                        f"Q*W {st['qw_seconds'] / max(st['qw_products'], 1) * 1e3:.2f} ms each",
                 qw_ms=st["qw_seconds"] / max(st["qw_products"], 1) * 1e3, wall_s=el,
+                host="%d OpenMP threads (OMP_PLACES=%s, OMP_PROC_BIND=%s) on %d logical CPUs, container CPU quota %s" % (
+                    xo.num_threads(), os.environ.get("OMP_PLACES"), os.environ.get("OMP_PROC_BIND"), _HOST_BUDGET[2],
+                    "none" if _HOST_BUDGET[1] is None else "%.1f CPUs" % _HOST_BUDGET[1]),
                 qw_host_GBs=((76.0 * bsr[1].size + 4 * (n + 1)) if bsr is not None else 8.0 * (3 * n) ** 2) / 1e9 /
                             max(st["qw_seconds"] / max(st["qw_products"], 1), 1e-12))
 
