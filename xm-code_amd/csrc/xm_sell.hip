@@ -736,12 +736,19 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
         const int pipe = (pipe_env >= 0) ? pipe_env : (quat ? (O == 3 ? 3 : 0) : (O == 3 ? 1 : 0));
         if (abl == 0 || O != 3) {
             if (quat) {
-                if (pipe == 2) {          // four wavefronts per SIMD, block loads one pair ahead
-                    if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<O, 1, 1>), g, b, 0, st, sa, W, sc, parts);
-                    else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<O, 0, 1>), g, b, 0, st, sa, W, sc, parts);
-                } else if (pipe == 3) {   // four wavefronts per SIMD, no software pipeline
-                    if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<O, 1, 0>), g, b, 0, st, sa, W, sc, parts);
-                    else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<O, 0, 0>), g, b, 0, st, sa, W, sc, parts);
+                bool launched = false;
+                if constexpr (O == 3) {   // the four-wavefront variants exist at o = 3 only (o = 4, 5 cannot reach that occupancy)
+                    if (pipe == 2) {          // four wavefronts per SIMD, block loads one pair ahead
+                        if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 1, 1>), g, b, 0, st, sa, W, sc, parts);
+                        else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 0, 1>), g, b, 0, st, sa, W, sc, parts);
+                        launched = true;
+                    } else if (pipe == 3) {   // four wavefronts per SIMD, no software pipeline
+                        if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 1, 0>), g, b, 0, st, sa, W, sc, parts);
+                        else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 0, 0>), g, b, 0, st, sa, W, sc, parts);
+                        launched = true;
+                    }
+                }
+                if (launched) {
                 } else if (pipe == 1) {
                     if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, 0, 1, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
                     else hipLaunchKernelGGL((qw_sell_kernel<O, 0, 0, 1, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
