@@ -53,6 +53,15 @@ def host_cpu_budget():
     return budget, quota, logical
 
 
+def _argv_gpus():
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            return sys.argv[i + 1]
+        if a.startswith("--gpus="):
+            return a.split("=", 1)[1]
+    return "1"
+
+
 _HOST_BUDGET = host_cpu_budget()
 _WS = int(os.environ.get("WORLD_SIZE", "1"))
 if _WS > 1:   # torchrun pins OMP_NUM_THREADS=1; give each rank its share of the usable host cores
@@ -63,12 +72,31 @@ os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")              # control-plane r
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")              # RCCL bootstrap of the single-node communicator likewise
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (multi-process runs)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")           # virtual devices (N ranks on one GPU) need a hardware queue per rank's stream (8 ranks: 16 queues)
-os.environ.setdefault("OMP_PROC_BIND", "spread")           # cpu_baseline: threads stay where they first touched their share of Q, spread over the L3 slices / memory controllers
-os.environ.setdefault("OMP_PLACES", "cores")
+if "WORLD_SIZE" not in os.environ and _argv_gpus() != "1":   # single-process multi-GPU, possibly N virtual devices on ONE GPU:
+    os.environ.setdefault("HSA_ENABLE_SDMA", "0")                                # their streams must not share the copy engine's in-order queue (copies become kernels)
+# cpu_baseline (rank 0 of a 1-GPU run only): OpenMP threads stay where they first touched their share of Q, spread over the L3 slices /
+# memory controllers.  NOT in multi-rank runs: a runtime that binds threads also binds the process's INITIAL thread to the first place
+# -- core 0 in every rank's process -- and every thread created later (the solver's host threads, the HIP runtime's) inherits that
+# mask: N busy-polling ranks on one core (found on 4 virtual ranks: device-side waits expired while the peers' host threads queued
+# for their time slice).  _FULL_AFFINITY is restored for the GPU part of every run and the binding re-applied for the host leg.
+_FULL_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+if _WS == 1 and _argv_gpus() == "1":
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
 
 import xmamd  # noqa: E402  (loads libxm_amd.so before torch so that one HIP runtime serves the process)
+
+
+def _unbind_main_thread():
+    """give the calling thread (and the threads it creates from now on) the process's original CPU mask back; returns the bound mask"""
+    if _FULL_AFFINITY is None:
+        return None
+    bound = os.sched_getaffinity(0)
+    if bound != _FULL_AFFINITY:
+        os.sched_setaffinity(0, _FULL_AFFINITY)
+    return bound
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -167,6 +195,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    bound_mask = _unbind_main_thread()   # an OpenMP runtime loaded by now may have bound this thread to its first place (see the top of the file)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -373,6 +402,8 @@ def main():
                                "algorithmic_bytes_per_launch": by, "kernel": "qw_dense_kernel<3, EPI_PLAIN>",
                                "workload": "same kernel on a 13682-camera (Final-13682-size) 13.5 GB random matrix, 20 launches"}
         del Qbig, Wbig, Obig
+    if rank == 0 and ngp == 1 and args.cpu_seconds > 0 and bound_mask is not None:
+        os.sched_setaffinity(0, bound_mask)   # the host leg: this thread is OpenMP thread 0 again, on its place
     if rank == 0 and ngp == 1 and args.cpu_seconds > 0 and Q is not None:
         out["cpu_baseline"] = cpu_baseline(Q, wl, args.cpu_seconds)
     elif rank == 0 and ngp == 1 and args.cpu_seconds > 0 and wl["kind"] == "vg" and args.storage in ("bsr", "vg"):

@@ -16,7 +16,10 @@ json.dump(b, open(os.path.join(P, f"{tag}_bench_venice1778.json"), "w"), indent=
 for src, dst in (("bench_vg100k_vg.log", "bench_vg100k_vg"), ("bench_vg100k_bsr.log", "bench_vg100k_bsr"), ("bench_2gpu_virtual.log", "bench_2gpu_virtual")):
     if os.path.exists(os.path.join(G, src)):
         json.dump(last_json(os.path.join(G, src)), open(os.path.join(P, f"{tag}_{dst}.json"), "w"), indent=1)
-shutil.copy(os.path.join(G, "kbench.log"), os.path.join(P, f"{tag}_kbench.txt"))
+if os.path.exists(os.path.join(G, "kbench.log")):
+    shutil.copy(os.path.join(G, "kbench.log"), os.path.join(P, f"{tag}_kbench.txt"))
+if os.path.exists(os.path.join(G, "kbench_multi.log")):   # gpu_r3_final2.sh: strips with every split factor + peer all-gather, final sources
+    shutil.copy(os.path.join(G, "kbench_multi.log"), os.path.join(P, f"{tag}_kbench_multi.txt"))
 shutil.copy(os.path.join(G, "pytest_gpu.log"), os.path.join(P, f"{tag}_pytest_gpu.txt"))
 stats = glob.glob(os.path.join(G, "prof_final", "**", "*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats, os.path.join(P, f"{tag}_kernel_stats_bench_venice1778.csv"))

@@ -371,7 +371,7 @@ def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, 
         assert np.array_equal(t["R"], ref["R"]) and np.array_equal(t["s"], ref["s"])
 
 
-@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("sell_esc", 2), ("dense_opts", 2)])
+@pytest.mark.parametrize("case,world", [("dense", 2), ("dense", 3), ("sell_esc", 2), ("dense_opts", 2), ("bsr", 4)])
 def test_one_process_per_gpu_over_ipc_handles_equals_the_single_process_team(xmamd, tmp_path, case, world):
     """xm_comm_init_ipc: the cross-process form of the direct peer exchange -- every rank is its own PROCESS (what
     `python -m torch.distributed.run` starts), exports its arena and tCG exchange buffer as hipIpcMemHandle_t through a shared-memory
@@ -399,6 +399,33 @@ def test_one_process_per_gpu_over_ipc_handles_equals_the_single_process_team(xma
         assert int(t["rank"]) == int(ref["rank"]) and int(t["status"]) == int(ref["status"]) == 1 and int(t["tcg"]) == int(ref["tcg"])
         assert np.array_equal(t["trace"], ref["trace"])
         assert np.array_equal(t["R"], ref["R"]) and np.array_equal(t["s"], ref["s"])
+
+
+@pytest.mark.parametrize("case", ["dense", "vg"])
+def test_eight_virtual_gpus(xmamd, tmp_path, case):
+    """the node's real shape, N = 8, as virtual devices: 8 host threads, 8-way partition with padding cameras (dense: 41 cameras -> 6
+    per rank, the last rank holds 5 inert ones; view graph with hubs: ranges balanced by stored blocks, + the XM^2 calls), 7 peers per
+    exchange.  Same certified optimum as one GPU.  (Each rank's stream needs a hardware queue of its own -- GPU_MAX_HW_QUEUES=16, set
+    by the binding before the runtime starts -- and a fresh process: a spinning wait that shares a queue with the push it waits for
+    ends in the bounded wait's XM_ERR_COMM, which is what a second 8-rank context in the same process ran into.  The ranks of one
+    process on one device also share the copy engine's in-order queue: HSA_ENABLE_SDMA=0 makes every copy a kernel on the rank's own
+    stream -- with the engine, rank A's device-to-host copy behind its wait kernel blocked rank B's copy in front of the push A was
+    waiting for (found here: deterministic stall at the first all-gather after the certificate).)"""
+    code = _team_worker_code()
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_SDMA="0", XM_WATCHDOG_S="60")
+    if case == "vg":
+        env["XM_BSR_SELL"] = "1"
+    one, eight = str(tmp_path / "one.npz"), str(tmp_path / "eight.npz")
+    _run(code, ["single", 1, one, case], env)
+    _run(code, ["team", 8, eight, case], env)
+    a, t = np.load(one), np.load(eight)
+    assert int(t["n_gpus"]) == 8 and int(t["exchange"]) == 2
+    assert int(t["rank"]) == int(a["rank"]) and int(t["status"]) == int(a["status"]) == 1
+    assert float(t["primal"]) == pytest.approx(float(a["primal"]), rel=1e-9)
+    assert tl.rotation_parity(t["R"], t["s"], a["R"], a["s"]) < 1e-6
+    if case == "vg":
+        assert np.allclose(t["res"], a["res"], rtol=1e-6, atol=1e-9)
+        assert float(t["primal2"]) == pytest.approx(float(a["primal2"]), rel=1e-8)
 
 
 def test_single_process_multi_gpu_viewgraph_hubs_and_xm2(xmamd, tmp_path):

@@ -559,10 +559,21 @@ struct PeerComm : Comm {
         if (xbuf) (void)hipFree(xbuf);
         if (herr) (void)hipHostFree(herr);
     }
-    static void *fine_alloc(size_t bytes) {
+    // ranks on one device (virtual devices of a single process) can live with ordinary memory; anything that crosses a device or a
+    // process boundary needs the fine-grained kind, and its absence is an error (xm_comm_init then keeps RCCL), never a silent downgrade
+    bool strict_fine() const {
+        if (g->kind() == 4) return true;
+        for (int p = 0; p < world; ++p) if (g->device[p] != g->device[rank]) return true;
+        return false;
+    }
+    void *fine_alloc(size_t bytes) const {
         void *p = nullptr;
         hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
-        if (e != hipSuccess) { (void)hipGetLastError(); XM_HIP_CHECK(hipMalloc(&p, bytes)); }   // single-device use does not need it
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (strict_fine()) throw Error(XM_ERR_COMM, std::string("peer communicator: no fine-grained device memory (") + hipGetErrorString(e) + ")");
+            XM_HIP_CHECK(hipMalloc(&p, bytes));
+        }
         XM_HIP_CHECK(hipMemset(p, 0, bytes));
         XM_HIP_CHECK(hipDeviceSynchronize());
         return p;

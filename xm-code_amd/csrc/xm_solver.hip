@@ -425,6 +425,10 @@ void Context::setup_rank(int o) {
         Pstrip_.alloc(mat);
     }
     scal_.alloc(2);
+    // the sliced-ELL product's partial-result buffer grows with o: (re)allocate it HERE, between the two barriers -- hipFree synchronises
+    // the whole device, and with several ranks of one process on one device ("virtual devices") a free between two collectives waits for
+    // a peer's spinning wait kernel that waits for this rank's next push (8 virtual ranks ran into exactly that at the first o = 4 product)
+    if (sell_ && sell_supports(o)) (void)sell_->parts(o);
     // pinned staging: partial sums, a whole replicated point (download_point) and a Lanczos vector
     ensure_pinned(std::max<size_t>((size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64, (size_t)ld_ * OP_ + (size_t)ntot_ + 1024));
     if (comm_->active()) comm_->host_barrier();   // nobody enqueues the next collective while somebody is still freeing
@@ -451,10 +455,12 @@ void Context::upload_point(const std::vector<double> &R_cm, int o, const std::ve
 void Context::download_point(std::vector<double> &R_cm, std::vector<double> &s_ex) {
     const size_t m = (size_t)3 * n_, mat = (size_t)nloc_ * 3 * OP_;
     std::vector<double> full((size_t)ntot_ * 3 * OP_), sf((size_t)ntot_);
-    XM_HIP_CHECK(hipMemcpyAsync(W_.p + (size_t)comm_->rank * mat, R_.p, mat * sizeof(double), hipMemcpyDeviceToDevice, st_));
+    // copies by KERNEL, not by the copy engine: the ranks of one process on one device share the engine's in-order queue, and a peer's
+    // device-to-host copy that waits there for its wait kernel would block this copy, i.e. the push that wait kernel is waiting for
+    launch_scale_copy(W_.p + (size_t)comm_->rank * mat, R_.p, 1.0, (int64_t)mat, st_);
     if (comm_->active()) comm_->allgather(W_.p, mat, st_);
     to_host(full.data(), W_.p, full.size() * sizeof(double));
-    XM_HIP_CHECK(hipMemcpyAsync(W_.p + (size_t)comm_->rank * nloc_, s_.p, (size_t)nloc_ * sizeof(double), hipMemcpyDeviceToDevice, st_));
+    launch_scale_copy(W_.p + (size_t)comm_->rank * nloc_, s_.p, 1.0, (int64_t)nloc_, st_);
     if (comm_->active()) comm_->allgather(W_.p, (size_t)nloc_, st_);
     to_host(sf.data(), W_.p, sf.size() * sizeof(double));
     XM_HIP_CHECK(hipMemsetAsync(W_.p, 0, W_.count * sizeof(double), st_));
