@@ -702,6 +702,17 @@ bool peer_selftest(PeerComm &c) {
     try {
         XM_HIP_CHECK(hipMalloc((void **)&d, h.size() * sizeof(double)));
         XM_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        {   // load the code object and run both kernels once on this rank alone (a group of one: nothing is pushed, nothing awaited), then
+            // meet the peers: the bounded waits below must measure the transport, not a peer that is still loading its kernels
+            PeerPtrs solo = c.ptrs();
+            solo.world = 1; solo.rank = 0;
+            solo.stage[0] = c.stage_of(c.rank); solo.flags[0] = c.flags_of(c.rank);
+            hipLaunchKernelGGL(peer_push_kernel, dim3(1), dim3(256), 0, st, solo, d, cnt, (size_t)0, 0, 0ull, c.tickets() + 6);
+            hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(256), 0, st, solo, d, cnt, (size_t)0, 0, 0ull, c.spin_ticks(), c.herr_dev, 0);
+            check_launch("peer self-test warm-up");
+            XM_HIP_CHECK(hipStreamSynchronize(st));
+            c.g->barrier(c.hb, "transport self-test");
+        }
         for (int it = 0; it < 9 && ok; ++it) {
             c.plain_reads = (it >= 3);
             std::fill(h.begin(), h.end(), -1.0);
@@ -728,7 +739,7 @@ std::shared_ptr<PeerComm> ipc_comm_try(int rank, int world, int device, const ch
     std::shared_ptr<PeerComm> c;
     unsigned long long hb = 0;
     try {
-        g = ipc_group_open(rank, world, device, name, limit, 5.0);   // short device-side waits while the transport is on probation
+        g = ipc_group_open(rank, world, device, name, limit, 10.0);   // shorter device-side waits while the transport is on probation
         if (!g->barrier_nothrow(hb)) { if (why) *why = "not every rank reached the rendezvous segment (ranks on several nodes?)"; return nullptr; }
         if (rank == 0) shm_unlink(name);   // everybody has it mapped
         c = std::make_shared<PeerComm>(g, rank, hb);
