@@ -166,6 +166,7 @@ int dots_multi_segments(int64_t len);
 void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, double *scratch, hipStream_t st);
 void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);
 void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hipStream_t st);
+void launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t st);   // bytes % 4 == 0; either side may be host-mapped memory
 void launch_lz_alpha(const double *c1j, const double *c2j, double *alpha_j, hipStream_t st);
 void launch_lz_next(double *dst, const double *w, const double *ww, double *beta_j, int64_t len, hipStream_t st);
 void launch_gemv_n(double *y, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);  // y = V c

@@ -2208,6 +2208,18 @@ void launch_lz_next(double *dst, const double *w, const double *ww, double *beta
     hipLaunchKernelGGL(lz_next_kernel, dim3(flat_grid(len)), dim3(256), 0, st, dst, w, ww, beta_j, len);
     check_launch("lz_next");
 }
+// plain copy in 4-byte words (staging through host-mapped memory without the copy engine, see Context::to_host)
+__global__ __launch_bounds__(256) void copy_words_kernel(unsigned int *__restrict__ dst, const unsigned int *__restrict__ src, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+void launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return;
+    if (bytes % 4 != 0) throw Error(-2, "launch_copy_words: size must be a multiple of 4 bytes");
+    const size_t nw = bytes / 4;
+    const int grid = (int)std::min<size_t>(1024, (nw + 255) / 256);
+    hipLaunchKernelGGL(copy_words_kernel, dim3(grid), dim3(256), 0, st, static_cast<unsigned int *>(dst), static_cast<const unsigned int *>(src), nw);
+    check_launch("copy_words");
+}
 void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hipStream_t st) {
     hipLaunchKernelGGL(scale_copy_kernel, dim3(flat_grid(len)), dim3(256), 0, st, dst, src, a, len);
     check_launch("scale_copy");

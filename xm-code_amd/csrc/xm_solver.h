@@ -213,6 +213,7 @@ private:
     unsigned long long *hstat_ = nullptr;      // host-mapped progress word (iter << 8 | status)
     unsigned long long *hstat_dev_ = nullptr;
     double *hpin_ = nullptr;                   // pinned host scratch for partial sums
+    double *hpin_dev_ = nullptr;               // the same buffer as the device addresses it (kernel copies of the peer communicators)
     size_t hpin_count_ = 0;
     int nA_ = 0, nB_ = 0;                      // partial counts (whole job)
     unsigned long long outer_seq_ = 0;         // sequence number of the host-mapped outer-iteration result block

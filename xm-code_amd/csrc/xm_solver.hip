@@ -47,7 +47,12 @@ void Context::to_host(void *dst, const void *src_dev, size_t bytes) {
     if (cap == 0) throw Error(XM_ERR_HIP, "staging buffer missing");
     for (size_t off = 0; off < bytes; off += cap) {
         const size_t n = std::min(cap, bytes - off);
-        XM_HIP_CHECK(hipMemcpyAsync(hpin_, s + off, n, hipMemcpyDeviceToHost, st_));
+        // Peer communicators: by KERNEL into the host-mapped staging buffer.  The copy engine (or, with HSA_ENABLE_SDMA=0, the runtime's
+        // shared blit queue) is ONE in-order queue per device: with several ranks of a process on one device, rank A's copy that waits
+        // there for A's wait kernel blocks rank B's copy, and B's push behind it is what A's wait kernel is waiting for (8 virtual ranks
+        // stalled exactly so at the all-gather after the certificate).  A kernel on the rank's own stream shares nothing.
+        if (comm_->peer() && n % 4 == 0) launch_copy_words(hpin_dev_, s + off, n, st_);
+        else XM_HIP_CHECK(hipMemcpyAsync(hpin_, s + off, n, hipMemcpyDeviceToHost, st_));
         XM_HIP_CHECK(hipStreamSynchronize(st_));
         std::memcpy(d + off, hpin_, n);
     }
@@ -60,15 +65,17 @@ void Context::to_dev(void *dst_dev, const void *src, size_t bytes) {
     for (size_t off = 0; off < bytes; off += cap) {
         const size_t n = std::min(cap, bytes - off);
         std::memcpy(hpin_, s + off, n);
-        XM_HIP_CHECK(hipMemcpyAsync(d + off, hpin_, n, hipMemcpyHostToDevice, st_));
+        if (comm_->peer() && n % 4 == 0) launch_copy_words(d + off, hpin_dev_, n, st_);
+        else XM_HIP_CHECK(hipMemcpyAsync(d + off, hpin_, n, hipMemcpyHostToDevice, st_));
         XM_HIP_CHECK(hipStreamSynchronize(st_));   // the staging buffer is reused by the next transfer
     }
 }
 void Context::ensure_pinned(size_t doubles) {
     if (doubles <= hpin_count_) return;
     if (hpin_) (void)hipHostFree(hpin_);
-    hpin_ = nullptr; hpin_count_ = 0;
-    XM_HIP_CHECK(hipHostMalloc((void **)&hpin_, doubles * sizeof(double), hipHostMallocDefault));
+    hpin_ = nullptr; hpin_dev_ = nullptr; hpin_count_ = 0;
+    XM_HIP_CHECK(hipHostMalloc((void **)&hpin_, doubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    XM_HIP_CHECK(hipHostGetDevicePointer((void **)&hpin_dev_, hpin_, 0));
     hpin_count_ = doubles;
 }
 
@@ -562,7 +569,8 @@ void Context::flush_gather() {
 }
 
 double Context::sum_parts(const double *dparts, int count) {
-    XM_HIP_CHECK(hipMemcpyAsync(hpin_, dparts, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st_));
+    if (comm_->peer()) launch_copy_words(hpin_dev_, dparts, (size_t)count * sizeof(double), st_);   // see to_host
+    else XM_HIP_CHECK(hipMemcpyAsync(hpin_, dparts, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st_));
     XM_HIP_CHECK(hipStreamSynchronize(st_));
     double t = 0.0;
     for (int i = 0; i < count; ++i) t += hpin_[i];
@@ -594,7 +602,8 @@ bool Context::agree_any(bool local) {
     double v = local ? 1.0 : 0.0;
     to_dev(partsM_.p + comm_->rank, &v, sizeof(double));
     comm_->allgather(partsM_.p, 1, st_);
-    XM_HIP_CHECK(hipMemcpyAsync(hpin_, partsM_.p, (size_t)world * sizeof(double), hipMemcpyDeviceToHost, st_));
+    if (comm_->peer()) launch_copy_words(hpin_dev_, partsM_.p, (size_t)world * sizeof(double), st_);   // see to_host
+    else XM_HIP_CHECK(hipMemcpyAsync(hpin_, partsM_.p, (size_t)world * sizeof(double), hipMemcpyDeviceToHost, st_));
     XM_HIP_CHECK(hipStreamSynchronize(st_));
     bool any = false;
     for (int r = 0; r < world; ++r) any = any || (hpin_[r] != 0.0);
