@@ -228,7 +228,8 @@ def main():
         if os.environ.get("XM_BENCH_SHM") == "1":    # debugging aid: the library's shared-memory test transport instead of RCCL
             xmamd._chk(xmamd.lib().xm_comm_init_shm(rank, world, local, b"/xm_bench_%d" % int(os.environ.get("MASTER_PORT", "0")), 256 << 20))
         elif os.environ.get("XM_BENCH_IPC") == "1":  # the direct peer exchange between processes WITHOUT RCCL beside it (two ranks may share a GPU)
-            xmamd._chk(xmamd.lib().xm_comm_init_ipc(rank, world, local, b"/xm_bench_ipc_%d" % int(os.environ.get("MASTER_PORT", "0")), 0.0))
+            xmamd._chk(xmamd.lib().xm_comm_init_ipc(rank, world, local, b"/xm_bench_ipc_%d" % int(os.environ.get("MASTER_PORT", "0")),
+                                                    float(os.environ.get("XM_BENCH_IPC_SPIN", "0"))))   # bound of the device-side waits, s (0 = 20)
         else:
             # data plane inside the C++ solver: direct peer writes through IPC-mapped buffers when every rank can map every peer and
             # the transport's self-test passes (ranks of one node), else RCCL all-gathers over xGMI (XM_COMM_PEER=0 forces RCCL)
