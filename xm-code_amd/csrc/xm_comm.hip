@@ -549,7 +549,11 @@ struct PeerComm : Comm {
                 (void)hipGetLastError();
             }
         }
-        alloc_arena(1 << 16);
+        // Between processes the buffers are sized generously ONCE (2 x 32 MB of landing zone here, 64 MB of tCG exchange buffer in
+        // xchg_setup: enough for 100 k cameras at the top rank): re-exporting a re-allocated buffer works (collective path below) but
+        // hipIpcOpenMemHandle has been seen to refuse the handle of an allocation that took the address of one this process had
+        // mapped before (bench flow after other GPU processes had run: "could not export or map"), so growth is kept for the rare case.
+        alloc_arena(g->kind() == 4 ? ((size_t)1 << 22) : ((size_t)1 << 16));
     }
     ~PeerComm() override {
         (void)hipDeviceSynchronize();
@@ -640,7 +644,7 @@ struct PeerComm : Comm {
         const size_t want = std::max<size_t>(doubles, 8);
         if (want > xcap) {
             if (xbuf) { g->unshare(rank, 1, hb, false); (void)hipFree(xbuf); }
-            xcap = want + want / 4;
+            xcap = std::max<size_t>(want + want / 4, g->kind() == 4 ? ((size_t)1 << 23) : 0);
             xbuf = static_cast<double *>(fine_alloc(xcap * sizeof(double)));
             size_t caps[kMaxPeers] = {};
             g->share(rank, 1, xbuf, xcap, pxbuf, caps, hb);
