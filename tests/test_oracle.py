@@ -228,3 +228,38 @@ def test_schur_tp_restatement_matches_reference_recover():
     assert np.abs(t - T["t_est"]).max() < 1e-9 * np.abs(T["t_est"]).max()
     assert np.abs(p - T["p_est"]).max() < 1e-9 * np.abs(T["p_est"]).max()
     assert np.all(t[:, 0] == 0.0)
+
+
+def test_xm2_round_by_hand_with_the_oracle(oracle):
+    """One round of the reference's XM^2 sequence (3_test_colmap_glomap.py:299-351) done with numpy and the CPU oracle on a 400-camera
+    hub view graph with 8 % gross outlier edges: solve, recovered-solution residuals, 90th-percentile filter, solve_rank3 at lam 0,
+    the lam decision from the rank-3 scales, final solve.  These are the numbers the GPU test
+    test_xm2_round_on_two_virtual_gpus_equals_the_single_gpu_round_and_the_oracle compares xm_ctx_xm2_round with (there recomputed on
+    the GPU box); recorded here so that a drift of the oracle itself shows up in the CPU suite."""
+    n = 400
+    H = tl.gen_vg_hubs(n, 8, 2, 0.3, 0.05, seed=12)
+    ei, ej, w, M = H["ei"], H["ej"], H["w"] * 0.2, H["M"].copy()
+    rng = np.random.default_rng(3)
+    for e in rng.choice(ei.size, size=int(ei.size * 0.08), replace=False):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        M[e] = q * np.sign(np.linalg.det(q))
+    Q = tl.bsr_to_dense(n, *tl.vg_from_edges(n, ei, ej, w, M))
+    R, s, info = oracle.solve(Q, 5, 1e-8, 20.0, 1000.0)
+    assert info["status"] == 1 and info["rank"] == 3 and info["cert"]["dual"] == pytest.approx(161.96882949118984, rel=1e-9)
+    rot, scale = tl.recover_rotations(R, s)
+    Y = np.stack([scale[i] * rot[:, 3 * i:3 * i + 3].T for i in range(n)])
+    res = np.array([np.sum((Y[ei[e]] - M[e] @ Y[ej[e]]) ** 2) for e in range(ei.size)])
+    err = w * res
+    thr = float(np.percentile(err, 90.0))
+    w2 = np.where(err > thr, 0.0, w)
+    assert thr == pytest.approx(0.04263070395615991, rel=1e-7) and int((w2 == 0).sum()) == 177
+    Q2 = tl.bsr_to_dense(n, *tl.vg_from_edges(n, ei, ej, w2, M))
+    R3, s3, _ = oracle.solve(Q2, 3, 1e-8, 0.0, 1000.0, mode=1)
+    avg, sd, small = float(s3[1:].mean()), float(s3[1:].std()), int((s3 < 0.1).sum())
+    assert avg == pytest.approx(0.3748172034893503, rel=1e-6) and sd == pytest.approx(0.06370245827607149, rel=1e-5)
+    assert abs(avg - 1) > 2 * sd and small == 0                      # -> regularised, lam = kept edges / cameras
+    lam = (w2 != 0).sum() / n
+    assert lam == pytest.approx(3.975)
+    Ro, so, io = oracle.solve(Q2, 5, 1e-8, lam, 1000.0)
+    assert io["status"] == 1 and io["rank"] == 3 and io["cert"]["dual"] == pytest.approx(3.562629993886309, rel=1e-8)
+    assert io["cert"]["min_eig"] > -1e-9
