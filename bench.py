@@ -295,7 +295,11 @@ def main():
         alg_bytes = (76.0 * nb + 4 * (n + 1)) / ngp + 2 * 8 * 3 * n * o_fin      # FULL-storage accounting whatever is streamed
         kname = "qw_bsr3_kernel<o, EPI_HESS>"
         if os.environ.get("XM_BSR_SELL") == "1" or (os.environ.get("XM_BSR_SELL") != "0" and nb / ngp >= 1000000):
-            kname = "qw_sell_kernel<o> + sell_reduce_kernel<o, EPI_HESS> (sliced-ELL over per-XCD column slabs; one product = both launches)"
+            if os.environ.get("XM_SELL_LAYOUT") == "1":
+                kname = "qw_sell_kernel<o> + sell_reduce_kernel<o, EPI_HESS> (sliced-ELL over per-XCD column slabs; one product = both launches)"
+            else:
+                kname = ("qw_sell2_kernel<o, EPI_HESS> (chunk-tiled sliced-ELL over per-XCD column slabs, ONE launch: the last slice to arrive for a "
+                         "chunk of 64 cameras adds the chunk's tiles and runs the fused epilogue)")
             if args.storage == "vg":
                 kname += ", view-graph codec: %.1f MB streamed per product for %.1f MB of full storage" % (last["qw_stream_bytes"] / 1e6, 76.0 * nb / ngp / 1e6)
     achieved = alg_bytes / (qw_ms * 1e-3) / 1e9 if qw_ms > 0 else 0.0

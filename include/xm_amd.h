@@ -101,7 +101,11 @@ typedef struct {
                                   1 RCCL all-gather, 2 direct peer writes */
     int32_t split_k;           /* dense product of a SMALL row strip with its columns split over several workgroups per camera group: 0 auto
                                   (multi-GPU runs whose strip has fewer than ~1.5 workgroups per CU), -1 off, 2..8 forced (also on one GPU) */
-    int32_t reserved[4];
+    int32_t sell_layout;       /* layout of the sliced-ELL copy: 0 auto (2 where it applies: fewer than 2^24 cameras), 1 = virtual rows sorted by length, two
+                                  launches per product (xm_sell.h), 2 = chunk-tiled, ONE launch per product with the epilogue run by the last slice to
+                                  arrive for a chunk of 64 cameras (xm_sell2.h) */
+    int32_t sell_kmax;         /* layout 2: most steps of a slice (longer (chunk, slab) lists -- hub cameras -- are cut); 0 = 32 */
+    int32_t reserved[2];
 } xm_tuning_t;
 
 typedef struct {
@@ -315,6 +319,16 @@ int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *b
  * row0 = global camera index of row 0 (which column is "the diagonal"). */
 int xm_sell_create2(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
                     int codec, int64_t row0, void **handle);
+/* the same with the LAYOUT chosen: 1 = sliced ELL over virtual rows sorted by length, two launches per product (xm_sell.h; lmax = longest
+ * virtual row, 0 = 64); 2 = chunk-tiled sliced ELL, ONE launch per product (xm-code_amd/csrc/xm_sell2.h; lmax = most steps of a slice, 0 = 32;
+ * ncols < 2^24). */
+int xm_sell_create3(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
+                    int codec, int64_t row0, int layout, void **handle);
+/* host-only view of layout 2 (CPU test of the index arithmetic, tests/test_sell_layout.py): sizes = {slices, steps, tiles, chunks}; arrays as
+ * xm-code_amd/csrc/xm_sell2.h:Sell2Host describes them (NULL = not wanted) */
+int xm_sell2_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int kmax, int64_t sizes[4],
+                    int64_t *slice_off, int32_t *slab_start, int32_t *slice_chunk, int32_t *slice_tile, int32_t *tile_ptr, uint8_t *kind,
+                    int64_t *src, int32_t *lane_meta);
 /* host-only: block (row-major 3x3, -w * rotation) -> stored quaternion -> the block the product kernel rebuilds (CPU test of the codec) */
 int xm_sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]);
 void xm_sell_destroy(void *handle);

@@ -18,6 +18,7 @@ ap.add_argument("--check", action="store_true")
 ap.add_argument("--no-csr", action="store_true")
 ap.add_argument("--reps", type=int, default=100)
 ap.add_argument("--codec", type=int, nargs="+", default=[0], help="0 = 9 doubles per block, 1 = view-graph codec (quaternion per block)")
+ap.add_argument("--layout", type=int, nargs="+", default=[1], help="1 = sorted virtual rows, two launches; 2 = chunk-tiled, one launch (XM_SELL2_PIPE=0|1 picks its loop)")
 a = ap.parse_args()
 n, deg = a.n, a.deg
 vgform = 1 in a.codec        # the codec needs a real view-graph matrix (rotation blocks), also for the banded / hub graphs
@@ -67,15 +68,16 @@ for o in a.o:
         print(f"CSR  n={n} deg={deg} nb={nb} o={o}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s algorithmic ({by/1e6:.1f} MB)", flush=True)
         if a.check:
             ref = xmamd.from_rm(dO.get(), 3 * n, o)
-    for S in [(S, cd) for S in a.slabs for cd in a.codec]:
-        S, cd = S
-        if (S, cd) not in mats:
-            mats[(S, cd)] = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=S, lmax=a.lmax, codec=cd)
+    for S in [(S, cd, lay) for S in a.slabs for cd in a.codec for lay in a.layout]:
+        S, cd, lay = S
+        if (S, cd, lay) not in mats:
+            mats[(S, cd, lay)] = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=S, lmax=(a.lmax if lay == 1 else 0), codec=cd, layout=lay)
         for gm in a.gather:
             if o == 1 and gm == 1:
                 continue
-            xmamd._chk(L.xm_qw_sell_time(mats[(S, cd)].h, o, dW.ptr, dO.ptr, gm, a.reps, C.byref(ms)))
-            line = f"SELL n={n} deg={deg} nb={nb} o={o} slabs={S} gather={gm} codec={cd} pipe={os.environ.get('XM_SELL_PIPE', 'dflt')}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s in full-storage accounting = {by/ms.value/1e6/8000:.3f} of 8 TB/s"
+            xmamd._chk(L.xm_qw_sell_time(mats[(S, cd, lay)].h, o, dW.ptr, dO.ptr, gm, a.reps, C.byref(ms)))
+            pipe = os.environ.get('XM_SELL_PIPE', 'dflt') if lay == 1 else os.environ.get('XM_SELL2_PIPE', 'dflt')
+            line = f"SELL layout={lay} n={n} deg={deg} nb={nb} o={o} slabs={S} gather={gm} codec={cd} pipe={pipe}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s in full-storage accounting = {by/ms.value/1e6/8000:.3f} of 8 TB/s"
             if ref is not None:
                 got = xmamd.from_rm(dO.get(), 3 * n, o)
                 line += f"   rel.err vs CSR kernel {tl.rel_fro(got, ref):.2e}"

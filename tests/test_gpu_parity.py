@@ -87,21 +87,25 @@ def test_retraction_matches_oracle(xmamd, oracle, o):
 @pytest.mark.parametrize("n,deg,o,slabs,lmax", [(1, 2, 3, 4, 64), (7, 3, 3, 8, 64), (200, 8, 3, 4, 64), (300, 20, 5, 2, 64), (1000, 12, 4, 8, 5),
                                                 (150, 40, 3, 1, 64), (211, 9, 1, 4, 64), (4000, 30, 3, 4, 64)])
 @pytest.mark.parametrize("gather", [0, 1])
-def test_qw_sell_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather):
-    """same product as test_qw_bsr3_matches_dense through the large-n layout: every slab count, both gather modes, virtual rows
-    cut at lmax, odd and even slice widths (paired steps + unpaired last step)"""
+@pytest.mark.parametrize("layout", [1, 2])
+def test_qw_sell_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather, layout):
+    """same product as test_qw_bsr3_matches_dense through the large-n layouts (1: sorted virtual rows, two launches; 2: chunk-tiled, one
+    launch with the per-camera sum done by the last slice to arrive): every slab count, both gather modes, virtual rows / slices cut at
+    lmax, odd and even slice widths (paired steps + unpaired last step)"""
     if o == 1 and gather == 1:
         pytest.skip("o = 1 has one gather mode")
     P = tl.gen_vg(n, deg=deg, sigma=0.3, seed=n + o)
     W = np.random.default_rng(n).standard_normal((3 * n, o))
     ref = oracle.qw(P["Q"], W, 1.5)
-    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax)
+    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, layout=layout)
     got = M.qw(W, 1.5, gather=gather)
+    again = M.qw(W, 1.5, gather=gather)               # the arrival counters of layout 2 are back at zero after every product
     M.close()
-    assert tl.rel_fro(got, ref) < 1e-13
+    assert tl.rel_fro(got, ref) < 1e-13 and np.array_equal(got, again)
 
 
-def test_qw_sell_skewed_degrees_and_unsorted_rows(xmamd):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_qw_sell_skewed_degrees_and_unsorted_rows(xmamd, layout):
     """hub cameras (rows of ~n/4 blocks among rows of ~20: cut into virtual rows of <= lmax blocks, partial results added per camera),
     cameras without blocks, rows handed over in arbitrary column order; the block-CSR kernel runs the same skewed matrix"""
     n = 6000
@@ -119,8 +123,9 @@ def test_qw_sell_skewed_degrees_and_unsorted_rows(xmamd):
     rows = np.repeat(np.arange(n), np.diff(rowptr))
     np.add.at(ref.reshape(n, 3, 3), rows, blocks @ Wc[colidx])
     for slabs, lmax in [(4, 64), (8, 16), (1, 1000)]:
-        M = xmamd.SellMatrix(rowptr, colidx, blocks, slabs=slabs, lmax=lmax)
+        M = xmamd.SellMatrix(rowptr, colidx, blocks, slabs=slabs, lmax=lmax, layout=layout)
         assert tl.rel_fro(M.qw(W), ref) < 1e-13
+        assert tl.rel_fro(M.qw(W, gather=1), ref) < 1e-13
         M.close()
     assert tl.rel_fro(xmamd.qw_bsr3(rowptr, colidx, blocks, W), ref) < 1e-13
 
@@ -130,16 +135,19 @@ def test_solve_through_sell_equals_csr_path(xmamd, monkeypatch):
     optimum of the block-CSR path: same rank, status, primal to 1e-12, rotations to 1e-8"""
     P = tl.gen_vg(700, deg=10, sigma=0.3, seed=11, dense=False)
     res = {}
-    for mode in ("0", "1"):
+    for mode, layout in (("0", "0"), ("1", "1"), ("1", "2")):        # block-CSR kernel | sliced ELL in two launches | chunk-tiled, one launch
         monkeypatch.setenv("XM_BSR_SELL", mode)
+        monkeypatch.setenv("XM_SELL_LAYOUT", layout)
         ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
-        res[mode] = ctx.solve(5, 1e-9, 20.0)
+        res[mode + layout] = ctx.solve(5, 1e-9, 20.0)
         ctx.close()
-    (R0, s0, i0), (R1, s1, i1) = res["0"], res["1"]
-    assert i0["rank"] == i1["rank"] and i0["status"] == i1["status"] == 1
-    assert i1["primal"] == pytest.approx(i0["primal"], rel=1e-12)
-    assert i1["min_eig"] == pytest.approx(i0["min_eig"], abs=1e-7)
-    assert tl.rotation_parity(R1, s1, R0, s0) < 1e-8
+    R0, s0, i0 = res["00"]
+    for key in ("11", "12"):
+        R1, s1, i1 = res[key]
+        assert i0["rank"] == i1["rank"] and i0["status"] == i1["status"] == 1
+        assert i1["primal"] == pytest.approx(i0["primal"], rel=1e-12)
+        assert i1["min_eig"] == pytest.approx(i0["min_eig"], abs=1e-7)
+        assert tl.rotation_parity(R1, s1, R0, s0) < 1e-8
 
 
 # ---------------------------------------------------------------------------------------------- whole solves

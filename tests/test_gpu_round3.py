@@ -34,7 +34,8 @@ def _weighted_vg(n, deg, seed, sigma=0.3):
 @pytest.mark.parametrize("n,deg,o,slabs,lmax", [(1, 2, 3, 4, 64), (7, 3, 3, 8, 64), (200, 8, 3, 4, 64), (300, 20, 5, 2, 64), (1000, 12, 4, 8, 5),
                                                 (150, 40, 3, 1, 64), (211, 9, 1, 4, 64), (4000, 30, 3, 4, 64)])
 @pytest.mark.parametrize("gather", [0, 1])
-def test_qw_sell_quaternion_codec_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_qw_sell_quaternion_codec_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather, layout):
     """the sliced-ELL product streaming 36 bytes per stored block (quaternion of the relative rotation scaled by sqrt(2w) + column index,
     diagonal blocks as one double per camera) equals the dense product of the same Q to 1e-12 (blocks are rebuilt in registers, so the
     difference to the 9-double storage is the codec's 1e-15 round trip); every slab count, both gather modes, cut rows, odd widths"""
@@ -44,11 +45,11 @@ def test_qw_sell_quaternion_codec_matches_dense(xmamd, oracle, n, deg, o, slabs,
     Q = tl.bsr_to_dense(n, P["rowptr"], P["colidx"], P["blocks"])
     W = np.random.default_rng(n).standard_normal((3 * n, o))
     ref = oracle.qw(Q, W, 1.5)
-    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=1)
+    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=1, layout=layout)
     got = M.qw(W, 1.5, gather=gather)
     M.close()
     assert tl.rel_fro(got, ref) < 1e-12
-    Mf = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=0)     # general blocks: unchanged bar
+    Mf = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=0, layout=layout)     # general blocks: unchanged bar
     assert tl.rel_fro(Mf.qw(W, 1.5, gather=gather), ref) < 1e-13
     Mf.close()
 
@@ -59,11 +60,12 @@ def test_round3_paths_are_bit_reproducible(xmamd, monkeypatch):
     virtual devices (peer exchange: whoever publishes first, the sums are added rank by rank) give the same bits on every run"""
     P = _weighted_vg(3000, 16, seed=4)
     W = np.random.default_rng(2).standard_normal((9000, 3))
-    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=4, codec=1)
-    a = M.qw(W, 1.0, gather=1)
-    for _ in range(3):
-        assert np.array_equal(M.qw(W, 1.0, gather=1), a)
-    M.close()
+    for layout in (1, 2):      # layout 2: whichever slice arrives last for a chunk, the tiles are added in tile order
+        M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=4, codec=1, layout=layout)
+        a = M.qw(W, 1.0, gather=1)
+        for _ in range(3):
+            assert np.array_equal(M.qw(W, 1.0, gather=1), a)
+        M.close()
     monkeypatch.setenv("XM_BSR_SELL", "1")
     V = tl.gen_vg(3000, deg=16, sigma=0.2, seed=4, dense=False)      # unit weights, lam at their scale: certifies at rank 3
     e = V["edges"]

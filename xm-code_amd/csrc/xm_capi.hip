@@ -8,6 +8,7 @@
 
 #include "xm_schur.h"
 #include "xm_sell.h"
+#include "xm_sell2.h"
 #include "xm_solver.h"
 
 struct xm_ctx {
@@ -529,23 +530,55 @@ int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int6
     return XM_OK;
     XM_CATCH
 }
-int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
-                   void **handle) {
+// host-only view of the chunk-tiled layout (xm_sell2.h) for the CPU tests; NULL arrays: only the sizes
+int xm_sell2_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int kmax, int64_t sizes[4],
+                    int64_t *slice_off, int32_t *slab_start, int32_t *slice_chunk, int32_t *slice_tile, int32_t *tile_ptr, uint8_t *kind,
+                    int64_t *src, int32_t *lane_meta) {
     XM_TRY
-    require_device();
-    if (!rowptr || !handle || n < 1) throw xm::Error(XM_ERR_ARG, "bad argument");
-    *handle = new xm::SellMatrix(rowptr, colidx, blocks, n, ncols, slabs, lmax, nullptr);
+    xm::Sell2Host h;
+    xm::sell2_build_host(rowptr, colidx, n, ncols, slabs, kmax > 0 ? kmax : 32, h);   // host only: no device needed
+    if (sizes) { sizes[0] = h.nslices; sizes[1] = h.nsteps; sizes[2] = h.ntiles; sizes[3] = h.nchunks; }
+    if (slice_off) std::copy(h.slice_off.begin(), h.slice_off.end(), slice_off);
+    if (slab_start) std::copy(h.slab_start.begin(), h.slab_start.end(), slab_start);
+    if (slice_chunk) std::copy(h.slice_chunk.begin(), h.slice_chunk.end(), slice_chunk);
+    if (slice_tile) std::copy(h.slice_tile.begin(), h.slice_tile.end(), slice_tile);
+    if (tile_ptr) std::copy(h.tile_ptr.begin(), h.tile_ptr.end(), tile_ptr);
+    if (kind) std::copy(h.kind.begin(), h.kind.end(), kind);
+    if (src) std::copy(h.src.begin(), h.src.end(), src);
+    if (lane_meta) std::copy(h.lane_meta.begin(), h.lane_meta.end(), lane_meta);
     return XM_OK;
     XM_CATCH
 }
-int xm_sell_create2(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
-                    int codec, int64_t row0, void **handle) {
+namespace {
+struct SellHandle {   // what xm_sell_create* hands out: one of the two layouts
+    std::unique_ptr<xm::SellMatrix> v1;
+    std::unique_ptr<xm::Sell2Matrix> v2;
+    int64_t nloc() const { return v2 ? v2->nloc() : v1->nloc(); }
+};
+void sell_product(SellHandle &h, int o, const double *dW, double alpha, const xm::CamArgs &a, int gather_mode, hipStream_t st) {
+    if (h.v2) xm::launch_qw_sell2(o, xm::EPI_PLAIN, *h.v2, dW, alpha, a, gather_mode, -1, st);
+    else xm::launch_qw_sell(o, xm::EPI_PLAIN, *h.v1, dW, alpha, a, gather_mode, st);
+}
+}  // namespace
+int xm_sell_create3(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
+                    int codec, int64_t row0, int layout, void **handle) {
     XM_TRY
     require_device();
-    if (!rowptr || !handle || n < 1 || row0 < 0) throw xm::Error(XM_ERR_ARG, "bad argument");
-    *handle = new xm::SellMatrix(rowptr, colidx, blocks, n, ncols, slabs, lmax, nullptr, codec, row0);
+    if (!rowptr || !handle || n < 1 || row0 < 0 || (layout != 1 && layout != 2)) throw xm::Error(XM_ERR_ARG, "bad argument");
+    std::unique_ptr<SellHandle> h(new SellHandle());
+    if (layout == 2) h->v2.reset(new xm::Sell2Matrix(rowptr, colidx, blocks, n, ncols, slabs, lmax > 0 ? lmax : 32, nullptr, codec, row0));
+    else h->v1.reset(new xm::SellMatrix(rowptr, colidx, blocks, n, ncols, slabs, lmax > 0 ? lmax : 64, nullptr, codec, row0));
+    *handle = h.release();
     return XM_OK;
     XM_CATCH
+}
+int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
+                   void **handle) {
+    return xm_sell_create3(rowptr, colidx, blocks, n, ncols, slabs, lmax, 0, 0, 1, handle);
+}
+int xm_sell_create2(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
+                    int codec, int64_t row0, void **handle) {
+    return xm_sell_create3(rowptr, colidx, blocks, n, ncols, slabs, lmax, codec, row0, 1, handle);
 }
 int xm_sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]) {
     XM_TRY
@@ -554,25 +587,25 @@ int xm_sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt
     return XM_OK;
     XM_CATCH
 }
-void xm_sell_destroy(void *handle) { delete static_cast<xm::SellMatrix *>(handle); }
+void xm_sell_destroy(void *handle) { delete static_cast<SellHandle *>(handle); }
 int xm_qw_sell(void *handle, int o, const double *dW, double *dOut, double alpha, int gather_mode, void *stream) {
     XM_TRY
     if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
-    xm::SellMatrix &m = *static_cast<xm::SellMatrix *>(handle);
-    xm::launch_qw_sell(o, xm::EPI_PLAIN, m, dW, alpha, plain_args(m.nloc(), dOut), gather_mode, (hipStream_t)stream);
+    SellHandle &m = *static_cast<SellHandle *>(handle);
+    sell_product(m, o, dW, alpha, plain_args(m.nloc(), dOut), gather_mode, (hipStream_t)stream);
     return XM_OK;
     XM_CATCH
 }
 int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gather_mode, int reps, double *ms_avg) {
     XM_TRY
     if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
-    xm::SellMatrix &m = *static_cast<xm::SellMatrix *>(handle);
+    SellHandle &m = *static_cast<SellHandle *>(handle);
     hipEvent_t e0, e1;
     XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
     const xm::CamArgs a = plain_args(m.nloc(), dOut);
-    for (int i = 0; i < 3; ++i) xm::launch_qw_sell(o, xm::EPI_PLAIN, m, dW, 1.0, a, gather_mode, nullptr);
+    for (int i = 0; i < 3; ++i) sell_product(m, o, dW, 1.0, a, gather_mode, nullptr);
     XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < reps; ++i) xm::launch_qw_sell(o, xm::EPI_PLAIN, m, dW, 1.0, a, gather_mode, nullptr);
+    for (int i = 0; i < reps; ++i) sell_product(m, o, dW, 1.0, a, gather_mode, nullptr);
     XM_HIP_CHECK(hipEventRecord(e1, nullptr));
     XM_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;

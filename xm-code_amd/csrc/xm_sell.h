@@ -118,6 +118,8 @@ private:
 // product = two launches: partial results per virtual row, then per-camera sum + fused epilogue (same CamArgs contract and
 // per-workgroup partial sums of the second launch, grid SellMatrix::reduce_grid(o, nloc)).  gm: 0 = each lane loads its own record of W,
 // 1 = records fetched element-per-lane and transposed through LDS.
+// host check of the view-graph structure the quaternion codec relies on (O(nb)); throws Error(XM_ERR_ARG)
+void check_viewgraph_blocks(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t nloc, int64_t row0);
 void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st);
 bool sell_supports(int o);
 void sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]);   // host: the codec's two maps

@@ -20,6 +20,9 @@ struct Settings {
     int sell = 0;                // 0 auto | 1 force | -1 off
     int sell_slabs = 4, sell_lmax = 64, sell_gather = 1;   // sell_gather: kernel gather mode (1 = LDS-transposed)
     int sell_codec = 0;          // 0 auto | 1 full | 2 quaternion
+    int sell_layout = 0;         // 0 auto (chunk-tiled where it applies) | 1 sorted virtual rows, two launches (xm_sell.h) | 2 chunk-tiled, one launch (xm_sell2.h)
+    int sell_kmax = 32;          // chunk-tiled layout: most steps of a slice
+    int sell_pipe = -1;          // chunk-tiled layout: -1 default | 0 single-buffered | 1 block loads one pair ahead (XM_SELL2_PIPE)
     int overlap = 0;             // 0 auto | -1 off
     double overlap_min_mb = 64.0;
     int64_t cert_dense_rows = 384;
@@ -107,6 +110,7 @@ struct DevBuf {
 void partition_cuts(int64_t n, int world, const int64_t *weights, std::vector<int64_t> &cuts);   // xm_solver.hip
 
 class SellMatrix;   // xm_sell.h
+class Sell2Matrix;  // xm_sell2.h
 class SchurOp;      // xm_schur.h
 
 struct PointState {  // everything the gradient epilogue writes for one point (R, s)
@@ -170,6 +174,7 @@ private:
     DevBuf<double> blocks_;
     int64_t nb_loc_ = 0;
     std::unique_ptr<SellMatrix> sell_;   // large block-sparse Q: sliced-ELL layout (xm_sell.h); the CSR arrays stay for the fallback kernels
+    std::unique_ptr<Sell2Matrix> sell2_; // the same in the chunk-tiled layout: product + epilogue in one launch (xm_sell2.h); at most one of the two exists
     int sell_gm_ = 0;
     std::unique_ptr<SchurOp> schur_;     // XM_STORAGE_SCHUR: matrix-free Q (xm_schur.h)
     // XM^2 edge description (attach_edges)

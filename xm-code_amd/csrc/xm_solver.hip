@@ -11,6 +11,7 @@
 //    per inner iteration, Dense/transpose.h:7-22).
 #include "xm_solver.h"
 #include "xm_sell.h"
+#include "xm_sell2.h"
 #include "xm_schur.h"
 
 #include <algorithm>
@@ -314,7 +315,10 @@ void Context::init(const xm_problem_t &prob_in) {
         if (cfg_.sell == 1 || (cfg_.sell == 0 && nb_loc_ >= 1000000)) {
             sell_gm_ = cfg_.sell_gather;
             const int codec = (cfg_.sell_codec == 2 || (cfg_.sell_codec == 0 && viewgraph)) ? SELL_CODEC_QUAT : SELL_CODEC_FULL;
-            sell_.reset(new SellMatrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_lmax, st_, codec, cam0_));
+            // chunk-tiled layout (product + per-camera sum + epilogue in ONE launch) wherever its 24-bit column field reaches
+            const bool tiled = cfg_.sell_layout == 2 || (cfg_.sell_layout == 0 && ntot_ < kSell2MaxCols);
+            if (tiled) sell2_.reset(new Sell2Matrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_kmax, st_, codec, cam0_));
+            else sell_.reset(new SellMatrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_lmax, st_, codec, cam0_));
         }
     } else if (storage_ == XM_STORAGE_SCHUR) {
         if (world != 1) throw Error(XM_ERR_ARG, "matrix-free storage is single-GPU in this version");
@@ -436,6 +440,7 @@ void Context::setup_rank(int o) {
     // the whole device, and with several ranks of one process on one device ("virtual devices") a free between two collectives waits for
     // a peer's spinning wait kernel that waits for this rank's next push (8 virtual ranks ran into exactly that at the first o = 4 product)
     if (sell_ && sell_supports(o)) (void)sell_->parts(o);
+    if (sell2_ && Sell2Matrix::supports(o, ntot_)) (void)sell2_->args(o);
     // pinned staging: partial sums, a whole replicated point (download_point) and a Lanczos vector
     ensure_pinned(std::max<size_t>((size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64, (size_t)ld_ * OP_ + (size_t)ntot_ + 1024));
     if (comm_->active()) comm_->host_barrier();   // nobody enqueues the next collective while somebody is still freeing
@@ -483,6 +488,7 @@ void Context::download_point(std::vector<double> &R_cm, std::vector<double> &s_e
 
 // workgroups of the product kernels == number of per-workgroup partial sums per epilogue slot
 int Context::prod_grid() const {
+    if (storage_ == XM_STORAGE_BSR3 && sell2_ && Sell2Matrix::supports(o_, ntot_)) return sell2_->nchunks();
     if (storage_ == XM_STORAGE_BSR3 && sell_ && sell_supports(o_)) return sell_->reduce_grid(o_, nloc_);
     return (storage_ == XM_STORAGE_BSR3) ? bsr_grid(nloc_) : qw_grid(nloc_);   // dense and matrix-free: one wavefront per camera
 }
@@ -534,6 +540,8 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
         else launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
     } else if (storage_ == XM_STORAGE_SCHUR) {
         schur_->product(o, epi, W_.p, alpha, a, st_);
+    } else if (sell2_ && Sell2Matrix::supports(o, ntot_)) {
+        launch_qw_sell2(o, epi, *sell2_, W_.p, alpha, a, sell_gm_, cfg_.sell_pipe, st_);
     } else if (sell_ && sell_supports(o)) {
         launch_qw_sell(o, epi, *sell_, W_.p, alpha, a, sell_gm_, st_);
     } else {
@@ -1072,6 +1080,7 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 if (storage_ == XM_STORAGE_DENSE && sym_ok_ && Pcol_.p && sym_variant() == 1) launch_qw_sym(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, Prow_.p, Pcol_.p, st_);
                 else if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
                 else if (storage_ == XM_STORAGE_SCHUR) schur_->product(1, EPI_CERT, vj, 1.0, a, st_);
+                else if (sell2_) launch_qw_sell2(1, EPI_CERT, *sell2_, vj, 1.0, a, 0, 0, st_);
                 else if (sell_) launch_qw_sell(1, EPI_CERT, *sell_, vj, 1.0, a, 0, st_);
                 else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_);
                 res_->qw_products++;
@@ -1388,6 +1397,7 @@ void Context::set_edge_weights(const double *w) {
     launch_edge_write(dense, ne_, ei_.p, ej_.p, eM_.p, ew_.p, cam0_, nloc_, inc_ptr_.p, inc_edge_.p, pos_ij_.p, pos_ji_.p, pos_d_.p,
                       dense ? nullptr : blocks_.p, dense ? dQ_ : nullptr, ld_, st_);
     if (sell_) sell_->refill(colidx_.p, blocks_.p, st_);   // the sliced-ELL copy follows the CSR values
+    if (sell2_) sell2_->refill(colidx_.p, blocks_.p, st_);
     XM_HIP_CHECK(hipStreamSynchronize(st_));
 }
 
@@ -1496,7 +1506,7 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     else if (storage_ == XM_STORAGE_SCHUR) res.qw_bytes = schur_->bytes_per_product(of);
     else res.qw_bytes = 76LL * nb_loc_ + 4LL * (n_ + 1) + 2LL * 8 * 3 * n_ * of;
     res.qw_stream_bytes = (storage_ == XM_STORAGE_DENSE) ? (res.sym_product ? 4LL : 8LL) * (3 * n_) * (3 * n_)
-                          : (storage_ == XM_STORAGE_BSR3) ? ((sell_ && sell_supports(of)) ? sell_->stream_bytes() : 76LL * nb_loc_) : 0;
+                          : (storage_ == XM_STORAGE_BSR3) ? ((sell2_ && Sell2Matrix::supports(of, ntot_)) ? sell2_->stream_bytes() : (sell_ && sell_supports(of)) ? sell_->stream_bytes() : 76LL * nb_loc_) : 0;
     res.n_gpus = comm_->world;
     res.exchange = !comm_->active() ? 0 : (xchg_.world > 1 ? 2 : 1);
     res.seconds = secs_since(t0);

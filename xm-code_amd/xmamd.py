@@ -28,7 +28,7 @@ EXPORTS = [
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_qw_dense_time", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_peer_allgather_bench", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_init_ipc", "xm_comm_finalize", "xm_partition", "xm_partition_blocks",
-    "xm_symv_plan", "xm_sell_layout", "xm_sell_create", "xm_sell_create2", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
+    "xm_symv_plan", "xm_sell_layout", "xm_sell_create", "xm_sell_create2", "xm_sell_create3", "xm_sell2_layout", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
     "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse",
 ]
 
@@ -40,7 +40,7 @@ class XmError(RuntimeError):
 class Tuning(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("sym", "sym_min_rows", "sell", "sell_slabs", "sell_lmax", "sell_gather", "sell_codec", "overlap",
                                          "overlap_min_mb", "cert_dense_rows", "lanczos_mmax", "lanczos_restarts", "watchdog_s", "balance",
-                                         "exchange", "split_k")] + [("reserved", C.c_int32 * 4)]
+                                         "exchange", "split_k", "sell_layout", "sell_kmax")] + [("reserved", C.c_int32 * 2)]
 
 
 class Problem(C.Structure):
@@ -142,6 +142,8 @@ def lib():
         L.xm_sell_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p] + [C.c_void_p] * 7
         L.xm_sell_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.xm_sell_create2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]
+        L.xm_sell_create3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        L.xm_sell2_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p] + [C.c_void_p] * 8
         L.xm_sell_quat_roundtrip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_sell_destroy.argtypes = [C.c_void_p]
         L.xm_sell_destroy.restype = None
@@ -324,18 +326,39 @@ def sell_layout(rowptr, colidx, ncols=None, slabs=4, lmax=64):
     return out
 
 
+def sell2_layout(rowptr, colidx, ncols=None, slabs=4, kmax=32):
+    """host-side description of the chunk-tiled sliced-ELL layout (xm_sell2.h) -- no GPU involved; used by the CPU tests"""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    n = rowptr.size - 1
+    ncols = n if ncols is None else ncols
+    sizes = np.zeros(4, dtype=np.int64)
+    args = (rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), n, ncols, slabs, kmax)
+    _chk(lib().xm_sell2_layout(*args, sizes.ctypes.data_as(C.c_void_p), *([None] * 8)))
+    nsl, nst, ntl, nch = (int(x) for x in sizes)
+    out = dict(nslices=nsl, nsteps=nst, ntiles=ntl, nchunks=nch, slabs=slabs,
+               slice_off=np.zeros(nsl + 1, dtype=np.int64), slab_start=np.zeros(slabs + 1, dtype=np.int32),
+               slice_chunk=np.zeros(max(nsl, 1), dtype=np.int32), slice_tile=np.zeros(max(nsl, 1), dtype=np.int32),
+               tile_ptr=np.zeros(nch + 1, dtype=np.int32), kind=np.zeros(max(nst, 1), dtype=np.uint8),
+               src=np.zeros(max(nst, 1) * 64, dtype=np.int64), lane_meta=np.zeros(max(nsl, 1) * 64, dtype=np.int32))
+    _chk(lib().xm_sell2_layout(*args, sizes.ctypes.data_as(C.c_void_p),
+                               *(out[k].ctypes.data_as(C.c_void_p) for k in ("slice_off", "slab_start", "slice_chunk", "slice_tile", "tile_ptr",
+                                                                             "kind", "src", "lane_meta"))))
+    return out
+
+
 class SellMatrix:
     """3x3-block sparse Q in the sliced-ELL device layout (xm_sell_create); product through xm_qw_sell"""
 
-    def __init__(self, rowptr, colidx, blocks, ncols=None, slabs=4, lmax=64, codec=0, row0=0):
-        """codec 1 = view-graph codec (quaternion per off-diagonal block, scalar per diagonal block)"""
+    def __init__(self, rowptr, colidx, blocks, ncols=None, slabs=4, lmax=0, codec=0, row0=0, layout=1):
+        """codec 1 = view-graph codec (quaternion per off-diagonal block, scalar per diagonal block); layout 1 = two launches per product
+        (xm_sell.h), 2 = chunk-tiled, one launch per product (xm_sell2.h)"""
         require_gpu()
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
         blocks = np.ascontiguousarray(blocks, dtype=np.float64)
         self.n = rowptr.size - 1
         self.h = C.c_void_p()
-        _chk(lib().xm_sell_create2(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
-                                   self.n, self.n if ncols is None else ncols, slabs, lmax, codec, row0, C.byref(self.h)))
+        _chk(lib().xm_sell_create3(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
+                                   self.n, self.n if ncols is None else ncols, slabs, lmax, codec, row0, layout, C.byref(self.h)))
 
     def qw(self, W, alpha=1.0, gather=0):
         W = np.asarray(W, dtype=np.float64)
