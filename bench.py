@@ -239,6 +239,20 @@ def main():
     import xm_testlib as tl
     t0 = time.time()
     Q = None
+    try:
+        return _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch, dist, bound_mask)
+    except xmamd.XmError as e:
+        # the library's transport ladder (direct peer writes -> RCCL) ended in XM_ERR_COMM, or a solve failed: still ONE JSON line, so that
+        # whoever launched this learns why instead of finding nothing
+        if rank == 0:
+            print(json.dumps({"metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
+                              "value": None, "unit": "tCG iters/s", "n_gpus": ngp, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": wl["desc"]}, "transport": None, "fallback": None, "error": str(e)}))
+        raise SystemExit(1)
+
+
+def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch, dist, bound_mask):
     if wl["kind"] == "dense":
         Q = tl.gen_dense(wl["n"], seed=wl["seed"])["Q"]
         ctx = xmamd.Context(Q=Q, **tkw)
@@ -258,6 +272,7 @@ def main():
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), **tkw)
             storage_desc = "3x3-block CSR, %d blocks (%.1f MB)" % (nb, 76.0 * nb / 1e6)
     gen_s = time.time() - t0
+    tr_kind, tr_name, tr_note = ctx.transport()   # which transport joins the ranks, and why a faster one was given up (library's ladder)
 
     def barrier():
         torch.cuda.synchronize()
@@ -326,6 +341,7 @@ def main():
                       if os.environ.get("XM_BENCH_IPC") == "1" and os.environ.get("XM_BENCH_SINGLE_DEVICE") == "1" else {}),
                    **({"devices": "%d VIRTUAL devices on one GPU (gpu_map = 1): functional run of the %d-rank flow, not a scaling measurement" % (team, team)}
                       if gpu_map == 1 else {})},
+        "transport": tr_name, "fallback": (tr_note or None),
         "solve": {"rank": last["rank"], "status": last["status"], "primal": last["primal"], "dual": last["dual"],
                   "min_eig": last["min_eig"], "tcg_iters_per_solve": last["tcg_iters"], "outer_iters": last["outer_iters"],
                   "qw_products": last["qw_products"], "lanczos_iters": last["lanczos_iters"],

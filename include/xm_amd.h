@@ -101,9 +101,9 @@ typedef struct {
                                   1 RCCL all-gather, 2 direct peer writes */
     int32_t split_k;           /* dense product of a SMALL row strip with its columns split over several workgroups per camera group: 0 auto
                                   (multi-GPU runs whose strip has fewer than ~1.5 workgroups per CU), -1 off, 2..8 forced (also on one GPU) */
-    int32_t sell_layout;       /* layout of the sliced-ELL copy: 0 auto (2 where it applies: fewer than 2^24 cameras), 1 = virtual rows sorted by length, two
-                                  launches per product (xm_sell.h), 2 = chunk-tiled, ONE launch per product with the epilogue run by the last slice to
-                                  arrive for a chunk of 64 cameras (xm_sell2.h) */
+    int32_t sell_layout;       /* layout of the sliced-ELL copy: 0 auto (= 1), 1 = virtual rows sorted by length, two launches per product (xm_sell.h),
+                                  2 = chunk-tiled, ONE launch per product with the epilogue run by the last slice to arrive for a chunk of 64
+                                  cameras (xm_sell2.h; fewer than 2^24 cameras; measured slower on MI355X, kept selectable) */
     int32_t sell_kmax;         /* layout 2: most steps of a slice (longer (chunk, slab) lists -- hub cameras -- are cut); 0 = 32 */
     int32_t reserved[2];
 } xm_tuning_t;
@@ -367,6 +367,12 @@ int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, dou
  * (bench.py does that with torch.distributed); every rank then calls xm_comm_init before xm_ctx_create. */
 int xm_comm_unique_id(unsigned char id[128]);
 int xm_comm_init(int rank, int world, int device, const unsigned char id[128], const char *rccl_path /* NULL = default search */);
+/* Which transport joins the ranks of a context -- *kind: 0 none (one GPU), 1 RCCL all-gathers, 2 shared-memory TEST transport, 3 direct peer
+ * writes between the host threads of this process (xm_problem_t.n_gpus), 4 direct peer writes between processes (IPC-mapped buffers) -- and,
+ * in note (NUL-terminated, truncated to note_cap), why a faster transport was given up for it (empty: first choice).  The multi-GPU modes try
+ * direct peer writes first (self-tested on the machine at context creation), then RCCL, and fail with XM_ERR_COMM naming both reasons. */
+int xm_ctx_transport(xm_ctx_t *ctx, int *kind, char *note, size_t note_cap);
+
 /* One process per GPU WITHOUT a collective library on the data path: every rank exports its exchange buffers as hipIpcMemHandle_t
  * through the POSIX shared-memory segment `name` (same string on every rank of the node, unique per job), maps the peers' and uses
  * the direct peer-write exchange of the single-process mode (fused into the tCG kernel).  xm_comm_init tries the same transport on

@@ -530,6 +530,19 @@ int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int6
     return XM_OK;
     XM_CATCH
 }
+// which transport joins the ranks of this context: 0 none (one GPU) | 1 RCCL | 2 shared-memory test transport | 3 direct peer writes between the
+// host threads of this process | 4 direct peer writes between processes (IPC); note = why a faster transport was given up (empty: it was not)
+int xm_ctx_transport(xm_ctx_t *ctx, int *kind, char *note, size_t note_cap) {
+    XM_TRY
+    if (!ctx || (!ctx->impl && !ctx->team)) throw xm::Error(XM_ERR_ARG, "null context");
+    const int k = ctx->team ? ctx->team->comm_kind() : ctx->impl->comm_kind();
+    const std::string &n = ctx->team ? ctx->team->fallback_note() : ctx->impl->fallback_note();
+    if (kind) *kind = k;
+    if (note && note_cap > 0) { std::strncpy(note, n.c_str(), note_cap - 1); note[note_cap - 1] = 0; }
+    return XM_OK;
+    XM_CATCH
+}
+
 // host-only view of the chunk-tiled layout (xm_sell2.h) for the CPU tests; NULL arrays: only the sizes
 int xm_sell2_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int kmax, int64_t sizes[4],
                     int64_t *slice_off, int32_t *slab_start, int32_t *slice_chunk, int32_t *slice_tile, int32_t *tile_ptr, uint8_t *kind,

@@ -338,6 +338,7 @@ struct PeerGroup {   // who the ranks of a peer communicator are and how they fi
     // before a shared allocation is freed: drop this process's view of the peers' allocations under `key`; collective (ends with a
     // barrier: the owner may free afterwards) unless `teardown`
     virtual void unshare(int me, int key, unsigned long long &hb, bool teardown) = 0;
+    virtual int ranks_on_device_of(int me) const = 0;   // ranks whose kernels run on rank me's GPU (itself included)
 };
 
 namespace {
@@ -365,6 +366,11 @@ struct LocalPeerGroup : PeerGroup {   // single process, one host thread per ran
         for (int r = 0; r < world; ++r) { addr[r] = tab[key][r]; metas[r] = meta[key][r]; }
     }
     void unshare(int, int, unsigned long long &, bool) override {}
+    int ranks_on_device_of(int me) const override {
+        int c = 0;
+        for (int r = 0; r < world; ++r) c += (device[r] == device[me]);
+        return c;
+    }
 };
 
 // One process per GPU: the directory lives in a POSIX shared-memory segment, allocations travel as hipIpcMemHandle_t (dmabuf export;
@@ -375,6 +381,7 @@ struct IpcShared {
     std::atomic<int> aborted;
     std::atomic<int> failed;      // a rank could not export or map: all ranks give the transport up together
     struct Slot { hipIpcMemHandle_t h; unsigned long long meta; } slot[2][kMaxPeers];
+    unsigned long long devid[kMaxPeers];   // identity of every rank's GPU (hash of its PCI bus id): which ranks share a device
 };
 struct IpcPeerGroup : PeerGroup {
     IpcShared *sh = nullptr;
@@ -399,7 +406,7 @@ struct IpcPeerGroup : PeerGroup {
             if (sh->aborted.load() || since(t0) > limit) return false;
             std::this_thread::yield();
         }
-        return true;
+        return sh->aborted.load() == 0;   // also for the rank whose arrival completed the count: an abort is everybody's
     }
     void barrier(unsigned long long &mine, const char *what) override {
         if (!barrier_nothrow(mine))
@@ -428,6 +435,11 @@ struct IpcPeerGroup : PeerGroup {
         for (int r = 0; r < world; ++r)
             if (mapped[key][r]) { (void)hipIpcCloseMemHandle(mapped[key][r]); mapped[key][r] = nullptr; }
         if (!teardown) barrier(hb, "release of the peers' buffers");
+    }
+    int ranks_on_device_of(int r0) const override {   // valid after the rendezvous barrier (every rank has published its devid)
+        int c = 0;
+        for (int r = 0; r < world; ++r) c += (sh->devid[r] == sh->devid[r0]);
+        return std::max(c, 1);
     }
 };
 }  // namespace
@@ -530,6 +542,7 @@ struct PeerComm : Comm {
     std::shared_ptr<Comm> keep;        // a library communicator created beside this one (xm_comm_init): destroyed with it
     int kind() const override { return g->kind(); }
     bool peer() const override { return true; }
+    int ranks_on_my_device() const override { return g->ranks_on_device_of(rank); }
     unsigned long long *flags_of(int r) const { return reinterpret_cast<unsigned long long *>(parena[r]); }
     unsigned long long *tickets() const { return reinterpret_cast<unsigned long long *>(arena) + kFlagWords; }
     double *stage_of(int r) const { return reinterpret_cast<double *>(static_cast<char *>(parena[r]) + kArenaHead); }
@@ -694,6 +707,13 @@ std::shared_ptr<IpcPeerGroup> ipc_group_open(int rank, int world, int device, co
     g->name = name; g->me = rank; g->world = world; g->limit = limit;
     for (int r = 0; r < world; ++r) g->device[r] = (r == rank) ? device : -1;
     if (spin_seconds > 0) g->spin_seconds = spin_seconds;
+    {   // which physical GPU this rank drives (two processes of a 1-GPU test box share one)
+        char bus[64] = {};
+        unsigned long long h = 1469598103934665603ull;
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); std::snprintf(bus, sizeof(bus), "device-%d", device); }
+        for (const char *c = bus; *c; ++c) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+        g->sh->devid[rank] = h | 1ull;
+    }
     return g;
 }
 
@@ -740,29 +760,59 @@ bool peer_selftest(PeerComm &c) {
     return ok;
 }
 
+}  // namespace
+bool peer_comm_selftest(Comm &c) {
+    PeerComm *pc = dynamic_cast<PeerComm *>(&c);
+    if (!pc) throw Error(XM_ERR_ARG, "peer_comm_selftest: not a peer communicator");
+    return peer_selftest(*pc);
+}
+std::shared_ptr<Comm> rccl_comm_create(int rank, int world, const unsigned char id[128]) {
+    if (world < 2 || rank < 0 || rank >= world || !id) throw Error(XM_ERR_ARG, "rccl_comm_create: bad rank/world/id");
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        load_rccl(nullptr);
+    }
+    auto c = std::make_shared<RcclComm>();
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, 128);
+    check(g_rccl.CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank");   // blocks until every rank of the group has called it
+    c->rank = rank;
+    c->world = world;
+    return c;
+}
+namespace {
 // all ranks return the same answer: a communicator that passed the self-test everywhere, or nullptr (why -> *why)
 std::shared_ptr<PeerComm> ipc_comm_try(int rank, int world, int device, const char *name, double limit, std::string *why) {
     std::shared_ptr<IpcPeerGroup> g;
     std::shared_ptr<PeerComm> c;
     unsigned long long hb = 0;
+    // every way out of the probation marks the group failed AND aborted first: a rank that is still waiting in one of the barriers
+    // below, or arrives at it late, then leaves with the same answer as this one (the decision is collective)
+    auto give_up = [&](const std::string &what) -> std::shared_ptr<PeerComm> {
+        if (why) *why = what;
+        if (g && g->sh) { g->sh->failed.store(1); g->sh->aborted.store(1); }
+        shm_unlink(name);   // whoever gets here first removes the name (a segment left behind would poison the next job of that name)
+        return nullptr;
+    };
     try {
         g = ipc_group_open(rank, world, device, name, limit, 10.0);   // shorter device-side waits while the transport is on probation
-        if (!g->barrier_nothrow(hb)) { if (why) *why = "not every rank reached the rendezvous segment (ranks on several nodes?)"; return nullptr; }
-        if (rank == 0) shm_unlink(name);   // everybody has it mapped
+        if (!g->barrier_nothrow(hb) || g->sh->failed.load()) return give_up("not every rank reached the rendezvous segment (ranks on several nodes?)");
         c = std::make_shared<PeerComm>(g, rank, hb);
+        // the tCG exchange buffer is exported and mapped HERE, once, at its full size: a handle that a peer cannot open must end in the
+        // collective fallback below, not in the middle of a solve
+        PeerXchg probe;
+        c->xchg_setup((size_t)1 << 20, probe);
     } catch (const Error &e) {
-        if (why) *why = e.what();
-        if (g && g->sh) { g->sh->failed.store(1); g->sh->aborted.store(1); }
-        return nullptr;
+        return give_up(e.what());
     }
     bool ok = false;
     try { ok = peer_selftest(*c); } catch (...) { ok = false; }
     if (!ok) g->sh->failed.store(1);
-    if (!g->barrier_nothrow(c->hb) || g->sh->failed.load()) {
-        if (why) *why = ok ? "a peer failed the transport self-test" : "the transport self-test failed on this rank";
-        g->sh->aborted.store(1);
-        return nullptr;
-    }
+    const bool met = g->barrier_nothrow(c->hb);
+    if (!met || g->sh->failed.load()) return give_up(ok ? "a peer failed the transport self-test" : "the transport self-test failed on this rank");
+    // confirmation: nobody installs the communicator before everybody has seen `failed` clear behind the barrier above
+    if (!g->barrier_nothrow(c->hb) || g->sh->failed.load()) return give_up("a peer gave the transport up after the self-test");
+    if (rank == 0) shm_unlink(name);   // everybody has it mapped and agrees
     g->limit = 120.0;   // ranks reach the solver's set-up barriers seconds apart (each uploads its own strip of Q first)
     return c;
 }
@@ -779,10 +829,16 @@ std::string ipc_name_of(const unsigned char id[128]) {   // every rank of a job 
 static std::shared_ptr<Comm> ipc_upgrade(int rank, int world, int device, const unsigned char id[128], const std::shared_ptr<Comm> &keep) {
     const char *pe = std::getenv("XM_COMM_PEER");
     if (world <= 1 || world > kMaxPeers || id == nullptr || (pe && *pe == '0')) return nullptr;
+    {   // a launcher that says the job spans several nodes (torch.distributed.run: LOCAL_WORLD_SIZE < WORLD_SIZE): the rendezvous segment
+        // is per node, nobody would ever complete it -- keep RCCL at once instead of after the rendezvous time-out
+        const char *lw = std::getenv("LOCAL_WORLD_SIZE");
+        if (lw && *lw && std::atoi(lw) != world) { keep->fallback_note = "direct peer exchange not used (ranks on several nodes): RCCL all-gather"; return nullptr; }
+    }
     std::string why;
     auto pc = ipc_comm_try(rank, world, device, ipc_name_of(id).c_str(), 30.0, &why);
     if (!pc) {
         if (std::getenv("XM_COMM_TRACE")) std::fprintf(stderr, "xm_comm_init: rank %d keeps RCCL (%s)\n", rank, why.c_str());
+        keep->fallback_note = "direct peer exchange not used (" + why + "): RCCL all-gather";
         return nullptr;
     }
     pc->g->spin_seconds = 20.0;

@@ -2131,7 +2131,8 @@ void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
                     double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat, double *Afull,
                     double *Wfull, int grouping, const PeerXchg &xchg, hipStream_t st) {
-    XM_DISPATCH_O(o, hipLaunchKernelGGL((cg_step_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st, nloc,
+    // grid = nB_loc: one |r|^2 partial sum per workgroup (Context::tcg_blocks: capped when the launch waits for its peers inside the kernel)
+    XM_DISPATCH_O(o, hipLaunchKernelGGL((cg_step_kernel<O_>), dim3(nB_loc), dim3(256), 0, st, nloc,
                                         scal_cur, scal_next, parts, nA_loc, nB_loc, world, HpR, Hps, R, s, pR, ps_cur, ps_next, vR,
                                         vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat, b_off, mat, Afull, Wfull, grouping, xchg));
     check_launch("cg_step");

@@ -280,7 +280,8 @@ SellArgs SellMatrix::args() const {
     a.diag = (codec_ == SELL_CODEC_QUAT) ? diag_.p : nullptr;
     a.row0 = row0_;
     a.wstride = 0;   // set per rank by the launcher (wstride(o))
-    a.coalesced_store = coalesced_ ? 1 : 0;
+    static const bool wt = [] { const char *e = std::getenv("XM_SELL_WT"); return e && *e == '1'; }();   // experiment: write-through partial stores
+    a.coalesced_store = coalesced_ ? (wt ? 2 : 1) : 0;
     return a;
 }
 
@@ -563,7 +564,11 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
 #pragma unroll
             for (int i = 0; i < (TOT2 + 63) / 64; ++i) {
                 const int idx = i * 64 + lane;
-                if (idx < TOT2) o2[idx] = l2[idx];
+                if (idx < TOT2) {
+                    // write-through: nothing of the partial results is left dirty in the L2 for the end of the launch to write back
+                    if (m.coalesced_store == 2) { const d2a v = l2[idx]; asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o2 + idx), "v"(v) : "memory"); }
+                    else o2[idx] = l2[idx];
+                }
             }
             return;
         }

@@ -66,7 +66,7 @@ struct Sell2Args {   // what the kernel sees
     const double *blk;      // pair [e][lane][2], single [e][lane]; e < 9 | 4 by codec
     const double *diag;     // quaternion codec: diagonal scalar per local camera (else nullptr)
     int64_t row0;
-    double *tiles;          // ntiles x (3 x o) x 64: planes of 64 lane values, two planes interleaved (16 bytes per lane), a last odd plane alone
+    double *tiles;          // ntiles x (3 x o) x 64: per tile 3 x o planes of 64 lane values
     unsigned int *arrived;  // nchunks arrival counters, zero between launches
     int nchunks;
     int S;

@@ -296,11 +296,11 @@ __device__ __forceinline__ void wave_lds_sync() {   // orders the LDS accesses o
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-// agent-scope (write-through) stores and L1-bypassing loads of the tiles: the hand-off between wavefronts on different XCDs
-__device__ __forceinline__ void st_agent16(double *p, d2a v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st_agent8(double *p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void ld_agent16(const double *p, d2a &v) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
-__device__ __forceinline__ void ld_agent8(const double *p, double &v) { asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+// agent-scope (write-through) stores and L1-bypassing loads of the tiles: the hand-off between wavefronts on different XCDs.  Builtins,
+// not inline assembly: the compiler has to know when a loaded register is valid (an asm load followed by a separate s_waitcnt lets it
+// copy the destination before the data has landed -- seen: lanes 12..15 of every 16 received stale values).
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // 64 consecutive records of REC doubles (one per lane): fetched with lane-consecutive loads and turned into record-per-lane through LDS
 template <int REC>
@@ -612,12 +612,11 @@ __device__ __forceinline__ void qw_sell2_body(const Sell2Args &m, const double *
         }
     }
     wave_lds_sync();
-    // the tile: planes of 64 lane values, two planes interleaved per 16-byte store, the odd last plane alone
+    // the tile: 3 x O planes of 64 lane values (every store instruction covers 512 contiguous bytes)
     {
-        double *tp = m.tiles + (size_t)tile * (64 * NV);
+        double *tp = m.tiles + (size_t)tile * (64 * NV) + lane;
 #pragma unroll
-        for (int i = 0; i < NV / 2; ++i) st_agent16(tp + i * 128 + lane * 2, d2a{tot[2 * i], tot[2 * i + 1]});
-        if (NV & 1) st_agent8(tp + (NV / 2) * 128 + lane, tot[NV - 1]);
+        for (int e = 0; e < NV; ++e) st_agent(tp + e * 64, tot[e]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile has reached memory before the arrival is counted
     const int t0 = m.tile_ptr[chunk], t1 = m.tile_ptr[chunk + 1];
@@ -643,32 +642,20 @@ __device__ __forceinline__ void qw_sell2_body(const Sell2Args &m, const double *
 #pragma unroll
         for (int e = 0; e < NV; ++e) sum[e] = 0.0;
         for (int t = t0; t < t1; t += TB) {
-            d2a v[TB][(NV / 2 > 0) ? NV / 2 : 1];
-            double u[TB];
+            double v[TB][NV];
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
+                const int tt = (t + b < t1) ? t + b : t1 - 1;   // clamped, unconditional loads; the surplus is not added
+                const double *tp = m.tiles + (size_t)tt * (64 * NV) + lane;
 #pragma unroll
-                for (int i = 0; i < NV / 2; ++i) v[b][i] = d2a{0.0, 0.0};
-                u[b] = 0.0;
-                if (t + b < t1) {   // wave-uniform
-                    const double *tp = m.tiles + (size_t)(t + b) * (64 * NV);
-#pragma unroll
-                    for (int i = 0; i < NV / 2; ++i) ld_agent16(tp + i * 128 + lane * 2, v[b][i]);
-                    if (NV & 1) ld_agent8(tp + (NV / 2) * 128 + lane, u[b]);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int b = 0; b < TB; ++b) {
-#pragma unroll
-                for (int i = 0; i < NV / 2; ++i) asm volatile("" : "+v"(v[b][i]));   // uses stay behind the wait
-                asm volatile("" : "+v"(u[b]));
+                for (int e = 0; e < NV; ++e) v[b][e] = ld_agent(tp + e * 64);
             }
 #pragma unroll
             for (int b = 0; b < TB; ++b) {   // tile order: the sum does not depend on which slice arrived last
+                if (t + b < t1) {
 #pragma unroll
-                for (int i = 0; i < NV / 2; ++i) { sum[2 * i] += v[b][i].x; sum[2 * i + 1] += v[b][i].y; }
-                if (NV & 1) sum[NV - 1] += u[b];
+                    for (int e = 0; e < NV; ++e) sum[e] += v[b][e];
+                }
             }
         }
 #pragma unroll

@@ -62,6 +62,10 @@ struct Comm {
     virtual void reserve(size_t doubles) { (void)doubles; }   // collective: staging capacity of allgather (per rank chunk * world)
     virtual void check_device_error() {}                      // throws XM_ERR_COMM when a device-side wait expired
     virtual void host_barrier() {}
+    // ranks of this communicator whose kernels run on THIS rank's device (1 on a real node; > 1 for virtual devices / processes sharing a GPU):
+    // a launch that waits for its peers inside the kernel must leave room for theirs (Context::tcg_blocks)
+    virtual int ranks_on_my_device() const { return 1; }
+    std::string fallback_note;   // why a faster transport was given up for this one (empty: first choice)
     void note(const char *what, double a, double b);   // XM_COMM_TRACE debugging aid
 private:
     FILE *trace_ = nullptr;
@@ -77,6 +81,10 @@ void comm_finalize();
 struct PeerGroup;
 std::shared_ptr<PeerGroup> peer_group_create(int world, const int *devices, double spin_seconds);
 std::shared_ptr<Comm> peer_comm_create(const std::shared_ptr<PeerGroup> &g, int rank);   // call on rank's own thread, device current
+bool peer_comm_selftest(Comm &c);   // collective over the ranks of a peer communicator: all-gathers with known contents through both read paths
+// library communicator for a rank driven by a host thread of THIS process (the fallback of the single-process multi-GPU mode): every
+// rank calls it concurrently with the same id (comm_unique_id) and its own device current
+std::shared_ptr<Comm> rccl_comm_create(int rank, int world, const unsigned char id[128]);
 void peer_group_abort(const std::shared_ptr<PeerGroup> &g);
 double peer_allgather_bench(int world, int gpu_map, int64_t count, int reps);   // microseconds per collective (xm_team.hip)                               // wakes every host-side wait with an error
 
@@ -135,6 +143,8 @@ public:
     // comm: the communicator of THIS context (nullptr = default_comm()); the HIP device current on the calling thread is the rank's
     explicit Context(const xm_problem_t &prob, std::shared_ptr<Comm> comm = nullptr);
     int rank() const { return comm_->rank; }
+    int comm_kind() const { return comm_->active() ? comm_->kind() : 0; }
+    const std::string &fallback_note() const { return comm_->fallback_note; }
     int world() const { return comm_->world; }
     int64_t cameras() const { return n_; }
     int64_t edges() const { return ne_; }
@@ -246,6 +256,7 @@ private:
     void download_point(std::vector<double> &R_cm, std::vector<double> &s_ex);
     CamArgs cam_args(int state) const;
     int prod_grid() const;
+    int tcg_blocks() const;   // workgroups of cg_step_kernel == |r|^2 partial sums per rank
     void product(int epi, int o, double alpha, const CamArgs &a);
     void gather_W();          // all-gather of the product input; deferred into the next product() when the overlap applies
     void flush_gather();      // perform a deferred gather now
@@ -272,6 +283,8 @@ public:
     Team(const Team &) = delete;
     Team &operator=(const Team &) = delete;
     int world() const;
+    int comm_kind() const;                       // Comm::kind() of the ranks' communicators
+    const std::string &fallback_note() const;    // why the direct peer exchange was given up (empty: it was not)
     void solve(const xm_options_t &opt, xm_result_t &res);
     void attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);
     void edge_residuals(double *res);

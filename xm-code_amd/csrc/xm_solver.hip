@@ -315,8 +315,11 @@ void Context::init(const xm_problem_t &prob_in) {
         if (cfg_.sell == 1 || (cfg_.sell == 0 && nb_loc_ >= 1000000)) {
             sell_gm_ = cfg_.sell_gather;
             const int codec = (cfg_.sell_codec == 2 || (cfg_.sell_codec == 0 && viewgraph)) ? SELL_CODEC_QUAT : SELL_CODEC_FULL;
-            // chunk-tiled layout (product + per-camera sum + epilogue in ONE launch) wherever its 24-bit column field reaches
-            const bool tiled = cfg_.sell_layout == 2 || (cfg_.sell_layout == 0 && ntot_ < kSell2MaxCols);
+            // layout: sorted virtual rows + a second launch for the per-camera sum (xm_sell.h) unless the chunk-tiled one-launch layout
+            // (xm_sell2.h) is asked for -- measured at 100 k cameras, o = 3, view-graph codec (profiles/r04_kbench_sell2.txt): 82.3 us
+            // in two launches against 90.3 us in one; both spend their time in the texture data path of the gather (PMC: TD busy 78 %),
+            // and the one-launch form pays 50 % more VALU and 25 % more LDS instructions for its row-end logic
+            const bool tiled = cfg_.sell_layout == 2 && ntot_ < kSell2MaxCols;
             if (tiled) sell2_.reset(new Sell2Matrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_kmax, st_, codec, cam0_));
             else sell_.reset(new SellMatrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_lmax, st_, codec, cam0_));
         }
@@ -390,7 +393,7 @@ void Context::setup_rank(int o) {
     }
     cur_ = 0;
     W_.alloc((size_t)ld_ * OP_ + 2);
-    const int nA_loc = prod_grid(), nB_loc = flat_grid((int64_t)mat);
+    const int nA_loc = prod_grid(), nB_loc = tcg_blocks();
     nA_ = nA_loc * world;
     nB_ = nB_loc * world;
     partsA_.alloc((size_t)3 * nA_);
@@ -410,7 +413,7 @@ void Context::setup_rank(int o) {
         partsB_.alloc(pb);
     }
     if (comm_->active()) Afull_.alloc(mat * world); else Afull_.release();
-    partsM_.alloc((size_t)std::max(nB_, 2 * ((nloc_ + 255) / 256) * world));
+    partsM_.alloc((size_t)std::max(std::max(nB_, flat_grid((int64_t)mat) * world), 2 * ((nloc_ + 255) / 256) * world));
     if (sym_ok_ && o >= 3 && o <= sym_max_o_) {
         Prow_.alloc(sym_prow_count(nloc_, ld_, o));
         Pcol_.alloc(sym_pcol_count(nloc_, ld_, o), false);
@@ -491,6 +494,15 @@ int Context::prod_grid() const {
     if (storage_ == XM_STORAGE_BSR3 && sell2_ && Sell2Matrix::supports(o_, ntot_)) return sell2_->nchunks();
     if (storage_ == XM_STORAGE_BSR3 && sell_ && sell_supports(o_)) return sell_->reduce_grid(o_, nloc_);
     return (storage_ == XM_STORAGE_BSR3) ? bsr_grid(nloc_) : qw_grid(nloc_);   // dense and matrix-free: one wavefront per camera
+}
+
+// cg_step_kernel waits for its peers INSIDE the launch when the direct exchange is fused into it: every workgroup of every rank that
+// shares this device has to be resident at once, or the resident ones wait for the others' turn for ever (until the bounded spin
+// expires).  256 CUs x 4 workgroups is admitted whatever the kernel's register count (cg_step: 61 VGPRs, 106 SGPRs -> 6 per CU).
+int Context::tcg_blocks() const {
+    int g = flat_grid((int64_t)nloc_ * 3 * OP_);
+    if (comm_->peer() && comm_->world > 1 && cfg_.exchange != 1) g = std::min(g, std::max(8, 1024 / std::max(1, comm_->ranks_on_my_device())));
+    return g;
 }
 
 CamArgs Context::cam_args(int state) const {
@@ -681,7 +693,7 @@ void Context::finish_profile() {
 int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     const bool stepped = (opt_->flags & XM_FLAG_HOST_STEPPED) != 0;
     const bool profile = (opt_->flags & XM_FLAG_PROFILE_QW) != 0;
-    const int nA_loc = prod_grid(), nB_loc = flat_grid((int64_t)nloc_ * 3 * OP_);
+    const int nA_loc = prod_grid(), nB_loc = tcg_blocks();
     const int rank = comm_->rank;
     double *Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
     const PointState &P = ps_[cur_];
@@ -889,7 +901,7 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         const long long drop_at = cfg_.debug_drop_finalize;
         if (drop_at >= 0 && (long long)outer_seq_ + 1 == drop_at) ++outer_seq_;
         else
-        launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, nB_, scal_.p + (enq & 1),
+        launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, nB_loc * comm_->world, scal_.p + (enq & 1),
                               reinterpret_cast<double *>(hstat_dev_) + 8, ++outer_seq_, grouping_, st_);
         volatile double *hres = wait_outer_result();
         double f_new = hres[0], rr_new = hres[1], loss_qu = hres[2];
@@ -1355,11 +1367,18 @@ double Context::xm2_filter(const double *rot, const double *scale, double pct, i
     launch_xm2_error(ne, ew_.p, res, eerr_.p, st_);
     DevBuf<unsigned int> hist;
     hist.alloc(65536 + 1);
-    // numpy.percentile, method "linear": h = (n - 1) q; x[floor h] + (h - floor h) (x[floor h + 1] - x[floor h])
-    const double hq = (double)(ne - 1) * pct / 100.0;
-    const int64_t k0 = (int64_t)std::floor(hq), k1 = std::min<int64_t>(k0 + 1, ne - 1);
-    const double x0 = radix_select(eerr_.p, ne, k0, hist.p, st_);
-    const double x1 = (k1 == k0) ? x0 : radix_select(eerr_.p, ne, k1, hist.p, st_);
+    // numpy.percentile, method "linear": h = (n - 1) q; x[floor h] + (h - floor h) (x[floor h + 1] - x[floor h]) -- over the edges that are
+    // still THERE: the reference deletes the removed ones before the next round's percentile (3_test_colmap_glomap.py:321-328).  Here a
+    // removed edge keeps its place with weight 0, hence error 0: the nz zeros sort in front of every live error (>= 0), so the k-th order
+    // statistic of the survivors is entry k + nz of the whole array.
+    int64_t nz = 0;
+    for (int64_t e = 0; e < ne; ++e) nz += (w_cur_[(size_t)e] == 0.0);
+    const int64_t nlive = ne - nz;
+    if (nlive < 1) throw Error(XM_ERR_ARG, "xm2_filter: every edge has been removed already");
+    const double hq = (double)(nlive - 1) * pct / 100.0;
+    const int64_t k0 = (int64_t)std::floor(hq), k1 = std::min<int64_t>(k0 + 1, nlive - 1);
+    const double x0 = radix_select(eerr_.p, ne, k0 + nz, hist.p, st_);
+    const double x1 = (k1 == k0) ? x0 : radix_select(eerr_.p, ne, k1 + nz, hist.p, st_);
     const double thr = x0 + (hq - (double)k0) * (x1 - x0);
     XM_HIP_CHECK(hipMemsetAsync(hist.p + 65536, 0, sizeof(unsigned int), st_));
     DevBuf<double> wn;

@@ -24,6 +24,8 @@ struct Team::Impl {
     int world = 1;
     std::vector<int> device;
     std::shared_ptr<PeerGroup> group;
+    int kind = 0;               // Comm::kind() of the transport in use (3 direct peer writes | 1 RCCL)
+    std::string fallback;       // why the direct peer writes were given up (empty: they were not)
     std::vector<std::unique_ptr<Context>> ctx;
     std::vector<std::shared_ptr<Comm>> comm;
     // worker pool
@@ -54,7 +56,7 @@ struct Team::Impl {
                 f(r);
             } catch (...) {
                 e = std::current_exception();
-                peer_group_abort(group);   // wake the other ranks out of their waits
+                if (group) peer_group_abort(group);   // wake the other ranks out of their waits
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -106,16 +108,53 @@ Team::Team(const xm_problem_t &prob, int n_gpus, int gpu_map) : p_(new Impl) {
     const Settings cfg = Settings::resolve(prob.tuning);
     // device-side waits give up after min(watchdog / 3, 30 s): long enough for a peer that lags, short enough not to look hung, and well
     // before the host-side watchdog of the rank that waits (so that the failure is reported as what it is: XM_ERR_COMM)
-    t.group = peer_group_create(n_gpus, t.device.data(), std::min(30.0, cfg.watchdog_s / 3.0));
     t.ctx.resize((size_t)n_gpus);
     t.comm.resize((size_t)n_gpus);
     t.err.resize((size_t)n_gpus);
     for (int r = 0; r < n_gpus; ++r) t.th.emplace_back([this, r] { p_->worker(r); });
+    // Transport ladder.  (1) direct peer writes (xm_comm.hip: PeerComm): every rank maps the peers' fine-grained arenas and the transport
+    // has to pass its self-test -- all-gathers with known contents through both read paths -- on THIS machine before a solver relies on
+    // it.  (2) RCCL, one communicator per host thread (the library's own transport over xGMI; one all-gather per tCG iteration instead
+    // of the fused exchange).  (3) XM_ERR_COMM naming both reasons.  XM_EXCHANGE=1 / xm_tuning_t.exchange = 1 asks for (2) directly.
+    // device-side waits give up after min(watchdog / 3, 30 s): long enough for a peer that lags, short enough not to look hung, and well
+    // before the host-side watchdog of the rank that waits (so that the failure is reported as what it is: XM_ERR_COMM)
+    std::string why_peer;
+    bool have = false;
+    if (cfg.exchange != 1) {
+        try {
+            t.group = peer_group_create(n_gpus, t.device.data(), std::min(30.0, cfg.watchdog_s / 3.0));
+            t.run([&](int r) {
+                t.comm[(size_t)r] = peer_comm_create(t.group, r);
+                if (!peer_comm_selftest(*t.comm[(size_t)r])) throw Error(XM_ERR_COMM, "peer communicator: the transport self-test failed on rank " + std::to_string(r));
+            });
+            have = true;
+            t.kind = 3;
+        } catch (const std::exception &e) {
+            why_peer = e.what();
+            for (int r = 0; r < n_gpus; ++r) { (void)hipSetDevice(t.device[(size_t)r]); (void)hipDeviceSynchronize(); t.comm[(size_t)r].reset(); }
+            t.group.reset();
+            { std::lock_guard<std::mutex> lk(t.mu); t.broken = false; }
+        }
+    } else {
+        why_peer = "RCCL requested (exchange = 1)";
+    }
+    if (!have) {
+        try {
+            unsigned char id[128];
+            comm_unique_id(id);
+            t.run([&](int r) { t.comm[(size_t)r] = rccl_comm_create(r, n_gpus, id); });
+            for (auto &c : t.comm) c->fallback_note = "direct peer writes not used (" + why_peer + "): RCCL all-gather per exchange";
+            t.kind = 1;
+            t.fallback = t.comm[0]->fallback_note;
+        } catch (const std::exception &e) {
+            const std::string why_rccl = e.what();
+            shutdown();
+            throw Error(XM_ERR_COMM, "multi-GPU context: no transport between the " + std::to_string(n_gpus) + " ranks -- direct peer writes: " + why_peer +
+                                         "; RCCL: " + why_rccl);
+        }
+    }
     try {
-        t.run([&](int r) {
-            t.comm[(size_t)r] = peer_comm_create(t.group, r);
-            t.ctx[(size_t)r].reset(new Context(prob, t.comm[(size_t)r]));
-        });
+        t.run([&](int r) { t.ctx[(size_t)r].reset(new Context(prob, t.comm[(size_t)r])); });
     } catch (...) {
         shutdown();
         throw;
@@ -144,6 +183,8 @@ void Team::shutdown() {
 Team::~Team() { shutdown(); }
 
 int Team::world() const { return p_->world; }
+int Team::comm_kind() const { return p_->kind; }
+const std::string &Team::fallback_note() const { return p_->fallback; }
 
 void Team::solve(const xm_options_t &opt, xm_result_t &res) {
     Impl &t = *p_;
