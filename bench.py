@@ -131,23 +131,67 @@ def source_sha256():
     return h.hexdigest()
 
 
-def recorded_traffic(workload, world):
-    """roofline.traffic: HBM-side bytes per launch of the dominant kernel from a rocprofv3 --pmc FETCH_SIZE pass over THIS command
-    (scripts/pmc_hess.sh).  Only a profile stamped with the hash of the current sources is quoted; otherwise None + the reason."""
+def recorded_traffic(leg, world=1):
+    """roofline.traffic: HBM-side bytes per product of the dominant kernel(s) from a rocprofv3 --pmc FETCH_SIZE pass over THIS command
+    (scripts/pmc_legs.py; round 1-3: scripts/pmc_hess.sh).  Only a profile stamped with the hash of the current sources is quoted;
+    otherwise None + the reason.  Returns (bytes, source, traced average duration in microseconds or None)."""
     import glob
-    if workload != "venice1778" or world != 1:
-        return None, "no PMC pass recorded for this workload / GPU count"
+    if world != 1:
+        return None, "no PMC pass recorded for this GPU count", None
     sha = source_sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_hess_bench.json")), reverse=True):
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_%s.json" % leg)), reverse=True)
+    if leg == "venice":
+        cands += sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_hess_bench.json")), reverse=True)
+    for f in cands:
         try:
             pmc = json.load(open(f))
         except Exception:
             continue
-        if pmc.get("source_sha256") == sha:
-            return pmc["hess_all_ranks_weighted"]["hbm_side_bytes_per_real_launch"], (
-                os.path.relpath(f, ROOT) + " (rocprofv3 --pmc FETCH_SIZE pass over this command's own Hessian launches on these sources, "
-                "no-ops dropped; x1024 x2 per MI355X_MICROARCH.md)")
-    return None, "no PMC profile stamped with the current source hash %s (run scripts/pmc_hess.sh on the GPU box)" % sha[:12]
+        if pmc.get("source_sha256") != sha:
+            continue
+        src = os.path.relpath(f, ROOT) + (" (rocprofv3 --pmc FETCH_SIZE pass over this command's own launches on these sources, no-ops dropped; "
+                                          "x1024 x2 per MI355X_MICROARCH.md; a --kernel-trace pass of the same command gives traced_us)")
+        if "per_product" in pmc:
+            return pmc["per_product"]["hbm_side_bytes"], src, pmc["per_product"].get("traced_us")
+        return pmc["hess_all_ranks_weighted"]["hbm_side_bytes_per_real_launch"], src, None
+    return None, "no PMC profile of leg '%s' stamped with the current source hash %s (run scripts/pmc_legs.py on the GPU box)" % (leg, sha[:12]), None
+
+
+RECORDED_ORACLE = {   # workload -> (recorded run of the CPU oracle, its anchored rotations, every k-th camera kept)
+    "venice1778": ("venice1778_oracle.json", "venice1778_oracle_rot.npy", 1),
+    "final13682": ("rome13682_oracle.json", "rome13682_oracle_rot.npy", 1),
+    "vg100k": ("vg100k_oracle.json", "vg100k_oracle_rot_every8.npy", 8),
+}
+
+
+def parity_vs_recorded_oracle(workload_name, R, s, primal):
+    """SURVEY 8d 'parity numbers between CPU and GPU results', computed IN THIS RUN: the timed GPU solution against the CPU oracle's recorded
+    solve of the same Q (tests/golden/synth, recorded by scripts/record_oracle_large.py) -- anchored rotations (north_star's <= 1e-6
+    relative Frobenius), a sample of 3x3 blocks R_i^T R_j of the rotation Gram matrix, and the optimum."""
+    import xm_testlib as tl
+    if workload_name not in RECORDED_ORACLE:
+        return None
+    fj, fr, every = RECORDED_ORACLE[workload_name]
+    g = os.path.join(ROOT, "tests", "golden", "synth")
+    if not (os.path.exists(os.path.join(g, fj)) and os.path.exists(os.path.join(g, fr))):
+        return None
+    c = json.load(open(os.path.join(g, fj)))
+    ref = np.load(os.path.join(g, fr))
+    rot, _ = tl.recover_rotations(R, s)
+    n = rot.shape[1] // 3
+    sub = rot.reshape(3, n, 3)[:, ::every, :].reshape(3, -1) if every > 1 else rot
+    ref = ref.reshape(3, -1)
+    m = sub.shape[1] // 3
+    idx = np.random.default_rng(12345).integers(0, m, size=(20000, 2))
+    A, B = sub.reshape(3, m, 3), ref.reshape(3, m, 3)
+    ga = np.einsum("aki,akj->kij", A[:, idx[:, 0], :], A[:, idx[:, 1], :])
+    gb = np.einsum("aki,akj->kij", B[:, idx[:, 0], :], B[:, idx[:, 1], :])
+    return {"rotations_rel_fro": tl.rel_fro(sub, ref), "gram_sample_rel_fro": tl.rel_fro(ga, gb),
+            "f_rel": abs(primal - c["f"]) / max(abs(c["f"]), 1e-300), "tolerance": 1e-6,
+            "against": "tests/golden/synth/%s + %s: the CPU oracle's recorded solve of the same Q (rank %s, %d tCG iterations)" % (fj, fr, c.get("rank", 3), c["tcg"]),
+            "cpu_wallclock_to_kkt_s": c.get("seconds"), "cpu_threads": c.get("threads"),
+            "cpu_wallclock_provenance": "oracle/xm_oracle.c to its certificate on %s OpenMP threads of the build container (scripts/record_oracle_large.py); "
+                                        "not re-run here: %.0f s" % (c.get("threads"), c.get("seconds", 0.0))}
 
 
 def cpu_baseline(Q, wl, budget_s, bsr=None):
@@ -167,7 +211,7 @@ def cpu_baseline(Q, wl, budget_s, bsr=None):
     el = time.time() - t0
     its = st["tcg_iters"]
     return dict(value=its / max(st["seconds"], 1e-9), unit="tCG iters/s", cores=xo.num_threads(), kind="port",
-                sample=f"rank-3 trust region of the same Q on the host for <= {budget_s:.0f}s of its own max_time clock: "
+                sample=f"RANK-3 STAGE ONLY (the GPU line is the whole staircase): rank-3 trust region of the same Q on the host for <= {budget_s:.0f}s of its own max_time clock: "
                        f"{its} tCG iters / {st['outer_iters']} outer in {st['seconds']:.1f}s (stop {st['stop_reason']}), "
                        f"Q*W {st['qw_seconds'] / max(st['qw_products'], 1) * 1e3:.2f} ms each",
                 qw_ms=st["qw_seconds"] / max(st["qw_products"], 1) * 1e3, wall_s=el,
@@ -175,7 +219,9 @@ def cpu_baseline(Q, wl, budget_s, bsr=None):
                     xo.num_threads(), os.environ.get("OMP_PLACES"), os.environ.get("OMP_PROC_BIND"), _HOST_BUDGET[2],
                     "none" if _HOST_BUDGET[1] is None else "%.1f CPUs" % _HOST_BUDGET[1]),
                 qw_host_GBs=((76.0 * bsr[1].size + 4 * (n + 1)) if bsr is not None else 8.0 * (3 * n) ** 2) / 1e9 /
-                            max(st["qw_seconds"] / max(st["qw_products"], 1), 1e-12))
+                            max(st["qw_seconds"] / max(st["qw_products"], 1), 1e-12),
+                residency=("L3 (the matrix fits the host's last-level caches: qw_host_GBs is a cache rate, not DRAM)"
+                           if ((76.0 * bsr[1].size) if bsr is not None else 8.0 * (3 * n) ** 2) < 400e6 else "DRAM"))
 
 
 def main():
@@ -287,8 +333,10 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
     barrier()
     t0 = time.perf_counter()
     infos = []
+    last_sol = None
     for i in range(args.steps):
-        infos.append(one_solve(flags=xmamd.FLAG_PROFILE_QW, grouping=i % 3)[2])
+        last_sol = one_solve(flags=xmamd.FLAG_PROFILE_QW, grouping=i % 3)
+        infos.append(last_sol[2])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -320,7 +368,8 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
     achieved = alg_bytes / (qw_ms * 1e-3) / 1e9 if qw_ms > 0 else 0.0
     # HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE (own pass, kernel-trace only), corrected as
     # MI355X_MICROARCH.md prescribes (KB -> bytes, x2 for the gfx950 wide-load half count); see profiles/r01_pmc_*.json
-    traffic, traffic_source = recorded_traffic(args.workload, world)
+    leg = {"venice1778": "venice", "vg100k": "vg100k_" + args.storage}.get(args.workload, args.workload)
+    traffic, traffic_source, traced_us = recorded_traffic(leg, world)
     out = {
         "metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
         "value": iters / elapsed, "unit": "tCG iters/s", "n_gpus": ngp, "steps": args.steps, "warmup": args.warmup,
@@ -348,7 +397,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                   "tr_seconds": last["tr_seconds"], "cert_seconds": last["cert_seconds"], "setup_gen_s": gen_s,
                   "tcg_iters_by_step": [i["tcg_iters"] for i in infos], "exchange": last.get("exchange")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_source, "kernel": kname + (" via the half-traffic symmetric path (qw_sym_kernel + sym_reduce_kernel; bytes counted at FULL storage, SURVEY 8d)" if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
+                     "traffic": traffic, "traffic_source": traffic_source, "traced_avg_launch_us": traced_us, "kernel": kname + (" via the half-traffic symmetric path (qw_sym_kernel + sym_reduce_kernel; bytes counted at FULL storage, SURVEY 8d)" if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); " + (
                              "per-rank Q is %.0f MB, inside the 256 MB Infinity Cache: the figure is cache-assisted, see roofline_hbm for the "
@@ -405,6 +454,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                                        "n_gpus": ngp, "value": di["tcg_iters"] / el, "unit": "tCG iters/s", "steps": 1, "warmup": "one outer iteration",
                                        "ms_per_step": el * 1e3, "rank": di["rank"], "status": di["status"], "tcg_iters_per_solve": di["tcg_iters"],
                                        "primal": di["primal"], "sym_product": di.get("sym_product"), "hess_launch_ms": dq_ms,
+                                       **dict(zip(("hess_traffic", "hess_traffic_source", "hess_traced_us"), recorded_traffic("rome_dense", world))),
                                        "hess_algorithmic_GBs": db / (dq_ms * 1e-3) / 1e9 if dq_ms > 0 else None}
     if rank == 0 and ngp == 1 and not args.no_hbm_check and wl["kind"] == "dense":
         # same kernel, matrix far beyond every cache: 13682 cameras = 13.5 GB of random f64 generated on the device
@@ -418,8 +468,10 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         ms = xmamd.C.c_double()
         xmamd._chk(xmamd.lib().xm_qw_dense_time(Qbig.data_ptr(), nb_, o_, Wbig.data_ptr(), Obig.data_ptr(), 20, xmamd.C.byref(ms)))
         by = 8.0 * (3 * nb_) ** 2 + 2 * 8 * 3 * nb_ * o_
+        htr, hsrc, hus = recorded_traffic("hbm13682", 1)
         out["roofline_hbm"] = {"bound": "hbm", "achieved": by / (ms.value * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": by / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms.value,
+                               "traffic": htr, "traffic_source": hsrc, "traced_avg_launch_us": hus,
                                "algorithmic_bytes_per_launch": by, "kernel": "qw_dense_kernel<3, EPI_PLAIN>",
                                "workload": "same kernel on a 13682-camera (Final-13682-size) 13.5 GB random matrix, 20 launches"}
         del Qbig, Wbig, Obig
@@ -429,6 +481,13 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         out["cpu_baseline"] = cpu_baseline(Q, wl, args.cpu_seconds)
     elif rank == 0 and ngp == 1 and args.cpu_seconds > 0 and wl["kind"] == "vg" and args.storage in ("bsr", "vg"):
         out["cpu_baseline"] = cpu_baseline(None, wl, args.cpu_seconds, bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+    if rank == 0 and "cpu_baseline" in out and last_sol is not None:
+        par = parity_vs_recorded_oracle(args.workload, last_sol[0], last_sol[1], last["primal"])
+        if par is not None:
+            out["cpu_baseline"]["parity"] = {k: par[k] for k in ("rotations_rel_fro", "gram_sample_rel_fro", "f_rel", "tolerance", "against")}
+            out["cpu_baseline"]["wallclock_to_kkt_s"] = par["cpu_wallclock_to_kkt_s"]
+            out["cpu_baseline"]["wallclock_to_kkt_threads"] = par["cpu_threads"]
+            out["cpu_baseline"]["wallclock_to_kkt_provenance"] = par["cpu_wallclock_provenance"]
     if world > 1:
         xmamd.lib().xm_comm_finalize()
         # Replica throughput: what N GPUs deliver on N INDEPENDENT Venice-size scenes (no data-path communication; the row

@@ -88,7 +88,9 @@ typedef struct {
     int32_t sell;              /* sliced-ELL copy of a block-sparse Q: 0 auto (>= 1 M blocks per GPU), 1 force, -1 off */
     int32_t sell_slabs;        /* 0 = 4 (1, 2, 4, 8) */
     int32_t sell_lmax;         /* 0 = 64 */
-    int32_t sell_gather;       /* how the rows of W are fetched: 0 = default (records fetched element-per-lane, transposed through LDS), 1 = one record per lane */
+    int32_t sell_gather;       /* how the rows of W are fetched: 0 = default (2), 1 = one record per lane, 2 = records fetched element-per-lane and
+                                  transposed through LDS, 3 = the two aligned 64-byte sectors of every record fetched by two quads of lanes straight
+                                  into LDS (global_load_lds_dwordx4; o = 3; measured 88 us against 83 us for mode 2 at 100 k cameras: kept selectable) */
     int32_t sell_codec;        /* 0 auto (view-graph storage: quaternion codec; BSR3: full blocks), 1 full blocks, 2 quaternion codec (XM_ERR_ARG if Q is not a view-graph matrix) */
     int32_t overlap;           /* split dense products outside the tCG around the all-gather of W: 0 auto (>= overlap_min_mb per rank), -1 off */
     int32_t overlap_min_mb;    /* 0 = 64 */
@@ -97,8 +99,9 @@ typedef struct {
     int32_t lanczos_restarts;  /* 0 = 12 */
     int32_t watchdog_s;        /* host spin loops give up after this many seconds without progress; 0 = 600 */
     int32_t balance;           /* row partition of block-sparse storage: 0 = by stored blocks, 1 = equal camera ranges */
-    int32_t exchange;          /* multi-GPU tCG exchange: 0 auto (direct peer writes when the ranks share this process or IPC is set up, else RCCL),
-                                  1 RCCL all-gather, 2 direct peer writes */
+    int32_t exchange;          /* multi-GPU tCG exchange: 0 auto (direct peer writes fused into the tCG kernel when the ranks share this process or IPC
+                                  is set up and the transport passes its self-test, else RCCL), 1 an all-gather between the launches (whatever the
+                                  transport), 2 direct peer writes, 3 RCCL even where peer writes would work (single-process mode) */
     int32_t split_k;           /* dense product of a SMALL row strip with its columns split over several workgroups per camera group: 0 auto
                                   (multi-GPU runs whose strip has fewer than ~1.5 workgroups per CU), -1 off, 2..8 forced (also on one GPU) */
     int32_t sell_layout;       /* layout of the sliced-ELL copy: 0 auto (= 1), 1 = virtual rows sorted by length, two launches per product (xm_sell.h),

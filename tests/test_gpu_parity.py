@@ -86,13 +86,13 @@ def test_retraction_matches_oracle(xmamd, oracle, o):
 # ---------------------------------------------------------------------------------------------- sliced-ELL product (xm_sell.hip)
 @pytest.mark.parametrize("n,deg,o,slabs,lmax", [(1, 2, 3, 4, 64), (7, 3, 3, 8, 64), (200, 8, 3, 4, 64), (300, 20, 5, 2, 64), (1000, 12, 4, 8, 5),
                                                 (150, 40, 3, 1, 64), (211, 9, 1, 4, 64), (4000, 30, 3, 4, 64)])
-@pytest.mark.parametrize("gather", [0, 1])
+@pytest.mark.parametrize("gather", [0, 1, 2])    # 2: sector windows through LDS-DMA (o = 3; other ranks take mode 1)
 @pytest.mark.parametrize("layout", [1, 2])
 def test_qw_sell_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather, layout):
     """same product as test_qw_bsr3_matches_dense through the large-n layouts (1: sorted virtual rows, two launches; 2: chunk-tiled, one
     launch with the per-camera sum done by the last slice to arrive): every slab count, both gather modes, virtual rows / slices cut at
     lmax, odd and even slice widths (paired steps + unpaired last step)"""
-    if o == 1 and gather == 1:
+    if o == 1 and gather >= 1:
         pytest.skip("o = 1 has one gather mode")
     P = tl.gen_vg(n, deg=deg, sigma=0.3, seed=n + o)
     W = np.random.default_rng(n).standard_normal((3 * n, o))
@@ -126,6 +126,7 @@ def test_qw_sell_skewed_degrees_and_unsorted_rows(xmamd, layout):
         M = xmamd.SellMatrix(rowptr, colidx, blocks, slabs=slabs, lmax=lmax, layout=layout)
         assert tl.rel_fro(M.qw(W), ref) < 1e-13
         assert tl.rel_fro(M.qw(W, gather=1), ref) < 1e-13
+        assert tl.rel_fro(M.qw(W, gather=2), ref) < 1e-13
         M.close()
     assert tl.rel_fro(xmamd.qw_bsr3(rowptr, colidx, blocks, W), ref) < 1e-13
 
@@ -766,7 +767,9 @@ def test_rccl_two_ranks_on_one_gpu_or_documented_refusal(xmamd, tmp_path):
         assert res[0]["primal"] == res[1]["primal"] == pytest.approx(i1["primal"], rel=1e-9) and res[0]["status"] == 1
     else:
         blob = " ".join(str(r.get("err", "")) for r in res) + " ".join(outs)
-        assert any(k in blob for k in ("Duplicate GPU", "invalid usage", "invalid argument", "unhandled", "RCCL", "TIMEOUT")), blob[-800:]
+        # the one documented refusal of this RCCL build: a communicator may hold each GPU only once.  A time-out, a crash or any other
+        # error is a failure of this test.
+        assert all(not r["ok"] for r in res) and "TIMEOUT" not in blob and ("invalid usage" in blob or "Duplicate GPU" in blob), blob[-800:]
 
 
 @pytest.mark.parametrize("n", [1, 2, 3])

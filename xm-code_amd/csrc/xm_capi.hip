@@ -281,7 +281,8 @@ int xm_dev_count(int *count) {
     return XM_OK;
 }
 int xm_dev_alloc(void **ptr, size_t bytes) {
-    XM_TRY require_device(); XM_HIP_CHECK(hipMalloc(ptr, bytes ? bytes : 8)); XM_HIP_CHECK(hipMemset(*ptr, 0, bytes ? bytes : 8)); XM_HIP_CHECK(hipDeviceSynchronize()); return XM_OK; XM_CATCH
+    XM_TRY require_device(); const size_t padded = (bytes ? bytes : 8) + 128;   /* slack: the sector-window gather reads whole 64-byte sectors around a record */
+    XM_HIP_CHECK(hipMalloc(ptr, padded)); XM_HIP_CHECK(hipMemset(*ptr, 0, padded)); XM_HIP_CHECK(hipDeviceSynchronize()); return XM_OK; XM_CATCH
 }
 int xm_dev_free(void *ptr) { XM_TRY XM_HIP_CHECK(hipFree(ptr)); return XM_OK; XM_CATCH }
 int xm_dev_h2d(void *dst, const void *src, size_t bytes) { XM_TRY XM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return XM_OK; XM_CATCH }

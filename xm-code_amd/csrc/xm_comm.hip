@@ -48,7 +48,9 @@ Settings Settings::resolve(const xm_tuning_t *t) {
     s.sell = tri(z.sell, "XM_BSR_SELL");
     s.sell_slabs = z.sell_slabs > 0 ? z.sell_slabs : (int)env_ll("XM_SELL_SLABS", 4);
     s.sell_lmax = z.sell_lmax > 0 ? z.sell_lmax : (int)env_ll("XM_SELL_LMAX", 64);
-    s.sell_gather = z.sell_gather > 0 ? 0 : (int)env_ll("XM_SELL_GATHER", 1);
+    // tuning field: 0 auto (= 2) | 1 one record per lane | 2 element-per-lane + LDS transposition | 3 sector windows through LDS-DMA (o = 3; else 2);
+    // XM_SELL_GATHER names the kernel's mode directly (0 | 1 | 2)
+    s.sell_gather = z.sell_gather > 0 ? z.sell_gather - 1 : (int)env_ll("XM_SELL_GATHER", 1);
     s.sell_codec = z.sell_codec > 0 ? z.sell_codec : (int)env_ll("XM_SELL_CODEC", 0);
     s.sell_layout = z.sell_layout > 0 ? z.sell_layout : (int)env_ll("XM_SELL_LAYOUT", 0);
     s.sell_kmax = z.sell_kmax > 0 ? z.sell_kmax : (int)env_ll("XM_SELL_KMAX", 32);

@@ -590,6 +590,183 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Gather mode 2 (o = 3): SECTOR WINDOWS THROUGH LDS-DMA.  MEASURED SLOWER than mode 1 (profiles/r04_kbench_sell_gather2.txt: 100 k cameras
+// 88.2 against 82.8 us with the view-graph codec, 115.0 against 110.5 with full blocks, banded graph 76.2 against 61.8) and therefore not the
+// default; kept selectable because it is the exact "two accesses per record" form.  The idea: what bounds modes 0 / 1 is the texture data path of the gather (PMC,
+// profiles/r04_pmc_sell_diag_layout1.json: TD busy 78 % of the launch, 16.1 M 64-byte cache accesses per product = 2.47 per gathered
+// record): the lanes that fetch one 72-byte record sit in two different quads of a load instruction, and the unit coalesces inside a
+// quad, so a record costs 2.5-3 accesses for the 2 sectors it occupies.  Here a record (always inside ONE 128-byte window of two aligned
+// sectors: the stride is 72 = 64 + 8 bytes and W is 64-byte aligned) is fetched by EIGHT lanes = two quads that each read one whole
+// aligned sector -- exactly 2 accesses per record -- with global_load_lds_dwordx4: the data lands in LDS at lane * 16 bytes, i.e. already
+// record after record (no VGPRs, no ds_write instruction), and lane L picks its 9 doubles at offset (column & 7) of its window.
+// One step of 64 records = 8 such instructions (instruction i takes record 8 g + i in lane group g: the column index comes from lane
+// (g << 3 | i) with ONE ds_swizzle).  The windows of step k + 1 are in flight while the FMAs of step k run; one 8.1 KB buffer per
+// wavefront (the instruction slabs are skewed by 16 bytes so that lanes with equal window offsets do not meet on one bank).
+// ------------------------------------------------------------------------------------------------------------------
+// instruction I of a step's window fetch: lane group g = lane >> 3 takes record 8 g + I, whose column sits in lane (lane & 0x38) | I
+template <int I>
+__device__ __forceinline__ void sell_fetch_window(int j, const double *__restrict__ W, int piece, double *slab0) {
+    const int jr = __builtin_amdgcn_ds_swizzle(j, 0x18 | (I << 5));   // bit-mask mode inside each half of the wavefront: and 0x18, or I
+    const double *win = W + (((size_t)jr * 9) & ~(size_t)7) + 2 * piece;
+    __builtin_amdgcn_global_load_lds(win, (__attribute__((address_space(3))) void *)(slab0 + I * 130), 16, 0, 0);
+}
+
+template <int CODEC>
+__device__ __forceinline__ void qw_sell_body_g2(const SellArgs &m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
+                                                double *__restrict__ parts) {
+    constexpr int O = 3, REC = 9, NV = 9;
+    constexpr int NQ = (CODEC == SELL_CODEC_QUAT) ? 4 : 9;
+    constexpr int SLAB = 130;            // doubles per instruction slab: 64 lanes x 16 bytes + 16 bytes of skew
+    constexpr int TW = 8 * SLAB;         // per wavefront
+    if (scal != nullptr) {
+        if (scal->status != 0) return;
+    }
+    __shared__ __attribute__((aligned(16))) double lds[4 * TW];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per = 8 / m.S;
+    const int x = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int slab = x / per, sub = x - slab * per;
+    const int c = m.slab_start[slab] + (bi * per + sub) * 4 + wave;
+    if (c >= m.slab_start[slab + 1]) return;   // wave-uniform
+    const int64_t off = m.slice_off[c];
+    const int w = (int)(m.slice_off[c + 1] - off);
+    const int np = w >> 1;
+    const bool tail = (w & 1) != 0;
+    const int32_t *cb = m.cols + off * 64;
+    const double *bb = m.blk + off * (64 * NQ);
+    double *T = lds + wave * TW;
+    const int piece = lane & 7;
+    // where this lane's own record starts inside its slab: record r = lane sits in slab (r & 7), lane group (r >> 3)
+    const double *mine = T + (lane & 7) * SLAB + (lane >> 3) * 16;
+
+    double acc[3][O];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
+
+    auto load_cols = [&](int p) -> i2a { return __builtin_nontemporal_load(reinterpret_cast<const i2a *>(cb) + (size_t)p * 64 + lane); };
+    auto load_blk = [&](int p, d2a (&q)[NQ]) {
+        const d2a *b = reinterpret_cast<const d2a *>(bb) + (size_t)p * (64 * NQ) + lane;
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) q[e] = __builtin_nontemporal_load(b + e * 64);
+    };
+    // the 64 windows of one step -> LDS (8 instructions; nothing lands in registers)
+    auto fetch = [&](int j) {
+        sell_fetch_window<0>(j, W, piece, T); sell_fetch_window<1>(j, W, piece, T); sell_fetch_window<2>(j, W, piece, T);
+        sell_fetch_window<3>(j, W, piece, T); sell_fetch_window<4>(j, W, piece, T); sell_fetch_window<5>(j, W, piece, T);
+        sell_fetch_window<6>(j, W, piece, T); sell_fetch_window<7>(j, W, piece, T);
+    };
+    auto landed = [&]() {   // every window (and every block load issued before) has arrived; the LDS reads below may not move above this
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto take = [&](int j, double (&wv)[REC]) {
+        const double *src = mine + (j & 7);   // (column * 9) mod 8 == column mod 8: the record's offset inside its window, in doubles
+#pragma unroll
+        for (int e = 0; e < REC; ++e) wv[e] = src[e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads have been SERVED before the next windows are requested into the same buffer
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // everybody has its record: the buffer may be refilled
+    };
+    auto fma_step = [&](const double (&q)[9], const double (&wv)[REC]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k)
+                acc[r][k] = fma(q[3 * r + 2], wv[2 * O + k], fma(q[3 * r + 1], wv[O + k], fma(q[3 * r], wv[k], acc[r][k])));
+    };
+    auto expand_x = [&](const d2a (&q)[NQ], double (&q0)[9]) {
+        if constexpr (CODEC == SELL_CODEC_QUAT) quat_to_block(q[0].x, q[1].x, q[2].x, q[3].x, q0);
+        else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) q0[e] = q[e].x;
+        }
+    };
+    auto expand_y = [&](const d2a (&q)[NQ], double (&q1)[9]) {
+        if constexpr (CODEC == SELL_CODEC_QUAT) quat_to_block(q[0].y, q[1].y, q[2].y, q[3].y, q1);
+        else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) q1[e] = q[e].y;
+        }
+    };
+    int jt = 0;
+    if (tail) jt = __builtin_nontemporal_load(cb + (size_t)np * 128 + lane);
+    if (np > 0) {
+        d2a q[NQ];
+        i2a jc = load_cols(0);
+        load_blk(0, q);
+        fetch(jc.x);
+        for (int p = 0; p < np; ++p) {
+            const bool more = (p + 1 < np);
+            i2a jn = load_cols(more ? p + 1 : p);   // clamped, unconditional
+            double qe[9], wv[REC];
+            landed();                 // step 2p (and the pair's blocks)
+            take(jc.x, wv);
+            fetch(jc.y);              // step 2p + 1 travels while step 2p is multiplied
+            expand_x(q, qe);
+            fma_step(qe, wv);
+            landed();                 // step 2p + 1 (and jn)
+            take(jc.y, wv);
+            expand_y(q, qe);          // the stored pair is consumed: its registers take the next pair's blocks
+            if (more) { load_blk(p + 1, q); fetch(jn.x); }
+            else if (tail) fetch(jt);
+            fma_step(qe, wv);
+            jc = jn;
+        }
+    } else if (tail) {
+        fetch(jt);
+    }
+    if (tail) {
+        double qt[9], wv[REC];
+        const double *b = bb + (size_t)np * (128 * NQ) + lane;
+        if constexpr (CODEC == SELL_CODEC_QUAT) {
+            double t4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t4[e] = __builtin_nontemporal_load(b + e * 64);
+            quat_to_block(t4[0], t4[1], t4[2], t4[3], qt);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) qt[e] = __builtin_nontemporal_load(b + e * 64);
+        }
+        landed();
+        take(jt, wv);
+        fma_step(qt, wv);
+    }
+    if (m.coalesced_store) {   // as in the other modes: one contiguous run of 64 x 9 doubles per slice, through LDS
+        constexpr int TOT2 = 64 * NV / 2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k) T[lane * NV + r * O + k] = acc[r][k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        d2a *o2 = reinterpret_cast<d2a *>(parts + (size_t)c * 64 * NV);
+        const d2a *l2 = reinterpret_cast<const d2a *>(T);
+#pragma unroll
+        for (int i = 0; i < (TOT2 + 63) / 64; ++i) {
+            const int idx = i * 64 + lane;
+            if (idx < TOT2) o2[idx] = l2[idx];
+        }
+        return;
+    }
+    const int slot = m.pslot[(size_t)c * 64 + lane];
+    if (slot >= 0) {
+        double *o = parts + (size_t)slot * 3 * O;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k) o[r * O + k] = acc[r][k];
+    }
+}
+template <int CODEC>
+__global__ __launch_bounds__(256) void qw_sell_g2_kernel(SellArgs m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
+                                                          double *__restrict__ parts) {
+    qw_sell_body_g2<CODEC>(m, W, scal, parts);
+}
+
 template <int O, int GM, int ABL = 0, int PIPE = 0, int CODEC = 0>
 __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
                                                        double *__restrict__ parts) {
@@ -697,11 +874,19 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
         }
         // block loads one pair ahead: worth 2-3 us at o = 3 with full blocks; beyond that the second block buffer costs the occupancy
         // (o = 5: 256 VGPRs).  Quaternion codec: a pair of blocks is 16 registers, the second buffer is cheap at every rank.
+        if (gm == 2 && (O != 3 || sa.wstride != 9 || (reinterpret_cast<uintptr_t>(W) & 63) != 0)) gm = 1;   // sector windows: o = 3, native stride, W 64-byte aligned
+        if constexpr (O == 3) {
+            if (gm == 2 && abl == 0) {
+                if (quat) hipLaunchKernelGGL((qw_sell_g2_kernel<SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
+                else hipLaunchKernelGGL((qw_sell_g2_kernel<SELL_CODEC_FULL>), g, b, 0, st, sa, W, sc, parts);
+            }
+        }
         static const int pipe_env = [] { const char *e = std::getenv("XM_SELL_PIPE"); return (e && *e) ? std::atoi(e) : -1; }();
         // measured at 100 k cameras, o = 3 (profiles/r03_kbench_sell.txt): full blocks 111.4 / 111.3 / 110.5 us for pipe 0 / 1 / 2; quaternion
         // codec 82.4 / 84.2 / 204.8 (spills) / 81.9 us for pipe 0 / 1 / 2 / 3 -> 3 (four wavefronts per SIMD, no software pipeline)
         const int pipe = (pipe_env >= 0) ? pipe_env : (quat ? (O == 3 ? 3 : 0) : (O == 3 ? 1 : 0));
-        if (abl == 0 || O != 3) {
+        if (gm == 2 && abl == 0) {
+        } else if (abl == 0 || O != 3) {
             if (quat) {
                 bool launched = false;
                 if constexpr (O == 3) {   // the four-wavefront variants exist at o = 3 only (o = 4, 5 cannot reach that occupancy)

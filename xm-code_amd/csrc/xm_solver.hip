@@ -392,7 +392,7 @@ void Context::setup_rank(int o) {
         ps_[k].G.alloc(mat); ps_[k].rgR.alloc(mat); ps_[k].egs.alloc(vec); ps_[k].rgs.alloc(vec); ps_[k].S0.alloc(vec * 9);
     }
     cur_ = 0;
-    W_.alloc((size_t)ld_ * OP_ + 2);
+    W_.alloc((size_t)ld_ * OP_ + 16);   // + slack: the sector-window gather of the sliced-ELL product reads whole 64-byte sectors around a record
     const int nA_loc = prod_grid(), nB_loc = tcg_blocks();
     nA_ = nA_loc * world;
     nB_ = nB_loc * world;

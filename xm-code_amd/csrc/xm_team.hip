@@ -115,12 +115,13 @@ Team::Team(const xm_problem_t &prob, int n_gpus, int gpu_map) : p_(new Impl) {
     // Transport ladder.  (1) direct peer writes (xm_comm.hip: PeerComm): every rank maps the peers' fine-grained arenas and the transport
     // has to pass its self-test -- all-gathers with known contents through both read paths -- on THIS machine before a solver relies on
     // it.  (2) RCCL, one communicator per host thread (the library's own transport over xGMI; one all-gather per tCG iteration instead
-    // of the fused exchange).  (3) XM_ERR_COMM naming both reasons.  XM_EXCHANGE=1 / xm_tuning_t.exchange = 1 asks for (2) directly.
+    // of the fused exchange).  (3) XM_ERR_COMM naming both reasons.  XM_EXCHANGE=3 / xm_tuning_t.exchange = 3 asks for (2) directly
+    // (exchange = 1 keeps the peer transport and only takes the exchange out of the tCG kernel).
     // device-side waits give up after min(watchdog / 3, 30 s): long enough for a peer that lags, short enough not to look hung, and well
     // before the host-side watchdog of the rank that waits (so that the failure is reported as what it is: XM_ERR_COMM)
     std::string why_peer;
     bool have = false;
-    if (cfg.exchange != 1) {
+    if (cfg.exchange != 3) {
         try {
             t.group = peer_group_create(n_gpus, t.device.data(), std::min(30.0, cfg.watchdog_s / 3.0));
             t.run([&](int r) {
@@ -136,7 +137,7 @@ Team::Team(const xm_problem_t &prob, int n_gpus, int gpu_map) : p_(new Impl) {
             { std::lock_guard<std::mutex> lk(t.mu); t.broken = false; }
         }
     } else {
-        why_peer = "RCCL requested (exchange = 1)";
+        why_peer = "RCCL requested (exchange = 3)";
     }
     if (!have) {
         try {
