@@ -308,6 +308,15 @@ int xm_spd_inverse(int64_t n, double *A);
  * dispatched last, first such group, chunks }. */
 int xm_symv_plan(int64_t n, int32_t plan[4]);
 
+/* Multi-rank symmetric dense product (xm-code_amd/csrc/xm_symw.h), host-only views for the CPU test tests/test_symw_plan.py: the work list of one
+ * rank -- geom = {T, Th, tie, t0, nsteps, nstrips, K, number of items}, items: (strip, first step, end step) triples (NULL: sizes only) -- and the
+ * predicate "row step t uses block (t, u)" of a matrix of T steps. */
+int xm_symw_plan(int64_t ntot, int nloc, int cam0, int K, int32_t geom[8], int32_t *items);
+int xm_symw_use(int T, int t, int u);
+/* timing of ONE rank's share of that product on this GPU (rank cam0 / nloc of `world`, an arbitrary row strip): ms[0] = sweep + column sums,
+ * ms[1] = per-camera sum + plain epilogue; *bytes = bytes of Q the sweep streams (half of the strip + the window's edge strips) */
+int xm_qw_symw_time(int64_t ntot, int nloc, int cam0, int o, int world, int reps, double ms[2], int64_t *bytes);
+
 /* Large block-sparse Q: "sliced ELL over per-XCD column slabs" (xm-code_amd/csrc/xm_sell.h).  Same product as xm_qw_bsr3
  * (the reference has no sparse product: Dense/matmul.h:42-87 on a dense Q); the matrix is described on the HOST as 3x3-block CSR
  * (rows n, global columns in [0, ncols)) and re-laid on the device.  slabs in {1,2,4,8}; lmax = longest virtual row (hub

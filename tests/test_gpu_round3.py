@@ -313,6 +313,12 @@ def _team_worker_code():
         elif case == "bsr" or case == "sell":
             P = tl.gen_vg(301, deg=10, sigma=0.1, seed=5)
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), **kw); args = (5, 1e-10, 10.0)
+        elif case == "dense_sym":                                 # symmetric window product of the row partition (XM_SYM=1 in the environment), rank escalation
+            P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
+            ctx = xmamd.Context(Q=P["Q"], **kw); args = (6, 1e-9, 3.0)
+        elif case == "rome_dense":                                # BASELINE config 5 in the reference's dense storage: 13.5 GB, every rank expands its rows
+            P = tl.gen_vg(13682, deg=30, sigma=0.05, seed=13682, dense=False)
+            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True, **kw); args = (5, 1e-6, 1000.0)
         elif case == "venice":                                    # BASELINE config 4: the headline workload itself, dense, whole staircase
             P = tl.gen_dense(1778, seed=1778)
             ctx = xmamd.Context(Q=P["Q"], **kw); args = (5, 1e-6, 0.0)
@@ -333,7 +339,8 @@ def _team_worker_code():
         ctx.close()
         if rank == 0 or mode.startswith("shm") or mode.startswith("ipc"):
             np.savez(out, R=R, s=s, primal=info["primal"], rank=info["rank"], status=info["status"], tcg=info["tcg_iters"],
-                     min_eig=info["min_eig"], trace=info["trace"], n_gpus=info["n_gpus"], exchange=info["exchange"], **extra)
+                     min_eig=info["min_eig"], trace=info["trace"], n_gpus=info["n_gpus"], exchange=info["exchange"], sym=info["sym_product"],
+                     stream=info["qw_stream_bytes"], **extra)
         if mode.startswith("shm") or mode.startswith("ipc"):
             xmamd.lib().xm_comm_finalize()
     """)
@@ -435,6 +442,52 @@ def test_eight_virtual_gpus(xmamd, tmp_path, case):
     if case == "vg":
         assert np.allclose(t["res"], a["res"], rtol=1e-6, atol=1e-9)
         assert float(t["primal2"]) == pytest.approx(float(a["primal2"]), rel=1e-8)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_symmetric_window_product_under_the_row_partition(xmamd, tmp_path, world):
+    """Dense symmetric Q on `world` ranks through the cyclic half window (xm_symw.h; forced on a test-sized problem with XM_SYM=1): every
+    rank streams about half of its row strip, the ranks all-gather their column sums between the two launches of a product.  The
+    single-process team must reproduce the `world`-process run over the shared-memory transport BIT FOR BIT (same partition, same
+    arithmetic, fixed summation orders) and both the single-GPU optimum (rank escalation included: o = 4, 5, 6 fall back to the general
+    kernel above sym_max_o)."""
+    code = _team_worker_code()
+    env = dict(os.environ, XM_SHM_TIMEOUT="60", GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="60", XM_SYM="1")
+    name = "/xm_t4s_" + uuid.uuid4().hex[:12]
+    outs = [str(tmp_path / f"shm{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, "-c", code, f"shm{r}", str(world), outs[r], "dense_sym", name], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
+    team, one = str(tmp_path / "team.npz"), str(tmp_path / "one.npz")
+    _run(code, ["team", world, team, "dense_sym"], env)
+    _run(code, ["single", 1, one, "dense"], dict(env, XM_SYM="0"))
+    t, a = np.load(team), np.load(one)
+    for o_ in outs:
+        b = np.load(o_)
+        assert int(b["sym"]) == 1 and np.array_equal(t["R"], b["R"]) and np.array_equal(t["s"], b["s"]) and np.array_equal(t["trace"], b["trace"])
+    assert int(t["sym"]) == 1 and int(t["exchange"]) == 1                      # all-gather between the launches (no fused exchange on this path)
+    assert int(t["rank"]) == int(a["rank"]) and int(t["status"]) == int(a["status"]) == 1
+    assert float(t["primal"]) == pytest.approx(float(a["primal"]), rel=1e-9)
+    assert tl.rotation_parity(t["R"], t["s"], a["R"], a["s"]) < 1e-6
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rome13682_dense_storage_on_virtual_ranks_vs_recorded_oracle(xmamd, tmp_path, world):
+    """the Final-13682-size Q in the reference's dense storage (13.5 GB over the ranks, every rank expands its own camera rows) on 2 and 4
+    virtual ranks through the symmetric window product at its real plan: sym_product == 1, every rank streams half of its strip (+ the
+    window's edge strips), the oracle's recorded optimum to 1e-9, rotations within 1e-6"""
+    c = json.load(open(os.path.join(G, "synth", "rome13682_oracle.json")))
+    out = str(tmp_path / "team.npz")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_SDMA="0", XM_WATCHDOG_S="120")
+    _run(_team_worker_code(), ["team", world, out, "rome_dense"], env, timeout=900)
+    t = np.load(out)
+    assert int(t["n_gpus"]) == world and int(t["sym"]) == 1 and int(t["rank"]) == 3 and int(t["status"]) == 1
+    strip = 8.0 * 3 * (13682 + world) / world * 3 * (13682 + world)
+    assert 0.45 * strip < int(t["stream"]) < 0.56 * strip
+    assert float(t["primal"]) == pytest.approx(c["f"], rel=1e-9)
+    rot, _ = tl.recover_rotations(t["R"], t["s"])
+    assert tl.rel_fro(rot, np.load(os.path.join(G, "synth", "rome13682_oracle_rot.npy"))) < 1e-6
 
 
 @pytest.mark.parametrize("case,world", [("venice", 2), ("venice", 8), ("rome_bsr", 4)])

@@ -9,6 +9,7 @@
 #include "xm_schur.h"
 #include "xm_sell.h"
 #include "xm_sell2.h"
+#include "xm_symw.h"
 #include "xm_solver.h"
 
 struct xm_ctx {
@@ -800,3 +801,66 @@ int xm_partition_blocks(int64_t n, const int64_t *rowptr, int world, int rank, i
 }
 
 }  // extern "C"
+
+// host-only view of the multi-rank symmetric window plan (xm_symw.h) for the CPU test: geom = {T, Th, tie, t0, nsteps, nstrips, K, items};
+// items: 3 ints each (strip, jb, je), NULL = only the sizes
+int xm_symw_plan(int64_t ntot, int nloc, int cam0, int K, int32_t geom[8], int32_t *items) {
+    XM_TRY
+    xm::SymwPlan p;
+    xm::symw_plan_build(ntot, nloc, cam0, K, p);
+    if (geom) {
+        geom[0] = p.g.T; geom[1] = p.g.Th; geom[2] = p.g.tie; geom[3] = p.g.t0; geom[4] = p.g.nsteps; geom[5] = p.g.nstrips; geom[6] = p.K;
+        geom[7] = (int32_t)p.items.size();
+    }
+    if (items)
+        for (size_t i = 0; i < p.items.size(); ++i) { items[3 * i] = p.items[i].s; items[3 * i + 1] = p.items[i].jb; items[3 * i + 2] = p.items[i].je; }
+    return XM_OK;
+    XM_CATCH
+}
+// block (t, u) used by row step t? (the predicate of the sweep's masks)
+int xm_symw_use(int T, int t, int u) {
+    xm::SymwGeom g;
+    g.T = T; g.Th = (T + 1) / 2; g.tie = (T % 2 == 0) ? 1 : 0; g.t0 = 0; g.nsteps = T; g.nstrips = (6 * T + xm::kSwStrip - 1) / xm::kSwStrip;
+    return xm::symw_use(g, t, u) ? 1 : 0;
+}
+
+// micro-benchmark of ONE rank's share of the multi-rank symmetric window product (xm_symw.h) on this GPU: rank `cam0 / nloc` of `world`,
+// its row strip filled with an arbitrary pattern (timing only).  ms[0] = sweep + column sums, ms[1] = per-camera sum + plain epilogue;
+// bytes = what the sweep streams.  The all-gather between the two is not part of it.
+int xm_qw_symw_time(int64_t ntot, int nloc, int cam0, int o, int world, int reps, double ms[2], int64_t *bytes) {
+    XM_TRY
+    require_device();
+    if (ntot < 2 || nloc < 2 || world < 1 || reps < 1 || !ms) throw xm::Error(XM_ERR_ARG, "bad argument");
+    const int64_t ld = xm::dense_ld(ntot);
+    xm::SymwProduct sp(ntot, nloc, cam0, ld, nullptr);
+    sp.ensure(o, world);
+    xm::DevBuf<double> Q, W, out;
+    Q.alloc((size_t)3 * nloc * (size_t)ld, false);
+    W.alloc((size_t)ld * xm::pitch_of(o) + 16);
+    out.alloc((size_t)3 * nloc * xm::pitch_of(o));
+    XM_HIP_CHECK(hipMemset(Q.p, 0x3c, (size_t)3 * nloc * (size_t)ld * sizeof(double)));   // finite pattern
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    xm::CamArgs a = plain_args(nloc, out.p);
+    a.cam0 = cam0;
+    hipEvent_t e0, e1, e2;
+    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1)); XM_HIP_CHECK(hipEventCreate(&e2));
+    const int rank = cam0 / nloc;
+    for (int i = 0; i < 2; ++i) { sp.sweep(o, Q.p, W.p, nullptr, rank, nullptr); sp.reduce(o, xm::EPI_PLAIN, 1.0, a, world, nullptr); }
+    float t_sw = 0, t_rd = 0;
+    for (int i = 0; i < reps; ++i) {
+        XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+        sp.sweep(o, Q.p, W.p, nullptr, rank, nullptr);
+        XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+        sp.reduce(o, xm::EPI_PLAIN, 1.0, a, world, nullptr);
+        XM_HIP_CHECK(hipEventRecord(e2, nullptr));
+        XM_HIP_CHECK(hipEventSynchronize(e2));
+        float x = 0, y = 0;
+        XM_HIP_CHECK(hipEventElapsedTime(&x, e0, e1)); XM_HIP_CHECK(hipEventElapsedTime(&y, e1, e2));
+        t_sw += x; t_rd += y;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    ms[0] = t_sw / reps; ms[1] = t_rd / reps;
+    if (bytes) *bytes = sp.stream_bytes();
+    return XM_OK;
+    XM_CATCH
+}

@@ -119,6 +119,7 @@ void partition_cuts(int64_t n, int world, const int64_t *weights, std::vector<in
 
 class SellMatrix;   // xm_sell.h
 class Sell2Matrix;  // xm_sell2.h
+class SymwProduct;  // xm_symw.h
 class SchurOp;      // xm_schur.h
 
 struct PointState {  // everything the gradient epilogue writes for one point (R, s)
@@ -220,6 +221,8 @@ private:
     DevBuf<double> ksum_;                      // column-split dense product of a small strip: partial sums per (slice, camera)
     DevBuf<unsigned int> kcount_;              //   arrival counters per camera group
     int ks_ = 1;
+    std::unique_ptr<SymwProduct> symw_;        // multi-rank dense, symmetric Q: half-traffic product through a cyclic half window (xm_symw.h)
+    void product_symw(int epi, int o, double alpha, const CamArgs &a);
     bool sym_ok_ = false;
     int sym_max_o_ = 4;
     bool eig_exact_ = false;                   // the last certificate ran the tridiagonalisation to completion (small n)

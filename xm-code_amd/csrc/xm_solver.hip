@@ -12,6 +12,7 @@
 #include "xm_solver.h"
 #include "xm_sell.h"
 #include "xm_sell2.h"
+#include "xm_symw.h"
 #include "xm_schur.h"
 
 #include <algorithm>
@@ -237,6 +238,8 @@ void Context::init(const xm_problem_t &prob_in) {
     int64_t longest = 1;
     for (int r = 0; r < world; ++r) longest = std::max(longest, cam_cut_[(size_t)r + 1] - cam_cut_[(size_t)r]);
     nloc_ = (int)longest;
+    // the symmetric window product of a multi-rank dense run works in steps of two cameras (xm_symw.h): an even count per rank
+    if (world > 1 && (nloc_ & 1) && cfg_.sym != -1 && (storage_ == XM_STORAGE_DENSE || storage_ == XM_STORAGE_BSR3_DENSE)) ++nloc_;
     cam0_ = rank * nloc_;
     g0_ = cam_cut_[(size_t)rank];
     ntot_ = (int64_t)nloc_ * world;
@@ -362,6 +365,56 @@ void Context::init(const xm_problem_t &prob_in) {
             sym_ok_ = force ? (da <= 1e-9 * mx) : (da == 0.0);
         }
     }
+    // Several ranks: every rank streams half of its row strip through a cyclic half window (xm_symw.h) -- the upper triangle cut into row
+    // strips would leave rank 0 with almost its whole strip.  Whether Q is symmetric cannot be seen from one strip: the ranks multiply one
+    // random vector both ways (general kernel / window product) and take the window product only if all of them agree to 1e-9.
+    symw_.reset();
+    if (storage_ == XM_STORAGE_DENSE && world > 1 && comm_->active() && cfg_.sym != -1 && (nloc_ % 2) == 0 &&
+        (cfg_.sym == 1 || 3 * n_ >= cfg_.sym_min_rows)) {
+        sym_max_o_ = (cfg_.sym == 1) ? 5 : 4;
+        symw_.reset(new SymwProduct(ntot_, nloc_, cam0_, ld_, st_));
+        comm_->reserve(symw_csum_count(ntot_, sym_max_o_) * (size_t)world + 4096);
+        symw_->ensure(sym_max_o_, world);   // once, for every rank of the staircase: no free between two collectives later on
+        DevBuf<double> x, y1, y2, flag;
+        x.alloc((size_t)ld_ + 16); y1.alloc((size_t)3 * nloc_); y2.alloc((size_t)3 * nloc_); flag.alloc((size_t)world);
+        std::vector<double> hx((size_t)ld_, 0.0);
+        unsigned long long lcg = 88172645463325252ull;
+        for (int64_t i = 0; i < 3 * ntot_; ++i) { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; hx[(size_t)i] = (double)(lcg >> 11) / 9007199254740992.0 - 0.5; }
+        XM_HIP_CHECK(hipMemcpyAsync(x.p, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+        CamArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.nloc = nloc_; pa.cam0 = cam0_;
+        pa.out = y1.p;
+        launch_qw_dense(1, EPI_PLAIN, dQ_, ld_, x.p, 1.0, pa, st_);
+        pa.out = y2.p;
+        symw_->sweep(1, dQ_, x.p, nullptr, rank, st_);
+        comm_->allgather(symw_->csum_all(), symw_->csum_count(1), st_);
+        symw_->reduce(1, EPI_PLAIN, 1.0, pa, world, st_);
+        std::vector<double> h1((size_t)3 * nloc_), h2((size_t)3 * nloc_);
+        XM_HIP_CHECK(hipMemcpyAsync(h1.data(), y1.p, h1.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipMemcpyAsync(h2.data(), y2.p, h2.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        double dmax = 0, ymax = 0;
+        bool bad = false;
+        for (size_t i = 0; i < h1.size(); ++i) {
+            if (h1[i] != h1[i] || h2[i] != h2[i]) bad = true;
+            dmax = std::max(dmax, std::fabs(h1[i] - h2[i])); ymax = std::max(ymax, std::fabs(h1[i]));
+        }
+        // the bound has to hold for the whole vector, not only for this rank's rows: every rank reports its own maxima
+        std::vector<double> rep((size_t)world * 2, 0.0);
+        DevBuf<double> repd;
+        repd.alloc((size_t)world * 2);
+        const double mine[2] = {bad ? 1e300 : dmax, ymax};
+        XM_HIP_CHECK(hipMemcpyAsync(repd.p + (size_t)rank * 2, mine, sizeof(mine), hipMemcpyHostToDevice, st_));
+        comm_->allgather(repd.p, 2, st_);
+        XM_HIP_CHECK(hipMemcpyAsync(rep.data(), repd.p, rep.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        double dall = 0, yall = 0;
+        for (int r = 0; r < world; ++r) { dall = std::max(dall, rep[(size_t)2 * r]); yall = std::max(yall, rep[(size_t)2 * r + 1]); }
+        q_asym_ = dall; q_max_ = yall;
+        if (!(dall <= 1e-9 * yall)) symw_.reset();   // identical decision on every rank (identical gathered numbers)
+        comm_->host_barrier();
+    }
     XM_HIP_CHECK(hipHostMalloc((void **)&hstat_, 256, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(hstat_, 0, 256);
     XM_HIP_CHECK(hipHostGetDevicePointer((void **)&hstat_dev_, hstat_, 0));
@@ -400,7 +453,7 @@ void Context::setup_rank(int o) {
     // tCG exchange buffers: two parity buffers of world chunks [rows of the image of Hp (multi-rank only) | 3*nA_loc | nB_loc]
     const size_t b_off = comm_->active() ? mat : 0;
     const size_t pb = (size_t)2 * (b_off * world + 3 * nA_ + nB_);
-    if (comm_->peer() && world > 1 && cfg_.exchange != 1) {
+    if (comm_->peer() && world > 1 && cfg_.exchange != 1 && !symw_) {   // (the window product all-gathers between its launches: lockstep loop)
         // direct peer exchange: the buffers live in memory every rank of the group can store into (collective, host-synchronised)
         partsB_.release();
         comm_->xchg_setup(pb, xchg_);
@@ -501,7 +554,7 @@ int Context::prod_grid() const {
 // expires).  256 CUs x 4 workgroups is admitted whatever the kernel's register count (cg_step: 61 VGPRs, 106 SGPRs -> 6 per CU).
 int Context::tcg_blocks() const {
     int g = flat_grid((int64_t)nloc_ * 3 * OP_);
-    if (comm_->peer() && comm_->world > 1 && cfg_.exchange != 1) g = std::min(g, std::max(8, 1024 / std::max(1, comm_->ranks_on_my_device())));
+    if (comm_->peer() && comm_->world > 1 && cfg_.exchange != 1 && !symw_) g = std::min(g, std::max(8, 1024 / std::max(1, comm_->ranks_on_my_device())));
     return g;
 }
 
@@ -548,7 +601,8 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
         flush_gather();
     }
     if (storage_ == XM_STORAGE_DENSE) {
-        if (sym_ok_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT && Pcol_.p) launch_qw_sym(o, epi, dQ_, ld_, W_.p, alpha, a, Prow_.p, Pcol_.p, st_);
+        if (symw_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT) product_symw(epi, o, alpha, a);
+        else if (sym_ok_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT && Pcol_.p) launch_qw_sym(o, epi, dQ_, ld_, W_.p, alpha, a, Prow_.p, Pcol_.p, st_);
         else launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
     } else if (storage_ == XM_STORAGE_SCHUR) {
         schur_->product(o, epi, W_.p, alpha, a, st_);
@@ -562,6 +616,13 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
     if (res_) res_->qw_products++;
 }
 
+// multi-rank symmetric Q: sweep of this rank's half window, all-gather of the ranks' column sums, per-camera sum + epilogue (xm_symw.h)
+void Context::product_symw(int epi, int o, double alpha, const CamArgs &a) {
+    symw_->sweep(o, dQ_, W_.p, (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr, comm_->rank, st_);
+    comm_->allgather(symw_->csum_all(), symw_->csum_count(o), st_);
+    symw_->reduce(o, epi, alpha, a, comm_->world, st_);
+}
+
 // "overlap the gather with the local (diagonal-strip) part of Q*W".  The rows of W this rank owns are final before the
 // all-gather starts, so the column tiles of Q that lie entirely inside the rank's own column range can be multiplied on a second
 // stream WHILE the collective runs; the rest of the product (all other tiles, + those raw sums, + the epilogue) follows the
@@ -569,7 +630,7 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
 // side) — inside the tCG the product input comes from replicated data and there is no gather to hide.  It costs
 // an extra launch, so it is used only when the per-rank matrix is large (XM_OVERLAP_MIN_MB, default 64; XM_OVERLAP=0 disables).
 bool Context::overlap_applies() const {
-    if (cfg_.overlap < 0 || !comm_->active() || storage_ != XM_STORAGE_DENSE || sym_ok_) return false;
+    if (cfg_.overlap < 0 || !comm_->active() || storage_ != XM_STORAGE_DENSE || sym_ok_ || symw_) return false;
     if ((double)nloc_ * 3.0 * (double)ld_ * 8.0 < cfg_.overlap_min_mb * 1048576.0) return false;
     const int tc = qw_dense_tile_cols();
     const int64_t c0 = 3 * (int64_t)cam0_, c1 = 3 * ((int64_t)cam0_ + nloc_);
@@ -1520,11 +1581,11 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     if (opt.flags & XM_FLAG_PROFILE_QW) finish_profile();
     // algorithmic bytes of one tCG product at the final rank
     const int of = std::max(3, std::min(out_rank, (int)opt.max_rank));
-    res.sym_product = (sym_ok_ && storage_ == XM_STORAGE_DENSE) ? 1 : 0;
+    res.sym_product = ((sym_ok_ || symw_) && storage_ == XM_STORAGE_DENSE) ? 1 : 0;
     if (storage_ == XM_STORAGE_DENSE) res.qw_bytes = 8LL * (3 * n_) * (3 * n_) + 2LL * 8 * 3 * n_ * of;
     else if (storage_ == XM_STORAGE_SCHUR) res.qw_bytes = schur_->bytes_per_product(of);
     else res.qw_bytes = 76LL * nb_loc_ + 4LL * (n_ + 1) + 2LL * 8 * 3 * n_ * of;
-    res.qw_stream_bytes = (storage_ == XM_STORAGE_DENSE) ? (res.sym_product ? 4LL : 8LL) * (3 * n_) * (3 * n_)
+    res.qw_stream_bytes = (storage_ == XM_STORAGE_DENSE) ? (symw_ ? symw_->stream_bytes() : (res.sym_product ? 4LL : 8LL) * (3 * n_) * (3 * n_))
                           : (storage_ == XM_STORAGE_BSR3) ? ((sell2_ && Sell2Matrix::supports(of, ntot_)) ? sell2_->stream_bytes() : (sell_ && sell_supports(of)) ? sell_->stream_bytes() : 76LL * nb_loc_) : 0;
     res.n_gpus = comm_->world;
     res.exchange = !comm_->active() ? 0 : (xchg_.world > 1 ? 2 : 1);

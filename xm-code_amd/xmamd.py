@@ -29,7 +29,7 @@ EXPORTS = [
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_qw_dense_time", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_peer_allgather_bench", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_init_ipc", "xm_comm_finalize", "xm_partition", "xm_partition_blocks",
     "xm_symv_plan", "xm_sell_layout", "xm_sell_create", "xm_sell_create2", "xm_sell_create3", "xm_sell2_layout", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
-    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport",
+    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport", "xm_symw_plan", "xm_symw_use", "xm_qw_symw_time",
 ]
 
 
@@ -110,6 +110,9 @@ def lib():
         L.xm_ctx_xm2_round.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Options), C.POINTER(Xm2Info), C.POINTER(Result)]
         L.xm_ctx_recover_tp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_ctx_transport.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+        L.xm_symw_plan.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.xm_symw_use.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.xm_qw_symw_time.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
         L.xm_dev_count.argtypes = [C.POINTER(C.c_int)]
         L.xm_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         L.xm_dev_free.argtypes = [C.c_void_p]
@@ -324,6 +327,18 @@ def sell_layout(rowptr, colidx, ncols=None, slabs=4, lmax=64):
                pslot=np.zeros(max(nsl, 1) * 64, dtype=np.int32), pptr=np.zeros(n + 1, dtype=np.int64))
     _chk(lib().xm_sell_layout(*args, sizes.ctypes.data_as(C.c_void_p),
                               *(out[k].ctypes.data_as(C.c_void_p) for k in ("slice_off", "slab_start", "kind", "src", "pslot", "pptr", "ridx"))))
+    return out
+
+
+def symw_plan(ntot, nloc, cam0, K=0):
+    """work list of one rank of the multi-rank symmetric window product (xm_symw.h) -- host only"""
+    geom = np.zeros(8, dtype=np.int32)
+    _chk(lib().xm_symw_plan(ntot, nloc, cam0, K, geom.ctypes.data_as(C.c_void_p), None))
+    items = np.zeros((max(int(geom[7]), 1), 3), dtype=np.int32)
+    _chk(lib().xm_symw_plan(ntot, nloc, cam0, K, geom.ctypes.data_as(C.c_void_p), items.ctypes.data_as(C.c_void_p)))
+    keys = ("T", "Th", "tie", "t0", "nsteps", "nstrips", "K", "nitems")
+    out = {k: int(v) for k, v in zip(keys, geom)}
+    out["items"] = items[: out["nitems"]]
     return out
 
 
