@@ -20,10 +20,8 @@ for world in a.worlds:
               f"({by.value/strip:.3f} of the {strip/1e6:.0f} MB strip) -> {by.value/ms[0]/1e6:7.1f} GB/s real, {strip/(ms[0]+ms[1])/1e6:7.1f} GB/s in full-strip accounting", flush=True)
     # the general kernel on one rank's full strip
     ld = xmamd.dense_ld(ntot)
-    import torch
-    Q = torch.full((3 * nloc * ld,), 0.25, dtype=torch.float64, device="cuda"); W = torch.zeros(ld * (a.o | 1) + 16, dtype=torch.float64, device="cuda")
-    O = torch.zeros(3 * nloc * (a.o | 1), dtype=torch.float64, device="cuda"); torch.cuda.synchronize()
+    Q = xmamd.DevArray(nbytes=3 * nloc * ld * 8); W = xmamd.DevArray(nbytes=(ld * (a.o | 1) + 16) * 8); O = xmamd.DevArray(nbytes=3 * nloc * (a.o | 1) * 8)
     ms1 = C.c_double()
-    xmamd._chk(L.xm_qw_dense_strip_time(Q.data_ptr(), nloc, ntot, a.o, W.data_ptr(), O.data_ptr(), a.reps, C.byref(ms1)))
+    xmamd._chk(L.xm_qw_dense_strip_time(Q.ptr, nloc, ntot, a.o, W.ptr, O.ptr, a.reps, C.byref(ms1)))
     print(f"full strip (general kernel) world={world}: {ms1.value*1e3:8.1f} us = {8.0*3*nloc*3*ntot/ms1.value/1e6:7.1f} GB/s", flush=True)
-    del Q, W, O
+    Q.free(); W.free(); O.free()

@@ -27,6 +27,7 @@ class RankModel:
         self.n, self.o, self.lam, self.rank, self.world, self.ag = n, o, lam, rank, world, allgather
         if cuts is None:
             per = -(-n // world)
+            per += (per & 1) if world > 1 else 0          # equal_range_len (xm_solver.hip): even ranges for more than one rank
             cuts = [min(n, r * per) for r in range(world + 1)]
         assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == n and all(b >= a for a, b in zip(cuts, cuts[1:]))
         self.cuts = list(cuts)

@@ -137,9 +137,8 @@ def test_solve_through_sell_equals_csr_path(xmamd, monkeypatch):
     P = tl.gen_vg(700, deg=10, sigma=0.3, seed=11, dense=False)
     res = {}
     for mode, layout in (("0", "0"), ("1", "1"), ("1", "2")):        # block-CSR kernel | sliced ELL in two launches | chunk-tiled, one launch
-        monkeypatch.setenv("XM_BSR_SELL", mode)
-        monkeypatch.setenv("XM_SELL_LAYOUT", layout)
-        ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+        tn = dict(sell=-1) if mode == "0" else dict(sell=1, sell_layout=int(layout))       # xm_tuning_t fields, not the environment
+        ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), tuning=tn)
         res[mode + layout] = ctx.solve(5, 1e-9, 20.0)
         ctx.close()
     R0, s0, i0 = res["00"]
@@ -936,10 +935,8 @@ def test_xm2_reweighting_on_resident_context(xmamd, monkeypatch, storage):
     ne = edges.shape[0]
     w0 = np.ones(ne)
     rowptr, colidx, blocks = tl.vg_assemble(n, edges, M, w0)
-    if storage == "sell":
-        monkeypatch.setenv("XM_BSR_SELL", "1")
     Qd = tl.bsr_to_dense(n, rowptr, colidx, blocks)
-    ctx = xmamd.Context(Q=Qd) if storage == "dense" else xmamd.Context(bsr=(rowptr, colidx, blocks))
+    ctx = xmamd.Context(Q=Qd) if storage == "dense" else xmamd.Context(bsr=(rowptr, colidx, blocks), tuning=(dict(sell=1) if storage == "sell" else None))
     ctx.attach_edges(edges[:, 0], edges[:, 1], M)
     R1, s1, i1 = ctx.solve(5, 1e-8, lam)
     assert i1["status"] == 1

@@ -67,12 +67,11 @@ def test_round3_paths_are_bit_reproducible(xmamd, monkeypatch):
             for _ in range(3):
                 assert np.array_equal(M.qw(W, 1.0, gather=gm), a)
         M.close()
-    monkeypatch.setenv("XM_BSR_SELL", "1")
     V = tl.gen_vg(3000, deg=16, sigma=0.2, seed=4, dense=False)      # unit weights, lam at their scale: certifies at rank 3
     e = V["edges"]
     runs = []
     for kw in ({}, {}, dict(n_gpus=2, gpu_map=1), dict(n_gpus=2, gpu_map=1)):
-        ctx = xmamd.Context(vg=(e[:, 0], e[:, 1], V["w"], V["M"]), n=3000, **kw)
+        ctx = xmamd.Context(vg=(e[:, 0], e[:, 1], V["w"], V["M"]), n=3000, tuning=dict(sell=1), **kw)
         runs.append(ctx.solve(5, 1e-8, 100.0))
         ctx.close()
     for a_, b_ in ((runs[0], runs[1]), (runs[2], runs[3])):
@@ -96,13 +95,13 @@ def test_quaternion_codec_rejects_general_blocks(xmamd):
 def test_viewgraph_storage_equals_bsr_storage(xmamd, monkeypatch):
     """XM_STORAGE_VIEWGRAPH (edge list in, quaternion-compressed sliced ELL on the device) against XM_STORAGE_BSR3 of the same Q:
     same certified optimum; the compressed stream is reported; the edges are attached for the XM^2 calls without xm_ctx_attach_edges"""
-    monkeypatch.setenv("XM_BSR_SELL", "1")                 # force the large-n layout on a test-sized graph
+    tn = dict(sell=1)                                       # xm_tuning_t: force the large-n layout on a test-sized graph
     P = _weighted_vg(700, 10, seed=11, sigma=0.2)
     lam = 20.0
-    cb = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+    cb = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), tuning=tn)
     Rb, sb, ib = cb.solve(5, 1e-9, lam)
     cb.close()
-    cv = xmamd.Context(vg=(P["ei"], P["ej"], P["w"], P["M"]), n=700)
+    cv = xmamd.Context(vg=(P["ei"], P["ej"], P["w"], P["M"]), n=700, tuning=tn)
     Rv, sv, iv = cv.solve(5, 1e-9, lam)
     assert iv["rank"] == ib["rank"] and iv["status"] == ib["status"] == 1
     assert iv["primal"] == pytest.approx(ib["primal"], rel=1e-11)
@@ -275,8 +274,9 @@ def test_split_k_solve_equals_plain_solve(xmamd, monkeypatch):
     strips of a multi-GPU run): gradient / Hessian / certificate epilogues run by the finishing slice -- same certified optimum"""
     P = tl.gen_vg(301, deg=10, sigma=0.2, seed=5)
     R0, s0, i0 = xmamd.solve_dense(P["Q"], 5, 1e-9, 10.0)
-    monkeypatch.setenv("XM_SPLIT_K", "3")
-    R1, s1, i1 = xmamd.solve_dense(P["Q"], 5, 1e-9, 10.0)
+    cs = xmamd.Context(Q=P["Q"], tuning=dict(split_k=3))             # xm_tuning_t.split_k
+    R1, s1, i1 = cs.solve(5, 1e-9, 10.0)
+    cs.close()
     assert i0["rank"] == i1["rank"] and i0["status"] == i1["status"] == 1
     assert i1["primal"] == pytest.approx(i0["primal"], rel=1e-11)
     assert tl.rotation_parity(R1, s1, R0, s0) < 1e-8

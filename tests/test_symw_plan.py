@@ -84,3 +84,67 @@ def test_window_product_model_reproduces_the_symmetric_product(xmamd, ntot, worl
                 acc += csum[r2, grow:grow + 3]
             out[grow:grow + 3] = acc
     assert np.linalg.norm(out - Q @ W) <= 1e-12 * np.linalg.norm(Q @ W)
+
+
+def _symw_rank_worker(rank, world, port, ntot, o, out_dir):
+    """one rank of the window product under torch.distributed/gloo: it sees ONLY its own row strip of Q; the column sums travel by all_gather"""
+    import os, sys
+    import torch
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.join(os.path.dirname(here), "xm-code_amd"))
+    import xmamd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(ntot)                      # the same seed everywhere: every rank could build Q, but keeps its strip only
+    M = 3 * ntot
+    A = rng.standard_normal((M, M)); Q = A + A.T
+    W = rng.standard_normal((M, o))
+    nloc = ntot // world
+    Qr = Q[3 * rank * nloc:3 * (rank + 1) * nloc].copy(); del Q, A
+    g = xmamd.symw_plan(ntot, nloc, rank * nloc, K=4)
+    lib = xmamd.lib()
+    T = g["T"]
+    prow, csum = {}, np.zeros((M, o))
+    for s, jb, je in g["items"]:
+        c0, c1 = s * 256, min(s * 256 + 256, M)
+        ucol = np.arange(c0, c1) // 6
+        for j in range(jb, je):
+            t = g["t0"] + j
+            mc = np.array([bool(lib.xm_symw_use(T, t, int(u))) and u != t for u in ucol]); mr = mc | (ucol == t)
+            B = Qr[6 * j:6 * j + 6, c0:c1]
+            prow[(int(s), j)] = (B * mr) @ W[c0:c1]
+            csum[c0:c1] += (B * mc).T @ W[6 * t:6 * t + 6]
+    gathered = [torch.zeros(M, o, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(csum))       # the one collective of a product
+    out = np.zeros((3 * nloc, o))
+    for cam in range(nloc):
+        j, t = cam // 2, g["t0"] + cam // 2
+        acc = np.zeros((3, o))
+        for s in range(g["nstrips"]):
+            if _any(g, t, s):
+                acc += prow[(s, j)][3 * (cam & 1):3 * (cam & 1) + 3]
+        grow = 3 * (rank * nloc + cam)
+        for r2 in range(world):                             # rank order: the same sum on every run
+            acc += gathered[r2][grow:grow + 3].numpy()
+        out[3 * cam:3 * cam + 3] = acc
+    np.save(os.path.join(out_dir, f"y{rank}.npy"), out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_window_product_under_gloo(xmamd, tmp_path, world):
+    """world_size 2 and 3 over torch.distributed/gloo: every rank multiplies from its own strip alone, all_gathers the column sums and adds, per
+    camera, its row sums and the ranks' column sums -- together the ranks reproduce Q @ W of the symmetric matrix"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    ntot, o = 22 * world, 3                                  # 22 cameras per rank
+    mp.spawn(_symw_rank_worker, args=(world, port, ntot, o, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(ntot)
+    M = 3 * ntot
+    A = rng.standard_normal((M, M)); Q = A + A.T
+    W = rng.standard_normal((M, o))
+    got = np.concatenate([np.load(str(tmp_path / f"y{r}.npy")) for r in range(world)], axis=0)
+    assert np.linalg.norm(got - Q @ W) <= 1e-12 * np.linalg.norm(Q @ W)

@@ -156,7 +156,7 @@ int solve_path(const char *dataset_path, unsigned max_rank, double tol, double l
     const int n_gpus = (int)std::max(1L, std::min(8L, std::getenv("XM_GPUS") ? std::atol(std::getenv("XM_GPUS")) : 1L));
     const int gpu_map = std::getenv("XM_GPU_MAP") ? std::atoi(std::getenv("XM_GPU_MAP")) : 0;
     if (strip) {
-        const int64_t per = (n + cm.world - 1) / cm.world;                       // same partition as xm_partition / Context
+        const int64_t per = xm::equal_range_len(n, cm.world);                    // same partition as xm_partition / Context
         const int64_t c0 = std::min<int64_t>(n, (int64_t)cm.rank * per), c1 = std::min<int64_t>(n, (int64_t)(cm.rank + 1) * per);
         read_bin_rows(base + "/Q.bin", 3 * c0, 3 * (c1 - c0), Q, rows, cols, skip);
         prob.q = Q.data(); prob.ldq = 3 * (c1 - c0); prob.q_row0 = 3 * c0;
@@ -784,7 +784,7 @@ int xm_comm_init_ipc(int rank, int world, int device, const char *name, double s
 int xm_comm_finalize(void) { XM_TRY xm::comm_finalize(); return XM_OK; XM_CATCH }
 int xm_partition(int64_t n, int world, int rank, int64_t *c0, int64_t *c1) {
     if (n < 0 || world < 1 || rank < 0 || rank >= world || !c0 || !c1) { g_err = "bad argument"; return XM_ERR_ARG; }
-    const int64_t per = (n + world - 1) / world;
+    const int64_t per = xm::equal_range_len(n, world);
     *c0 = std::min<int64_t>(n, (int64_t)rank * per);
     *c1 = std::min<int64_t>(n, (int64_t)(rank + 1) * per);
     return XM_OK;

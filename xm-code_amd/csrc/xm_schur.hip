@@ -4,6 +4,7 @@
 #include "xm_schur.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -310,6 +311,14 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
 void SchurOp::set_weights(const double *w, hipStream_t st) {
     if (!w) throw Error(XM_ERR_ARG, "matrix-free Q: null weights");
     const int64_t N = n_, M = m_, nobs = nobs_;
+    static const bool trace = [] { const char *e = std::getenv("XM_SCHUR_TRACE"); return e && *e == '1'; }();   // set-up phase times on stderr
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "schur set-up: %-28s %8.1f ms\n", what, std::chrono::duration<double>(now - tp).count() * 1e3);
+        tp = now;
+    };
     std::vector<double> Q1((size_t)N * 9, 0.0), c((size_t)N * 3, 0.0), Q2((size_t)N, 0.0), Q3((size_t)M, 0.0);
     std::vector<double> c_w((size_t)nobs), l_w((size_t)nobs), d_lw((size_t)ltotal_, 0.0);
     for (int64_t e = 0; e < nobs; ++e) {
@@ -323,6 +332,7 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
         Q2[(size_t)i] += w[e]; Q3[(size_t)l] += w[e];                                             // :68-69
         c_w[(size_t)pos_c_[(size_t)e]] = w[e]; l_w[(size_t)pos_l_[(size_t)e]] = w[e]; d_lw[(size_t)dpos_l_[(size_t)e]] = w[e];
     }
+    lap("Q1, c, Q2, Q3 (host)");
     std::vector<double> q3inv((size_t)M), q3inv_slot((size_t)M);   // by landmark (host: VT) and by slot (device)
     for (int64_t l = 0; l < M; ++l) {
         q3inv[(size_t)l] = (Q3[(size_t)l] > 0.0) ? 1.0 / Q3[(size_t)l] : 0.0;
@@ -362,6 +372,7 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
             for (auto &th : pool) th.join();
         }
     }
+    lap("VT rows (host threads)");
     auto put = [&](DevBuf<double> &buf, const std::vector<double> &v) {
         if (!v.empty()) XM_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
     };
@@ -371,6 +382,7 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
         tmp.alloc((size_t)mr * mr, false); inv.alloc((size_t)mr * mr, false);
         XM_HIP_CHECK(hipMemcpy(tmp.p, VT.data(), (size_t)mr * mr * sizeof(double), hipMemcpyHostToDevice));
         std::vector<double>().swap(VT);
+        lap("VT to the device");
         if (!hubs.empty()) {
             DevBuf<double> du;
             du.alloc((size_t)mr, false);
@@ -384,10 +396,14 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
                 XM_HIP_CHECK(hipStreamSynchronize(st));   // u is reused
             }
         }
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        lap("hub rank-1 terms (device)");
         if (!spd_inverse_device((int)mr, tmp.p, inv.p, st))
             throw Error(XM_ERR_ARG, "matrix-free Q: the reduced camera Laplacian is not positive definite (observation graph not connected?)");
+        lap("SPD inverse (device)");
         launch_transpose_pad(inv.p, mr, mr, mr, vtinv_.p, ldv_, st);   // (symmetric: the transposition is immaterial)
         XM_HIP_CHECK(hipStreamSynchronize(st));
+        lap("layout of the inverse");
     }
 }
 

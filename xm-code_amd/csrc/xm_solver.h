@@ -116,6 +116,7 @@ struct DevBuf {
 };
 
 void partition_cuts(int64_t n, int world, const int64_t *weights, std::vector<int64_t> &cuts);   // xm_solver.hip
+int64_t equal_range_len(int64_t n, int world);   // cameras per rank of the equal partition (even for world > 1)
 
 class SellMatrix;   // xm_sell.h
 class Sell2Matrix;  // xm_sell2.h

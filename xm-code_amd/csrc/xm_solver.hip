@@ -187,9 +187,16 @@ static void build_viewgraph_csr(int64_t n, int64_t ne, const int32_t *ei, const 
 // Contiguous camera ranges of a row partition: cuts[r] .. cuts[r+1] belongs to rank r.  weights == nullptr: equal ranges of
 // ceil(n / world) cameras (dense rows).  weights = the rowptr of a 3x3-block CSR matrix: ranges balanced by STORED BLOCKS -- rank r
 // starts at the first camera whose rowptr reaches r/world of all blocks.
+// cameras per rank of the equal partition: ceil(n / world), made EVEN when there is more than one rank (the symmetric window product of a
+// multi-rank dense run works in steps of two cameras, xm_symw.h); the last rank takes the remainder, padding stays at the end
+int64_t equal_range_len(int64_t n, int world) {
+    int64_t per = (n + world - 1) / std::max(world, 1);
+    if (world > 1 && (per & 1)) ++per;
+    return per;
+}
 void partition_cuts(int64_t n, int world, const int64_t *weights, std::vector<int64_t> &cuts) {
     cuts.assign((size_t)world + 1, 0);
-    const int64_t per = (n + world - 1) / world;
+    const int64_t per = equal_range_len(n, world);
     for (int r = 0; r <= world; ++r) cuts[(size_t)r] = std::min<int64_t>(n, (int64_t)r * per);
     if (weights && world > 1) {
         const int64_t nb = weights[n] - weights[0];
@@ -237,9 +244,8 @@ void Context::init(const xm_problem_t &prob_in) {
     partition_cuts(n_, world, (storage_ == XM_STORAGE_BSR3 && cfg_.balance == 0) ? prob.rowptr : nullptr, cam_cut_);
     int64_t longest = 1;
     for (int r = 0; r < world; ++r) longest = std::max(longest, cam_cut_[(size_t)r + 1] - cam_cut_[(size_t)r]);
+    if (world > 1 && !((storage_ == XM_STORAGE_BSR3) && cfg_.balance == 0)) longest = std::max(longest, equal_range_len(n_, world));   // (a last rank with few cameras)
     nloc_ = (int)longest;
-    // the symmetric window product of a multi-rank dense run works in steps of two cameras (xm_symw.h): an even count per rank
-    if (world > 1 && (nloc_ & 1) && cfg_.sym != -1 && (storage_ == XM_STORAGE_DENSE || storage_ == XM_STORAGE_BSR3_DENSE)) ++nloc_;
     cam0_ = rank * nloc_;
     g0_ = cam_cut_[(size_t)rank];
     ntot_ = (int64_t)nloc_ * world;
