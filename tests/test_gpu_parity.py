@@ -1005,6 +1005,35 @@ def test_matrix_free_product_equals_dense_Q(xmamd, o):
     assert tl.rel_fro(got, 2.0 * (Q @ W)) < 1e-11
 
 
+def test_matrix_free_device_assembly_equals_host_assembly(xmamd, tmp_path):
+    """round 4: the weight-dependent factors (Q1, c, Q2, 1/Q3, the reduced camera Laplacian row by row in LDS) are assembled on the device;
+    the host assembly stays for observation lists that name a (camera, landmark) pair twice.  Same product from both (a scene with hub
+    landmarks and zero weights), from a list WITH a duplicated pair (host path taken automatically), and against the numpy restatement."""
+    import subprocess, sys, textwrap
+    S = tl.gen_scene(300, 4000, 6, seed=9)
+    w = S["w"].copy(); w[::11] = 0.0
+    W = np.random.default_rng(3).standard_normal((900, 3))
+    ref = tl.schur_qw_numpy(S["cam"], S["lm"], S["p"], w, W)
+    ctx = xmamd.Context(obs=(S["cam"], S["lm"], S["p"], w))
+    dev = ctx.qw(W)
+    ctx.close()
+    assert tl.rel_fro(dev, ref) < 1e-10
+    np.savez(tmp_path / "in.npz", cam=S["cam"], lm=S["lm"], p=S["p"], w=w, W=W)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {os.path.join(root, 'xm-code_amd')!r})
+        import numpy as np, xmamd
+        z = np.load(sys.argv[1]); ctx = xmamd.Context(obs=(z["cam"], z["lm"], z["p"], z["w"])); np.save(sys.argv[2], ctx.qw(z["W"])); ctx.close()
+    """)
+    subprocess.check_call([sys.executable, "-c", code, str(tmp_path / "in.npz"), str(tmp_path / "host.npy")], env=dict(os.environ, XM_SCHUR_HOST_ASSEMBLY="1"), timeout=600)
+    assert tl.rel_fro(dev, np.load(tmp_path / "host.npy")) < 1e-11
+    cam2 = np.concatenate([S["cam"], S["cam"][5:6]]); lm2 = np.concatenate([S["lm"], S["lm"][5:6]])        # observation 5 named twice
+    p2 = np.concatenate([S["p"], S["p"][5:6] + 0.01]); w2 = np.concatenate([w, [0.7]])
+    c2 = xmamd.Context(obs=(cam2, lm2, p2, w2))
+    assert tl.rel_fro(c2.qw(W), tl.schur_qw_numpy(cam2, lm2, p2, w2, W)) < 1e-10
+    c2.close()
+
+
 def test_matrix_free_solve_matches_dense_solve(xmamd):
     """SIMPLE2 solved matrix-free (XM_STORAGE_SCHUR: Q never formed) against the solve of the dense Q the reference's create_matrix
     wrote: same optimum, certificate and rotations <= 1e-6 (north_star), and against the golden of the dense path"""

@@ -500,7 +500,9 @@ int xm_spd_inverse(int64_t n, double *A) {
     a.alloc((size_t)n * n, false); x.alloc((size_t)n * n, false);
     XM_HIP_CHECK(hipMemcpy(a.p, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
     if (!xm::spd_inverse_device((int)n, a.p, x.p, nullptr)) throw xm::Error(XM_ERR_ARG, "matrix is not positive definite");
-    XM_HIP_CHECK(hipMemcpy(A, x.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+    xm::spd_inverse_layout((int)n, x.p, a.p, n, nullptr);   // full symmetric matrix from the computed lower triangle (a is free now)
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    XM_HIP_CHECK(hipMemcpy(A, a.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
     return XM_OK;
     XM_CATCH
 }

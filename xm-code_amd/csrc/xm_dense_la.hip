@@ -178,7 +178,10 @@ static void gemm_sub(int m, int n, int k, const double *A, int64_t lda, int ta, 
     hipLaunchKernelGGL(la_gemm_sub_kernel, g, dim3(256), 0, st, m, n, k, A, lda, ta, B, ldb, tb, C, ldc, lower_only);
 }
 
-// A (device, column-major n x n, ld = n, lower triangle read) is overwritten by its Cholesky factor; X (device, n x n) receives A^-1.
+// A (device, column-major n x n, ld = n, lower triangle read) is overwritten by its Cholesky factor; X (device, n x n) receives the LOWER
+// triangle of A^-1 (rows >= columns; what lies above the diagonal is scratch): Y = L^-1 is lower triangular, and of X = L^-T Y only the
+// lower triangle is computed -- both substitutions then touch the columns [0, i + b) of block row i only, half the flops of the full
+// solves with the identity.  spd_inverse_layout() writes the full symmetric matrix in the dense kernel's layout from it.
 // Returns false when A is not positive definite.
 bool spd_inverse_device(int n, double *A, double *X, hipStream_t st) {
     if (n <= 0) return true;
@@ -197,27 +200,65 @@ bool spd_inverse_device(int n, double *A, double *X, hipStream_t st) {
     }
     check_launch("spd_inverse(cholesky)");
     static const bool trace = [] { const char *e = std::getenv("XM_SCHUR_TRACE"); return e && *e == '1'; }();
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
     int h = 0;
     XM_HIP_CHECK(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, st));
     XM_HIP_CHECK(hipStreamSynchronize(st));
     if (h) return false;
+    if (trace) { std::fprintf(stderr, "spd_inverse: Cholesky factorisation %8.1f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3); t0 = std::chrono::steady_clock::now(); }
     hipLaunchKernelGGL(la_identity_kernel, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, st, n, X, ld);
-    for (int i = 0; i < n; i += kLaB) {   // forward: Y_i = L_ii^-1 (I_i - L[i, 0:i] Y[0:i, :])
-        const int b = std::min(kLaB, n - i);
-        gemm_sub(b, n, i, A + i, ld, 0, X, ld, 0, X + i, ld, 0, st);
-        hipLaunchKernelGGL(la_trsm_left_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b, n, A + (size_t)i + (size_t)i * ld, ld, 0, X + i, ld);
+    for (int i = 0; i < n; i += kLaB) {   // forward: Y_i = L_ii^-1 (I_i - L[i, 0:i] Y[0:i, :]); Y is lower triangular: columns [0, i + b)
+        const int b = std::min(kLaB, n - i), nc = i + b;
+        gemm_sub(b, nc, i, A + i, ld, 0, X, ld, 0, X + i, ld, 0, st);
+        hipLaunchKernelGGL(la_trsm_left_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, b, nc, A + (size_t)i + (size_t)i * ld, ld, 0, X + i, ld);
     }
-    for (int i = ((n - 1) / kLaB) * kLaB; i >= 0; i -= kLaB) {   // backward: X_i = L_ii^-T (Y_i - L[i+b:, i]^T X[i+b:, :])
-        const int b = std::min(kLaB, n - i), below = n - i - b;
-        gemm_sub(b, n, below, A + (size_t)(i + b) + (size_t)i * ld, ld, 1, X + i + b, ld, 0, X + i, ld, 0, st);
-        hipLaunchKernelGGL(la_trsm_left_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b, n, A + (size_t)i + (size_t)i * ld, ld, 1, X + i, ld);
+    for (int i = ((n - 1) / kLaB) * kLaB; i >= 0; i -= kLaB) {   // backward: X_i = L_ii^-T (Y_i - L[i+b:, i]^T X[i+b:, :]), lower triangle: columns [0, i + b)
+        const int b = std::min(kLaB, n - i), below = n - i - b, nc = i + b;
+        gemm_sub(b, nc, below, A + (size_t)(i + b) + (size_t)i * ld, ld, 1, X + i + b, ld, 0, X + i, ld, 0, st);
+        hipLaunchKernelGGL(la_trsm_left_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, b, nc, A + (size_t)i + (size_t)i * ld, ld, 1, X + i, ld);
     }
     check_launch("spd_inverse(solve)");
     XM_HIP_CHECK(hipStreamSynchronize(st));
-    if (trace) std::fprintf(stderr, "spd_inverse: two triangular solves with the identity %8.1f ms (after the factorisation)\n",
+    if (trace) std::fprintf(stderr, "spd_inverse: two triangular substitutions (lower triangle) %8.1f ms\n",
                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     return true;
+}
+
+// dst (row-major, n rows, leading dimension ldd, zero padding untouched) = the full symmetric matrix whose LOWER triangle X holds (column-major, ld = n)
+__global__ __launch_bounds__(256) void la_sym_layout_kernel(int64_t n, const double *__restrict__ X, double *__restrict__ dst, int64_t ldd) {
+    __shared__ double T[64][65];
+    // tile (bi, bj) of dst, bj >= bi: upper tiles come transposed from the mirror tile of X's lower triangle, lower tiles straight
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (c0 > r0) {          // strictly upper tile of dst: dst[r][c] = X(c, r), read coalesced along X's rows (index c) and transposed through LDS
+        for (int k = ty; k < 64; k += 4) {
+            const int64_t c = c0 + tx, r = r0 + k;
+            T[k][tx] = (c < n && r < n) ? X[(size_t)c + (size_t)r * n] : 0.0;   // X(c, r): row c >= column r
+        }
+        __syncthreads();
+        for (int k = ty; k < 64; k += 4) {
+            const int64_t r = r0 + k, c = c0 + tx;
+            if (r < n && c < n) dst[(size_t)r * ldd + c] = T[k][tx];
+        }
+    } else {                // diagonal and lower tiles: dst[r][c] = X(max(r, c), min(r, c)); X is column-major, so read along r and transpose
+        for (int k = ty; k < 64; k += 4) {
+            const int64_t r = r0 + tx, c = c0 + k;
+            double v = 0.0;
+            if (r < n && c < n) v = (r >= c) ? X[(size_t)r + (size_t)c * n] : X[(size_t)c + (size_t)r * n];
+            T[tx][k] = v;
+        }
+        __syncthreads();
+        for (int k = ty; k < 64; k += 4) {
+            const int64_t r = r0 + k, c = c0 + tx;
+            if (r < n && c < n) dst[(size_t)r * ldd + c] = T[k][tx];
+        }
+    }
+}
+void spd_inverse_layout(int n, const double *X, double *dst, int64_t ldd, hipStream_t st) {
+    if (n <= 0) return;
+    const unsigned nt = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(la_sym_layout_kernel, dim3(nt, nt), dim3(256), 0, st, (int64_t)n, X, dst, ldd);
+    check_launch("spd_inverse_layout");
 }
 
 }  // namespace xm

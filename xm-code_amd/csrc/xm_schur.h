@@ -26,8 +26,11 @@ namespace xm {
 
 constexpr int64_t kSchurMaxCams = 40000;   // (N-1)^2 inverse + workspace = 3 x 8 N^2 bytes during set-up: 38 GB at the limit
 
-// A (device, column-major n x n, lower triangle read) -> Cholesky factor; X <- A^-1 (full symmetric).  false: not positive definite
+// A (device, column-major n x n, lower triangle read) -> Cholesky factor; X <- the LOWER triangle of A^-1 (above the diagonal: scratch).
+// false: not positive definite
 bool spd_inverse_device(int n, double *A, double *X, hipStream_t st);
+// dst (row-major n x n, leading dimension ldd) <- the full symmetric inverse from X's lower triangle
+void spd_inverse_layout(int n, const double *X, double *dst, int64_t ldd, hipStream_t st);
 // A (device, column-major n x n) -= q * u u^T  (u: device, n doubles)
 void rank1_sub_device(int n, double *A, const double *u, double q, hipStream_t st);
 
@@ -75,6 +78,12 @@ private:
     std::vector<int64_t> cam_obs_;            // observation (input index) at each position of the by-camera lists
     int o_alloc_ = 0, o_last_ = 0;
     void ensure(int o);
+    // weight-dependent factors assembled on the device (set_weights_device); the host version serves lists with duplicate (camera, landmark) pairs
+    DevBuf<int64_t> pos_c_dev_, dpos_l_dev_;
+    DevBuf<double> w_in_, q2_;
+    bool dup_pairs_ = false;
+    std::vector<int64_t> hub_lm_, hub_obs_ptr_, hub_obs_;
+    void set_weights_device(const double *w, hipStream_t st);
 };
 
 }  // namespace xm

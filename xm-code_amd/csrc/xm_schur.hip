@@ -228,6 +228,107 @@ __global__ __launch_bounds__(256) void schur_cam_y_kernel(int64_t nobs, const in
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// device: everything that depends on the weights (round 4; the host version below stays as the fall-back for observation lists that name
+// a (camera, landmark) pair twice).  utils/creatematrix.py:62-175 restated on the observation level.
+// ------------------------------------------------------------------------------------------------------------------
+// weights in input order -> the by-camera and by-landmark arrays
+__global__ __launch_bounds__(256) void schur_scatter_w_kernel(int64_t nobs, const double *__restrict__ w, const int64_t *__restrict__ pos_c,
+                                                               const int64_t *__restrict__ dpos_l, double *__restrict__ cam_w, double *__restrict__ lm_w) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nobs) return;
+    const double x = w[e];
+    cam_w[pos_c[e]] = x;
+    lm_w[dpos_l[e]] = x;
+}
+// per camera: Q1 = sum w p p^T (creatematrix.py:26), c = V1 = sum w p (:27), Q2 = sum w (:68); one wavefront per camera, lane-strided
+// list order + DPP tree (fixed order)
+__global__ __launch_bounds__(256) void schur_cam_sums_kernel(int64_t n, int64_t nobs, const int64_t *__restrict__ cam_ptr, const double *__restrict__ cam_w,
+                                                              const double *__restrict__ cam_p, double *__restrict__ Q1, double *__restrict__ c,
+                                                              double *__restrict__ q2) {
+    const int gl = threadIdx.x & 63;
+    const int64_t cam = (int64_t)blockIdx.x * kQwWaves + (threadIdx.x >> 6);
+    double a[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) a[k] = 0.0;
+    if (cam < n)
+        for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 64) {
+            const double w = cam_w[e], p0 = cam_p[e], p1 = cam_p[nobs + e], p2 = cam_p[2 * nobs + e];
+            const double pp[3] = {p0, p1, p2};
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                a[9 + x] += w * pp[x];
+#pragma unroll
+                for (int y = 0; y < 3; ++y) a[3 * x + y] += w * pp[x] * pp[y];
+            }
+            a[12] += w;
+        }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) a[k] = wave_sum(a[k]);
+    if (cam < n && gl == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Q1[cam * 9 + k] = a[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[cam * 3 + k] = a[9 + k];
+        q2[cam] = a[12];
+    }
+}
+// per landmark slot: 1 / Q3, Q3 = sum w over its observations (:69); a landmark without weight drops out (0)
+__global__ __launch_bounds__(kSchurHeavyThreads) void schur_lm_q3_kernel(SchurLm L, double *__restrict__ q3inv) {
+    const bool heavy = (int64_t)blockIdx.x < L.nheavy;
+    int64_t l, e, e_end, step;
+    if (heavy) {
+        l = blockIdx.x; e = L.ptr[l] + threadIdx.x; e_end = L.ptr[l + 1]; step = kSchurHeavyThreads;
+    } else {
+        const int64_t t = ((int64_t)blockIdx.x - L.nheavy) * kSchurHeavyThreads + threadIdx.x;
+        l = L.nheavy + t;
+        if (l >= L.m) return;
+        e = L.gbase[t >> 6] + (t & 63); e_end = e + (int64_t)64 * L.deg[l]; step = 64;
+    }
+    double acc[1] = {0.0};
+    for (; e < e_end; e += step) acc[0] += L.w[e];
+    if (heavy) {
+        if (!heavy_block_sum<1>(acc)) return;
+    }
+    q3inv[l] = (acc[0] > 0.0) ? 1.0 / acc[0] : 0.0;
+}
+// the reduced camera Laplacian VT = Q2_bar - V3_bar Q3^-1 V3_bar^T (:150-166) row by row: ONE wavefront per camera a, the row (columns
+// [col0, col0 + ncol)) in LDS; the camera's observations are walked in list order and for each the landmark's observation list is spread
+// over the lanes (a landmark names a camera once: no two lanes meet on one entry; the additions into an entry happen in the camera's
+// observation order -- the order of the host assembly this replaces).  Landmarks with more than kSchurHeavy observations are full rank-1
+// terms and are applied afterwards (rank1_sub_device).
+__global__ __launch_bounds__(64) void schur_vt_rows_kernel(int64_t mr, int64_t col0, int ncol, const int64_t *__restrict__ cam_ptr,
+                                                            const int32_t *__restrict__ cam_lm, const double *__restrict__ cam_w, SchurLm L,
+                                                            const double *__restrict__ q3inv, const double *__restrict__ q2, double *__restrict__ VT) {
+    extern __shared__ double row[];
+    const int lane = threadIdx.x;
+    const int64_t a = (int64_t)blockIdx.x + 1;
+    for (int j = lane; j < ncol; j += 64) row[j] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && a - 1 >= col0 && a - 1 < col0 + ncol) row[a - 1 - col0] = q2[a];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t e = cam_ptr[a]; e < cam_ptr[a + 1]; ++e) {   // wave-uniform
+        const int64_t sl = cam_lm[e];
+        const double wa = cam_w[e];
+        if (sl < L.nheavy || wa == 0.0) continue;
+        const double qi = q3inv[sl];
+        if (qi == 0.0) continue;
+        const int64_t t = sl - L.nheavy;
+        if (lane < L.deg[sl]) {
+            const int64_t at = L.gbase[t >> 6] + (t & 63) + (int64_t)64 * lane;
+            const int64_t b = L.cam[at];
+            const int64_t j = b - 1 - col0;
+            if (b != 0 && j >= 0 && j < ncol) row[j] -= wa * L.w[at] * qi;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    double *out = VT + (size_t)(a - 1) * (size_t)mr + (size_t)col0;   // row a-1 of the symmetric matrix = its column a-1 (column-major)
+    for (int j = lane; j < ncol; j += 64) out[j] = row[j];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // host: factors from the observation list (utils/creatematrix.py:62-175, restated on the observation level)
 // ------------------------------------------------------------------------------------------------------------------
 SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *cam, const int32_t *lm, const double *p, const double *w,
@@ -295,6 +396,33 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     };
     up(cam_ptr_, cp_); up(lm_ptr_, hptr); up(gbase_, gbase); up(ldeg_, ldeg); up(cam_lm_, c_lm); up(lm_cam_, d_lcam); up(cam_p_, c_p); up(lm_p_, d_lp);
     up(obs_cam_, hcam_); up(obs_lm_, o_lm); up(obs_p_, hp_);
+    up(pos_c_dev_, pos_c_); up(dpos_l_dev_, dpos_l_);
+    w_in_.alloc((size_t)nobs, false); q2_.alloc((size_t)N, false);
+    {   // a (camera, landmark) pair named twice would put two lanes of the device assembly on one entry of VT: such a list keeps the host path
+        std::vector<int64_t> seen((size_t)N, -1);
+        dup_pairs_ = false;
+        for (int64_t l = 0; l < M && !dup_pairs_; ++l)
+            for (int64_t e2 = lp_[(size_t)l]; e2 < lp_[(size_t)l + 1]; ++e2) {
+                const int64_t b = lcam_[(size_t)e2];
+                if (seen[(size_t)b] == l) { dup_pairs_ = true; break; }
+                seen[(size_t)b] = l;
+            }
+        static const bool force_host = [] { const char *e = std::getenv("XM_SCHUR_HOST_ASSEMBLY"); return e && *e == '1'; }();
+        if (force_host) dup_pairs_ = true;
+    }
+    hub_lm_.clear(); hub_obs_ptr_.assign(1, 0); hub_obs_.clear();   // heavy landmarks: their observations (input indices), for the rank-1 terms
+    {
+        std::vector<std::vector<int64_t>> by((size_t)nheavy_);
+        for (int64_t e = 0; e < nobs; ++e) {
+            const int64_t sl = slot_of_[(size_t)lm[e]];
+            if (sl < nheavy_) by[(size_t)sl].push_back(e);
+        }
+        for (int64_t sl = 0; sl < nheavy_; ++sl) {
+            hub_lm_.push_back(sl);
+            hub_obs_.insert(hub_obs_.end(), by[(size_t)sl].begin(), by[(size_t)sl].end());
+            hub_obs_ptr_.push_back((int64_t)hub_obs_.size());
+        }
+    }
     cam_w_.alloc((size_t)nobs, false); lm_w_.alloc((size_t)ltotal_, false);
     Q1_.alloc((size_t)N * 9, false); c_.alloc((size_t)N * 3, false); q3inv_.alloc((size_t)M, false);
     const int64_t mr = N - 1;
@@ -310,6 +438,7 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
 // weight makes VT singular -> XM_ERR_ARG.
 void SchurOp::set_weights(const double *w, hipStream_t st) {
     if (!w) throw Error(XM_ERR_ARG, "matrix-free Q: null weights");
+    if (!dup_pairs_) { set_weights_device(w, st); return; }
     const int64_t N = n_, M = m_, nobs = nobs_;
     static const bool trace = [] { const char *e = std::getenv("XM_SCHUR_TRACE"); return e && *e == '1'; }();   // set-up phase times on stderr
     auto tp = std::chrono::steady_clock::now();
@@ -401,10 +530,87 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
         if (!spd_inverse_device((int)mr, tmp.p, inv.p, st))
             throw Error(XM_ERR_ARG, "matrix-free Q: the reduced camera Laplacian is not positive definite (observation graph not connected?)");
         lap("SPD inverse (device)");
-        launch_transpose_pad(inv.p, mr, mr, mr, vtinv_.p, ldv_, st);   // (symmetric: the transposition is immaterial)
+        spd_inverse_layout((int)mr, inv.p, vtinv_.p, ldv_, st);
         XM_HIP_CHECK(hipStreamSynchronize(st));
         lap("layout of the inverse");
     }
+}
+
+// The same on the device: weights uploaded once, per-camera / per-landmark sums, the reduced camera Laplacian row by row in LDS (the host
+// needed 0.2 + 0.3 s for them at 13 682 cameras and 0.18 s to ship the 1.5 GB matrix), hub landmarks as rank-1 terms, inverse, layout.
+void SchurOp::set_weights_device(const double *w, hipStream_t st) {
+    const int64_t N = n_, M = m_, nobs = nobs_;
+    static const bool trace = [] { const char *e = std::getenv("XM_SCHUR_TRACE"); return e && *e == '1'; }();
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "schur set-up: %-28s %8.1f ms\n", what, std::chrono::duration<double>(now - tp).count() * 1e3);
+        tp = now;
+    };
+    for (int64_t e = 0; e < nobs; ++e)
+        if (!(w[e] >= 0.0)) throw Error(XM_ERR_ARG, "matrix-free Q: negative or NaN weight");
+    XM_HIP_CHECK(hipMemcpyAsync(w_in_.p, w, (size_t)nobs * sizeof(double), hipMemcpyHostToDevice, st));
+    XM_HIP_CHECK(hipMemsetAsync(lm_w_.p, 0, (size_t)ltotal_ * sizeof(double), st));   // the padding entries of the packed landmark lists
+    hipLaunchKernelGGL(schur_scatter_w_kernel, dim3((unsigned)((nobs + 255) / 256)), dim3(256), 0, st, nobs, w_in_.p, pos_c_dev_.p, dpos_l_dev_.p,
+                       cam_w_.p, lm_w_.p);
+    hipLaunchKernelGGL(schur_cam_sums_kernel, dim3((unsigned)((N + kQwWaves - 1) / kQwWaves)), dim3(256), 0, st, N, nobs, cam_ptr_.p, cam_w_.p, cam_p_.p,
+                       Q1_.p, c_.p, q2_.p);
+    SchurLm L;
+    L.m = m_; L.nheavy = nheavy_; L.total = ltotal_; L.ptr = lm_ptr_.p; L.gbase = gbase_.p; L.deg = ldeg_.p; L.cam = lm_cam_.p; L.w = lm_w_.p; L.p = lm_p_.p;
+    const int64_t nlight = M - nheavy_;
+    hipLaunchKernelGGL(schur_lm_q3_kernel, dim3((unsigned)(nheavy_ + (nlight + kSchurHeavyThreads - 1) / kSchurHeavyThreads)), dim3(kSchurHeavyThreads), 0, st, L,
+                       q3inv_.p);
+    check_launch("schur set-up (sums)");
+    lap("weights, Q1, c, Q2, 1/Q3 (device)");
+    const int64_t mr = N - 1;
+    if (mr <= 0) { XM_HIP_CHECK(hipStreamSynchronize(st)); return; }
+    DevBuf<double> tmp, inv;
+    tmp.alloc((size_t)mr * mr, false); inv.alloc((size_t)mr * mr, false);
+    constexpr int64_t kColsPerPass = 16384;   // 128 KB of LDS per wavefront (one workgroup per CU; gfx950 has 160 KB)
+    {
+        static const bool once = [] {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_vt_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(kColsPerPass * sizeof(double)));
+            (void)hipGetLastError();
+            return e == hipSuccess;
+        }();
+        (void)once;
+    }
+    for (int64_t col0 = 0; col0 < mr; col0 += kColsPerPass) {
+        const int ncol = (int)std::min<int64_t>(kColsPerPass, mr - col0);
+        hipLaunchKernelGGL(schur_vt_rows_kernel, dim3((unsigned)mr), dim3(64), (size_t)ncol * sizeof(double), st, mr, col0, ncol, cam_ptr_.p, cam_lm_.p,
+                           cam_w_.p, L, q3inv_.p, q2_.p, tmp.p);
+    }
+    check_launch("schur set-up (VT rows)");
+    lap("VT rows (device)");
+    if (nheavy_ > 0) {   // hub landmarks in slot order (fixed): VT -= (1/Q3_l) u u^T, u = the weights of l's observations by camera
+        std::vector<double> q3h((size_t)nheavy_);
+        XM_HIP_CHECK(hipMemcpyAsync(q3h.data(), q3inv_.p, (size_t)nheavy_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        DevBuf<double> du;
+        du.alloc((size_t)mr, false);
+        std::vector<double> u((size_t)mr);
+        for (int64_t h = 0; h < nheavy_; ++h) {
+            if (q3h[(size_t)h] == 0.0) continue;
+            std::fill(u.begin(), u.end(), 0.0);
+            for (int64_t k = hub_obs_ptr_[(size_t)h]; k < hub_obs_ptr_[(size_t)h + 1]; ++k) {
+                const int64_t e = hub_obs_[(size_t)k];
+                if (hcam_[(size_t)e] != 0) u[(size_t)hcam_[(size_t)e] - 1] += w[e];
+            }
+            XM_HIP_CHECK(hipMemcpyAsync(du.p, u.data(), (size_t)mr * sizeof(double), hipMemcpyHostToDevice, st));
+            rank1_sub_device((int)mr, tmp.p, du.p, q3h[(size_t)h], st);
+            XM_HIP_CHECK(hipStreamSynchronize(st));   // u is reused
+        }
+    }
+    lap("hub rank-1 terms (device)");
+    if (!spd_inverse_device((int)mr, tmp.p, inv.p, st))
+        throw Error(XM_ERR_ARG, "matrix-free Q: the reduced camera Laplacian is not positive definite (observation graph not connected?)");
+    lap("SPD inverse (device)");
+    spd_inverse_layout((int)mr, inv.p, vtinv_.p, ldv_, st);
+    XM_HIP_CHECK(hipStreamSynchronize(st));
+    lap("layout of the inverse");
 }
 
 // residual of every observation at the point whose scaled rows are U (camera records of 3 * pitch_of(o) doubles):
