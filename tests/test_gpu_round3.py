@@ -319,6 +319,15 @@ def _team_worker_code():
         elif case == "rome_dense":                                # BASELINE config 5 in the reference's dense storage: 13.5 GB, every rank expands its rows
             P = tl.gen_vg(13682, deg=30, sigma=0.05, seed=13682, dense=False)
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True, **kw); args = (5, 1e-6, 1000.0)
+        elif case == "schur":                                     # matrix-free Q from the observation list (hub landmarks, zero weights)
+            S = tl.gen_scene(300, 4000, 6, seed=9)
+            w = S["w"].copy(); w[::11] = 0.0
+            lam = 1.5 * float(np.sum(w * np.sum(S["p"] ** 2, axis=1)) / 900)
+            ctx = xmamd.Context(obs=(S["cam"], S["lm"], S["p"], w), **kw); args = (5, 1e-8, lam)
+        elif case == "schur_final":                               # Final-13682 size: 13 682 cameras, 800 k landmarks, 6.4 M observations
+            S = tl.gen_scene(13682, 800000, 8, seed=13682)
+            lam = 1.5 * float(np.sum(S["w"] * np.sum(S["p"] ** 2, axis=1)) / (3 * 13682))
+            ctx = xmamd.Context(obs=(S["cam"], S["lm"], S["p"], S["w"]), **kw); args = (5, 1e-6, lam)
         elif case == "venice":                                    # BASELINE config 4: the headline workload itself, dense, whole staircase
             P = tl.gen_dense(1778, seed=1778)
             ctx = xmamd.Context(Q=P["Q"], **kw); args = (5, 1e-6, 0.0)
@@ -469,6 +478,23 @@ def test_symmetric_window_product_under_the_row_partition(xmamd, tmp_path, world
     assert int(t["sym"]) == 1 and int(t["exchange"]) == 1                      # all-gather between the launches (no fused exchange on this path)
     assert int(t["rank"]) == int(a["rank"]) and int(t["status"]) == int(a["status"]) == 1
     assert float(t["primal"]) == pytest.approx(float(a["primal"]), rel=1e-9)
+    assert tl.rotation_parity(t["R"], t["s"], a["R"], a["s"]) < 1e-6
+
+
+@pytest.mark.parametrize("case,world", [("schur", 2), ("schur", 3), ("schur_final", 2)])
+def test_matrix_free_context_under_the_row_partition(xmamd, tmp_path, case, world):
+    """XM_STORAGE_SCHUR on several ranks (round 4): every rank builds the factors from the whole observation list, multiplies its own rows of
+    the reduced camera Laplacian's inverse, the ranks all-gather x_cam, and the chain's last kernel + epilogue run for the rank's cameras.
+    Same certified optimum as the single-GPU context (rotations <= 1e-6), at test size and at Final-13682 size (6.4 M observations)."""
+    code = _team_worker_code()
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_SDMA="0", XM_WATCHDOG_S="120")
+    one, team = str(tmp_path / "one.npz"), str(tmp_path / "team.npz")
+    _run(code, ["single", 1, one, case], env, timeout=900)
+    _run(code, ["team", world, team, case], env, timeout=900)
+    a, t = np.load(one), np.load(team)
+    assert int(t["n_gpus"]) == world and int(t["exchange"]) == 1              # all-gathers between the launches
+    assert int(t["rank"]) == int(a["rank"]) and int(t["status"]) == int(a["status"]) == 1
+    assert float(t["primal"]) == pytest.approx(float(a["primal"]), rel=1e-8)
     assert tl.rotation_parity(t["R"], t["s"], a["R"], a["s"]) < 1e-6
 
 

@@ -28,12 +28,16 @@ constexpr int kLaB = 64;   // block size
 // 16][k = lane / 16], B[k = lane / 16][j = lane % 16], D[row = lane / 16 + 4 reg][col = lane % 16].
 // lower_only: skip tiles strictly above the diagonal (syrk).
 typedef double la_v4 __attribute__((ext_vector_type(4)));
+// The K chunks are DOUBLE-BUFFERED (round 4): chunk k + 1 travels from memory into registers while the matrix cores work on chunk k out
+// of LDS, and is stored into the other LDS buffer behind the one barrier per chunk.  The substitutions of the inverse launch at most
+// n / 64 workgroups with K up to n: one workgroup per CU, so nothing else hides the load latency (13 681 rows: 0.8 s -> see
+// profiles/r04_schur_setup.txt).
 __global__ __launch_bounds__(256) void la_gemm_sub_kernel(int m, int n, int k, const double *__restrict__ A, int64_t lda, int ta,
                                                            const double *__restrict__ B, int64_t ldb, int tb, double *__restrict__ C,
                                                            int64_t ldc, int lower_only) {
     const int bi = blockIdx.x, bj = blockIdx.y;
     if (lower_only && bj > bi) return;
-    __shared__ double As[16][kLaB + 1], Bs[16][kLaB + 1];   // As[kk][i], Bs[kk][j]
+    __shared__ double As[2][16][kLaB + 1], Bs[2][16][kLaB + 1];   // [buffer][kk][i / j]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = bi * kLaB, j0 = bj * kLaB;
     const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;   // this wavefront's quarter of the tile
@@ -43,30 +47,50 @@ __global__ __launch_bounds__(256) void la_gemm_sub_kernel(int m, int n, int k, c
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = la_v4{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < k; k0 += 16) {
-        for (int e = threadIdx.x; e < 16 * kLaB; e += 256) {
-            // consecutive threads run along the contiguous direction of each operand (rows of a stored matrix)
-            const int ia = ta ? e / 16 : e % kLaB, ka = ta ? e % 16 : e / kLaB;
-            const int jb = tb ? e % kLaB : e / 16, kb = tb ? e / kLaB : e % 16;
-            double va = 0.0, vb = 0.0;
-            if (i0 + ia < m && k0 + ka < k) va = ta ? A[(size_t)(k0 + ka) + (size_t)(i0 + ia) * lda] : A[(size_t)(i0 + ia) + (size_t)(k0 + ka) * lda];
-            if (j0 + jb < n && k0 + kb < k) vb = tb ? B[(size_t)(j0 + jb) + (size_t)(k0 + kb) * ldb] : B[(size_t)(k0 + kb) + (size_t)(j0 + jb) * ldb];
-            As[ka][ia] = va;
-            Bs[kb][jb] = vb;
+    // each thread moves 4 elements of either operand per chunk; consecutive threads run along the contiguous direction of the stored matrix
+    int ia[4], ka[4], jb[4], kb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        ia[q] = ta ? e / 16 : e % kLaB; ka[q] = ta ? e % 16 : e / kLaB;
+        jb[q] = tb ? e % kLaB : e / 16; kb[q] = tb ? e / kLaB : e % 16;
+    }
+    double va[4], vb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            va[q] = 0.0; vb[q] = 0.0;
+            if (i0 + ia[q] < m && k0 + ka[q] < k)
+                va[q] = ta ? A[(size_t)(k0 + ka[q]) + (size_t)(i0 + ia[q]) * lda] : A[(size_t)(i0 + ia[q]) + (size_t)(k0 + ka[q]) * lda];
+            if (j0 + jb[q] < n && k0 + kb[q] < k)
+                vb[q] = tb ? B[(size_t)(j0 + jb[q]) + (size_t)(k0 + kb[q]) * ldb] : B[(size_t)(k0 + kb[q]) + (size_t)(j0 + jb[q]) * ldb];
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { As[buf][ka[q]][ia[q]] = va[q]; Bs[buf][kb[q]][jb[q]] = vb[q]; }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < k; k0 += 16) {
+        const bool more = k0 + 16 < k;
+        if (more) fetch(k0 + 16);
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
             const int kk = kq * 4 + lk;
             double av[2], bv[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { av[u] = As[kk][r0 + 16 * u + l16]; bv[u] = Bs[kk][c0 + 16 * u + l16]; }
+            for (int u = 0; u < 2; ++u) { av[u] = As[buf][kk][r0 + 16 * u + l16]; bv[u] = Bs[buf][kk][c0 + 16 * u + l16]; }
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[x], av[y], acc[x][y], 0, 0, 0);
         }
+        if (more) stash(buf ^ 1);   // the other buffer: nobody reads it during this chunk
         __syncthreads();
+        buf ^= 1;
     }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -207,15 +231,29 @@ bool spd_inverse_device(int n, double *A, double *X, hipStream_t st) {
     if (h) return false;
     if (trace) { std::fprintf(stderr, "spd_inverse: Cholesky factorisation %8.1f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3); t0 = std::chrono::steady_clock::now(); }
     hipLaunchKernelGGL(la_identity_kernel, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, st, n, X, ld);
-    for (int i = 0; i < n; i += kLaB) {   // forward: Y_i = L_ii^-1 (I_i - L[i, 0:i] Y[0:i, :]); Y is lower triangular: columns [0, i + b)
-        const int b = std::min(kLaB, n - i), nc = i + b;
-        gemm_sub(b, nc, i, A + i, ld, 0, X, ld, 0, X + i, ld, 0, st);
-        hipLaunchKernelGGL(la_trsm_left_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, b, nc, A + (size_t)i + (size_t)i * ld, ld, 0, X + i, ld);
+    // Both substitutions advance in SUPER blocks of kLaS = 256 rows: one GEMM with everything outside the super block (K up to n, 4 x
+    // n / 64 workgroups: every CU busy), then its four 64-row blocks in turn (small GEMM inside the super block + the 64 x 64 triangular
+    // solve).  With 64-row steps alone the chain was 2 x 214 launches of at most 214 workgroups each.
+    constexpr int kLaS = 4 * kLaB;
+    for (int I = 0; I < n; I += kLaS) {   // forward: Y_I = L_II^-1 (I_I - L[I, 0:I] Y[0:I, :]); Y is lower triangular: columns [0, row end)
+        const int B = std::min(kLaS, n - I);
+        gemm_sub(B, I + B, I, A + I, ld, 0, X, ld, 0, X + I, ld, 0, st);
+        for (int i = I; i < I + B; i += kLaB) {
+            const int b = std::min(kLaB, n - i), nc = i + b;
+            gemm_sub(b, nc, i - I, A + (size_t)i + (size_t)I * ld, ld, 0, X + I, ld, 0, X + i, ld, 0, st);
+            hipLaunchKernelGGL(la_trsm_left_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, b, nc, A + (size_t)i + (size_t)i * ld, ld, 0, X + i, ld);
+        }
     }
-    for (int i = ((n - 1) / kLaB) * kLaB; i >= 0; i -= kLaB) {   // backward: X_i = L_ii^-T (Y_i - L[i+b:, i]^T X[i+b:, :]), lower triangle: columns [0, i + b)
-        const int b = std::min(kLaB, n - i), below = n - i - b, nc = i + b;
-        gemm_sub(b, nc, below, A + (size_t)(i + b) + (size_t)i * ld, ld, 1, X + i + b, ld, 0, X + i, ld, 0, st);
-        hipLaunchKernelGGL(la_trsm_left_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, b, nc, A + (size_t)i + (size_t)i * ld, ld, 1, X + i, ld);
+    for (int I = ((n - 1) / kLaS) * kLaS; I >= 0; I -= kLaS) {   // backward: X_I = L_II^-T (Y_I - L[I+B:, I]^T X[I+B:, :]), lower triangle: columns [0, I + B)
+        const int B = std::min(kLaS, n - I), below = n - I - B, ncI = I + B;
+        gemm_sub(B, ncI, below, A + (size_t)(I + B) + (size_t)I * ld, ld, 1, X + I + B, ld, 0, X + I, ld, 0, st);
+        for (int i = I + ((B - 1) / kLaB) * kLaB; i >= I; i -= kLaB) {
+            const int b = std::min(kLaB, n - i), inside = I + B - i - b;   // rows of the super block below block i
+            // (all the columns of the super block's range: the entries right of block i's own diagonal are scratch, but the blocks above need
+            // X[i, c] for c up to their own diagonal only, which lies left of i + b)
+            gemm_sub(b, i + b, inside, A + (size_t)(i + b) + (size_t)i * ld, ld, 1, X + i + b, ld, 0, X + i, ld, 0, st);
+            hipLaunchKernelGGL(la_trsm_left_kernel, dim3((i + b + 255) / 256), dim3(256), 0, st, b, i + b, A + (size_t)i + (size_t)i * ld, ld, 1, X + i, ld);
+        }
     }
     check_launch("spd_inverse(solve)");
     XM_HIP_CHECK(hipStreamSynchronize(st));

@@ -37,8 +37,11 @@ void rank1_sub_device(int n, double *A, const double *u, double q, hipStream_t s
 class SchurOp {
 public:
     // cam / lm: 0-based indices of the nobs observations, p: nobs x 3 (row-major), w: nobs
+    // comm (not owned; may be null): the communicator of a row-partitioned context -- every rank holds all the observations and repeats
+    // the landmark kernels, multiplies its own rows of VT^-1 only and all-gathers x_cam; the last kernel runs for the rank's cameras
+    // (CamArgs.nloc / cam0)
     SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *cam, const int32_t *lm, const double *p, const double *w,
-            hipStream_t st);
+            hipStream_t st, Comm *comm = nullptr);
     // Y = alpha * Q * W for all n cameras (W: camera records of 3 * pitch_of(o) doubles), same CamArgs / epilogue contract and
     // per-workgroup partial sums (grid qw_grid(n)) as launch_qw_dense
     void product(int o, int epi, const double *W, double alpha, const CamArgs &a, hipStream_t st);
@@ -55,6 +58,9 @@ public:
 
 private:
     int64_t n_ = 0, m_ = 0, nobs_ = 0, nred_ = 0, ldv_ = 0;   // nred = cameras of the padded (N-1) system / 3
+    Comm *comm_ = nullptr;
+    int world_ = 1, rank_ = 0;
+    int64_t nred_loc_ = 0, nred_pad_ = 0;                     // pseudo-cameras per rank, padded total
     DevBuf<int64_t> cam_ptr_, lm_ptr_;
     DevBuf<int32_t> cam_lm_, lm_cam_;         // by camera: landmark of each observation; by landmark: camera
     // landmarks are numbered by degree (descending) on the device; the first nheavy_ (more than kSchurHeavy observations) keep contiguous

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kSchurHeavyThreads) void schur_lm_x_kernel(SchurLm 
 
 // Y_i = Q1_i W_i - c_i x_cam_i + sum_{obs of i} w p x_l, then the common tail of the Q*W kernels (xm_device.h)
 template <int O, int EPI>
-__global__ __launch_bounds__(256) void schur_cam_y_kernel(int64_t nobs, const int64_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_lm,
+__global__ __launch_bounds__(256) void schur_cam_y_kernel(int64_t n, int64_t nobs, const int64_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_lm,
                                                            const double *__restrict__ cam_w, const double *__restrict__ cam_p,
                                                            const double *__restrict__ Q1, const double *__restrict__ c,
                                                            const double *__restrict__ W, const double *__restrict__ xc,
@@ -192,16 +192,17 @@ __global__ __launch_bounds__(256) void schur_cam_y_kernel(int64_t nobs, const in
     }
     __shared__ double red[kQwWaves][3];
     const int gl = threadIdx.x & 63, slot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cam = blockIdx.x * kQwWaves + slot;
-    const bool active = cam < a.nloc;
+    const int lcam = blockIdx.x * kQwWaves + slot;   // camera of THIS rank (epilogue arrays); cam: its global index (observation lists, W, Q1, c)
+    const bool active = lcam < a.nloc;
+    const int64_t cam = (int64_t)a.cam0 + lcam;
     EpiOps eops;
-    epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
+    epi_prefetch<O, EPI>(eops, active ? lcam : 0, gl, active, a);
     double acc[3][O];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
-    if (active) {
+    if (active && cam < n) {   // (cam >= n: an inert padding camera of the row partition -- zero row)
         for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 64) {
             const double w = cam_w[e];
             double x[O];
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void schur_cam_y_kernel(int64_t nobs, const in
                 }
         }
     }
-    qw_finish<O, EPI, 64, kQwWaves>(cam, gl, slot, active, acc, alpha, a, eops, red);
+    qw_finish<O, EPI, 64, kQwWaves>(lcam, gl, slot, active, acc, alpha, a, eops, red);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -332,7 +333,10 @@ __global__ __launch_bounds__(64) void schur_vt_rows_kernel(int64_t mr, int64_t c
 // host: factors from the observation list (utils/creatematrix.py:62-175, restated on the observation level)
 // ------------------------------------------------------------------------------------------------------------------
 SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *cam, const int32_t *lm, const double *p, const double *w,
-                 hipStream_t st) {
+                 hipStream_t st, Comm *comm) {
+    comm_ = (comm && comm->active()) ? comm : nullptr;
+    world_ = comm_ ? comm_->world : 1;
+    rank_ = comm_ ? comm_->rank : 0;
     if (n < 1 || n_landmarks < 1 || nobs < 1 || !cam || !lm || !p || !w) throw Error(XM_ERR_ARG, "matrix-free Q: bad observation list");
     if (n > kSchurMaxCams) throw Error(XM_ERR_ARG, "matrix-free Q: more than " + std::to_string(kSchurMaxCams) + " cameras");
     n_ = n; m_ = n_landmarks; nobs_ = nobs;
@@ -428,7 +432,11 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     const int64_t mr = N - 1;
     nred_ = std::max<int64_t>(1, (mr + 2) / 3);
     ldv_ = dense_ld(nred_);
-    vtinv_.alloc((size_t)3 * nred_ * (size_t)ldv_);
+    // several ranks: the rows of VT^-1 are dealt out in equal ranges of pseudo-cameras (3 rows each); every rank keeps the whole inverse
+    // (the set-up is replicated) but multiplies only its own rows, and the ranks all-gather x_cam
+    nred_loc_ = (nred_ + world_ - 1) / world_;
+    nred_pad_ = nred_loc_ * world_;
+    vtinv_.alloc((size_t)3 * nred_pad_ * (size_t)ldv_);
     set_weights(w, st);
 }
 
@@ -684,7 +692,7 @@ void SchurOp::ensure(int o) {
     const size_t OP = (size_t)pitch_of(o);
     h_.alloc((size_t)m_ * OP); xl_.alloc((size_t)m_ * OP);
     r_.alloc((size_t)ldv_ * OP + 2);            // product input of the dense kernel: ldv rows, zero beyond N-1
-    xc_.alloc((size_t)3 * nred_ * OP + 2);
+    xc_.alloc((size_t)3 * nred_pad_ * OP + 2);
     // VT^-1 is symmetric: above XM_SCHUR_SYM_MIN_ROWS rows (default 6144, the threshold of the dense solver) the chain applies it with
     // the half-traffic kernel (upper triangle only; o = 3, 4)
     static const int64_t sym_min = [] { const char *e = std::getenv("XM_SCHUR_SYM_MIN_ROWS"); return (e && *e) ? (int64_t)std::atoll(e) : (int64_t)6144; }();
@@ -706,27 +714,37 @@ template <int O>
 static void schur_product_o(int epi, int64_t n, int64_t nobs, const SchurLm &L, const int64_t *cam_ptr, const int32_t *cam_lm, const double *cam_w, const double *cam_p,
                             const double *Q1,
                             const double *c, const double *q3inv, const double *vtinv, int64_t nred, int64_t ldv, double *h, double *r,
-                            double *xc, double *xl, const double *W, double alpha, const CamArgs &a, double *sym_prow, double *sym_pcol, hipStream_t st) {
+                            double *xc, double *xl, const double *W, double alpha, const CamArgs &a, double *sym_prow, double *sym_pcol, hipStream_t st,
+                            Comm *comm, int64_t nred_loc) {
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
     const int64_t nheavy = L.nheavy, nlight = L.m - L.nheavy;
-    const dim3 b(256), gc(qw_grid((int)n));
+    const dim3 b(256), gc(qw_grid((int)n)), gy(qw_grid(a.nloc));
     const dim3 glm((unsigned)(nheavy + (nlight + kSchurHeavyThreads - 1) / kSchurHeavyThreads)), blm(kSchurHeavyThreads);
     hipLaunchKernelGGL((schur_lm_h_kernel<O>), glm, blm, 0, st, L, q3inv, W, sc, h);
     hipLaunchKernelGGL((schur_cam_r_kernel<O>), gc, b, 0, st, (int)n, cam_ptr, cam_lm, cam_w, c, W, h, sc, r);
     if (n > 1) {
+        constexpr int OPc = pitch_of(O);
         CamArgs pa;
         std::memset(&pa, 0, sizeof(pa));
-        pa.nloc = (int)nred; pa.out = xc; pa.scal = a.scal;
-        if (sym_prow && (O == 3 || O == 4)) launch_qw_sym(O, EPI_PLAIN, vtinv, ldv, r, 1.0, pa, sym_prow, sym_pcol, st);
-        else launch_qw_dense(O, EPI_PLAIN, vtinv, ldv, r, 1.0, pa, st);
+        pa.scal = a.scal;
+        if (comm) {   // this rank's rows of VT^-1, then everybody's x_cam (equal chunks: the system is padded to world * nred_loc pseudo-cameras)
+            const int64_t a0 = (int64_t)comm->rank * nred_loc;
+            pa.nloc = (int)nred_loc; pa.out = xc + (size_t)3 * a0 * OPc;
+            launch_qw_dense(O, EPI_PLAIN, vtinv + (size_t)3 * a0 * (size_t)ldv, ldv, r, 1.0, pa, st);
+            comm->allgather(xc, (size_t)3 * nred_loc * OPc, st);
+        } else {
+            pa.nloc = (int)nred; pa.out = xc;
+            if (sym_prow && (O == 3 || O == 4)) launch_qw_sym(O, EPI_PLAIN, vtinv, ldv, r, 1.0, pa, sym_prow, sym_pcol, st);
+            else launch_qw_dense(O, EPI_PLAIN, vtinv, ldv, r, 1.0, pa, st);
+        }
     }
     hipLaunchKernelGGL((schur_lm_x_kernel<O>), glm, blm, 0, st, L, q3inv, h, xc, sc, xl);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_PLAIN>), gc, b, 0, st, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_GRAD>), gc, b, 0, st, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_HESS>), gc, b, 0, st, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_PLAIN>), gy, b, 0, st, n, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_GRAD>), gy, b, 0, st, n, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((schur_cam_y_kernel<O, EPI_HESS>), gy, b, 0, st, n, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break;
         case EPI_CERT:
-            if constexpr (O == 1) { hipLaunchKernelGGL((schur_cam_y_kernel<1, EPI_CERT>), gc, b, 0, st, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break; }
+            if constexpr (O == 1) { hipLaunchKernelGGL((schur_cam_y_kernel<1, EPI_CERT>), gy, b, 0, st, n, nobs, cam_ptr, cam_lm, cam_w, cam_p, Q1, c, W, xc, xl, alpha, a); break; }
             throw Error(XM_ERR_ARG, "certificate operator needs o == 1");
         default: throw Error(XM_ERR_ARG, "bad epilogue");
     }
@@ -742,7 +760,8 @@ void SchurOp::product(int o, int epi, const double *W, double alpha, const CamAr
     SchurLm L;
     L.m = m_; L.nheavy = nheavy_; L.total = ltotal_; L.ptr = lm_ptr_.p; L.gbase = gbase_.p; L.deg = ldeg_.p; L.cam = lm_cam_.p; L.w = lm_w_.p; L.p = lm_p_.p;
     XM_DISPATCH_O(o, (schur_product_o<O_>(epi, n_, nobs_, L, cam_ptr_.p, cam_lm_.p, cam_w_.p, cam_p_.p, Q1_.p,
-                                         c_.p, q3inv_.p, vtinv_.p, nred_, ldv_, h_.p, r_.p, xc_.p, xl_.p, W, alpha, a, vt_sym_ ? sym_prow_.p : (double *)nullptr, sym_pcol_.p, st)));
+                                         c_.p, q3inv_.p, vtinv_.p, nred_, ldv_, h_.p, r_.p, xc_.p, xl_.p, W, alpha, a, (vt_sym_ && !comm_) ? sym_prow_.p : (double *)nullptr, sym_pcol_.p, st,
+                                         comm_, nred_loc_)));
     check_launch("schur_product");
 }
 

@@ -333,8 +333,9 @@ void Context::init(const xm_problem_t &prob_in) {
             else sell_.reset(new SellMatrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_lmax, st_, codec, cam0_));
         }
     } else if (storage_ == XM_STORAGE_SCHUR) {
-        if (world != 1) throw Error(XM_ERR_ARG, "matrix-free storage is single-GPU in this version");
-        schur_.reset(new SchurOp(n_, prob.n_landmarks, prob.nobs, prob.obs_cam, prob.obs_lm, prob.obs_p, prob.obs_w, st_));
+        // several ranks (round 4): every rank builds the factors from the whole observation list; the rows of VT^-1 and the cameras of the
+        // last kernel of the chain are partitioned (xm_schur.h)
+        schur_.reset(new SchurOp(n_, prob.n_landmarks, prob.nobs, prob.obs_cam, prob.obs_lm, prob.obs_p, prob.obs_w, st_, comm_.get()));
         w_cur_.assign(prob.obs_w, prob.obs_w + prob.nobs);
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
@@ -459,7 +460,7 @@ void Context::setup_rank(int o) {
     // tCG exchange buffers: two parity buffers of world chunks [rows of the image of Hp (multi-rank only) | 3*nA_loc | nB_loc]
     const size_t b_off = comm_->active() ? mat : 0;
     const size_t pb = (size_t)2 * (b_off * world + 3 * nA_ + nB_);
-    if (comm_->peer() && world > 1 && cfg_.exchange != 1 && !symw_) {   // (the window product all-gathers between its launches: lockstep loop)
+    if (comm_->peer() && world > 1 && cfg_.exchange != 1 && !symw_ && storage_ != XM_STORAGE_SCHUR) {   // (the window product and the matrix-free chain all-gather between their launches: lockstep loop)
         // direct peer exchange: the buffers live in memory every rank of the group can store into (collective, host-synchronised)
         partsB_.release();
         comm_->xchg_setup(pb, xchg_);
@@ -560,7 +561,7 @@ int Context::prod_grid() const {
 // expires).  256 CUs x 4 workgroups is admitted whatever the kernel's register count (cg_step: 61 VGPRs, 106 SGPRs -> 6 per CU).
 int Context::tcg_blocks() const {
     int g = flat_grid((int64_t)nloc_ * 3 * OP_);
-    if (comm_->peer() && comm_->world > 1 && cfg_.exchange != 1 && !symw_) g = std::min(g, std::max(8, 1024 / std::max(1, comm_->ranks_on_my_device())));
+    if (comm_->peer() && comm_->world > 1 && cfg_.exchange != 1 && !symw_ && storage_ != XM_STORAGE_SCHUR) g = std::min(g, std::max(8, 1024 / std::max(1, comm_->ranks_on_my_device())));
     return g;
 }
 
@@ -1335,7 +1336,9 @@ void Context::edge_residuals(double *res) {
         std::memset(&opt, 0, sizeof(opt));
         const xm_options_t *keep = opt_;
         opt_ = &opt;
-        launch_scale_rows(o_, nloc_, R_.p, s_.p, W_.p, st_);
+        launch_scale_rows(o_, nloc_, R_.p, s_.p, W_.p + (size_t)cam0_ * 3 * OP_, st_);
+        gather_W();
+        flush_gather();
         CamArgs a = cam_args(cur_);
         a.out = HpR_.p;
         schur_->residuals(o_, W_.p, res, a, st_);

@@ -100,7 +100,6 @@ Team::Team(const xm_problem_t &prob, int n_gpus, int gpu_map) : p_(new Impl) {
     XM_HIP_CHECK(hipGetDeviceCount(&ndev));
     if (gpu_map == 0 && n_gpus > ndev)
         throw Error(XM_ERR_ARG, "n_gpus = " + std::to_string(n_gpus) + " but only " + std::to_string(ndev) + " HIP devices are visible (gpu_map = 1 runs every rank on device 0)");
-    if (prob.storage == XM_STORAGE_SCHUR) throw Error(XM_ERR_ARG, "matrix-free storage is single-GPU in this version");
     if (prob.storage == XM_STORAGE_DENSE && prob.q_on_device) throw Error(XM_ERR_ARG, "q_on_device needs a single-GPU context");
     t.world = n_gpus;
     t.device.resize((size_t)n_gpus);
