@@ -444,7 +444,7 @@ def test_eight_virtual_gpus(xmamd, tmp_path, case):
     _run(code, ["single", 1, one, case], env)
     _run(code, ["team", 8, eight, case], env)
     a, t = np.load(one), np.load(eight)
-    assert int(t["n_gpus"]) == 8 and int(t["exchange"]) == 2
+    assert int(t["n_gpus"]) == 8 and int(t["exchange"]) == 1     # more than four ranks on ONE device: host-synchronised collectives (Comm::device_waits)
     assert int(t["rank"]) == int(a["rank"]) and int(t["status"]) == int(a["status"]) == 1
     assert float(t["primal"]) == pytest.approx(float(a["primal"]), rel=1e-9)
     assert tl.rotation_parity(t["R"], t["s"], a["R"], a["s"]) < 1e-6
@@ -528,7 +528,7 @@ def test_multi_rank_baseline_sizes_vs_recorded_oracle(xmamd, tmp_path, case, wor
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_SDMA="0", XM_WATCHDOG_S="120")
     _run(_team_worker_code(), ["team", world, out, case], env, timeout=900)
     t = np.load(out)
-    assert int(t["n_gpus"]) == world and int(t["exchange"]) == 2
+    assert int(t["n_gpus"]) == world and int(t["exchange"]) == (2 if world <= 4 else 1)
     assert int(t["rank"]) == c.get("rank", 3) and int(t["status"]) == 1
     assert float(t["primal"]) == pytest.approx(c["f"], rel=1e-8)
     rot, _ = tl.recover_rotations(t["R"], t["s"])

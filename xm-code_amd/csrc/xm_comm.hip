@@ -545,6 +545,7 @@ struct PeerComm : Comm {
     int kind() const override { return g->kind(); }
     bool peer() const override { return true; }
     int ranks_on_my_device() const override { return g->ranks_on_device_of(rank); }
+    bool device_waits() const override { return g->ranks_on_device_of(rank) <= 4; }
     unsigned long long *flags_of(int r) const { return reinterpret_cast<unsigned long long *>(parena[r]); }
     unsigned long long *tickets() const { return reinterpret_cast<unsigned long long *>(arena) + kFlagWords; }
     double *stage_of(int r) const { return reinterpret_cast<double *>(static_cast<char *>(parena[r]) + kArenaHead); }
@@ -649,9 +650,18 @@ struct PeerComm : Comm {
         if (world > 1) {
             const int grid = (int)std::min<size_t>(64, (count + 2047) / 2048);
             hipLaunchKernelGGL(peer_push_kernel, dim3(grid), dim3(256), 0, st, pp, buf + (size_t)rank * count, count, slot_off, slot, seq, tickets() + slot);
+            const bool host_sync = !device_waits();
+            if (host_sync) {   // many ranks on one GPU: everybody's push has landed before anybody's second launch starts (it then finds its flags set)
+                XM_HIP_CHECK(hipStreamSynchronize(st));
+                g->barrier(hb, "all-gather (host-synchronised)");
+            }
             const int wgrid = (int)std::min<size_t>(128, (count * world + 2047) / 2048);
             hipLaunchKernelGGL(peer_wait_kernel, dim3(wgrid), dim3(256), 0, st, pp, buf, count, slot_off, slot, seq, spin_ticks(), herr_dev, plain_reads);
             check_launch("peer_allgather");
+            if (host_sync) {   // and everybody has read this slot before anybody pushes into it again
+                XM_HIP_CHECK(hipStreamSynchronize(st));
+                g->barrier(hb, "all-gather (host-synchronised, read)");
+            }
         }
     }
     // collective (host-synchronised): tCG exchange buffer of at least `doubles` (grow-only; the same argument on every rank) with

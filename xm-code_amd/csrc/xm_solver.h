@@ -65,6 +65,10 @@ struct Comm {
     // ranks of this communicator whose kernels run on THIS rank's device (1 on a real node; > 1 for virtual devices / processes sharing a GPU):
     // a launch that waits for its peers inside the kernel must leave room for theirs (Context::tcg_blocks)
     virtual int ranks_on_my_device() const { return 1; }
+    // may a kernel of this rank wait for its peers ON THE DEVICE?  Not when more than four ranks share one GPU (a test vehicle): a waiting
+    // kernel holds its hardware queue, and the queues of eight ranks' pushes and waits are more than the device keeps active at once --
+    // the collectives are then synchronised through the host and the tCG exchange is not fused into cg_step
+    virtual bool device_waits() const { return true; }
     std::string fallback_note;   // why a faster transport was given up for this one (empty: first choice)
     void note(const char *what, double a, double b);   // XM_COMM_TRACE debugging aid
 private:

@@ -460,7 +460,7 @@ void Context::setup_rank(int o) {
     // tCG exchange buffers: two parity buffers of world chunks [rows of the image of Hp (multi-rank only) | 3*nA_loc | nB_loc]
     const size_t b_off = comm_->active() ? mat : 0;
     const size_t pb = (size_t)2 * (b_off * world + 3 * nA_ + nB_);
-    if (comm_->peer() && world > 1 && cfg_.exchange != 1 && !symw_ && storage_ != XM_STORAGE_SCHUR) {   // (the window product and the matrix-free chain all-gather between their launches: lockstep loop)
+    if (comm_->peer() && world > 1 && cfg_.exchange != 1 && !symw_ && storage_ != XM_STORAGE_SCHUR && comm_->device_waits()) {   // (the window product and the matrix-free chain all-gather between their launches: lockstep loop)
         // direct peer exchange: the buffers live in memory every rank of the group can store into (collective, host-synchronised)
         partsB_.release();
         comm_->xchg_setup(pb, xchg_);
@@ -561,7 +561,7 @@ int Context::prod_grid() const {
 // expires).  256 CUs x 4 workgroups is admitted whatever the kernel's register count (cg_step: 61 VGPRs, 106 SGPRs -> 6 per CU).
 int Context::tcg_blocks() const {
     int g = flat_grid((int64_t)nloc_ * 3 * OP_);
-    if (comm_->peer() && comm_->world > 1 && cfg_.exchange != 1 && !symw_ && storage_ != XM_STORAGE_SCHUR) g = std::min(g, std::max(8, 1024 / std::max(1, comm_->ranks_on_my_device())));
+    if (comm_->peer() && comm_->world > 1 && cfg_.exchange != 1 && !symw_ && storage_ != XM_STORAGE_SCHUR && comm_->device_waits()) g = std::min(g, std::max(8, 1024 / std::max(1, comm_->ranks_on_my_device())));
     return g;
 }
 
