@@ -350,6 +350,11 @@ int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gat
  * Rout = MGS_rows(R + t*D) (Dense/batchedQR.h:42-67), sout = s*exp(t*ds/s) (trustregion.h:19-24), s[0] stays 1 */
 int xm_retract(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t,
                double *dRout, double *dsout, void *stream);
+/* the same with the kernel form chosen -- variant 0: one thread per camera (the default), 1: polar retraction, 2: MGS-QR with a quad of lanes
+ * per camera and DPP reductions (`north_star`'s cross-lane form; measured slower, kept as the recorded alternative) -- and, if ms_avg is
+ * not NULL, timed over `reps` launches */
+int xm_retract_variant(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t, double *dRout,
+                       double *dsout, int variant, int reps, double *ms_avg);
 /* the same with the polar retraction (XM_RETRACT_POLAR): Rout_i = (M M^T)^{-1/2} M, M = R_i + t D_i */
 int xm_retract_polar(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t,
                      double *dRout, double *dsout, void *stream);

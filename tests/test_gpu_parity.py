@@ -83,6 +83,26 @@ def test_retraction_matches_oracle(xmamd, oracle, o):
     assert tl.stiefel_defect(Rn) < 1e-13
 
 
+@pytest.mark.parametrize("o", [3, 4, 5, 10])
+def test_retraction_quad_per_camera_matches_oracle(xmamd, oracle, o):
+    """the measured alternative of the MGS-QR retraction (a quad of lanes per camera, DPP reductions -- `north_star`'s cross-lane form;
+    scripts/kbench_retract.py records why the thread-per-camera kernel stays the default): same result as the oracle's Gram-Schmidt"""
+    rng = np.random.default_rng(o)
+    n = 131                                                                  # not a multiple of 64: a partly filled workgroup
+    R = oracle.mgs_rows(rng.standard_normal((3 * n, o)))
+    D = 0.3 * rng.standard_normal((3 * n, o)); s = rng.uniform(0.5, 2.0, n); s[0] = 1.0
+    ds = rng.standard_normal(n)
+    dR = xmamd.DevArray(xmamd.to_rm(R)); dD = xmamd.DevArray(xmamd.to_rm(D)); dsv = xmamd.DevArray(s); dds = xmamd.DevArray(ds)
+    dRo = xmamd.DevArray(nbytes=dR.nbytes); dso = xmamd.DevArray(nbytes=dsv.nbytes)
+    xmamd._chk(xmamd.lib().xm_retract_variant(n, o, dR.ptr, dsv.ptr, dD.ptr, dds.ptr, 0.7, dRo.ptr, dso.ptr, 2, 1, None))
+    Rn, sn = xmamd.from_rm(dRo.get(), 3 * n, o), dso.get()
+    for b in (dR, dD, dsv, dds, dRo, dso):
+        b.free()
+    assert np.allclose(Rn, oracle.mgs_rows(R + 0.7 * D), atol=1e-13)
+    exp = s * np.exp(0.7 * ds / s); exp[0] = 1.0
+    assert np.allclose(sn, exp, rtol=1e-14) and tl.stiefel_defect(Rn) < 1e-13
+
+
 # ---------------------------------------------------------------------------------------------- sliced-ELL product (xm_sell.hip)
 @pytest.mark.parametrize("n,deg,o,slabs,lmax", [(1, 2, 3, 4, 64), (7, 3, 3, 8, 64), (200, 8, 3, 4, 64), (300, 20, 5, 2, 64), (1000, 12, 4, 8, 5),
                                                 (150, 40, 3, 1, 64), (211, 9, 1, 4, 64), (4000, 30, 3, 4, 64)])

@@ -394,6 +394,26 @@ int xm_retract_polar(int64_t n, int o, const double *dR, const double *ds, const
     return XM_OK;
     XM_CATCH
 }
+// variant: 0 thread per camera (MGS-QR) | 1 polar | 2 MGS-QR with a quad of lanes per camera; *ms_avg (may be NULL: one untimed call) = HIP-event average
+int xm_retract_variant(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t, double *dRout,
+                       double *dsout, int variant, int reps, double *ms_avg) {
+    XM_TRY
+    if (variant < 0 || variant > 2 || reps < 1) throw xm::Error(XM_ERR_ARG, "bad argument");
+    xm::launch_retract(o, (int)n, 0, dR, ds, dD, dds, t, dRout, dsout, nullptr, nullptr, variant);
+    if (!ms_avg) { XM_HIP_CHECK(hipDeviceSynchronize()); return XM_OK; }
+    hipEvent_t e0, e1;
+    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) xm::launch_retract(o, (int)n, 0, dR, ds, dD, dds, t, dRout, dsout, nullptr, nullptr, variant);
+    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+    XM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_avg = (double)ms / reps;
+    return XM_OK;
+    XM_CATCH
+}
 int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
     XM_TRY
     hipEvent_t e0, e1;

@@ -151,7 +151,8 @@ void launch_model_value(int o, int nloc, const double *vR, const double *vs, con
                         const double *rgR, const double *rgs, const double *s, double *parts, hipStream_t st);
 void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,
                            unsigned long long seq, int grouping, hipStream_t st);
-// polar != 0: polar retraction (XM_RETRACT_POLAR) instead of the reference's Gram-Schmidt retraction
+// polar: 0 the reference's Gram-Schmidt retraction, one thread per camera | 1 polar retraction (XM_RETRACT_POLAR) | 2 Gram-Schmidt with a quad
+// of lanes per camera (measured alternative, scripts/kbench_retract.py)
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
                     double *Rout, double *sout, double *Wloc, hipStream_t st, int polar = 0);
 void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *QsR, const double *R, const double *s,

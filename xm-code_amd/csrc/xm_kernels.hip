@@ -1433,6 +1433,61 @@ __global__ __launch_bounds__(256) void retract_kernel(int nloc, int cam0, const 
     }
 }
 
+// The same retraction (MGS-QR form) with a QUAD of lanes per camera -- `north_star` asks for cross-lane reductions per camera; the
+// thread-per-camera kernel above is the default because it measures faster (scripts/kbench_retract.py, profiles/r04_kbench_retract.txt).
+// Lane g of the quad owns columns g, g + 4, g + 8 of the camera's 3 x O block; the dot products of Gram-Schmidt are quad sums (two DPP
+// butterflies).  Kept as the measured alternative (launch_retract variant 1); same results up to the summation order of the dot products.
+template <int O>
+__global__ __launch_bounds__(256) void retract_quad_kernel(int nloc, int cam0, const double *__restrict__ R, const double *__restrict__ s,
+                                                            const double *__restrict__ D, const double *__restrict__ ds, double t,
+                                                            double *Rout, double *sout, double *Wloc) {
+    constexpr int OP = pitch_of(O), NC = (O + 3) / 4;
+    const int g = threadIdx.x & 3;
+    const int cam = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool active = cam < nloc;
+    const size_t base = (size_t)(active ? cam : 0) * 3 * OP;
+    double q[3][NC];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = g + 4 * c;
+            q[r][c] = (active && k < O) ? R[base + r * OP + k] + t * D[base + r * OP + k] : 0.0;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double qq = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qq += q[i][c] * q[i][c];
+        qq = sqrt(group_sum<4>(qq));
+        if (!active) qq = 1.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) q[i][c] /= qq;
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j) {
+            double uu = 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) uu += q[i][c] * q[j][c];
+            uu = group_sum<4>(uu);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) q[j][c] -= uu * q[i][c];
+        }
+    }
+    if (!active) return;
+    const double so = s[cam];
+    const double sn = ((cam0 + cam) == 0 || ds == nullptr) ? so : so * exp(t * ds[cam] / so);
+    if (sout && g == 0) sout[cam] = sn;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = g + 4 * c;
+            if (k < O) { Rout[base + r * OP + k] = q[r][c]; if (Wloc) Wloc[base + r * OP + k] = sn * q[r][c]; }
+        }
+        if (OP > O && g == 0) { Rout[base + r * OP + O] = 0.0; if (Wloc) Wloc[base + r * OP + O] = 0.0; }
+    }
+}
+
 // Certificate multipliers, closed form per camera of the least-squares problem that the reference hands to Eigen's LSCG
 // (checkeig.h:56-220): generators of camera 0 are the six symmetric unit matrices, of camera i>=1 the five
 // traceless / off-diagonal ones.  Output: Lam_i = sum_k y_k A_k (row-major 3x3), dz_i = 2 lam (|sR row 3i|^2 - 1)
@@ -2150,7 +2205,10 @@ void launch_outer_finalize(const double *partsA, int nA_loc, int world, const do
 }
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
                     double *Rout, double *sout, double *Wloc, hipStream_t st, int polar) {
-    if (polar) {
+    if (polar == 2) {   // the quad-per-camera form of the MGS-QR retraction (measured alternative)
+        XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_quad_kernel<O_>), dim3((nloc + 63) / 64), dim3(256), 0, st, nloc, cam0, R, s, D, ds, t,
+                                            Rout, sout, Wloc));
+    } else if (polar) {
         XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 1>), dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, R, s, D, ds, t,
                                             Rout, sout, Wloc));
     } else {
