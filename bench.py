@@ -358,7 +358,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         alg_bytes = (76.0 * nb + 4 * (n + 1)) / ngp + 2 * 8 * 3 * n * o_fin      # FULL-storage accounting whatever is streamed
         kname = "qw_bsr3_kernel<o, EPI_HESS>"
         if os.environ.get("XM_BSR_SELL") == "1" or (os.environ.get("XM_BSR_SELL") != "0" and nb / ngp >= 1000000):
-            if os.environ.get("XM_SELL_LAYOUT") == "1":
+            if os.environ.get("XM_SELL_LAYOUT", "0") != "2":    # the default layout (xm_tuning_t.sell_layout 0 / 1)
                 kname = "qw_sell_kernel<o> + sell_reduce_kernel<o, EPI_HESS> (sliced-ELL over per-XCD column slabs; one product = both launches)"
             else:
                 kname = ("qw_sell2_kernel<o, EPI_HESS> (chunk-tiled sliced-ELL over per-XCD column slabs, ONE launch: the last slice to arrive for a "
@@ -369,7 +369,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
     # HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE (own pass, kernel-trace only), corrected as
     # MI355X_MICROARCH.md prescribes (KB -> bytes, x2 for the gfx950 wide-load half count); see profiles/r01_pmc_*.json
     leg = {"venice1778": "venice", "vg100k": "vg100k_" + args.storage}.get(args.workload, args.workload)
-    traffic, traffic_source, traced_us = recorded_traffic(leg, world)
+    traffic, traffic_source, traced_us = recorded_traffic(leg, ngp)
     out = {
         "metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
         "value": iters / elapsed, "unit": "tCG iters/s", "n_gpus": ngp, "steps": args.steps, "warmup": args.warmup,
@@ -454,7 +454,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                                        "n_gpus": ngp, "value": di["tcg_iters"] / el, "unit": "tCG iters/s", "steps": 1, "warmup": "one outer iteration",
                                        "ms_per_step": el * 1e3, "rank": di["rank"], "status": di["status"], "tcg_iters_per_solve": di["tcg_iters"],
                                        "primal": di["primal"], "sym_product": di.get("sym_product"), "hess_launch_ms": dq_ms,
-                                       **dict(zip(("hess_traffic", "hess_traffic_source", "hess_traced_us"), recorded_traffic("rome_dense", world))),
+                                       **dict(zip(("hess_traffic", "hess_traffic_source", "hess_traced_us"), recorded_traffic("rome_dense", ngp))),
                                        "hess_algorithmic_GBs": db / (dq_ms * 1e-3) / 1e9 if dq_ms > 0 else None}
     if rank == 0 and ngp == 1 and not args.no_hbm_check and wl["kind"] == "dense":
         # same kernel, matrix far beyond every cache: 13682 cameras = 13.5 GB of random f64 generated on the device

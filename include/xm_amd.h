@@ -90,7 +90,9 @@ typedef struct {
     int32_t sell_lmax;         /* 0 = 64 */
     int32_t sell_gather;       /* how the rows of W are fetched: 0 = default (2), 1 = one record per lane, 2 = records fetched element-per-lane and
                                   transposed through LDS, 3 = the two aligned 64-byte sectors of every record fetched by two quads of lanes straight
-                                  into LDS (global_load_lds_dwordx4; o = 3; measured 88 us against 83 us for mode 2 at 100 k cameras: kept selectable) */
+                                  into LDS (global_load_lds_dwordx4; o = 3; measured 85-88 us against 83 us for mode 2 at 100 k cameras: kept selectable), 5 = the same
+                                  sector windows into registers (view-graph codec, o = 3; 82.0-82.2 against 82.8-83.8 us at 100 k cameras, 70.6 against 62.1 on a
+                                  banded graph: kept selectable; 4 is unused) */
     int32_t sell_codec;        /* 0 auto (view-graph storage: quaternion codec; BSR3: full blocks), 1 full blocks, 2 quaternion codec (XM_ERR_ARG if Q is not a view-graph matrix) */
     int32_t overlap;           /* split dense products outside the tCG around the all-gather of W: 0 auto (>= overlap_min_mb per rank), -1 off */
     int32_t overlap_min_mb;    /* 0 = 64 */

@@ -33,8 +33,8 @@ def _weighted_vg(n, deg, seed, sigma=0.3):
 # ---------------------------------------------------------------------------------------------- view-graph codec
 @pytest.mark.parametrize("n,deg,o,slabs,lmax", [(1, 2, 3, 4, 64), (7, 3, 3, 8, 64), (200, 8, 3, 4, 64), (300, 20, 5, 2, 64), (1000, 12, 4, 8, 5),
                                                 (150, 40, 3, 1, 64), (211, 9, 1, 4, 64), (4000, 30, 3, 4, 64)])
-@pytest.mark.parametrize("gather", [0, 1, 2])    # 2: sector windows through LDS-DMA (o = 3; other ranks take mode 1)
-@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("gather", [0, 1, 2, 3, 4])    # o = 3 only (other ranks take mode 1): 2 sector windows through LDS-DMA, 3 aligned
+@pytest.mark.parametrize("layout", [1, 2])             # 8-byte element fetch, 4 sector windows into registers (codec + layout 1)
 def test_qw_sell_quaternion_codec_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather, layout):
     """the sliced-ELL product streaming 36 bytes per stored block (quaternion of the relative rotation scaled by sqrt(2w) + column index,
     diagonal blocks as one double per camera) equals the dense product of the same Q to 1e-12 (blocks are rebuilt in registers, so the

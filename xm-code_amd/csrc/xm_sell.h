@@ -76,6 +76,7 @@ struct SellArgs {   // what the kernels see
 
 class SellMatrix {
 public:
+    int64_t ncols() const { return ncols_; }
     // blocks: host, 9 doubles per block (row-major 3x3), indexed like colidx
     // codec SELL_CODEC_QUAT: throws Error(XM_ERR_ARG) unless every off-diagonal block is -w * rotation and every diagonal block d * I
     // (relative 1e-9); row0 = global camera index of local row 0

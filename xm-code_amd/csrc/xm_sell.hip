@@ -326,12 +326,31 @@ typedef double d2a __attribute__((ext_vector_type(2)));               // 16-byte
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));   // pair at 8-byte alignment (records of W)
 typedef int i2a __attribute__((ext_vector_type(2)));
 
+// gather mode 4: instruction I of a step's sector-window fetch (o = 3).  Lane group g = lane >> 3 takes record 8 g + I (its column sits in
+// lane (lane & 0x38) | I: one ds_swizzle in bit-mask mode) and lane (lane & 7) loads 16 bytes of the record's 128-byte window of two
+// 64-byte-aligned sectors: a quad reads exactly one aligned sector, so a record costs exactly two cache accesses.
+// MEASURED (profiles/r04_pmc_sell_gather_accesses.txt, r04_kbench_sell_gather4.txt): 13.76 M vector-L1 accesses per product instead of
+// 16.14 M, the SAME 8.66 M requests to the L2 and the same duration (82.0-82.2 against 82.8-83.8 us; banded graph 70.6 against 62.1) --
+// the product is not bound by the access count.  What the counters of the default kernel say (r04_pmc_sell_diag2_memory_path.json): the
+// vector L1 waits for L2 data in 61 % of its active cycles with on average 74 lines outstanding per CU (8.66 M requests x 388 cycles /
+// 178 k cycles / 256 CUs) -- 1.54 M stream lines at ~1 380 cycles (HBM) hold 63 % of those slots, 7.1 M gathered lines at ~173 cycles
+// (L2 hits) the rest; L2 tag stalls, TLB misses and request-path stalls are ~0.  Resident wavefronts (LDS halved, o = 4 / 5 at three
+// instead of two workgroups per CU), the L1 policy of the gathered lines (sc1, sc0 sc1) and a 128-byte record pitch change the duration
+// by < 2 % (r04_kbench_sell_lds_occ.txt, r04_kbench_sell_cache_policy.txt); nt on the gather evicts W from the L2: 123-128 us.
+template <int I>
+__device__ __forceinline__ d2a sell_window_load(int j, const double *__restrict__ W, int piece) {
+    const int jr = __builtin_amdgcn_ds_swizzle(j, 0x18 | (I << 5));
+    const unsigned boff = ((((unsigned)jr * 9u) & ~7u) + 2u * (unsigned)piece) * 8u;   // 32-bit byte offset + uniform base
+    return *reinterpret_cast<const d2a *>(reinterpret_cast<const char *>(W) + boff);
+}
+
 template <int O, int GM, int NQ = 9>
 struct SellBuf {   // one pipeline stage: two steps of blocks and the two gathered records of W
     static constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2;
     d2a q[NQ];
     double w[2][(GM == 0) ? REC : 1];
     d2u raw[2][(GM == 1) ? NPR : 1];
+    d2a win[2][(GM == 4) ? 8 : 1];
 };
 
 template <int O, int GM, int ABL = 0, int PIPE = 0, int CODEC = 0>   // PIPE 1: block loads run one pair ahead.  ABL: ablation bits for timing experiments (1 no block loads, 2 no gather, 4 no partial store).  CODEC: SELL_CODEC_*
@@ -342,7 +361,10 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     if (scal != nullptr) {
         if (scal->status != 0) return;
     }
-    __shared__ __attribute__((aligned(16))) double lds[(GM == 1) ? 4 * 2 * 64 * RECP : 2];
+    // ONE transposition buffer per wavefront (the two steps of a pair go through it one after the other; transpose1 ends with a wavefront
+    // fence): 20 KB per workgroup at o = 3, 32 KB at o = 4 / 5 -- with one buffer per step (40 / 64 KB) the LDS, not the registers, capped
+    // the resident workgroups per CU (o = 4 / 5: two)
+    __shared__ __attribute__((aligned(16))) double lds[(GM == 4) ? 4 * 8 * 130 : (GM != 0) ? 4 * 64 * RECP : 2];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int per = 8 / m.S;
     const int x = blockIdx.x & 7, bi = blockIdx.x >> 3;
@@ -355,7 +377,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     const bool tail = (w & 1) != 0;
     const int32_t *cb = m.cols + off * 64;
     const double *bb = m.blk + off * (64 * NQ);
-    double *L = lds + ((GM == 1) ? wave * 2 * 64 * RECP : 0);
+    double *L = lds + ((GM == 4) ? wave * 8 * 130 : (GM != 0) ? wave * 64 * RECP : 0);
 
     double acc[3][O];
 #pragma unroll
@@ -401,7 +423,8 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             const int rec = g / NPR, part = g - rec * NPR;
             const int start = (2 * part < REC - 2) ? 2 * part : REC - 2;
             const int jr = __shfl(j, rec, 64);
-            raw[i] = *reinterpret_cast<const d2u *>(W + (size_t)jr * m.wstride + start);
+            const unsigned boff = ((unsigned)jr * (unsigned)m.wstride + (unsigned)start) * 8u;   // 32-bit byte offset + uniform base (W < 4 GB: checked on the host)
+            raw[i] = *reinterpret_cast<const d2u *>(reinterpret_cast<const char *>(W) + boff);
         }
     };
     auto transpose1 = [&](const d2u (&raw)[NPR], double *Ls, double (&wv)[REC]) {
@@ -420,6 +443,27 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             if (2 * i < REC) wv[2 * i] = t.x;
             if (2 * i + 1 < REC) wv[2 * i + 1] = t.y;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // GM 4 (o = 3, native stride, W 64-byte aligned): aligned sector windows, two cache accesses per record (modes 1 / 3: ~2.5)
+    auto gather4 = [&](int j, d2a (&win)[8]) {
+        const int piece = lane & 7;
+        win[0] = sell_window_load<0>(j, W, piece); win[1] = sell_window_load<1>(j, W, piece);
+        win[2] = sell_window_load<2>(j, W, piece); win[3] = sell_window_load<3>(j, W, piece);
+        win[4] = sell_window_load<4>(j, W, piece); win[5] = sell_window_load<5>(j, W, piece);
+        win[6] = sell_window_load<6>(j, W, piece); win[7] = sell_window_load<7>(j, W, piece);
+    };
+    auto transpose4 = [&](const d2a (&win)[8], double *Ls, int j, double (&wv)[REC]) {
+        // instruction slabs of 64 x 16 bytes + 16 bytes of skew; record r = lane sits in slab (r & 7) at lane group (r >> 3), and starts
+        // (column mod 8) doubles into its window ((column * 9) mod 8 == column mod 8)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<d2a *>(Ls + i * 130 + lane * 2) = win[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const double *src = Ls + (lane & 7) * 130 + (lane >> 3) * 16 + (j & 7);
+#pragma unroll
+        for (int e = 0; e < REC; ++e) wv[e] = src[e];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
@@ -443,6 +487,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
                 }
             }
         } else if constexpr (GM == 0) { gather0(j.x, B.w[0]); gather0(j.y, B.w[1]); }
+        else if constexpr (GM == 4) { gather4(j.x, B.win[0]); gather4(j.y, B.win[1]); }
         else { gather1(j.x, B.raw[0]); gather1(j.y, B.raw[1]); }
     };
 
@@ -469,11 +514,17 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             if constexpr (GM == 0) {
                 fma_step(q0, A.w[0]);
                 fma_step(q1, A.w[1]);
+            } else if constexpr (GM == 4) {
+                double w0[REC];
+                transpose4(A.win[0], L, jc.x, w0);
+                fma_step(q0, w0);
+                transpose4(A.win[1], L, jc.y, w0);
+                fma_step(q1, w0);
             } else {
                 double w0[REC];
                 transpose1(A.raw[0], L, w0);
                 fma_step(q0, w0);
-                transpose1(A.raw[1], L + 64 * RECP, w0);
+                transpose1(A.raw[1], L, w0);
                 fma_step(q1, w0);
             }
             if constexpr (PF) asm volatile("" : "+v"(jnn.x), "+v"(jnn.y));   // keeps the index prefetch in this iteration
@@ -509,11 +560,17 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             if constexpr (GM == 0) {
                 fma_step(q0, A.w[0]);
                 fma_step(q1, A.w[1]);
+            } else if constexpr (GM == 4) {
+                double w0[REC];
+                transpose4(A.win[0], L, jc.x, w0);
+                fma_step(q0, w0);
+                transpose4(A.win[1], L, jc.y, w0);
+                fma_step(q1, w0);
             } else {
                 double w0[REC];
                 transpose1(A.raw[0], L, w0);
                 fma_step(q0, w0);
-                transpose1(A.raw[1], L + 64 * RECP, w0);
+                transpose1(A.raw[1], L, w0);
                 fma_step(q1, w0);
             }
             // keep the prefetch in THIS iteration: without a use here the compiler moves the load across the back edge to the top of
@@ -539,6 +596,12 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             double wt[REC];
             gather0(jt, wt);
             fma_step(qt, wt);
+        } else if constexpr (GM == 4) {
+            d2a wint[8];
+            double w0[REC];
+            gather4(jt, wint);
+            transpose4(wint, L, jt, w0);
+            fma_step(qt, w0);
         } else {
             d2u rawt[NPR];
             double w0[REC];
@@ -547,7 +610,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             fma_step(qt, w0);
         }
     }
-    if constexpr (GM == 1 && !(ABL & 4)) {
+    if constexpr (GM != 0 && !(ABL & 4)) {
         if (m.coalesced_store) {
             // the 64 records of the slice are one contiguous run of 64 * 3 * O doubles (slot = slice * 64 + lane): transposed through
             // LDS and written with lane-consecutive 16-byte stores (5 fully coalesced instructions at o = 3) instead of 3 * O
@@ -874,6 +937,7 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
         }
         // block loads one pair ahead: worth 2-3 us at o = 3 with full blocks; beyond that the second block buffer costs the occupancy
         // (o = 5: 256 VGPRs).  Quaternion codec: a pair of blocks is 16 registers, the second buffer is cheap at every rank.
+        if (gm != 0 && (uint64_t)m.ncols() * (uint64_t)sa.wstride * 8u >= (1ull << 32)) gm = 0;   // modes 1-3 address W with 32-bit byte offsets
         if (gm == 2 && (O != 3 || sa.wstride != 9 || (reinterpret_cast<uintptr_t>(W) & 63) != 0)) gm = 1;   // sector windows: o = 3, native stride, W 64-byte aligned
         if constexpr (O == 3) {
             if (gm == 2 && abl == 0) {
@@ -885,6 +949,8 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
         // measured at 100 k cameras, o = 3 (profiles/r03_kbench_sell.txt): full blocks 111.4 / 111.3 / 110.5 us for pipe 0 / 1 / 2; quaternion
         // codec 82.4 / 84.2 / 204.8 (spills) / 81.9 us for pipe 0 / 1 / 2 / 3 -> 3 (four wavefronts per SIMD, no software pipeline)
         const int pipe = (pipe_env >= 0) ? pipe_env : (quat ? (O == 3 ? 3 : 0) : (O == 3 ? 1 : 0));
+        if (gm == 4 && !(O == 3 && quat && pipe == 3)) gm = 1;   // compiled for the view-graph codec at o = 3
+        if (gm == 4 && (sa.wstride != 9 || (reinterpret_cast<uintptr_t>(W) & 63) != 0)) gm = 1;   // sector windows: native stride, W 64-byte aligned   // aligned element fetch: compiled for the view-graph codec at o = 3
         if (gm == 2 && abl == 0) {
         } else if (abl == 0 || O != 3) {
             if (quat) {
@@ -895,7 +961,8 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
                         else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 0, 1>), g, b, 0, st, sa, W, sc, parts);
                         launched = true;
                     } else if (pipe == 3) {   // four wavefronts per SIMD, no software pipeline
-                        if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 1, 0>), g, b, 0, st, sa, W, sc, parts);
+                        if (gm == 4) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 4, 0>), g, b, 0, st, sa, W, sc, parts);
+                        else if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 1, 0>), g, b, 0, st, sa, W, sc, parts);
                         else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 0, 0>), g, b, 0, st, sa, W, sc, parts);
                         launched = true;
                     }

@@ -18,7 +18,7 @@ struct Settings {
     int sym = 0;                 // 0 auto | 1 force | -1 off
     int64_t sym_min_rows = 6144;
     int sell = 0;                // 0 auto | 1 force | -1 off
-    int sell_slabs = 4, sell_lmax = 64, sell_gather = 1;   // sell_gather: kernel gather mode (0 record per lane | 1 LDS-transposed, the default | 2 sector windows through LDS-DMA at o = 3: measured slower)
+    int sell_slabs = 4, sell_lmax = 64, sell_gather = 1;   // sell_gather: kernel gather mode (0 record per lane | 1 LDS-transposed, the default | 2 sector windows through LDS-DMA at o = 3: measured slower | 4 sector windows into registers, codec + o = 3: equal on random graphs, slower on banded ones)
     int sell_codec = 0;          // 0 auto | 1 full | 2 quaternion
     int sell_layout = 0;         // 0 auto (chunk-tiled where it applies) | 1 sorted virtual rows, two launches (xm_sell.h) | 2 chunk-tiled, one launch (xm_sell2.h)
     int sell_kmax = 32;          // chunk-tiled layout: most steps of a slice
