@@ -110,7 +110,10 @@ typedef struct {
                                   2 = chunk-tiled, ONE launch per product with the epilogue run by the last slice to arrive for a chunk of 64
                                   cameras (xm_sell2.h; fewer than 2^24 cameras; measured slower on MI355X, kept selectable) */
     int32_t sell_kmax;         /* layout 2: most steps of a slice (longer (chunk, slab) lists -- hub cameras -- are cut); 0 = 32 */
-    int32_t reserved[2];
+    int32_t sell_wpad;         /* sliced-ELL product inside the truncated CG (single GPU, rank 3..5): the kernels that write the product input also write
+                                  a copy at a record pitch of 128 bytes, which the gather reads (one cache line per record instead of 1.4 / 1.9):
+                                  0 auto (when the column pattern has no locality: random view graphs yes, banded ones no) | 1 always | -1 never */
+    int32_t reserved[1];
 } xm_tuning_t;
 
 typedef struct {
@@ -338,6 +341,9 @@ int xm_sell_create2(const int64_t *rowptr, const int32_t *colidx, const double *
  * ncols < 2^24). */
 int xm_sell_create3(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
                     int codec, int64_t row0, int layout, void **handle);
+/* host-only: distinct 128-byte lines of W the 64 lanes of a step touch, summed over every 4th step -- records of 72 bytes (o = 3), of 120 bytes
+ * (o = 4, 5) at their native pitch, and at the 128-byte pitch: the figures behind the automatic choice of xm_tuning_t.sell_wpad */
+int xm_sell_locality(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t lines[3]);
 /* host-only view of layout 2 (CPU test of the index arithmetic, tests/test_sell_layout.py): sizes = {slices, steps, tiles, chunks}; arrays as
  * xm-code_amd/csrc/xm_sell2.h:Sell2Host describes them (NULL = not wanted) */
 int xm_sell2_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int kmax, int64_t sizes[4],
@@ -348,6 +354,11 @@ int xm_sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt
 void xm_sell_destroy(void *handle);
 int xm_qw_sell(void *handle, int o, const double *dW, double *dOut, double alpha, int gather_mode, void *stream);
 int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gather_mode, int reps, double *ms_avg);
+/* the same products with the input ALSO given at a record pitch of 16 doubles (dWpad16[cam * 16 + e] = dW[cam * 3 * pitch + e]; o = 3..5, layout 1;
+ * NULL = not given): the gather reads one 128-byte line per camera.  Inside the solver the kernels that write the product input of the truncated
+ * CG write that copy as well (xm_tuning_t.sell_wpad). */
+int xm_qw_sell_padded(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, double alpha, int gather_mode, void *stream);
+int xm_qw_sell_time_padded(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, int gather_mode, int reps, double *ms_avg);
 /* per-camera kernels (device, row-major 3n x o; s: n):
  * Rout = MGS_rows(R + t*D) (Dense/batchedQR.h:42-67), sout = s*exp(t*ds/s) (trustregion.h:19-24), s[0] stays 1 */
 int xm_retract(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t,

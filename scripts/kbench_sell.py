@@ -18,6 +18,7 @@ ap.add_argument("--check", action="store_true")
 ap.add_argument("--no-csr", action="store_true")
 ap.add_argument("--reps", type=int, default=100)
 ap.add_argument("--codec", type=int, nargs="+", default=[0], help="0 = 9 doubles per block, 1 = view-graph codec (quaternion per block)")
+ap.add_argument("--padded", action="store_true", help="hand W over at the 128-byte record pitch as well (what the solver's tCG does: xm_tuning_t.sell_wpad)")
 ap.add_argument("--layout", type=int, nargs="+", default=[1], help="1 = sorted virtual rows, two launches; 2 = chunk-tiled, one launch (XM_SELL2_PIPE=0|1 picks its loop)")
 a = ap.parse_args()
 n, deg = a.n, a.deg
@@ -60,6 +61,7 @@ for o in a.o:
     OP = o | 1
     Wh = rng.standard_normal((3 * n, o))
     dW = xmamd.DevArray(xmamd.to_rm(Wh)); dO = xmamd.DevArray(nbytes=3 * n * OP * 8)
+    dP = xmamd.DevArray(xmamd.pad16(Wh)) if (a.padded and 3 <= o <= 5) else None
     by = 76.0 * nb + 4 * (n + 1) + 2 * 8 * 3 * n * o
     ref = None
     ms = C.c_double()
@@ -75,11 +77,12 @@ for o in a.o:
         for gm in a.gather:
             if o == 1 and gm == 1:
                 continue
-            xmamd._chk(L.xm_qw_sell_time(mats[(S, cd, lay)].h, o, dW.ptr, dO.ptr, gm, a.reps, C.byref(ms)))
+            xmamd._chk(L.xm_qw_sell_time_padded(mats[(S, cd, lay)].h, o, dW.ptr, dP.ptr if (dP is not None and lay == 1) else None, dO.ptr, gm, a.reps, C.byref(ms)))
             pipe = os.environ.get('XM_SELL_PIPE', 'dflt') if lay == 1 else os.environ.get('XM_SELL2_PIPE', 'dflt')
-            line = f"SELL layout={lay} n={n} deg={deg} nb={nb} o={o} slabs={S} gather={gm} codec={cd} pipe={pipe}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s in full-storage accounting = {by/ms.value/1e6/8000:.3f} of 8 TB/s"
+            line = f"SELL layout={lay} n={n} deg={deg} nb={nb} o={o} slabs={S} gather={gm} codec={cd} pipe={pipe}{' padded-W' if (dP is not None and lay == 1) else ''}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s in full-storage accounting = {by/ms.value/1e6/8000:.3f} of 8 TB/s"
             if ref is not None:
                 got = xmamd.from_rm(dO.get(), 3 * n, o)
                 line += f"   rel.err vs CSR kernel {tl.rel_fro(got, ref):.2e}"
             print(line, flush=True)
     dW.free(); dO.free()
+    if dP is not None: dP.free()

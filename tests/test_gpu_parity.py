@@ -120,8 +120,9 @@ def test_qw_sell_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather, la
     M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, layout=layout)
     got = M.qw(W, 1.5, gather=gather)
     again = M.qw(W, 1.5, gather=gather)               # the arrival counters of layout 2 are back at zero after every product
+    padded = M.qw(W, 1.5, gather=gather, padded=True) if (layout == 1 and o >= 3) else got   # input also at the 128-byte record pitch
     M.close()
-    assert tl.rel_fro(got, ref) < 1e-13 and np.array_equal(got, again)
+    assert tl.rel_fro(got, ref) < 1e-13 and np.array_equal(got, again) and tl.rel_fro(padded, ref) < 1e-13
 
 
 @pytest.mark.parametrize("layout", [1, 2])
@@ -168,6 +169,27 @@ def test_solve_through_sell_equals_csr_path(xmamd, monkeypatch):
         assert i1["primal"] == pytest.approx(i0["primal"], rel=1e-12)
         assert i1["min_eig"] == pytest.approx(i0["min_eig"], abs=1e-7)
         assert tl.rotation_parity(R1, s1, R0, s0) < 1e-8
+
+
+@pytest.mark.parametrize("storage", ["bsr", "vg"])
+def test_padded_product_input_of_the_tcg_changes_nothing(xmamd, storage):
+    """xm_tuning_t.sell_wpad: inside the truncated CG the kernels that write the product input (tcg_init, cg_step) also write it at a
+    record pitch of 128 bytes and the sliced-ELL gather reads that copy -- same numbers in the same order, so the whole solve (staircase
+    3 -> 4 -> 5: records of 9 and of 15 doubles) is bit-identical with and without it"""
+    P = tl.gen_vg(900, deg=12, sigma=0.6, seed=5, dense=False)
+    out = {}
+    for wpad in (1, -1):
+        tn = dict(sell=1, sell_wpad=wpad)
+        if storage == "vg":      # view-graph storage: quaternion codec
+            e = P["edges"]
+            ctx = xmamd.Context(vg=(e[:, 0].astype(np.int32), e[:, 1].astype(np.int32), np.ones(e.shape[0]), P["M"]), n=900, tuning=tn)
+        else:
+            ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), tuning=tn)
+        out[wpad] = ctx.solve(5, 1e-9, 30.0)
+        ctx.close()
+    (R1, s1, i1), (R0, s0, i0) = out[1], out[-1]
+    assert i1["rank"] == i0["rank"] and i1["status"] == i0["status"] and i1["tcg_iters"] == i0["tcg_iters"] > 0
+    assert i1["primal"] == i0["primal"] and np.array_equal(R1, R0) and np.array_equal(s1, s0)
 
 
 # ---------------------------------------------------------------------------------------------- whole solves

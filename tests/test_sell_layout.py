@@ -241,3 +241,20 @@ def test_sell2_layout_rejects_malformed_input(xmamd):
         xmamd.sell2_layout(np.array([0, 1, 2]), np.array([0, 1], dtype=np.int32), slabs=3)
     with pytest.raises(xmamd.XmError):
         xmamd.sell2_layout(np.array([0, 1, 2]), np.array([0, 1], dtype=np.int32), ncols=1 << 24)   # 24-bit column field
+
+
+def test_column_locality_decides_the_padded_copy(xmamd):
+    """xm_tuning_t.sell_wpad = 0 (auto): the copy of W at the 128-byte record pitch is used when the lanes of a step touch fewer lines
+    with it than at the native pitch -- a random view graph (1.4 / 1.9 lines per 72- / 120-byte record against 1) yes, a banded graph
+    (neighbouring columns share lines: 0.56 / 0.94 against 1) no"""
+    n = 4000
+    P = tl.gen_vg(n, deg=30, sigma=0.1, seed=3, dense=False)
+    l72, l120, lp = xmamd.sell_locality(P["rowptr"], P["colidx"], slabs=4)
+    assert lp * 1.25 < l72 < lp * 1.6 and lp * 1.7 < l120 < lp * 2.1
+    h = 15
+    lo = np.maximum(np.arange(n) - h, 0); hi = np.minimum(np.arange(n) + h, n - 1)
+    cnt = hi - lo + 1
+    rowptr = np.zeros(n + 1, dtype=np.int64); rowptr[1:] = np.cumsum(cnt)
+    colidx = (np.repeat(lo, cnt) + (np.arange(rowptr[-1]) - np.repeat(rowptr[:-1], cnt))).astype(np.int32)
+    l72, l120, lp = xmamd.sell_locality(rowptr, colidx, slabs=4)
+    assert l72 < 0.75 * lp and l120 < 1.05 * lp          # the rule (10 % margin) keeps the native pitch for both record sizes

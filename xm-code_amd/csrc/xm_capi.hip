@@ -554,6 +554,17 @@ int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int6
     return XM_OK;
     XM_CATCH
 }
+// host-only: the column-locality figures behind the automatic choice of xm_tuning_t.sell_wpad (SellHost::lines_*):
+// lines[0..2] = distinct 128-byte lines of W per sampled step at the native pitch of 72-byte records, of 120-byte records, at the 128-byte pitch
+int xm_sell_locality(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t lines[3]) {
+    XM_TRY
+    if (!lines) throw xm::Error(XM_ERR_ARG, "null output");
+    xm::SellHost h;
+    xm::sell_build_host(rowptr, colidx, n, ncols, slabs, lmax, h);
+    lines[0] = h.lines_native72; lines[1] = h.lines_native120; lines[2] = h.lines_padded;
+    return XM_OK;
+    XM_CATCH
+}
 // which transport joins the ranks of this context: 0 none (one GPU) | 1 RCCL | 2 shared-memory test transport | 3 direct peer writes between the
 // host threads of this process | 4 direct peer writes between processes (IPC); note = why a faster transport was given up (empty: it was not)
 int xm_ctx_transport(xm_ctx_t *ctx, int *kind, char *note, size_t note_cap) {
@@ -592,9 +603,10 @@ struct SellHandle {   // what xm_sell_create* hands out: one of the two layouts
     std::unique_ptr<xm::Sell2Matrix> v2;
     int64_t nloc() const { return v2 ? v2->nloc() : v1->nloc(); }
 };
-void sell_product(SellHandle &h, int o, const double *dW, double alpha, const xm::CamArgs &a, int gather_mode, hipStream_t st) {
+void sell_product(SellHandle &h, int o, const double *dW, double alpha, const xm::CamArgs &a, int gather_mode, hipStream_t st,
+                  const double *dWpad16 = nullptr) {
     if (h.v2) xm::launch_qw_sell2(o, xm::EPI_PLAIN, *h.v2, dW, alpha, a, gather_mode, -1, st);
-    else xm::launch_qw_sell(o, xm::EPI_PLAIN, *h.v1, dW, alpha, a, gather_mode, st);
+    else xm::launch_qw_sell(o, xm::EPI_PLAIN, *h.v1, dW, alpha, a, gather_mode, st, dWpad16);
 }
 }  // namespace
 int xm_sell_create3(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
@@ -633,16 +645,27 @@ int xm_qw_sell(void *handle, int o, const double *dW, double *dOut, double alpha
     return XM_OK;
     XM_CATCH
 }
+int xm_qw_sell_padded(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, double alpha, int gather_mode, void *stream) {
+    XM_TRY
+    if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
+    SellHandle &m = *static_cast<SellHandle *>(handle);
+    sell_product(m, o, dW, alpha, plain_args(m.nloc(), dOut), gather_mode, (hipStream_t)stream, dWpad16);
+    return XM_OK;
+    XM_CATCH
+}
 int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gather_mode, int reps, double *ms_avg) {
+    return xm_qw_sell_time_padded(handle, o, dW, nullptr, dOut, gather_mode, reps, ms_avg);
+}
+int xm_qw_sell_time_padded(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, int gather_mode, int reps, double *ms_avg) {
     XM_TRY
     if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
     SellHandle &m = *static_cast<SellHandle *>(handle);
     hipEvent_t e0, e1;
     XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
     const xm::CamArgs a = plain_args(m.nloc(), dOut);
-    for (int i = 0; i < 3; ++i) sell_product(m, o, dW, 1.0, a, gather_mode, nullptr);
+    for (int i = 0; i < 3; ++i) sell_product(m, o, dW, 1.0, a, gather_mode, nullptr, dWpad16);
     XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < reps; ++i) sell_product(m, o, dW, 1.0, a, gather_mode, nullptr);
+    for (int i = 0; i < reps; ++i) sell_product(m, o, dW, 1.0, a, gather_mode, nullptr, dWpad16);
     XM_HIP_CHECK(hipEventRecord(e1, nullptr));
     XM_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;

@@ -54,6 +54,7 @@ Settings Settings::resolve(const xm_tuning_t *t) {
     s.sell_codec = z.sell_codec > 0 ? z.sell_codec : (int)env_ll("XM_SELL_CODEC", 0);
     s.sell_layout = z.sell_layout > 0 ? z.sell_layout : (int)env_ll("XM_SELL_LAYOUT", 0);
     s.sell_kmax = z.sell_kmax > 0 ? z.sell_kmax : (int)env_ll("XM_SELL_KMAX", 32);
+    s.sell_wpad = tri(z.sell_wpad, "XM_SELL_WPAD");
     s.sell_pipe = (int)env_ll("XM_SELL2_PIPE", -1);
     s.overlap = (z.overlap < 0) ? -1 : ((env_has("XM_OVERLAP") && env_ll("XM_OVERLAP", 1) == 0) ? -1 : 0);
     s.overlap_min_mb = z.overlap_min_mb > 0 ? (double)z.overlap_min_mb : env_f("XM_OVERLAP_MIN_MB", 64.0);

@@ -141,12 +141,12 @@ int flat_grid(int64_t elems);
 void launch_scale_rows(int o, int nloc, const double *R, const double *s, double *Wloc, hipStream_t st);
 void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, const double *R, const double *s, double *rR,
                      double *rs, double *pR, double *ps, double *vR, double *vs, double *HvR, double *Hvs, double *Wloc,
-                     TcgScal *scal0, double rr, double delta, unsigned long long *hstat, hipStream_t st);
+                     TcgScal *scal0, double rr, double delta, unsigned long long *hstat, hipStream_t st, double *Wpad = nullptr);
 void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *parts, int nA_loc, int nB_loc, int world,
                     const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
                     double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat, double *Afull,
-                    double *Wfull, int grouping, const struct PeerXchg &xchg, hipStream_t st);
+                    double *Wfull, int grouping, const struct PeerXchg &xchg, hipStream_t st, double *Wpad = nullptr);   // Wpad: single-rank only
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs,
                         const double *rgR, const double *rgs, const double *s, double *parts, hipStream_t st);
 void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,

@@ -1035,14 +1035,16 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
                                                         const double *__restrict__ R, const double *__restrict__ s,
                                                         double *rR, double *rs, double *pR, double *ps, double *vR, double *vs,
                                                         double *HvR, double *Hvs, double *Wloc, TcgScal *scal0, double rr,
-                                                        double delta, unsigned long long *hstat) {
+                                                        double delta, unsigned long long *hstat, double *Wpad) {
     constexpr int OP = pitch_of(O);
     const int64_t total = (int64_t)nloc * 3 * OP;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int cam = (int)(i / (3 * OP));
         const double g = rgR[i], gs = rgs[cam];
         rR[i] = g; pR[i] = -g; vR[i] = 0.0; HvR[i] = 0.0;
-        Wloc[i] = s[cam] * (-g) + (-gs) * R[i];
+        const double wv = s[cam] * (-g) + (-gs) * R[i];
+        Wloc[i] = wv;
+        if (Wpad) Wpad[(size_t)cam * 16 + (i - (int64_t)cam * (3 * OP))] = wv;   // copy at a 128-byte record pitch for the sliced-ELL gather (xm_sell.h)
         if (i % (3 * OP) == 0) { rs[cam] = gs; ps[cam] = -gs; vs[cam] = 0.0; Hvs[cam] = 0.0; }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1070,7 +1072,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
                                                        double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR,
                                                        const double *__restrict__ rs_cur, double *rs_next, double *Wloc,
                                                        double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat,
-                                                       double *Afull, double *Wfull, int grp, PeerXchg x) {
+                                                       double *Afull, double *Wfull, int grp, PeerXchg x, double *Wpad) {
     constexpr int OP = pitch_of(O);
     __shared__ double sh[4];
     __shared__ double sh16[16];
@@ -1214,7 +1216,11 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
                 const double pn = beta * pv - rn;
                 const double psn = beta * psv - rsn;
                 pR[i] = pn;
-                if (!Afull) Wloc[i] = sv * pn + psn * Rv;
+                if (!Afull) {
+                    const double wv = sv * pn + psn * Rv;
+                    Wloc[i] = wv;
+                    if (Wpad) Wpad[(size_t)camf * 16 + (i - (int64_t)camf * (3 * OP))] = wv;
+                }
                 if (own0) ps_next[camf] = psn;
             }
             if (own0) { rs_next[camf] = rsn; const double q = rsn / sv; acc += q * q; }
@@ -1236,7 +1242,11 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
                 const double pn = beta * pi - rn;
                 const double psn = beta * psi - rsn;
                 pR[i] = pn;
-                if (!Afull) Wloc[i] = s[cam] * pn + psn * R[i];
+                if (!Afull) {
+                    const double wv = s[cam] * pn + psn * R[i];
+                    Wloc[i] = wv;
+                    if (Wpad) Wpad[(size_t)cam * 16 + (i - (int64_t)cam * (3 * OP))] = wv;
+                }
                 if (own) ps_next[cam] = psn;
             }
             if (own) { rs_next[cam] = rsn; const double q = rsn / s[cam]; acc += q * q; }
@@ -2176,20 +2186,20 @@ void launch_scale_rows(int o, int nloc, const double *R, const double *s, double
 }
 void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, const double *R, const double *s, double *rR, double *rs,
                      double *pR, double *ps, double *vR, double *vs, double *HvR, double *Hvs, double *Wloc, TcgScal *scal0,
-                     double rr, double delta, unsigned long long *hstat, hipStream_t st) {
+                     double rr, double delta, unsigned long long *hstat, hipStream_t st, double *Wpad) {
     XM_DISPATCH_O(o, hipLaunchKernelGGL((tcg_init_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
-                                        nloc, rgR, rgs, R, s, rR, rs, pR, ps, vR, vs, HvR, Hvs, Wloc, scal0, rr, delta, hstat));
+                                        nloc, rgR, rgs, R, s, rR, rs, pR, ps, vR, vs, HvR, Hvs, Wloc, scal0, rr, delta, hstat, Wpad));
     check_launch("tcg_init");
 }
 void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *parts, int nA_loc, int nB_loc, int world,
                     const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
                     double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat, double *Afull,
-                    double *Wfull, int grouping, const PeerXchg &xchg, hipStream_t st) {
+                    double *Wfull, int grouping, const PeerXchg &xchg, hipStream_t st, double *Wpad) {
     // grid = nB_loc: one |r|^2 partial sum per workgroup (Context::tcg_blocks: capped when the launch waits for its peers inside the kernel)
     XM_DISPATCH_O(o, hipLaunchKernelGGL((cg_step_kernel<O_>), dim3(nB_loc), dim3(256), 0, st, nloc,
                                         scal_cur, scal_next, parts, nA_loc, nB_loc, world, HpR, Hps, R, s, pR, ps_cur, ps_next, vR,
-                                        vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat, b_off, mat, Afull, Wfull, grouping, xchg));
+                                        vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat, b_off, mat, Afull, Wfull, grouping, xchg, Wpad));
     check_launch("cg_step");
 }
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs, const double *rgR,

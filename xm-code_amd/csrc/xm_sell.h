@@ -39,6 +39,10 @@ struct SellHost {
     std::vector<int32_t> pslot;       // nslices * 64: where (slice, lane) stores its partial result, -1 = padding lane
     std::vector<int32_t> ridx;        // nparts: storage index of the k-th listed partial result (see pptr)
     std::vector<int64_t> pptr;        // nloc + 1: the partial results of camera r are ridx[pptr[r] .. pptr[r+1])
+    // distinct 128-byte lines of W the 64 lanes of a step touch, summed over every 4th step: records of 72 bytes (o = 3) and of 120 bytes
+    // (o = 4, 5) at their native pitch, and records at the 128-byte pitch (== distinct columns).  Random graphs: 1.4 / 1.9 against 1 line
+    // per record; graphs with column locality (banded): ~0.6 / 1 against 1 -- there the padded copy of W loses (xm_sell.h: Wpad16)
+    int64_t lines_native72 = 0, lines_native120 = 0, lines_padded = 0;
     std::vector<int64_t> diag_src;    // view-graph codec only (diag_row0 >= 0): CSR position of row r's diagonal block (-1: none); those
                                       // blocks are NOT in the slices (they are d * I, applied by the second launch from one double)
 };
@@ -77,6 +81,8 @@ struct SellArgs {   // what the kernels see
 class SellMatrix {
 public:
     int64_t ncols() const { return ncols_; }
+    // does a copy of W at the 128-byte record pitch shorten the gather of rank o?  (fewer lines per step than at the native pitch, 10 % margin)
+    bool padded_pays(int o) const { return o >= 3 && 3 * pitch_of(o) <= 16 && lines_padded_ * 11 < (3 * pitch_of(o) <= 9 ? lines72_ : lines120_) * 10; }
     // blocks: host, 9 doubles per block (row-major 3x3), indexed like colidx
     // codec SELL_CODEC_QUAT: throws Error(XM_ERR_ARG) unless every off-diagonal block is -w * rotation and every diagonal block d * I
     // (relative 1e-9); row0 = global camera index of local row 0
@@ -101,6 +107,7 @@ private:
     int64_t nloc_ = 0, nparts_ = 0, nsteps_ = 0, nslices_ = 0;
     int S_ = 1, grid_ = 0;
     int64_t ncols_ = 0, max_list_ = 0;   // max_list_: most partial results of one camera
+    int64_t lines72_ = 0, lines120_ = 0, lines_padded_ = 0;   // SellHost::lines_*
     DevBuf<double> wpad_;      // W repacked at 16 doubles per camera (XM_SELL_WSTRIDE=16)
     bool coalesced_ = false;   // partial results written as one contiguous run per slice (slice-order slots)
     DevBuf<int64_t> slice_off_, pptr_;
@@ -121,7 +128,11 @@ private:
 // 1 = records fetched element-per-lane and transposed through LDS.
 // host check of the view-graph structure the quaternion codec relies on (O(nb)); throws Error(XM_ERR_ARG)
 void check_viewgraph_blocks(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t nloc, int64_t row0);
-void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st);
+// Wpad16 (optional): the same W at a record pitch of 16 doubles (one 128-byte line per camera; o = 3..5).  The gather then touches one
+// line per record instead of 1.4 (o = 3) / 1.9 (o = 4, 5): main launch 72.8 -> 63.6 us (o = 3), 89.2 -> 79.4 us (o = 4) at 100 k
+// cameras (profiles/r04_trace_sell_pitch16.txt).  The solver's tCG writes that copy from the kernels that produce W (tcg_init / cg_step).
+void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st,
+                    const double *Wpad16 = nullptr);
 bool sell_supports(int o);
 void sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]);   // host: the codec's two maps
 

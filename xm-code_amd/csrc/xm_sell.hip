@@ -116,6 +116,22 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
     }
     out.nslices = (int64_t)out.slice_off.size() - 1;
     out.nsteps = out.slice_off.back();
+    {   // column locality of the gather (SellHost::lines_*): every 4th step
+        std::vector<int64_t> a72, a120, ac;
+        for (int64_t t = 0; t < out.nsteps; t += 4) {
+            a72.clear(); a120.clear(); ac.clear();
+            for (int l = 0; l < 64; ++l) {
+                const int64_t q = out.src[(size_t)t * 64 + l];
+                if (q < 0) continue;
+                const int64_t c = colidx[q];
+                ac.push_back(c);
+                a72.push_back((c * 72) >> 7); a72.push_back((c * 72 + 71) >> 7);
+                a120.push_back((c * 120) >> 7); a120.push_back((c * 120 + 119) >> 7);
+            }
+            auto distinct = [](std::vector<int64_t> &v) { std::sort(v.begin(), v.end()); return (int64_t)(std::unique(v.begin(), v.end()) - v.begin()); };
+            out.lines_padded += distinct(ac); out.lines_native72 += distinct(a72); out.lines_native120 += distinct(a120);
+        }
+    }
     out.nstore = slice_order ? out.nslices * 64 : out.nparts;
     out.slice_order = slice_order;
     if (out.nstore > 2147483000LL) throw Error(XM_ERR_ARG, "SELL: too many partial results");
@@ -205,6 +221,7 @@ SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const doubl
     SellHost h;
     sell_build_host(rowptr, colidx, nloc, ncols, S, lmax, h, codec == SELL_CODEC_QUAT ? row0 : -1);
     ncols_ = ncols;
+    lines72_ = h.lines_native72; lines120_ = h.lines_native120; lines_padded_ = h.lines_padded;
     max_list_ = 0;
     for (int64_t r = 0; r < nloc; ++r) max_list_ = std::max<int64_t>(max_list_, h.pptr[(size_t)r + 1] - h.pptr[(size_t)r]);
     nloc_ = nloc; nparts_ = h.nstore; nsteps_ = h.nsteps; nslices_ = h.nslices; S_ = S;
@@ -353,7 +370,7 @@ struct SellBuf {   // one pipeline stage: two steps of blocks and the two gather
     d2a win[2][(GM == 4) ? 8 : 1];
 };
 
-template <int O, int GM, int ABL = 0, int PIPE = 0, int CODEC = 0>   // PIPE 1: block loads run one pair ahead.  ABL: ablation bits for timing experiments (1 no block loads, 2 no gather, 4 no partial store).  CODEC: SELL_CODEC_*
+template <int O, int GM, int ABL = 0, int PIPE = 0, int CODEC = 0>   // PIPE 1: block loads run one pair ahead.  ABL: ablation bits for timing experiments (1 no block loads, 2 no gather, 4 no partial store, 8 loads only: no codec / LDS / FMA work).  CODEC: SELL_CODEC_*
 __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
                                              double *__restrict__ parts) {
     constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2, RECP = (REC + 1) & ~1;
@@ -555,6 +572,15 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             gather_pair(jc, A);
             __builtin_amdgcn_sched_barrier(0);   // every load of the pair is in flight before the first FMA (the scheduler would
                                                  // otherwise trickle them to save registers: 4-5 dependent round trips per pair)
+            if constexpr ((ABL & 8) != 0 && GM == 1) {   // traffic only: every loaded value is consumed by one add (no codec, LDS or FMA work)
+#pragma unroll
+                for (int e = 0; e < NQ; ++e) acc[0][0] += A.q[e].x + A.q[e].y;
+#pragma unroll
+                for (int i = 0; i < NPR; ++i) acc[1][0] += (A.raw[0][i].x + A.raw[0][i].y) + (A.raw[1][i].x + A.raw[1][i].y);
+                asm volatile("" : "+v"(jn.x), "+v"(jn.y));
+                jc = jn;
+                continue;
+            }
             double q0[9], q1[9];
             expand(A.q, q0, q1);
             if constexpr (GM == 0) {
@@ -912,14 +938,16 @@ void sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9
 }
 
 template <int O>
-static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st) {
+static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st, const double *Wpad16) {
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
     double *parts = m.parts(O);
     SellArgs sa = m.args();
     sa.wstride = m.wstride(O);
     const bool quat = m.codec() == SELL_CODEC_QUAT;
+    const bool padded = Wpad16 != nullptr && O >= 3 && 3 * pitch_of(O) <= 16;   // the caller keeps a copy of W at the 128-byte record pitch
+    if (padded) { sa.wstride = 16; W = Wpad16; }
     if (m.grid() > 0) {
-        W = m.pack_w(O, W, st);
+        if (!padded) W = m.pack_w(O, W, st);
         const dim3 g(m.grid()), b(256);
         static const int abl = [] { const char *e = std::getenv("XM_SELL_ABLATE"); return (e && *e) ? std::atoi(e) : 0; }();   // timing experiments only
         if constexpr (O == 3) {
@@ -931,7 +959,7 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
             }
             if (abl != 0 && quat) {
 #define XM_ABL_CASE(G, A) if (gm == G && abl == A) hipLaunchKernelGGL((qw_sell_kernel<3, G, A, 0, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
-                XM_ABL_CASE(1, 1) XM_ABL_CASE(1, 2) XM_ABL_CASE(1, 4) XM_ABL_CASE(1, 6)
+                XM_ABL_CASE(1, 1) XM_ABL_CASE(1, 2) XM_ABL_CASE(1, 4) XM_ABL_CASE(1, 6) XM_ABL_CASE(1, 8) XM_ABL_CASE(1, 12)
 #undef XM_ABL_CASE
             }
         }
@@ -999,7 +1027,7 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
 #undef XM_SELL_REDUCE
 }
 
-void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st) {
+void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha, const CamArgs &a, int gm, hipStream_t st, const double *Wpad16) {
     if (a.nloc <= 0) return;
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(XM_ERR_ARG, "certificate operator needs o == 1");
@@ -1014,10 +1042,10 @@ void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha
         else hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT, 16>), dim3(m.reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride);
     } else {
         switch (o) {
-            case 1: qw_sell_o<1>(epi, m, W, alpha, a, 0, st); break;
-            case 3: qw_sell_o<3>(epi, m, W, alpha, a, gm, st); break;
-            case 4: qw_sell_o<4>(epi, m, W, alpha, a, gm, st); break;
-            case 5: qw_sell_o<5>(epi, m, W, alpha, a, gm, st); break;
+            case 1: qw_sell_o<1>(epi, m, W, alpha, a, 0, st, nullptr); break;
+            case 3: qw_sell_o<3>(epi, m, W, alpha, a, gm, st, Wpad16); break;
+            case 4: qw_sell_o<4>(epi, m, W, alpha, a, gm, st, Wpad16); break;
+            case 5: qw_sell_o<5>(epi, m, W, alpha, a, gm, st, Wpad16); break;
             default: throw Error(XM_ERR_ARG, "SELL product is instantiated for o = 1, 3, 4, 5");
         }
     }

@@ -21,6 +21,8 @@ struct Settings {
     int sell_slabs = 4, sell_lmax = 64, sell_gather = 1;   // sell_gather: kernel gather mode (0 record per lane | 1 LDS-transposed, the default | 2 sector windows through LDS-DMA at o = 3: measured slower | 4 sector windows into registers, codec + o = 3: equal on random graphs, slower on banded ones)
     int sell_codec = 0;          // 0 auto | 1 full | 2 quaternion
     int sell_layout = 0;         // 0 auto (chunk-tiled where it applies) | 1 sorted virtual rows, two launches (xm_sell.h) | 2 chunk-tiled, one launch (xm_sell2.h)
+    int sell_wpad = 0;           // the tCG keeps a copy of W at a 128-byte record pitch for the sliced-ELL gather (single rank, o = 3..5): 0 when the
+                                 // column pattern says it pays (SellMatrix::padded_pays) | 1 always | -1 never (XM_SELL_WPAD=1 | 0)
     int sell_kmax = 32;          // chunk-tiled layout: most steps of a slice
     int sell_pipe = -1;          // chunk-tiled layout: -1 default | 0 single-buffered | 1 block loads one pair ahead (XM_SELL2_PIPE)
     int overlap = 0;             // 0 auto | -1 off
@@ -218,6 +220,9 @@ private:
     // ---- per-rank workspace -------------------------------------------------------------------------------------
     int o_ = 0, OP_ = 0;
     DevBuf<double> R_, s_, Rc_, sc_, W_, D_;
+    DevBuf<double> wpad_;   // sliced-ELL storage, single rank, o = 3..5: the tCG's product input at a record pitch of 16 doubles (Settings.sell_wpad)
+    double *wpad() const { return (wpad_.p && wpad_on_) ? wpad_.p : nullptr; }
+    bool wpad_on_ = false;   // for the current rank (setup_rank)
     PointState ps_[2];
     int cur_ = 0;
     DevBuf<double> rR_, rs_, rsB_, pR_, psA_, psB_, vR_, vs_, HvR_, Hvs_, HpR_, Hps_;

@@ -452,6 +452,8 @@ void Context::setup_rank(int o) {
         ps_[k].G.alloc(mat); ps_[k].rgR.alloc(mat); ps_[k].egs.alloc(vec); ps_[k].rgs.alloc(vec); ps_[k].S0.alloc(vec * 9);
     }
     cur_ = 0;
+    wpad_on_ = sell_ && cfg_.sell_wpad >= 0 && !comm_->active() && sell_supports(o) && o >= 3 && 3 * OP_ <= 16 && (cfg_.sell_wpad == 1 || sell_->padded_pays(o));
+    if (wpad_on_ && !wpad_.p) wpad_.alloc((size_t)ntot_ * 16 + 16);   // zero-filled: the pad is never written
     W_.alloc((size_t)ld_ * OP_ + 16);   // + slack: the sector-window gather of the sliced-ELL product reads whole 64-byte sectors around a record
     const int nA_loc = prod_grid(), nB_loc = tcg_blocks();
     nA_ = nA_loc * world;
@@ -616,7 +618,8 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
     } else if (sell2_ && Sell2Matrix::supports(o, ntot_)) {
         launch_qw_sell2(o, epi, *sell2_, W_.p, alpha, a, sell_gm_, cfg_.sell_pipe, st_);
     } else if (sell_ && sell_supports(o)) {
-        launch_qw_sell(o, epi, *sell_, W_.p, alpha, a, sell_gm_, st_);
+        // inside the tCG the kernels that write W keep a copy at the 128-byte record pitch (run_tcg): the gather reads that one
+        launch_qw_sell(o, epi, *sell_, W_.p, alpha, a, sell_gm_, st_, (epi == EPI_HESS && o == o_) ? wpad() : nullptr);
     } else {
         launch_qw_bsr3(o, epi, rowptr_.p, colidx_.p, blocks_.p, W_.p, alpha, a, st_);
     }
@@ -768,7 +771,7 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     if (comm_->active()) comm_->note("tcg_start", rr, delta);
     *hstat_ = ~0ull;
     launch_tcg_init(o_, nloc_, P.rgR.p, P.rgs.p, R_.p, s_.p, rR_.p, rs_.p, pR_.p, psA_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, Wloc,
-                    scal_.p, rr, delta, hstat_dev_, st_);
+                    scal_.p, rr, delta, hstat_dev_, st_, wpad());
     gather_W();
     // Iterations in flight ahead of the last one seen finished; the excess become no-op launches.  With a communicator the
     // loop must issue the SAME number of collectives on every rank although ranks poll at different moments: iteration j is
@@ -809,7 +812,7 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
         launch_cg_step(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), pcur, nA_loc, nB_loc, comm_->world, HpR_.p, Hps_.p, R_.p,
                        s_.p, pR_.p, par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, rR_.p,
                        par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pnext + (size_t)rank * chunk + b_off + 3 * nA_loc, hstat_dev_,
-                       (int)b_off, (int64_t)mat, comm_->active() ? Afull_.p : nullptr, W_.p, grouping_, xchg_, st_);
+                       (int)b_off, (int64_t)mat, comm_->active() ? Afull_.p : nullptr, W_.p, grouping_, xchg_, st_, wpad());
     };
     auto read_scal = [&](int par) {
         TcgScal sc;

@@ -28,7 +28,7 @@ EXPORTS = [
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_retract_variant", "xm_qw_dense_time", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_peer_allgather_bench", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_init_ipc", "xm_comm_finalize", "xm_partition", "xm_partition_blocks",
-    "xm_symv_plan", "xm_sell_layout", "xm_sell_create", "xm_sell_create2", "xm_sell_create3", "xm_sell2_layout", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time",
+    "xm_symv_plan", "xm_sell_layout", "xm_sell_locality", "xm_sell_create", "xm_sell_create2", "xm_sell_create3", "xm_sell2_layout", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time", "xm_qw_sell_padded", "xm_qw_sell_time_padded",
     "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport", "xm_symw_plan", "xm_symw_use", "xm_qw_symw_time",
 ]
 
@@ -40,7 +40,7 @@ class XmError(RuntimeError):
 class Tuning(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("sym", "sym_min_rows", "sell", "sell_slabs", "sell_lmax", "sell_gather", "sell_codec", "overlap",
                                          "overlap_min_mb", "cert_dense_rows", "lanczos_mmax", "lanczos_restarts", "watchdog_s", "balance",
-                                         "exchange", "split_k", "sell_layout", "sell_kmax")] + [("reserved", C.c_int32 * 2)]
+                                         "exchange", "split_k", "sell_layout", "sell_kmax", "sell_wpad")] + [("reserved", C.c_int32 * 1)]
 
 
 class Problem(C.Structure):
@@ -146,6 +146,7 @@ def lib():
         L.xm_partition.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.xm_partition_blocks.argtypes = [C.c_int64, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.xm_sell_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p] + [C.c_void_p] * 7
+        L.xm_sell_locality.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.xm_sell_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.xm_sell_create2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]
         L.xm_sell_create3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
@@ -155,6 +156,8 @@ def lib():
         L.xm_sell_destroy.restype = None
         L.xm_qw_sell.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
         L.xm_qw_sell_time.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.xm_qw_sell_padded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        L.xm_qw_sell_time_padded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -250,6 +253,16 @@ def dense_from_bsr3(rowptr, colidx, blocks):
     return d
 
 
+def pad16(W):
+    """W (3n x o, o <= 5) at a record pitch of 16 doubles: camera c's 3 x pitch_of(o) row-major block at [16 c, 16 c + 3 pitch_of(o))"""
+    W = np.asarray(W, dtype=np.float64)
+    n, o = W.shape[0] // 3, W.shape[1]
+    rec = 3 * pitch_of(o)
+    out = np.zeros((n, 16))
+    out[:, :rec] = to_rm(W).reshape(-1)[: n * rec].reshape(n, rec)
+    return out.reshape(-1)
+
+
 def qw_dense(Q, W, alpha=1.0, dq=None, sym=False):
     """alpha * Q @ W on the GPU through xm_qw_dense (Q: 3n x 3n, W: 3n x o); sym=True: the half-traffic symmetric kernel."""
     require_gpu()
@@ -332,6 +345,16 @@ def sell_layout(rowptr, colidx, ncols=None, slabs=4, lmax=64):
     return out
 
 
+def sell_locality(rowptr, colidx, ncols=None, slabs=4, lmax=64):
+    """(lines at the native pitch of 72-byte records, of 120-byte records, at the 128-byte pitch) -- host only (xm_sell_locality)"""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    n = rowptr.size - 1
+    out = np.zeros(3, dtype=np.int64)
+    _chk(lib().xm_sell_locality(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), n, n if ncols is None else ncols, slabs, lmax,
+                                out.ctypes.data_as(C.c_void_p)))
+    return tuple(int(x) for x in out)
+
+
 def symw_plan(ntot, nloc, cam0, K=0):
     """work list of one rank of the multi-rank symmetric window product (xm_symw.h) -- host only"""
     geom = np.zeros(8, dtype=np.int32)
@@ -378,14 +401,18 @@ class SellMatrix:
         _chk(lib().xm_sell_create3(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
                                    self.n, self.n if ncols is None else ncols, slabs, lmax, codec, row0, layout, C.byref(self.h)))
 
-    def qw(self, W, alpha=1.0, gather=0):
+    def qw(self, W, alpha=1.0, gather=0, padded=False):
+        """padded=True: the input is also handed over at a record pitch of 16 doubles (xm_qw_sell_padded; o = 3..5, layout 1)"""
         W = np.asarray(W, dtype=np.float64)
         o = W.shape[1]
         dW = DevArray(to_rm(W)); dO = DevArray(nbytes=3 * self.n * pitch_of(o) * 8)
-        _chk(lib().xm_qw_sell(self.h, o, dW.ptr, dO.ptr, alpha, gather, None))
+        dP = DevArray(pad16(W)) if padded else None
+        _chk(lib().xm_qw_sell_padded(self.h, o, dW.ptr, dP.ptr if padded else None, dO.ptr, alpha, gather, None))
         _chk(lib().xm_dev_sync())
         out = from_rm(dO.get(), 3 * self.n, o)
         dW.free(); dO.free()
+        if padded:
+            dP.free()
         return out
 
     def close(self):
