@@ -363,6 +363,8 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
             else:
                 kname = ("qw_sell2_kernel<o, EPI_HESS> (chunk-tiled sliced-ELL over per-XCD column slabs, ONE launch: the last slice to arrive for a "
                          "chunk of 64 cameras adds the chunk's tiles and runs the fused epilogue)")
+            if team == 1 and world == 1 and ctx.sell_wpad():
+                kname += "; the gather reads the copy of W that tcg_init / cg_step keep at a 128-byte record pitch (xm_tuning_t.sell_wpad, automatic)"
             if args.storage == "vg":
                 kname += ", view-graph codec: %.1f MB streamed per product for %.1f MB of full storage" % (last["qw_stream_bytes"] / 1e6, 76.0 * nb / ngp / 1e6)
     achieved = alg_bytes / (qw_ms * 1e-3) / 1e9 if qw_ms > 0 else 0.0

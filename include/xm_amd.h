@@ -402,6 +402,8 @@ int xm_comm_init(int rank, int world, int device, const unsigned char id[128], c
  * in note (NUL-terminated, truncated to note_cap), why a faster transport was given up for it (empty: first choice).  The multi-GPU modes try
  * direct peer writes first (self-tested on the machine at context creation), then RCCL, and fail with XM_ERR_COMM naming both reasons. */
 int xm_ctx_transport(xm_ctx_t *ctx, int *kind, char *note, size_t note_cap);
+/* *on = 1 when the truncated CG of the last solved rank kept its product input at the 128-byte record pitch as well (xm_tuning_t.sell_wpad) */
+int xm_ctx_sell_wpad(xm_ctx_t *ctx, int *on);
 
 /* One process per GPU WITHOUT a collective library on the data path: every rank exports its exchange buffers as hipIpcMemHandle_t
  * through the POSIX shared-memory segment `name` (same string on every rank of the node, unique per job), maps the peers' and uses

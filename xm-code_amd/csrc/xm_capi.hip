@@ -578,6 +578,15 @@ int xm_ctx_transport(xm_ctx_t *ctx, int *kind, char *note, size_t note_cap) {
     XM_CATCH
 }
 
+// 1 when the tCG of the last solved rank kept its product input at the 128-byte record pitch as well (xm_tuning_t.sell_wpad); 0 otherwise / several GPUs
+int xm_ctx_sell_wpad(xm_ctx_t *ctx, int *on) {
+    XM_TRY
+    if (!ctx || (!ctx->impl && !ctx->team) || !on) throw xm::Error(XM_ERR_ARG, "null argument");
+    *on = (ctx->impl && ctx->impl->sell_wpad_on()) ? 1 : 0;
+    return XM_OK;
+    XM_CATCH
+}
+
 // host-only view of the chunk-tiled layout (xm_sell2.h) for the CPU tests; NULL arrays: only the sizes
 int xm_sell2_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int kmax, int64_t sizes[4],
                     int64_t *slice_off, int32_t *slab_start, int32_t *slice_chunk, int32_t *slice_tile, int32_t *tile_ptr, uint8_t *kind,

@@ -93,7 +93,6 @@ public:
     SellArgs args() const;
     void refill(const int32_t *d_colidx, const double *d_blocks, hipStream_t st);   // values changed on the device (XM^2 re-weighting)
     double *parts(int o);
-    const double *pack_w(int o, const double *W, hipStream_t st);   // W as the kernel wants it (repacked when the stride differs)
     int wstride(int o) const;
     int reduce_gw(int o) const;                 // lanes per camera in the second launch (4 | 16)
     int reduce_grid(int o, int nloc) const;     // workgroups of the second launch == per-workgroup partial sums per epilogue slot          // partial-result buffer for rank o (grow-only)
@@ -108,7 +107,6 @@ private:
     int S_ = 1, grid_ = 0;
     int64_t ncols_ = 0, max_list_ = 0;   // max_list_: most partial results of one camera
     int64_t lines72_ = 0, lines120_ = 0, lines_padded_ = 0;   // SellHost::lines_*
-    DevBuf<double> wpad_;      // W repacked at 16 doubles per camera (XM_SELL_WSTRIDE=16)
     bool coalesced_ = false;   // partial results written as one contiguous run per slice (slice-order slots)
     DevBuf<int64_t> slice_off_, pptr_;
     DevBuf<int32_t> slab_start_, cols_, pslot_, ridx_;

@@ -302,31 +302,11 @@ SellArgs SellMatrix::args() const {
     return a;
 }
 
-// XM_SELL_WSTRIDE=16 (experiment, default off): W repacked at 16 doubles per camera so that a gathered record is ONE 128-byte line
-// instead of 1.8 (PMC at the native 72-byte stride: 9.3 M L2 hits for 5.1 M gathered records + 3.4 M misses of the block stream).
-// Measured at 100 k cameras incl. the 7 -> 13 MB repack launch: o = 3 112.3 vs 111.5 us, o = 4 123.3 vs 126.3, o = 5 132.1 vs 137.8,
-// banded graph 113.6 vs 93.0 (the padded slab no longer fits the L2 share) -- the L2 request count is not what bounds the product.
-static int sell_wstride_env() {
-    static const int v = [] { const char *e = std::getenv("XM_SELL_WSTRIDE"); return (e && *e) ? std::atoi(e) : 0; }();
-    return v;
-}
-int SellMatrix::wstride(int o) const {
-    const int rec = 3 * pitch_of(o);
-    return (sell_wstride_env() == 16 && rec < 16 && o >= 3) ? 16 : rec;
-}
-__global__ __launch_bounds__(256) void sell_pack_w_kernel(int64_t n, int rec, const double *__restrict__ W, double *__restrict__ Wp) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n * 16) return;
-    const int64_t c = t >> 4;
-    const int e = (int)(t & 15);
-    Wp[t] = (e < rec) ? W[c * rec + e] : 0.0;
-}
-const double *SellMatrix::pack_w(int o, const double *W, hipStream_t st) {
-    if (wstride(o) != 16) return W;
-    if (!wpad_.p) wpad_.alloc((size_t)ncols_ * 16 + 2);
-    hipLaunchKernelGGL(sell_pack_w_kernel, dim3((unsigned)((ncols_ * 16 + 255) / 256)), dim3(256), 0, st, ncols_, 3 * pitch_of(o), W, wpad_.p);
-    return wpad_.p;
-}
+// Record pitch of W as the kernels see it: the native 3 x pitch_of(o) doubles, or 16 when the caller hands over a padded copy
+// (launch_qw_sell: Wpad16).  Round 3 tried a repacking launch in front of every product (XM_SELL_WSTRIDE=16) and saw no gain: the 7.5 us of
+// that launch hid the 9-10 us the main launch gains (profiles/r04_trace_sell_pitch16.txt); the copy now comes from the kernels that
+// write W anyway.
+int SellMatrix::wstride(int o) const { return 3 * pitch_of(o); }
 
 double *SellMatrix::parts(int o) {
     if (o > parts_o_) {
@@ -352,8 +332,11 @@ typedef int i2a __attribute__((ext_vector_type(2)));
 // vector L1 waits for L2 data in 61 % of its active cycles with on average 74 lines outstanding per CU (8.66 M requests x 388 cycles /
 // 178 k cycles / 256 CUs) -- 1.54 M stream lines at ~1 380 cycles (HBM) hold 63 % of those slots, 7.1 M gathered lines at ~173 cycles
 // (L2 hits) the rest; L2 tag stalls, TLB misses and request-path stalls are ~0.  Resident wavefronts (LDS halved, o = 4 / 5 at three
-// instead of two workgroups per CU), the L1 policy of the gathered lines (sc1, sc0 sc1) and a 128-byte record pitch change the duration
-// by < 2 % (r04_kbench_sell_lds_occ.txt, r04_kbench_sell_cache_policy.txt); nt on the gather evicts W from the L2: 123-128 us.
+// instead of two workgroups per CU) and the L1 policy of the gathered lines (sc1, sc0 sc1) change the duration by < 2 %
+// (r04_kbench_sell_lds_occ.txt, r04_kbench_sell_cache_policy.txt; nt on the gather evicts W from the L2: 123-128 us), and a kernel
+// that only LOADS (no codec, LDS or FMA work) takes the same 81-82 us (r04_kbench_sell_loads_only.txt): the duration follows the number
+// of LINES requested times their latency.  What does shorten it is fewer lines per record: W at a 128-byte record pitch (Wpad16 of
+// launch_qw_sell) -- 5.09 M instead of 7.1 M gathered lines, main launch 72.8 -> 63.6 us.
 template <int I>
 __device__ __forceinline__ d2a sell_window_load(int j, const double *__restrict__ W, int piece) {
     const int jr = __builtin_amdgcn_ds_swizzle(j, 0x18 | (I << 5));
@@ -947,7 +930,6 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
     const bool padded = Wpad16 != nullptr && O >= 3 && 3 * pitch_of(O) <= 16;   // the caller keeps a copy of W at the 128-byte record pitch
     if (padded) { sa.wstride = 16; W = Wpad16; }
     if (m.grid() > 0) {
-        if (!padded) W = m.pack_w(O, W, st);
         const dim3 g(m.grid()), b(256);
         static const int abl = [] { const char *e = std::getenv("XM_SELL_ABLATE"); return (e && *e) ? std::atoi(e) : 0; }();   // timing experiments only
         if constexpr (O == 3) {

@@ -152,6 +152,7 @@ public:
     explicit Context(const xm_problem_t &prob, std::shared_ptr<Comm> comm = nullptr);
     int rank() const { return comm_->rank; }
     int comm_kind() const { return comm_->active() ? comm_->kind() : 0; }
+    bool sell_wpad_on() const { return wpad_on_; }   // the sliced-ELL gather of the current rank's tCG reads W at the 128-byte record pitch
     const std::string &fallback_note() const { return comm_->fallback_note; }
     int world() const { return comm_->world; }
     int64_t cameras() const { return n_; }

@@ -29,7 +29,7 @@ EXPORTS = [
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_retract_variant", "xm_qw_dense_time", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_peer_allgather_bench", "xm_qw_bsr3_time", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_init_ipc", "xm_comm_finalize", "xm_partition", "xm_partition_blocks",
     "xm_symv_plan", "xm_sell_layout", "xm_sell_locality", "xm_sell_create", "xm_sell_create2", "xm_sell_create3", "xm_sell2_layout", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time", "xm_qw_sell_padded", "xm_qw_sell_time_padded",
-    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport", "xm_symw_plan", "xm_symw_use", "xm_qw_symw_time",
+    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport", "xm_ctx_sell_wpad", "xm_symw_plan", "xm_symw_use", "xm_qw_symw_time",
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
         L.xm_ctx_xm2_round.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Options), C.POINTER(Xm2Info), C.POINTER(Result)]
         L.xm_ctx_recover_tp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_ctx_transport.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+        L.xm_ctx_sell_wpad.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.xm_symw_plan.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.xm_symw_use.argtypes = [C.c_int, C.c_int, C.c_int]
         L.xm_qw_symw_time.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
@@ -521,6 +522,12 @@ class Context:
         k = C.c_int(0); buf = C.create_string_buffer(512)
         _chk(lib().xm_ctx_transport(self.h, C.byref(k), buf, 512))
         return k.value, self.TRANSPORTS.get(k.value, "?"), buf.value.decode()
+
+    def sell_wpad(self):
+        """True when the tCG of the last solved rank read its product input at the 128-byte record pitch (xm_ctx_sell_wpad)"""
+        on = C.c_int(0)
+        _chk(lib().xm_ctx_sell_wpad(self.h, C.byref(on)))
+        return bool(on.value)
 
     def qw(self, W, alpha=1.0):
         """alpha * Q @ W through the context's storage (xm_ctx_qw)"""
