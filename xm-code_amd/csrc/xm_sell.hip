@@ -928,6 +928,8 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
     sa.wstride = m.wstride(O);
     const bool quat = m.codec() == SELL_CODEC_QUAT;
     const bool padded = Wpad16 != nullptr && O >= 3 && 3 * pitch_of(O) <= 16;   // the caller keeps a copy of W at the 128-byte record pitch
+    const double *Wn = W;            // the second launch walks the cameras in order: the native pitch is the denser read there
+    const int wn = sa.wstride;
     if (padded) { sa.wstride = 16; W = Wpad16; }
     if (m.grid() > 0) {
         const dim3 g(m.grid()), b(256);
@@ -1000,9 +1002,9 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
     const dim3 g(m.reduce_grid(O, a.nloc)), b(256);
 #define XM_SELL_REDUCE(GW_)                                                                                                                          \
     switch (epi) {                                                                                                                                  \
-        case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride); break; \
-        case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride); break;   \
-        case EPI_HESS: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_HESS, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride); break;   \
+        case EPI_PLAIN: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_PLAIN, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, Wn, sa.row0, wn); break; \
+        case EPI_GRAD: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_GRAD, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, Wn, sa.row0, wn); break;   \
+        case EPI_HESS: hipLaunchKernelGGL((sell_reduce_kernel<O, EPI_HESS, GW_>), g, b, 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, Wn, sa.row0, wn); break;   \
         default: throw Error(XM_ERR_ARG, "bad epilogue");                                                                                           \
     }
     if (m.reduce_gw(O) == 4) { XM_SELL_REDUCE(4) } else { XM_SELL_REDUCE(16) }
