@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -385,6 +386,7 @@ struct IpcShared {
     std::atomic<int> failed;      // a rank could not export or map: all ranks give the transport up together
     struct Slot { hipIpcMemHandle_t h; unsigned long long meta; } slot[2][kMaxPeers];
     unsigned long long devid[kMaxPeers];   // identity of every rank's GPU (hash of its PCI bus id): which ranks share a device
+    std::atomic<unsigned long long> stamp; // wall-clock nanoseconds at which rank 0 created THIS segment (0: not initialised yet)
 };
 struct IpcPeerGroup : PeerGroup {
     IpcShared *sh = nullptr;
@@ -709,12 +711,41 @@ void peer_group_abort(const std::shared_ptr<PeerGroup> &g) { if (g) g->abort(); 
 namespace {
 std::shared_ptr<IpcPeerGroup> ipc_group_open(int rank, int world, int device, const char *name, double limit, double spin_seconds) {
     if (world > kMaxPeers) throw Error(XM_ERR_ARG, "direct peer exchange supports up to " + std::to_string(kMaxPeers) + " ranks");
-    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) throw Error(XM_ERR_COMM, "shm_open failed");
-    if (ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) { close(fd); throw Error(XM_ERR_COMM, "ftruncate failed"); }
-    void *p = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) throw Error(XM_ERR_COMM, "mmap failed");
+    // A segment a crashed job left under the same name would hand this job non-zero counters.  Rank 0 removes whatever carries the name and
+    // creates the segment exclusively (zero-filled) and stamps it with its creation time; the others open WITHOUT O_CREAT and accept only a
+    // completely sized segment whose stamp is recent (a stale one is dropped and re-opened until rank 0 has replaced it).
+    auto wall_ns = [] { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count(); };
+    void *p = MAP_FAILED;
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) throw Error(XM_ERR_COMM, "shm_open failed");
+        if (ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) { close(fd); throw Error(XM_ERR_COMM, "ftruncate failed"); }
+        p = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) throw Error(XM_ERR_COMM, "mmap failed");
+        static_cast<IpcShared *>(p)->stamp.store(wall_ns(), std::memory_order_release);
+    } else {
+        const auto t0 = clk::now();
+        const unsigned long long fresh = (unsigned long long)((limit + 60.0) * 1e9);
+        for (;;) {
+            const int fd = shm_open(name, O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat sb;
+                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= sizeof(IpcShared)) {
+                    void *q = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                    if (q != MAP_FAILED) {
+                        const unsigned long long st = static_cast<IpcShared *>(q)->stamp.load(std::memory_order_acquire), now = wall_ns();
+                        if (st != 0 && now - st < fresh) { p = q; close(fd); break; }
+                        munmap(q, sizeof(IpcShared));
+                    }
+                }
+                close(fd);
+            }
+            if (since(t0) > limit) throw Error(XM_ERR_COMM, "peer rendezvous: rank 0 did not create the shared segment in time");
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
     auto g = std::make_shared<IpcPeerGroup>();
     g->sh = static_cast<IpcShared *>(p);   // a fresh segment is zero-filled
     g->name = name; g->me = rank; g->world = world; g->limit = limit;
