@@ -152,6 +152,25 @@ def test_qw_sell_skewed_degrees_and_unsorted_rows(xmamd, layout):
     assert tl.rel_fro(xmamd.qw_bsr3(rowptr, colidx, blocks, W), ref) < 1e-13
 
 
+def test_qw_sell_wide_matrix_against_csr_arithmetic(xmamd):
+    """70 000 cameras (too wide for a dense reference) in one slab and in four, full blocks and view-graph codec, every gather mode and the
+    padded product input, against the product computed from the CSR arrays with numpy"""
+    n = 70000
+    P = tl.gen_vg(n, deg=4, sigma=0.2, seed=2, dense=False)
+    rng = np.random.default_rng(4)
+    W = rng.standard_normal((3 * n, 3))
+    ref = np.zeros((3 * n, 3))
+    rows = np.repeat(np.arange(n), np.diff(P["rowptr"]))
+    np.add.at(ref.reshape(n, 3, 3), rows, P["blocks"] @ W.reshape(n, 3, 3)[P["colidx"]])
+    for slabs in (1, 4):
+        for codec in (0, 1):
+            M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, codec=codec)
+            for gather in (0, 1, 2, 4):
+                assert tl.rel_fro(M.qw(W, gather=gather), ref) < 1e-12, (slabs, codec, gather)
+            assert tl.rel_fro(M.qw(W, gather=1, padded=True), ref) < 1e-12
+            M.close()
+
+
 def test_solve_through_sell_equals_csr_path(xmamd, monkeypatch):
     """the whole solver (gradient / Hessian / certificate epilogues, Lanczos with o = 1) on the sliced-ELL product reaches the
     optimum of the block-CSR path: same rank, status, primal to 1e-12, rotations to 1e-8"""
