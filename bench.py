@@ -224,6 +224,40 @@ def cpu_baseline(Q, wl, budget_s, bsr=None):
                            if ((76.0 * bsr[1].size) if bsr is not None else 8.0 * (3 * n) ** 2) < 400e6 else "DRAM"))
 
 
+def _error_line(ngp, args, workload_desc, msg):
+    """the ONE JSON line of a run that could not produce its measurement (transport ladder ended in XM_ERR_COMM, a solve failed, a peer
+    rank died, the watchdog fired): whoever launched this learns why instead of finding nothing"""
+    print(json.dumps({"metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
+                      "value": None, "unit": "tCG iters/s", "n_gpus": ngp, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                      "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": workload_desc}, "transport": None, "fallback": None, "error": msg}), flush=True)
+
+
+_PHASE = ["start"]     # where the run is: named in the watchdog's / the signal handler's error line
+
+
+def _arm_guards(rank, ngp, args, workload_desc):
+    """several ranks: (a) a watchdog -- a collective that never returns (a peer that died outside the library's bounded waits, a library
+    initialisation that hangs) ends in the error line after XM_BENCH_TIMEOUT_S seconds (default 1800) instead of in silence; (b) rank 0
+    prints the error line when the launcher tears the job down because another rank failed (SIGTERM)"""
+    import signal, threading
+    limit = float(os.environ.get("XM_BENCH_TIMEOUT_S", "1800"))
+
+    def fire():
+        if rank == 0:
+            _error_line(ngp, args, workload_desc, "watchdog: no result after %.0f s (phase: %s)" % (limit, _PHASE[0]))
+        os._exit(3)
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    if rank == 0:
+        def on_term(signum, frame):
+            _error_line(ngp, args, workload_desc, "terminated by the launcher (signal %d) in phase: %s -- another rank failed" % (signum, _PHASE[0]))
+            os._exit(4)
+        signal.signal(signal.SIGTERM, on_term)
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,6 +295,31 @@ def main():
     retr = xmamd.RETRACT_POLAR if args.retraction == "polar" else xmamd.RETRACT_QR
     xmamd.require_gpu()
     torch.cuda.set_device(local)
+    wl = workload(args.workload)
+    guard = _arm_guards(rank, ngp, args, wl["desc"]) if ngp > 1 else None
+    try:
+        _init_ranks(rank, world, local, dist)
+    except xmamd.XmError as e:
+        if rank == 0:
+            _error_line(ngp, args, wl["desc"], "communicator: " + str(e))
+        raise SystemExit(1)
+    import xm_testlib as tl
+    t0 = time.time()
+    Q = None
+    try:
+        return _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch, dist, bound_mask)
+    except xmamd.XmError as e:
+        # the library's transport ladder (direct peer writes -> RCCL) ended in XM_ERR_COMM, or a solve failed: still ONE JSON line
+        if rank == 0:
+            _error_line(ngp, args, wl["desc"], str(e))
+        raise SystemExit(1)
+    finally:
+        if guard is not None:
+            guard.cancel()
+
+
+def _init_ranks(rank, world, local, dist):
+    _PHASE[0] = "communicator"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only (id exchange, barrier, max)
@@ -281,24 +340,9 @@ def main():
             # the transport's self-test passes (ranks of one node), else RCCL all-gathers over xGMI (XM_COMM_PEER=0 forces RCCL)
             xmamd._chk(xmamd.lib().xm_comm_init(rank, world, local, box[0], None))
 
-    wl = workload(args.workload)
-    import xm_testlib as tl
-    t0 = time.time()
-    Q = None
-    try:
-        return _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch, dist, bound_mask)
-    except xmamd.XmError as e:
-        # the library's transport ladder (direct peer writes -> RCCL) ended in XM_ERR_COMM, or a solve failed: still ONE JSON line, so that
-        # whoever launched this learns why instead of finding nothing
-        if rank == 0:
-            print(json.dumps({"metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
-                              "value": None, "unit": "tCG iters/s", "n_gpus": ngp, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
-                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": wl["desc"]}, "transport": None, "fallback": None, "error": str(e)}))
-        raise SystemExit(1)
-
 
 def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch, dist, bound_mask):
+    _PHASE[0] = "context set-up (Q upload, transport ladder of the single-process mode)"
     if wl["kind"] == "dense":
         Q = tl.gen_dense(wl["n"], seed=wl["seed"])["Q"]
         ctx = xmamd.Context(Q=Q, **tkw)
@@ -328,9 +372,11 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
     def one_solve(flags=0, grouping=0):
         return ctx.solve(wl["max_rank"], wl["tol"], wl["lam"], flags=flags, retraction=retr, grouping=grouping)
 
+    _PHASE[0] = "warm-up solves"
     for i in range(args.warmup):
         one_solve(grouping=i % 3)
     barrier()
+    _PHASE[0] = "timed solves"
     t0 = time.perf_counter()
     infos = []
     last_sol = None
@@ -339,6 +385,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         infos.append(last_sol[2])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _PHASE[0] = "after the timed solves (secondary legs)"
     barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
