@@ -258,3 +258,18 @@ def test_column_locality_decides_the_padded_copy(xmamd):
     colidx = (np.repeat(lo, cnt) + (np.arange(rowptr[-1]) - np.repeat(rowptr[:-1], cnt))).astype(np.int32)
     l72, l120, lp = xmamd.sell_locality(rowptr, colidx, slabs=4)
     assert l72 < 0.75 * lp and l120 < 1.05 * lp          # the rule (10 % margin) keeps the native pitch for both record sizes
+
+
+@pytest.mark.parametrize("o", [3, 4, 5])
+def test_padded_record_layout(xmamd, o):
+    """xmamd.pad16 = what tcg_init / cg_step write beside W: camera c's 3 x pitch_of(o) row-major record at [16 c, 16 c + 3 pitch_of(o)),
+    zeros behind it -- element (3 c + r, k) of W sits at 16 c + r * pitch_of(o) + k"""
+    n = 7
+    W = np.random.default_rng(o).standard_normal((3 * n, o))
+    P = xmamd.pad16(W).reshape(n, 16)
+    OP = xmamd.pitch_of(o)
+    for c in range(n):
+        for r in range(3):
+            assert np.array_equal(P[c, r * OP:r * OP + o], W[3 * c + r])
+            assert np.all(P[c, r * OP + o:(r + 1) * OP] == 0.0)
+        assert np.all(P[c, 3 * OP:] == 0.0)
