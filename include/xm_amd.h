@@ -45,11 +45,13 @@ extern "C" {
 
 const char *xm_last_error(void);
 const char *xm_version(void);
-/* ABI revision of the structs below.  Revision 3 (this one): xm_problem_t, xm_options_t and xm_result_t START with `struct_size`, which the
+/* ABI revision of the structs below.  Since revision 3 xm_problem_t, xm_options_t and xm_result_t START with `struct_size`, which the
  * caller sets to sizeof(its own struct).  The library copies min(struct_size, its own sizeof) bytes, treats what the caller did not
- * pass as zero and never writes past the caller's size, so a caller compiled against a shorter (older, revision >= 3) header keeps
- * working; struct_size == 0 is rejected with XM_ERR_ARG (revisions 1-2 had no size field and are NOT binary compatible). */
-#define XM_ABI_REVISION 3
+ * pass as zero and never writes past the caller's size, so a caller compiled against a shorter (older) header keeps working;
+ * struct_size == 0 is rejected with XM_ERR_ARG (revisions 1-2 had no size field and are NOT binary compatible).  Revision 4 (this
+ * one): xm_tuning_t re-laid (the fields that selected removed experiment kernels are gone, test / matrix-free switches added) -- a
+ * caller that passes a NON-NULL xm_problem_t.tuning must be compiled against this header; timing hooks moved to xm_bench.h. */
+#define XM_ABI_REVISION 4
 int xm_abi_revision(void);
 
 /* ================================================================== 1. file-based surface == the reference's pybind functions */
@@ -79,41 +81,43 @@ typedef struct xm_ctx xm_ctx_t;
                                   utils/creatematrix.py:create_matrix(weight, edges, landmarks) takes (creatematrix.py:51); the product applies
                                   Q = Q1 - Vtp_bar Qtp_bar^{-1} Vtp_bar^T as a factor chain (xm-code_amd/csrc/xm_schur.h).  Single GPU. */
 
-/* Context-creation settings that select kernels / layouts (all 0 = the defaults = automatic choice).  Environment variables of the
- * same meaning (XM_SYM, XM_BSR_SELL, ... -- scripts/README.md) override a zero field, are read ONCE inside xm_ctx_create and never
- * afterwards (no getenv during a solve). */
+/* Context-creation settings that select kernels / layouts (all 0 = the defaults = automatic choice).  They are the ONLY way to select
+ * a kernel or a layout: the library reads no environment variable for that (the variables it does read are listed in INTEGRATION.md:
+ * XM_QUIET, XM_GPUS, XM_GPU_MAP, XM_RETRACTION, XM_WATCHDOG_S for callers of the file surface, which has no tuning argument, and
+ * XM_COMM_PEER, XM_COMM_TRACE, XM_FORCE_COMM, XM_SHM_TIMEOUT, XM_SHM_ASYNC for the process-level communicator set-up of section 4). */
 typedef struct {
     int32_t sym;               /* half-traffic symmetric dense product: 0 auto (3n >= sym_min_rows, exactly symmetric Q), 1 force (1e-9 asymmetry accepted), -1 off */
-    int32_t sym_min_rows;      /* 0 = 6144 */
-    int32_t sell;              /* sliced-ELL copy of a block-sparse Q: 0 auto (>= 1 M blocks per GPU), 1 force, -1 off */
+    int32_t sym_min_rows;      /* 0 = 6144 (also the row count from which the matrix-free storage applies its inverse with the symmetric kernel) */
+    int32_t sell;              /* sliced-ELL copy of a block-sparse Q: 0 auto (by size, xm_solver.hip), 1 force, -1 off */
     int32_t sell_slabs;        /* 0 = 4 (1, 2, 4, 8) */
     int32_t sell_lmax;         /* 0 = 64 */
-    int32_t sell_gather;       /* how the rows of W are fetched: 0 = default (2), 1 = one record per lane, 2 = records fetched element-per-lane and
-                                  transposed through LDS, 3 = the two aligned 64-byte sectors of every record fetched by two quads of lanes straight
-                                  into LDS (global_load_lds_dwordx4; o = 3; measured 85-88 us against 83 us for mode 2 at 100 k cameras: kept selectable), 5 = the same
-                                  sector windows into registers (view-graph codec, o = 3; 82.0-82.2 against 82.8-83.8 us at 100 k cameras, 70.6 against 62.1 on a
-                                  banded graph: kept selectable; 4 is unused) */
+    int32_t sell_gather;       /* how the records of W are fetched: 0 = default (2), 1 = one record per lane, 2 = records fetched element-per-lane and
+                                  transposed through LDS; anything else: XM_ERR_ARG */
     int32_t sell_codec;        /* 0 auto (view-graph storage: quaternion codec; BSR3: full blocks), 1 full blocks, 2 quaternion codec (XM_ERR_ARG if Q is not a view-graph matrix) */
     int32_t overlap;           /* split dense products outside the tCG around the all-gather of W: 0 auto (>= overlap_min_mb per rank), -1 off */
-    int32_t overlap_min_mb;    /* 0 = 64 */
+    int32_t overlap_min_mb;    /* 0 = 64; -1 = no minimum (tests) */
     int32_t cert_dense_rows;   /* certificate: complete tridiagonalisation for 3n <= this; 0 = 384 */
     int32_t lanczos_mmax;      /* 0 = 400 */
     int32_t lanczos_restarts;  /* 0 = 12 */
-    int32_t watchdog_s;        /* host spin loops give up after this many seconds without progress; 0 = 600 */
+    int32_t watchdog_s;        /* host spin loops give up after this many seconds without progress; 0 = XM_WATCHDOG_S, else 600 */
     int32_t balance;           /* row partition of block-sparse storage: 0 = by stored blocks, 1 = equal camera ranges */
     int32_t exchange;          /* multi-GPU tCG exchange: 0 auto (direct peer writes fused into the tCG kernel when the ranks share this process or IPC
                                   is set up and the transport passes its self-test, else RCCL), 1 an all-gather between the launches (whatever the
                                   transport), 2 direct peer writes, 3 RCCL even where peer writes would work (single-process mode) */
     int32_t split_k;           /* dense product of a SMALL row strip with its columns split over several workgroups per camera group: 0 auto
                                   (multi-GPU runs whose strip has fewer than ~1.5 workgroups per CU), -1 off, 2..8 forced (also on one GPU) */
-    int32_t sell_layout;       /* layout of the sliced-ELL copy: 0 auto (= 1), 1 = virtual rows sorted by length, two launches per product (xm_sell.h),
-                                  2 = chunk-tiled, ONE launch per product with the epilogue run by the last slice to arrive for a chunk of 64
-                                  cameras (xm_sell2.h; fewer than 2^24 cameras; measured slower on MI355X, kept selectable) */
-    int32_t sell_kmax;         /* layout 2: most steps of a slice (longer (chunk, slab) lists -- hub cameras -- are cut); 0 = 32 */
     int32_t sell_wpad;         /* sliced-ELL product inside the truncated CG (single GPU, rank 3..5): the kernels that write the product input also write
                                   a copy at a record pitch of 128 bytes, which the gather reads (one cache line per record instead of 1.4 / 1.9):
                                   0 auto (when the column pattern has no locality: random view graphs yes, banded ones no) | 1 always | -1 never */
-    int32_t reserved[1];
+    int32_t exchange_fence;    /* 1: the direct peer exchange publishes with plain stores + a system-scope release fence instead of write-through stores */
+    int32_t schur_host_assembly; /* XM_STORAGE_SCHUR: 1 = assemble the reduced camera Laplacian on the host (the reference's route, utils/creatematrix.py:137-260) */
+    int32_t schur_trace;       /* XM_STORAGE_SCHUR: 1 = set-up phase times on stderr */
+    int32_t schur_solver;      /* XM_STORAGE_SCHUR: how the reduced camera Laplacian is applied inside the product: 0 auto (dense inverse up to
+                                  schur_dense_max cameras, preconditioned CG above), 1 dense inverse, 2 preconditioned CG (xm-code_amd/csrc/xm_schur.h) */
+    int32_t schur_dense_max;   /* 0 = 20000 */
+    int32_t debug_drop_finalize; /* tests: the k-th outer iteration loses its result kernel (the host must come back with XM_ERR_HIP) */
+    int32_t debug_peer_mute;   /* tests: rank 1 never publishes its tCG epoch (a dead peer: the bounded waits must expire) */
+    int32_t reserved[4];
 } xm_tuning_t;
 
 typedef struct {
@@ -296,10 +300,9 @@ int xm_dense_from_bsr3(const int64_t *rowptr, const int32_t *colidx, const doubl
 /* out = alpha * Q * W.  dq from xm_dense_upload; dW, dOut: device, row-major 3n x o (o in 1,3..10).
  * Replaces cublasDgemm via DnMatDnMat (Dense/matmul.h:42-87). stream: hipStream_t or NULL. */
 int xm_qw_dense(const double *dq, int64_t n, int o, const double *dW, double *dOut, double alpha, void *stream);
-/* same product from 3x3-block CSR (device arrays; blocks row-major 9 doubles) */
-/* the same product reading only the upper block triangle of a SYMMETRIC Q (o in 3..5; allocates its scratch per call) */
+/* the same product reading only the upper block triangle of a SYMMETRIC Q (o in 1, 3..5; allocates its scratch per call) */
 int xm_qw_dense_sym(const double *dq, int64_t n, int o, const double *dW, double *dOut, double alpha, void *stream);
-int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
+/* same product from 3x3-block CSR (device arrays; blocks row-major 9 doubles) */
 int xm_qw_bsr3(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o,
                const double *dW, double *dOut, double alpha, void *stream);
 
@@ -318,14 +321,10 @@ int xm_symv_plan(int64_t n, int32_t plan[4]);
  * predicate "row step t uses block (t, u)" of a matrix of T steps. */
 int xm_symw_plan(int64_t ntot, int nloc, int cam0, int K, int32_t geom[8], int32_t *items);
 int xm_symw_use(int T, int t, int u);
-/* timing of ONE rank's share of that product on this GPU (rank cam0 / nloc of `world`, an arbitrary row strip): ms[0] = sweep + column sums,
- * ms[1] = per-camera sum + plain epilogue; *bytes = bytes of Q the sweep streams (half of the strip + the window's edge strips) */
-int xm_qw_symw_time(int64_t ntot, int nloc, int cam0, int o, int world, int reps, double ms[2], int64_t *bytes);
-
 /* Large block-sparse Q: "sliced ELL over per-XCD column slabs" (xm-code_amd/csrc/xm_sell.h).  Same product as xm_qw_bsr3
  * (the reference has no sparse product: Dense/matmul.h:42-87 on a dense Q); the matrix is described on the HOST as 3x3-block CSR
  * (rows n, global columns in [0, ncols)) and re-laid on the device.  slabs in {1,2,4,8}; lmax = longest virtual row (hub
- * cameras are cut); gather_mode 0 | 1 selects how the rows of W are fetched.  xm_sell_layout is host-only (CPU tests): with
+ * cameras are cut); gather_mode 0 (a record of W per lane) | 1 (LDS-transposed, the solver's default) selects how the rows of W are fetched.  xm_sell_layout is host-only (CPU tests): with
  * NULL arrays it fills sizes = {slices, steps, partial results, virtual rows, entries of the partial-result array}. */
 int xm_sell_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t sizes[5],
                    int64_t *slice_off, int32_t *slab_start, uint8_t *kind, int64_t *src, int32_t *pslot, int64_t *pptr, int32_t *ridx);
@@ -336,56 +335,24 @@ int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *b
  * row0 = global camera index of row 0 (which column is "the diagonal"). */
 int xm_sell_create2(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
                     int codec, int64_t row0, void **handle);
-/* the same with the LAYOUT chosen: 1 = sliced ELL over virtual rows sorted by length, two launches per product (xm_sell.h; lmax = longest
- * virtual row, 0 = 64); 2 = chunk-tiled sliced ELL, ONE launch per product (xm-code_amd/csrc/xm_sell2.h; lmax = most steps of a slice, 0 = 32;
- * ncols < 2^24). */
-int xm_sell_create3(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
-                    int codec, int64_t row0, int layout, void **handle);
 /* host-only: distinct 128-byte lines of W the 64 lanes of a step touch, summed over every 4th step -- records of 72 bytes (o = 3), of 120 bytes
  * (o = 4, 5) at their native pitch, and at the 128-byte pitch: the figures behind the automatic choice of xm_tuning_t.sell_wpad */
 int xm_sell_locality(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int lmax, int64_t lines[3]);
-/* host-only view of layout 2 (CPU test of the index arithmetic, tests/test_sell_layout.py): sizes = {slices, steps, tiles, chunks}; arrays as
- * xm-code_amd/csrc/xm_sell2.h:Sell2Host describes them (NULL = not wanted) */
-int xm_sell2_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int kmax, int64_t sizes[4],
-                    int64_t *slice_off, int32_t *slab_start, int32_t *slice_chunk, int32_t *slice_tile, int32_t *tile_ptr, uint8_t *kind,
-                    int64_t *src, int32_t *lane_meta);
 /* host-only: block (row-major 3x3, -w * rotation) -> stored quaternion -> the block the product kernel rebuilds (CPU test of the codec) */
 int xm_sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]);
 void xm_sell_destroy(void *handle);
 int xm_qw_sell(void *handle, int o, const double *dW, double *dOut, double alpha, int gather_mode, void *stream);
-int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gather_mode, int reps, double *ms_avg);
 /* the same products with the input ALSO given at a record pitch of 16 doubles (dWpad16[cam * 16 + e] = dW[cam * 3 * pitch + e]; o = 3..5, layout 1;
  * NULL = not given): the gather reads one 128-byte line per camera.  Inside the solver the kernels that write the product input of the truncated
  * CG write that copy as well (xm_tuning_t.sell_wpad). */
 int xm_qw_sell_padded(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, double alpha, int gather_mode, void *stream);
-int xm_qw_sell_time_padded(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, int gather_mode, int reps, double *ms_avg);
 /* per-camera kernels (device, row-major 3n x o; s: n):
  * Rout = MGS_rows(R + t*D) (Dense/batchedQR.h:42-67), sout = s*exp(t*ds/s) (trustregion.h:19-24), s[0] stays 1 */
 int xm_retract(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t,
                double *dRout, double *dsout, void *stream);
-/* the same with the kernel form chosen -- variant 0: one thread per camera (the default), 1: polar retraction, 2: MGS-QR with a quad of lanes
- * per camera and DPP reductions (`north_star`'s cross-lane form; measured slower, kept as the recorded alternative) -- and, if ms_avg is
- * not NULL, timed over `reps` launches */
-int xm_retract_variant(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t, double *dRout,
-                       double *dsout, int variant, int reps, double *ms_avg);
 /* the same with the polar retraction (XM_RETRACT_POLAR): Rout_i = (M M^T)^{-1/2} M, M = R_i + t D_i */
 int xm_retract_polar(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t,
                      double *dRout, double *dsout, void *stream);
-/* timing helper for bench.py: average milliseconds of `reps` back-to-back xm_qw_dense launches (HIP events) */
-int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
-/* the same for a ROW STRIP of nloc cameras of an n-camera matrix (what one rank of an N-GPU row partition multiplies: dq = 3 nloc rows x
- * xm_dense_ld(n)); used to state the expected per-iteration time of the partitioned solve from measured pieces */
-int xm_qw_dense_strip_time(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
-/* the strip product with its COLUMNS split over `ks` workgroups per camera group (ks = 0: the small-strip policy picks; 1: no split):
- * out = alpha * Q_strip * W; with reps > 0 also the average launch time */
-int xm_qw_dense_strip_ks(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, double alpha, int ks, int reps,
-                         double *ms_avg, int *ks_used);
-/* micro-benchmark of the direct peer-write all-gather (xm-code_amd/csrc/xm_comm.hip): `world` ranks (one host thread each; gpu_map 1 = all
- * on device 0) gather `count` doubles per rank `reps` times; us_avg = average time per collective on rank 0, stream time */
-int xm_peer_allgather_bench(int world, int gpu_map, int64_t count, int reps, double *us_avg);
-int xm_qw_bsr3_time(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o, const double *dW,
-                    double *dOut, int reps, double *ms_avg);
-
 /* Solution recovery, the step right after the solve (replaces the rotation/scale part of
  * utils/recoversolution.py:recover_XM, lines 12-86): R (3n x r column-major) and s (n) as written to R.bin / s.bin ->
  * rot: 3 x 3n column-major, block i = the anchored orthogonal 3x3 of camera i (block 0 = identity), scale: n.
@@ -404,6 +371,14 @@ int xm_comm_init(int rank, int world, int device, const unsigned char id[128], c
 int xm_ctx_transport(xm_ctx_t *ctx, int *kind, char *note, size_t note_cap);
 /* *on = 1 when the truncated CG of the last solved rank kept its product input at the 128-byte record pitch as well (xm_tuning_t.sell_wpad) */
 int xm_ctx_sell_wpad(xm_ctx_t *ctx, int *on);
+/* which product kernel serves the tCG of this context at rank o (3..10): XM_PRODUCT_* below */
+#define XM_PRODUCT_DENSE       0   /* qw_dense_kernel */
+#define XM_PRODUCT_DENSE_SYM   1   /* half-traffic symmetric dense product (one GPU: qw_symv_kernel; several: the cyclic half window) */
+#define XM_PRODUCT_BSR3        2   /* qw_bsr3_kernel (3x3-block CSR, one launch) */
+#define XM_PRODUCT_SELL        3   /* sliced ELL, 9 doubles per block (two launches) */
+#define XM_PRODUCT_SELL_QUAT   4   /* sliced ELL, view-graph codec */
+#define XM_PRODUCT_SCHUR       5   /* matrix-free factor chain */
+int xm_ctx_product_kind(xm_ctx_t *ctx, int o, int *kind);
 
 /* One process per GPU WITHOUT a collective library on the data path: every rank exports its exchange buffers as hipIpcMemHandle_t
  * through the POSIX shared-memory segment `name` (same string on every rank of the node, unique per job), maps the peers' and uses

@@ -23,6 +23,11 @@ def test_header_symbols_exported(xmamd):
     assert not missing, f"symbols declared in xm_amd.h but not exported: {missing}"
     assert set(xmamd.EXPORTS) <= declared
     assert b"gfx950" in L.xm_version()
+    # the timing hooks of the micro-benchmarks live in their own header, which the product header does not pull in
+    assert "xm_bench.h" not in hdr and not any(d.endswith("_time") or d.endswith("_bench") for d in declared)
+    bh = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "xm_bench.h")).read(), flags=re.S)
+    bdecl = set(re.findall(r"\b(xm_[a-z0-9_]+)\s*\(", bh))
+    assert bdecl == set(xmamd.BENCH_EXPORTS) and not [s for s in sorted(bdecl) if not hasattr(L, s)]
 
 
 def test_struct_layout_matches_header(xmamd):
@@ -35,7 +40,7 @@ def test_struct_layout_matches_header(xmamd):
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = tuple(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
     assert sizes == tuple(ctypes.sizeof(t) for t in (xmamd.Problem, xmamd.Options, xmamd.Result, xmamd.Tuning, xmamd.Xm2Info))
-    assert xmamd.lib().xm_abi_revision() == 3
+    assert xmamd.lib().xm_abi_revision() == 4
 
 
 def test_block_balanced_partition(xmamd):
@@ -150,3 +155,18 @@ def test_layout_helpers(xmamd):
     rm = xmamd.to_rm(M4)
     assert rm.shape == (6, 5) and np.all(rm[:, 4] == 0) and np.array_equal(xmamd.from_rm(rm, 6, 4), M4)
     assert xmamd.dense_ld(149) == 512 and xmamd.dense_ld(1778) == 5376
+
+
+def test_no_kernel_is_selected_through_the_environment():
+    """xm_tuning_t is the only way to select a kernel or a layout: the sources read ten environment variables, all of them deployment
+    switches of the file surface (which has no tuning argument) or of the process-level communicator set-up -- the list in
+    include/xm_amd.h and INTEGRATION.md"""
+    import glob
+    allowed = {"XM_QUIET", "XM_GPUS", "XM_GPU_MAP", "XM_RETRACTION", "XM_WATCHDOG_S", "XM_COMM_PEER", "XM_COMM_TRACE", "XM_FORCE_COMM",
+               "XM_SHM_TIMEOUT", "XM_SHM_ASYNC"}
+    read = set()
+    for f in glob.glob(os.path.join(ROOT, "xm-code_amd", "csrc", "*")):
+        read |= set(re.findall(r'getenv\("(XM_[A-Z0-9_]+)"\)', open(f).read()))
+    assert read <= allowed, sorted(read - allowed)
+    hdr = open(os.path.join(ROOT, "include", "xm_amd.h")).read()
+    assert all(v in hdr for v in read)

@@ -33,9 +33,8 @@ def _weighted_vg(n, deg, seed, sigma=0.3):
 # ---------------------------------------------------------------------------------------------- view-graph codec
 @pytest.mark.parametrize("n,deg,o,slabs,lmax", [(1, 2, 3, 4, 64), (7, 3, 3, 8, 64), (200, 8, 3, 4, 64), (300, 20, 5, 2, 64), (1000, 12, 4, 8, 5),
                                                 (150, 40, 3, 1, 64), (211, 9, 1, 4, 64), (4000, 30, 3, 4, 64)])
-@pytest.mark.parametrize("gather", [0, 1, 2, 3, 4])    # o = 3 only (other ranks take mode 1): 2 sector windows through LDS-DMA, 3 aligned
-@pytest.mark.parametrize("layout", [1, 2])             # 8-byte element fetch, 4 sector windows into registers (codec + layout 1)
-def test_qw_sell_quaternion_codec_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather, layout):
+@pytest.mark.parametrize("gather", [0, 1])
+def test_qw_sell_quaternion_codec_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather):
     """the sliced-ELL product streaming 36 bytes per stored block (quaternion of the relative rotation scaled by sqrt(2w) + column index,
     diagonal blocks as one double per camera) equals the dense product of the same Q to 1e-12 (blocks are rebuilt in registers, so the
     difference to the 9-double storage is the codec's 1e-15 round trip); every slab count, both gather modes, cut rows, odd widths"""
@@ -45,29 +44,28 @@ def test_qw_sell_quaternion_codec_matches_dense(xmamd, oracle, n, deg, o, slabs,
     Q = tl.bsr_to_dense(n, P["rowptr"], P["colidx"], P["blocks"])
     W = np.random.default_rng(n).standard_normal((3 * n, o))
     ref = oracle.qw(Q, W, 1.5)
-    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=1, layout=layout)
+    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=1)
     got = M.qw(W, 1.5, gather=gather)
-    padded = M.qw(W, 1.5, gather=gather, padded=True) if (layout == 1 and o >= 3) else got   # input also at the 128-byte record pitch
+    padded = M.qw(W, 1.5, gather=gather, padded=True) if o >= 3 else got   # input also at the 128-byte record pitch
     M.close()
     assert tl.rel_fro(got, ref) < 1e-12 and tl.rel_fro(padded, ref) < 1e-12
-    Mf = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=0, layout=layout)     # general blocks: unchanged bar
+    Mf = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=slabs, lmax=lmax, codec=0)     # general blocks: unchanged bar
     assert tl.rel_fro(Mf.qw(W, 1.5, gather=gather), ref) < 1e-13
     Mf.close()
 
 
-def test_round3_paths_are_bit_reproducible(xmamd, monkeypatch):
+def test_round3_paths_are_bit_reproducible(xmamd):
     """fixed summation orders in the round-3 kernels too: the sliced-ELL product with the view-graph codec (blocks rebuilt in registers,
     partial results added in list order, diagonal term by a fixed lane), a whole solve on view-graph storage, and a whole solve on two
     virtual devices (peer exchange: whoever publishes first, the sums are added rank by rank) give the same bits on every run"""
     P = _weighted_vg(3000, 16, seed=4)
     W = np.random.default_rng(2).standard_normal((9000, 3))
-    for layout in (1, 2):      # layout 2: whichever slice arrives last for a chunk, the tiles are added in tile order
-        M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=4, codec=1, layout=layout)
-        for gm in (1, 2):
-            a = M.qw(W, 1.0, gather=gm)
-            for _ in range(3):
-                assert np.array_equal(M.qw(W, 1.0, gather=gm), a)
-        M.close()
+    M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=4, codec=1)
+    for gm in (0, 1):
+        a = M.qw(W, 1.0, gather=gm)
+        for _ in range(3):
+            assert np.array_equal(M.qw(W, 1.0, gather=gm), a)
+    M.close()
     V = tl.gen_vg(3000, deg=16, sigma=0.2, seed=4, dense=False)      # unit weights, lam at their scale: certifies at rank 3
     e = V["edges"]
     runs = []
@@ -270,8 +268,8 @@ def test_column_split_strip_product_matches_oracle(xmamd, oracle, nloc, n, o, ks
         assert np.array_equal(again, got)
 
 
-def test_split_k_solve_equals_plain_solve(xmamd, monkeypatch):
-    """the whole solver through the column-split product (forced on one GPU with XM_SPLIT_K; on its own it switches on for the small
+def test_split_k_solve_equals_plain_solve(xmamd):
+    """the whole solver through the column-split product (forced on one GPU with xm_tuning_t.split_k; on its own it switches on for the small
     strips of a multi-GPU run): gradient / Hessian / certificate epilogues run by the finishing slice -- same certified optimum"""
     P = tl.gen_vg(301, deg=10, sigma=0.2, seed=5)
     R0, s0, i0 = xmamd.solve_dense(P["Q"], 5, 1e-9, 10.0)
@@ -291,9 +289,9 @@ def _team_worker_code():
         import numpy as np, xmamd, xm_testlib as tl
         mode, world, out, case = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
         rank = 0
-        kw = {{}}
+        kw = dict(tuning=tl.env_tuning())           # xm_tuning_t fields of this case (XMT_TUNING: a variable of the tests, not of the library)
         if mode == "team":
-            kw = dict(n_gpus=world, gpu_map=1)
+            kw.update(n_gpus=world, gpu_map=1)
         elif mode.startswith("shm"):
             rank = int(mode[3:])
             xmamd._chk(xmamd.lib().xm_comm_init_shm(rank, world, 0, sys.argv[5].encode(), 64 << 20))
@@ -314,7 +312,7 @@ def _team_worker_code():
         elif case == "bsr" or case == "sell":
             P = tl.gen_vg(301, deg=10, sigma=0.1, seed=5)
             ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), **kw); args = (5, 1e-10, 10.0)
-        elif case == "dense_sym":                                 # symmetric window product of the row partition (XM_SYM=1 in the environment), rank escalation
+        elif case == "dense_sym":                                 # symmetric window product of the row partition (tuning sym = 1), rank escalation
             P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
             ctx = xmamd.Context(Q=P["Q"], **kw); args = (6, 1e-9, 3.0)
         elif case == "rome_dense":                                # BASELINE config 5 in the reference's dense storage: 13.5 GB, every rank expands its rows
@@ -370,12 +368,12 @@ def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, 
     virtual devices on the one GPU of the test box: own stream each, peer pointers are plain pointers).  Must reproduce the
     `world`-process run over the shared-memory transport BIT FOR BIT (same partition, same arithmetic, same summation orders) --
     R, s and the whole (loss, |g|, inner count, exit reason) trace -- with the fused exchange (2; payload through write-through
-    stores, and in its release-fence form XM_EXCHANGE_LITE=0) and with the un-fused peer all-gather between the launches
-    (XM_EXCHANGE=1)."""
+    stores, and in its release-fence form xm_tuning_t.exchange_fence) and with the un-fused peer all-gather between the launches
+    (xm_tuning_t.exchange = 1)."""
     code = _team_worker_code()
     env = dict(os.environ, XM_SHM_TIMEOUT="60", GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="60")
-    if case in ("sell", "sell_esc"):
-        env["XM_BSR_SELL"] = "1"
+    tn = dict(sell=1) if case in ("sell", "sell_esc") else {}
+    env["XMT_TUNING"] = json.dumps(tn)
     name = "/xm_t3_" + uuid.uuid4().hex[:12]
     outs = [str(tmp_path / f"shm{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, "-c", code, f"shm{r}", str(world), outs[r], case, name], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -387,11 +385,11 @@ def test_single_process_multi_gpu_equals_the_multi_process_run(xmamd, tmp_path, 
         assert p.returncode == 0
     ref = np.load(outs[0])
     # fused exchange (write-through payload stores), un-fused peer all-gather, fused exchange in its release-fence form
-    for k, (ex, extra) in enumerate((("2", {}), ("1", {}), ("2", {"XM_EXCHANGE_LITE": "0"}))):
+    for k, (ex, extra) in enumerate(((2, {}), (1, {}), (2, {"exchange_fence": 1}))):
         out = str(tmp_path / f"team{k}.npz")
-        _run(code, ["team", world, out, case], dict(env, XM_EXCHANGE=ex, **extra))
+        _run(code, ["team", world, out, case], dict(env, XMT_TUNING=json.dumps(dict(tn, exchange=ex, **extra))))
         t = np.load(out)
-        assert int(t["n_gpus"]) == world and int(t["exchange"]) == (2 if ex == "2" else 1)
+        assert int(t["n_gpus"]) == world and int(t["exchange"]) == (2 if ex == 2 else 1)
         assert int(t["rank"]) == int(ref["rank"]) and int(t["status"]) == int(ref["status"]) == 1 and int(t["tcg"]) == int(ref["tcg"])
         assert np.array_equal(t["trace"], ref["trace"])
         assert np.array_equal(t["R"], ref["R"]) and np.array_equal(t["s"], ref["s"])
@@ -406,7 +404,7 @@ def test_one_process_per_gpu_over_ipc_handles_equals_the_single_process_team(xma
     code = _team_worker_code()
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="60")
     if case == "sell_esc":
-        env["XM_BSR_SELL"] = "1"
+        env["XMT_TUNING"] = '{"sell": 1}'
     ref_out = str(tmp_path / "team.npz")
     _run(code, ["team", world, ref_out, case], env)
     ref = np.load(ref_out)
@@ -440,7 +438,7 @@ def test_eight_virtual_gpus(xmamd, tmp_path, case):
     code = _team_worker_code()
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_SDMA="0", XM_WATCHDOG_S="60")
     if case == "vg":
-        env["XM_BSR_SELL"] = "1"
+        env["XMT_TUNING"] = '{"sell": 1}'
     one, eight = str(tmp_path / "one.npz"), str(tmp_path / "eight.npz")
     _run(code, ["single", 1, one, case], env)
     _run(code, ["team", 8, eight, case], env)
@@ -456,13 +454,13 @@ def test_eight_virtual_gpus(xmamd, tmp_path, case):
 
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_symmetric_window_product_under_the_row_partition(xmamd, tmp_path, world):
-    """Dense symmetric Q on `world` ranks through the cyclic half window (xm_symw.h; forced on a test-sized problem with XM_SYM=1): every
+    """Dense symmetric Q on `world` ranks through the cyclic half window (xm_symw.h; forced on a test-sized problem with tuning sym = 1): every
     rank streams about half of its row strip, the ranks all-gather their column sums between the two launches of a product.  The
     single-process team must reproduce the `world`-process run over the shared-memory transport BIT FOR BIT (same partition, same
     arithmetic, fixed summation orders) and both the single-GPU optimum (rank escalation included: o = 4, 5, 6 fall back to the general
     kernel above sym_max_o)."""
     code = _team_worker_code()
-    env = dict(os.environ, XM_SHM_TIMEOUT="60", GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="60", XM_SYM="1")
+    env = dict(os.environ, XM_SHM_TIMEOUT="60", GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="60", XMT_TUNING='{"sym": 1}')
     name = "/xm_t4s_" + uuid.uuid4().hex[:12]
     outs = [str(tmp_path / f"shm{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, "-c", code, f"shm{r}", str(world), outs[r], "dense_sym", name], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -471,7 +469,7 @@ def test_symmetric_window_product_under_the_row_partition(xmamd, tmp_path, world
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
     team, one = str(tmp_path / "team.npz"), str(tmp_path / "one.npz")
     _run(code, ["team", world, team, "dense_sym"], env)
-    _run(code, ["single", 1, one, "dense"], dict(env, XM_SYM="0"))
+    _run(code, ["single", 1, one, "dense"], dict(env, XMT_TUNING='{"sym": -1}'))
     t, a = np.load(team), np.load(one)
     for o_ in outs:
         b = np.load(o_)
@@ -537,13 +535,33 @@ def test_multi_rank_baseline_sizes_vs_recorded_oracle(xmamd, tmp_path, case, wor
     assert 0.5 * c["tcg"] <= int(t["tcg"]) <= 2.0 * c["tcg"]
 
 
+def test_multi_rank_symmetric_window_is_automatic_only_for_an_exactly_symmetric_matrix(xmamd):
+    """the policy of one GPU (half-traffic kernel by itself only when Q == Q^T exactly; 1e-9 accepted under sym = 1) holds under the row
+    partition too, where no rank sees an entry and its mirror image: the strips' order-independent checksums modulo 2^64 are
+    all-gathered (launch_symhash).  One entry moved by 1e-13 of the largest one -- far inside the 1e-9 of the random-vector probe --
+    keeps the general kernel in automatic mode and is accepted when forced."""
+    P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
+    Q = P["Q"]
+    assert np.array_equal(Q, Q.T)
+    Qp = Q.copy(); Qp[5, 70] += 1e-13 * np.abs(Q).max()
+
+    def picked(Qx, sym):
+        ctx = xmamd.Context(Q=Qx, n_gpus=2, gpu_map=1, tuning=dict(sym=sym, sym_min_rows=1))
+        k = ctx.product_kind(3)
+        _, _, info = ctx.solve(3, 1e-1, 3.0, max_time=0.0, mode=xmamd.MODE_RANK3)
+        ctx.close()
+        assert (k == "dense_sym") == bool(info["sym_product"])
+        return int(info["sym_product"])
+    assert picked(Q, 0) == 1 and picked(Qp, 0) == 0 and picked(Qp, 1) == 1 and picked(Q, -1) == 0
+
+
 def test_single_process_multi_gpu_viewgraph_hubs_and_xm2(xmamd, tmp_path):
     """view-graph storage on 2 and 3 virtual devices with HUB cameras (3 cameras see 30 % of the others): the partition is balanced
     by stored blocks, so the ranges are unequal and every replicated vector is addressed through the padded numbering; the
     quaternion-compressed sliced ELL is forced on.  The certified optimum equals the single-GPU one, and so does the XM^2 round
     (residuals, re-weighting, warm re-solve) that fans out to the ranks."""
     code = _team_worker_code()
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", XM_BSR_SELL="1", XM_WATCHDOG_S="60")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", XMT_TUNING='{"sell": 1}', XM_WATCHDOG_S="60")
     one = str(tmp_path / "one.npz")
     _run(code, ["single", 1, one, "vg"], env)
     a = np.load(one)
@@ -593,14 +611,14 @@ def test_file_surface_on_two_virtual_gpus(xmamd, tmp_path):
 
 def test_a_dead_peer_becomes_an_error_not_a_hang(xmamd, tmp_path):
     """every device-side wait of the peer exchange is bounded: with the group's spin limit at 2 s (a third of the host watchdog) and one
-    rank made to skip its push (XM_DEBUG_PEER_MUTE=1) the solve must come back with XM_ERR_COMM, promptly, and the GPU must still work
+    rank made to skip its push (xm_tuning_t.debug_peer_mute) the solve must come back with XM_ERR_COMM, promptly, and the GPU must still work
     afterwards"""
     code = textwrap.dedent(f"""
         import sys, os, time
         sys.path.insert(0, {os.path.join(ROOT, 'xm-code_amd')!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
         import numpy as np, xmamd, xm_testlib as tl
         P = tl.gen_vg(41, deg=3, sigma=1.5, seed=40)
-        ctx = xmamd.Context(Q=P["Q"], n_gpus=2, gpu_map=1)
+        ctx = xmamd.Context(Q=P["Q"], n_gpus=2, gpu_map=1, tuning=dict(debug_peer_mute=1))
         t0 = time.time()
         try:
             ctx.solve(6, 1e-9, 3.0)
@@ -611,7 +629,7 @@ def test_a_dead_peer_becomes_an_error_not_a_hang(xmamd, tmp_path):
         R, s, info = xmamd.solve_dense(P["Q"], 6, 1e-9, 3.0)
         print("AFTER", info["status"])
     """)
-    out = _run(code, [], dict(os.environ, GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="6", XM_DEBUG_PEER_MUTE="1"), timeout=300)
+    out = _run(code, [], dict(os.environ, GPU_MAX_HW_QUEUES="16", XM_WATCHDOG_S="6"), timeout=300)
     err = [l for l in out.splitlines() if l.startswith("ERR")]
     assert err and "-4" in err[0] and float(err[0].split()[1]) < 60.0, out[-800:]
     assert "AFTER 1" in out

@@ -106,143 +106,6 @@ def test_sell_layout_rejects_malformed_input(xmamd):
         xmamd.sell_layout(np.array([0, 1, 2]), np.array([0, 1], dtype=np.int32), slabs=3)  # slabs must divide 8
 
 
-# ---------------------------------------------------------------------------------------------------------------------------------
-# chunk-tiled layout (xm-code_amd/csrc/xm_sell2.hip:sell2_build_host): the numpy restatement below walks the description exactly as
-# sell2_fill_kernel / qw_sell2_kernel do (column word with the row and row-end bits, one accumulator per lane, first run kept aside,
-# row slots, the per-row assembly from lane_meta, tiles added in tile order by the chunk's last arrival)
-# ---------------------------------------------------------------------------------------------------------------------------------
-def _emulate2(L, colidx, blocks, W, o, n):
-    nst = L["nsteps"]
-    cols = np.zeros(max(nst, 1) * 64, dtype=np.int64)
-    blk = np.zeros(max(nst, 1) * 576)
-    B9 = blocks.reshape(-1, 9)
-    for g in range(nst):                                   # sell2_fill_kernel
-        kd = int(L["kind"][g])
-        for lane in range(64):
-            sw = int(L["src"][g * 64 + lane])
-            pad = sw < 0
-            s = sw & ((1 << 48) - 1)
-            fl = 0 if pad else (sw >> 48) & 127
-            c = (0 if pad else int(colidx[s])) | ((fl & 63) << 24) | ((fl >> 6) << 31)
-            q = np.zeros(9) if pad else B9[s]
-            if kd == 2:
-                cols[g * 64 + lane] = c
-                blk[g * 576 + np.arange(9) * 64 + lane] = q
-            else:
-                gb = g - kd
-                cols[gb * 64 + lane * 2 + kd] = c
-                blk[gb * 576 + np.arange(9) * 128 + lane * 2 + kd] = q
-    Wc = W.reshape(-1, 3, o)
-    tiles = np.full((max(L["ntiles"], 1), 64, 3, o), np.nan)
-    for c in range(L["nslices"]):                          # qw_sell2_kernel, first half: wave = slice
-        off = int(L["slice_off"][c]); w = int(L["slice_off"][c + 1]) - off
-        npair, tail = w >> 1, w & 1
-        RA = np.zeros((64, 3, o)); A = np.zeros((64, 3, o))
-        for lane in range(64):
-            acc = np.zeros((3, o)); first = True
-            words = []
-            for p in range(npair):
-                for h in range(2):
-                    words.append((cols[off * 64 + p * 128 + 2 * lane + h], blk[off * 576 + p * 1152 + np.arange(9) * 128 + 2 * lane + h]))
-            if tail:
-                words.append((cols[off * 64 + npair * 128 + lane], blk[off * 576 + npair * 1152 + np.arange(9) * 64 + lane]))
-            for jw, q in words:
-                jw = int(jw)
-                acc += q.reshape(3, 3) @ Wc[jw & 0xffffff]
-                if jw >> 31:                               # the row ends after this block
-                    if first:
-                        A[lane] = acc; first = False
-                    else:
-                        RA[(jw >> 24) & 63] = acc
-                    acc = np.zeros((3, o))
-            meta = int(L["lane_meta"][c * 64 + lane])
-            if first:
-                A[lane] = acc
-            elif meta & (1 << 13):
-                RA[(meta >> 14) & 63] = acc
-            else:
-                assert not acc.any()                       # nothing may be left behind
-        tot = RA.copy()
-        for lane in range(64):
-            meta = int(L["lane_meta"][c * 64 + lane])
-            la, nA = meta & 63, (meta >> 6) & 127
-            for j in range(nA):
-                tot[lane] += A[la + j]
-        t = int(L["slice_tile"][c])
-        assert np.isnan(tiles[t]).all()                    # a tile is written exactly once
-        tiles[t] = tot
-    out = np.zeros((n, 3, o))
-    for k in range(L["nchunks"]):                          # second half: the last arrival adds the chunk's tiles in tile order
-        t0, t1 = int(L["tile_ptr"][k]), int(L["tile_ptr"][k + 1])
-        assert t1 > t0
-        s = np.zeros((64, 3, o))
-        for t in range(t0, t1):
-            assert not np.isnan(tiles[t]).any()
-            s += tiles[t]
-        hi = min(n, (k + 1) * 64)
-        out[k * 64:hi] = s[: hi - k * 64]
-        assert not s[hi - k * 64:].any()
-    return out.reshape(3 * n, o)
-
-
-@pytest.mark.parametrize("n,deg,slabs,kmax,o", [(1, 2, 1, 32, 3), (7, 3, 4, 32, 3), (150, 9, 8, 32, 3), (300, 30, 4, 2, 4), (200, 12, 2, 1, 5),
-                                                 (97, 20, 1, 32, 1), (130, 60, 4, 32, 3)])
-def test_sell2_layout_reproduces_bsr_product(xmamd, n, deg, slabs, kmax, o):
-    P = tl.gen_vg(n, deg=deg, sigma=0.3, seed=n + o, dense=True)
-    L = xmamd.sell2_layout(P["rowptr"], P["colidx"], slabs=slabs, kmax=kmax)
-    W = np.random.default_rng(n).standard_normal((3 * n, o))
-    got = _emulate2(L, P["colidx"], P["blocks"], W, o, n)
-    assert tl.rel_fro(got, P["Q"] @ W) < 1e-13
-    used = L["src"][L["src"] >= 0] & ((1 << 48) - 1)
-    assert used.size == P["colidx"].size and np.unique(used).size == used.size          # every block exactly once
-    assert L["slab_start"][0] == 0 and L["slab_start"][-1] == L["nslices"] and L["nchunks"] == (n + 63) // 64
-    wd = np.diff(L["slice_off"])
-    assert wd.max() <= kmax and L["tile_ptr"][-1] == L["ntiles"] == L["nslices"]
-    for s in range(slabs):                                                               # slab rule + slices of a slab in chunk order
-        ch = L["slice_chunk"][L["slab_start"][s]:L["slab_start"][s + 1]]
-        assert np.all(np.diff(ch) >= 0)
-        for c in range(L["slab_start"][s], L["slab_start"][s + 1]):
-            src = L["src"][L["slice_off"][c] * 64:L["slice_off"][c + 1] * 64]
-            real = src[src >= 0]
-            cols = P["colidx"][real & ((1 << 48) - 1)]
-            assert np.all(cols.astype(np.int64) * slabs // n == s)
-            rows = (real >> 48) & 63                                                     # row bits name the block's camera inside the chunk
-            assert np.all(np.searchsorted(P["rowptr"], real & ((1 << 48) - 1), side="right") - 1 == L["slice_chunk"][c] * 64 + rows)
-            assert src.size - real.size < 64                                             # padding: less than one step
-
-
-def test_sell2_layout_unsorted_rows_hub_and_empty_rows(xmamd):
-    """rows given in arbitrary column order, a hub camera (its chunk is cut into several slices), cameras and a whole chunk without any block"""
-    rng = np.random.default_rng(5)
-    n = 260
-    rows = [rng.choice(n, size=k, replace=False) for k in rng.integers(0, 7, size=n)]
-    rows[17] = rng.permutation(n)                                    # hub: sees everybody
-    rows[3] = np.array([], dtype=int); rows[n - 1] = np.array([], dtype=int)
-    for r in range(128, 192):
-        rows[r] = np.array([], dtype=int)                             # chunk 2 is empty: it still has to run its epilogue
-    rowptr = np.zeros(n + 1, dtype=np.int64); rowptr[1:] = np.cumsum([len(r) for r in rows])
-    colidx = np.concatenate(rows).astype(np.int32)
-    blocks = rng.standard_normal((colidx.size, 3, 3))
-    L = xmamd.sell2_layout(rowptr, colidx, slabs=4, kmax=1)
-    W = rng.standard_normal((3 * n, 3))
-    ref = tl.bsr_to_dense(n, rowptr, colidx, blocks) @ W
-    assert tl.rel_fro(_emulate2(L, colidx, blocks, W, 3, n), ref) < 1e-13
-    nt = np.diff(L["tile_ptr"])
-    assert nt[2] == 1 and nt[0] > 4 and np.all(nt >= 1)              # the empty chunk has its one (empty) slice, the hub's chunk several per slab
-    assert np.diff(L["slice_off"]).max() <= 1
-
-
-def test_sell2_layout_rejects_malformed_input(xmamd):
-    with pytest.raises(xmamd.XmError):
-        xmamd.sell2_layout(np.array([0, 2, 1]), np.array([0, 1], dtype=np.int32))
-    with pytest.raises(xmamd.XmError):
-        xmamd.sell2_layout(np.array([0, 1, 2]), np.array([0, 5], dtype=np.int32))
-    with pytest.raises(xmamd.XmError):
-        xmamd.sell2_layout(np.array([0, 1, 2]), np.array([0, 1], dtype=np.int32), slabs=3)
-    with pytest.raises(xmamd.XmError):
-        xmamd.sell2_layout(np.array([0, 1, 2]), np.array([0, 1], dtype=np.int32), ncols=1 << 24)   # 24-bit column field
-
-
 def test_column_locality_decides_the_padded_copy(xmamd):
     """xm_tuning_t.sell_wpad = 0 (auto): the copy of W at the 128-byte record pitch is used when the lanes of a step touch fewer lines
     with it than at the native pitch -- a random view graph (1.4 / 1.9 lines per 72- / 120-byte record against 1) yes, a banded graph

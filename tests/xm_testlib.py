@@ -496,3 +496,11 @@ def schur_residuals_numpy(cam, lm, p, w, U):
     xc = np.zeros((N, o)); xc[1:] = np.linalg.solve(VT, r[1:])
     xl = h.copy(); tmp = np.zeros((M, o)); np.add.at(tmp, lm, w[:, None] * xc[cam]); xl += tmp * q3i[:, None]
     return np.sum((pu - xc[cam] + xl[lm]) ** 2, axis=1)
+
+
+def env_tuning():
+    """xm_tuning_t fields for a worker process of a test, handed over as JSON in XMT_TUNING (a variable of the TESTS: the library itself
+    selects no kernel or layout through the environment) -> dict for xmamd.Context(tuning=...), or None"""
+    import json as _json
+    t = os.environ.get("XMT_TUNING")
+    return _json.loads(t) if t else None

@@ -1,0 +1,199 @@
+// xm_bench.hip -- timing hooks of the micro-benchmarks (include/xm_bench.h; scripts/kbench_*.py).  Not part of the product ABI
+// (include/xm_amd.h does not declare them): HIP-event timings of single kernels through the same launchers the solver uses.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/xm_bench.h"
+#include "xm_schur.h"
+#include "xm_sell.h"
+#include "xm_symw.h"
+#include "xm_solver.h"
+
+namespace {
+thread_local std::string g_berr;
+int bfail(const xm::Error &e) { g_berr = e.what(); return e.code; }
+int bfail(const std::exception &e) { g_berr = e.what(); return XM_ERR_HIP; }
+#define XM_TRY try {
+#define XM_CATCH                                                       \
+    }                                                                  \
+    catch (const xm::Error &e) { return bfail(e); }                    \
+    catch (const std::exception &e) { return bfail(e); }
+void require_device() {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1) throw xm::Error(XM_ERR_HIP, "no HIP device available");
+}
+xm::CamArgs plain_args(int64_t n, double *out) {
+    xm::CamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.nloc = (int)n;
+    a.out = out;
+    return a;
+}
+// average milliseconds of `reps` back-to-back calls of f() on the NULL stream after `warm` untimed ones
+template <class F>
+double time_launches(int warm, int reps, F f) {
+    hipEvent_t e0, e1;
+    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < warm; ++i) f();
+    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) f();
+    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+    XM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return (double)ms / std::max(reps, 1);
+}
+}  // namespace
+
+extern "C" {
+const char *xm_bench_last_error(void) { return g_berr.c_str(); }
+
+int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
+    XM_TRY
+    const xm::CamArgs a = plain_args(n, dOut);
+    const int64_t ld = xm::dense_ld(n);
+    const double ms = time_launches(3, reps, [&] { xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr); });
+    if (ms_avg) *ms_avg = ms;
+    return XM_OK;
+    XM_CATCH
+}
+int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
+    XM_TRY
+    const int64_t ld = xm::dense_ld(n);
+    xm::DevBuf<double> prow, pcol;
+    prow.alloc(xm::sym_prow_count((int)n, ld, o));
+    pcol.alloc(xm::sym_pcol_count((int)n, ld, o), false);
+    const xm::CamArgs a = plain_args(n, dOut);
+    const double ms = time_launches(3, reps, [&] { xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, prow.p, pcol.p, nullptr); });
+    if (ms_avg) *ms_avg = ms;
+    return XM_OK;
+    XM_CATCH
+}
+int xm_qw_dense_strip_time(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
+    XM_TRY
+    if (nloc < 1 || nloc > n) throw xm::Error(XM_ERR_ARG, "bad strip");
+    const xm::CamArgs a = plain_args(nloc, dOut);
+    const int64_t ld = xm::dense_ld(n);
+    const double ms = time_launches(3, reps, [&] { xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr); });
+    if (ms_avg) *ms_avg = ms;
+    return XM_OK;
+    XM_CATCH
+}
+int xm_qw_dense_strip_ks(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, double alpha, int ks, int reps,
+                         double *ms_avg, int *ks_used) {
+    XM_TRY
+    if (nloc < 1 || nloc > n || ks < 0 || ks > 8) throw xm::Error(XM_ERR_ARG, "bad argument");
+    const int64_t ld = xm::dense_ld(n);
+    if (ks == 0) ks = xm::qw_dense_split_k((int)nloc, ld);
+    if (ks_used) *ks_used = ks;
+    xm::CamArgs a = plain_args(nloc, dOut);
+    xm::DevBuf<double> ksum;
+    xm::DevBuf<unsigned int> kcount;
+    if (ks > 1) {
+        ksum.alloc((size_t)ks * nloc * 3 * xm::pitch_of(o));
+        kcount.alloc((size_t)xm::qw_grid((int)nloc));
+        a.ks = ks; a.ksum = ksum.p; a.kcount = kcount.p;
+    }
+    xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, alpha, a, nullptr);
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    if (reps > 0) {
+        const double ms = time_launches(0, reps, [&] { xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, alpha, a, nullptr); });
+        if (ms_avg) *ms_avg = ms;
+    }
+    return XM_OK;
+    XM_CATCH
+}
+int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int64_t n, int o, const double *dW, double *dOut, int reps,
+                    double *ms_avg) {
+    XM_TRY
+    const xm::CamArgs a = plain_args(n, dOut);
+    const double ms = time_launches(3, reps, [&] { xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr); });
+    if (ms_avg) *ms_avg = ms;
+    return XM_OK;
+    XM_CATCH
+}
+// handle: what xm_sell_create / xm_sell_create2 returned; dWpad16 may be NULL (include/xm_amd.h: xm_qw_sell_padded)
+int xm_qw_sell_time(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, int gather_mode, int reps, double *ms_avg) {
+    XM_TRY
+    if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
+    if (gather_mode != 0 && gather_mode != 1) throw xm::Error(XM_ERR_ARG, "gather_mode must be 0 or 1");
+    xm::SellMatrix &m = *static_cast<xm::SellMatrix *>(handle);
+    const xm::CamArgs a = plain_args(m.nloc(), dOut);
+    const double ms = time_launches(3, reps, [&] { xm::launch_qw_sell(o, xm::EPI_PLAIN, m, dW, 1.0, a, gather_mode, nullptr, dWpad16); });
+    if (ms_avg) *ms_avg = ms;
+    return XM_OK;
+    XM_CATCH
+}
+// variant: 0 thread per camera (MGS-QR) | 1 polar | 2 MGS-QR with a quad of lanes per camera; *ms_avg (may be NULL: one untimed call) = HIP-event average
+int xm_retract_variant(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t, double *dRout,
+                       double *dsout, int variant, int reps, double *ms_avg) {
+    XM_TRY
+    if (variant < 0 || variant > 2 || reps < 1) throw xm::Error(XM_ERR_ARG, "bad argument");
+    xm::launch_retract(o, (int)n, 0, dR, ds, dD, dds, t, dRout, dsout, nullptr, nullptr, variant);
+    if (!ms_avg) { XM_HIP_CHECK(hipDeviceSynchronize()); return XM_OK; }
+    *ms_avg = time_launches(0, reps, [&] { xm::launch_retract(o, (int)n, 0, dR, ds, dD, dds, t, dRout, dsout, nullptr, nullptr, variant); });
+    return XM_OK;
+    XM_CATCH
+}
+// xm_recover_rotations with the projection kernel chosen -- variant 0: one thread per camera (the default), 1: one wavefront per camera with
+// cross-lane reductions (north_star's form) -- and that launch timed over `reps` repetitions
+int xm_recover_rotations_variant(int64_t n, int r, const double *R, const double *s, double *rot, double *scale, int *n_negative_det, int variant,
+                                 int reps, double *ms_avg) {
+    XM_TRY
+    xm::recover_rotations(n, r, R, s, rot, scale, n_negative_det, variant, reps, ms_avg);
+    return XM_OK;
+    XM_CATCH
+}
+int xm_peer_allgather_bench(int world, int gpu_map, int64_t count, int reps, double *us_avg) {
+    XM_TRY
+    require_device();
+    if (us_avg) *us_avg = xm::peer_allgather_bench(world, gpu_map, count, reps);
+    return XM_OK;
+    XM_CATCH
+}
+// ONE rank's share of the multi-rank symmetric window product (xm_symw.h) on this GPU: rank `cam0 / nloc` of `world`, its row strip filled
+// with an arbitrary pattern (timing only).  ms[0] = sweep + column sums, ms[1] = per-camera sum + plain epilogue; bytes = what the sweep
+// streams.  The all-gather between the two is not part of it.
+int xm_qw_symw_time(int64_t ntot, int nloc, int cam0, int o, int world, int reps, double ms[2], int64_t *bytes) {
+    XM_TRY
+    require_device();
+    if (ntot < 2 || nloc < 2 || world < 1 || reps < 1 || !ms) throw xm::Error(XM_ERR_ARG, "bad argument");
+    if (cam0 < 0 || cam0 % nloc != 0 || cam0 / nloc >= world || (int64_t)nloc * world < ntot || !(o == 1 || (o >= 3 && o <= 5)))
+        throw xm::Error(XM_ERR_ARG, "xm_qw_symw_time: cam0 must be rank * nloc with rank < world, nloc * world >= ntot, o in 1, 3..5");
+    const int64_t ld = xm::dense_ld(ntot);
+    xm::SymwProduct sp(ntot, nloc, cam0, ld, nullptr);
+    sp.ensure(o, world);
+    xm::DevBuf<double> Q, W, out;
+    Q.alloc((size_t)3 * nloc * (size_t)ld, false);
+    W.alloc((size_t)ld * xm::pitch_of(o) + 16);
+    out.alloc((size_t)3 * nloc * xm::pitch_of(o));
+    XM_HIP_CHECK(hipMemset(Q.p, 0x3c, (size_t)3 * nloc * (size_t)ld * sizeof(double)));   // finite pattern
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    xm::CamArgs a = plain_args(nloc, out.p);
+    a.cam0 = cam0;
+    hipEvent_t e0, e1, e2;
+    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1)); XM_HIP_CHECK(hipEventCreate(&e2));
+    const int rank = cam0 / nloc;
+    for (int i = 0; i < 2; ++i) { sp.sweep(o, Q.p, W.p, nullptr, rank, nullptr); sp.reduce(o, xm::EPI_PLAIN, 1.0, a, world, nullptr); }
+    float t_sw = 0, t_rd = 0;
+    for (int i = 0; i < reps; ++i) {
+        XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+        sp.sweep(o, Q.p, W.p, nullptr, rank, nullptr);
+        XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+        sp.reduce(o, xm::EPI_PLAIN, 1.0, a, world, nullptr);
+        XM_HIP_CHECK(hipEventRecord(e2, nullptr));
+        XM_HIP_CHECK(hipEventSynchronize(e2));
+        float x = 0, y = 0;
+        XM_HIP_CHECK(hipEventElapsedTime(&x, e0, e1)); XM_HIP_CHECK(hipEventElapsedTime(&y, e1, e2));
+        t_sw += x; t_rd += y;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    ms[0] = t_sw / reps; ms[1] = t_rd / reps;
+    if (bytes) *bytes = sp.stream_bytes();
+    return XM_OK;
+    XM_CATCH
+}
+
+}  // extern "C"

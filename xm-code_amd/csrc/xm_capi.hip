@@ -8,7 +8,6 @@
 
 #include "xm_schur.h"
 #include "xm_sell.h"
-#include "xm_sell2.h"
 #include "xm_symw.h"
 #include "xm_solver.h"
 
@@ -193,7 +192,7 @@ int solve_path(const char *dataset_path, unsigned max_rank, double tol, double l
 extern "C" {
 
 const char *xm_last_error(void) { return g_err.c_str(); }
-const char *xm_version(void) { return "xm-amd 0.3 (gfx950)"; }
+const char *xm_version(void) { return "xm-amd 0.5 (gfx950)"; }
 int xm_abi_revision(void) { return XM_ABI_REVISION; }
 
 int xm_solve(const char *p, unsigned int max_rank, double tol, double lam, double max_time) {
@@ -328,7 +327,7 @@ int xm_dense_from_bsr3(const int64_t *rowptr, const int32_t *colidx, const doubl
     XM_CATCH
 }
 
-static xm::CamArgs plain_args(int64_t n, double *out) {
+xm::CamArgs plain_args(int64_t n, double *out) {
     xm::CamArgs a;
     std::memset(&a, 0, sizeof(a));
     a.nloc = (int)n;
@@ -349,27 +348,6 @@ int xm_qw_dense_sym(const double *dq, int64_t n, int o, const double *dW, double
     pcol.alloc(xm::sym_pcol_count((int)n, ld, o), false);
     xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, alpha, plain_args(n, dOut), prow.p, pcol.p, (hipStream_t)stream);
     XM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    return XM_OK;
-    XM_CATCH
-}
-int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
-    XM_TRY
-    const int64_t ld = xm::dense_ld(n);
-    xm::DevBuf<double> prow, pcol;
-    prow.alloc(xm::sym_prow_count((int)n, ld, o));
-    pcol.alloc(xm::sym_pcol_count((int)n, ld, o), false);
-    hipEvent_t e0, e1;
-    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
-    const xm::CamArgs a = plain_args(n, dOut);
-    for (int i = 0; i < 3; ++i) xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, prow.p, pcol.p, nullptr);
-    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < reps; ++i) xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, prow.p, pcol.p, nullptr);
-    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
-    XM_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (ms_avg) *ms_avg = (double)ms / reps;
     return XM_OK;
     XM_CATCH
 }
@@ -394,121 +372,7 @@ int xm_retract_polar(int64_t n, int o, const double *dR, const double *ds, const
     return XM_OK;
     XM_CATCH
 }
-// variant: 0 thread per camera (MGS-QR) | 1 polar | 2 MGS-QR with a quad of lanes per camera; *ms_avg (may be NULL: one untimed call) = HIP-event average
-int xm_retract_variant(int64_t n, int o, const double *dR, const double *ds, const double *dD, const double *dds, double t, double *dRout,
-                       double *dsout, int variant, int reps, double *ms_avg) {
-    XM_TRY
-    if (variant < 0 || variant > 2 || reps < 1) throw xm::Error(XM_ERR_ARG, "bad argument");
-    xm::launch_retract(o, (int)n, 0, dR, ds, dD, dds, t, dRout, dsout, nullptr, nullptr, variant);
-    if (!ms_avg) { XM_HIP_CHECK(hipDeviceSynchronize()); return XM_OK; }
-    hipEvent_t e0, e1;
-    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
-    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < reps; ++i) xm::launch_retract(o, (int)n, 0, dR, ds, dD, dds, t, dRout, dsout, nullptr, nullptr, variant);
-    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
-    XM_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *ms_avg = (double)ms / reps;
-    return XM_OK;
-    XM_CATCH
-}
-int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
-    XM_TRY
-    hipEvent_t e0, e1;
-    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
-    const xm::CamArgs a = plain_args(n, dOut);
-    const int64_t ld = xm::dense_ld(n);
-    for (int i = 0; i < 3; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr);
-    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < reps; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr);
-    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
-    XM_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (ms_avg) *ms_avg = (double)ms / reps;
-    return XM_OK;
-    XM_CATCH
-}
 
-int xm_qw_dense_strip_time(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
-    XM_TRY
-    if (nloc < 1 || nloc > n) throw xm::Error(XM_ERR_ARG, "bad strip");
-    hipEvent_t e0, e1;
-    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
-    const xm::CamArgs a = plain_args(nloc, dOut);
-    const int64_t ld = xm::dense_ld(n);
-    for (int i = 0; i < 3; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr);
-    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < reps; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr);
-    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
-    XM_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (ms_avg) *ms_avg = (double)ms / reps;
-    return XM_OK;
-    XM_CATCH
-}
-int xm_qw_dense_strip_ks(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, double alpha, int ks, int reps,
-                         double *ms_avg, int *ks_used) {
-    XM_TRY
-    if (nloc < 1 || nloc > n || ks < 0 || ks > 8) throw xm::Error(XM_ERR_ARG, "bad argument");
-    const int64_t ld = xm::dense_ld(n);
-    if (ks == 0) ks = xm::qw_dense_split_k((int)nloc, ld);
-    if (ks_used) *ks_used = ks;
-    xm::CamArgs a = plain_args(nloc, dOut);
-    xm::DevBuf<double> ksum;
-    xm::DevBuf<unsigned int> kcount;
-    if (ks > 1) {
-        ksum.alloc((size_t)ks * nloc * 3 * xm::pitch_of(o));
-        kcount.alloc((size_t)xm::qw_grid((int)nloc));
-        a.ks = ks; a.ksum = ksum.p; a.kcount = kcount.p;
-    }
-    xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, alpha, a, nullptr);
-    XM_HIP_CHECK(hipDeviceSynchronize());
-    if (reps > 0) {
-        hipEvent_t e0, e1;
-        XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
-        XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < reps; ++i) xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, alpha, a, nullptr);
-        XM_HIP_CHECK(hipEventRecord(e1, nullptr));
-        XM_HIP_CHECK(hipEventSynchronize(e1));
-        float ms = 0;
-        XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        if (ms_avg) *ms_avg = (double)ms / reps;
-    }
-    return XM_OK;
-    XM_CATCH
-}
-int xm_peer_allgather_bench(int world, int gpu_map, int64_t count, int reps, double *us_avg) {
-    XM_TRY
-    require_device();
-    if (us_avg) *us_avg = xm::peer_allgather_bench(world, gpu_map, count, reps);
-    return XM_OK;
-    XM_CATCH
-}
-int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int64_t n, int o, const double *dW, double *dOut, int reps,
-                    double *ms_avg) {
-    XM_TRY
-    hipEvent_t e0, e1;
-    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
-    const xm::CamArgs a = plain_args(n, dOut);
-    for (int i = 0; i < 3; ++i) xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr);
-    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < reps; ++i) xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr);
-    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
-    XM_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (ms_avg) *ms_avg = (double)ms / reps;
-    return XM_OK;
-    XM_CATCH
-}
 
 
 // inverse of a symmetric positive definite matrix on the device (xm_dense_la.hip; set-up step of the matrix-free storage)
@@ -578,6 +442,14 @@ int xm_ctx_transport(xm_ctx_t *ctx, int *kind, char *note, size_t note_cap) {
     XM_CATCH
 }
 
+int xm_ctx_product_kind(xm_ctx_t *ctx, int o, int *kind) {
+    XM_TRY
+    if (!ctx || (!ctx->impl && !ctx->team) || !kind) throw xm::Error(XM_ERR_ARG, "null argument");
+    *kind = ctx->team ? ctx->team->product_kind(o) : ctx->impl->product_kind(o);
+    return XM_OK;
+    XM_CATCH
+}
+
 // 1 when the tCG of the last solved rank kept its product input at the 128-byte record pitch as well (xm_tuning_t.sell_wpad); 0 otherwise / several GPUs
 int xm_ctx_sell_wpad(xm_ctx_t *ctx, int *on) {
     XM_TRY
@@ -587,56 +459,18 @@ int xm_ctx_sell_wpad(xm_ctx_t *ctx, int *on) {
     XM_CATCH
 }
 
-// host-only view of the chunk-tiled layout (xm_sell2.h) for the CPU tests; NULL arrays: only the sizes
-int xm_sell2_layout(const int64_t *rowptr, const int32_t *colidx, int64_t n, int64_t ncols, int slabs, int kmax, int64_t sizes[4],
-                    int64_t *slice_off, int32_t *slab_start, int32_t *slice_chunk, int32_t *slice_tile, int32_t *tile_ptr, uint8_t *kind,
-                    int64_t *src, int32_t *lane_meta) {
-    XM_TRY
-    xm::Sell2Host h;
-    xm::sell2_build_host(rowptr, colidx, n, ncols, slabs, kmax > 0 ? kmax : 32, h);   // host only: no device needed
-    if (sizes) { sizes[0] = h.nslices; sizes[1] = h.nsteps; sizes[2] = h.ntiles; sizes[3] = h.nchunks; }
-    if (slice_off) std::copy(h.slice_off.begin(), h.slice_off.end(), slice_off);
-    if (slab_start) std::copy(h.slab_start.begin(), h.slab_start.end(), slab_start);
-    if (slice_chunk) std::copy(h.slice_chunk.begin(), h.slice_chunk.end(), slice_chunk);
-    if (slice_tile) std::copy(h.slice_tile.begin(), h.slice_tile.end(), slice_tile);
-    if (tile_ptr) std::copy(h.tile_ptr.begin(), h.tile_ptr.end(), tile_ptr);
-    if (kind) std::copy(h.kind.begin(), h.kind.end(), kind);
-    if (src) std::copy(h.src.begin(), h.src.end(), src);
-    if (lane_meta) std::copy(h.lane_meta.begin(), h.lane_meta.end(), lane_meta);
-    return XM_OK;
-    XM_CATCH
-}
-namespace {
-struct SellHandle {   // what xm_sell_create* hands out: one of the two layouts
-    std::unique_ptr<xm::SellMatrix> v1;
-    std::unique_ptr<xm::Sell2Matrix> v2;
-    int64_t nloc() const { return v2 ? v2->nloc() : v1->nloc(); }
-};
-void sell_product(SellHandle &h, int o, const double *dW, double alpha, const xm::CamArgs &a, int gather_mode, hipStream_t st,
-                  const double *dWpad16 = nullptr) {
-    if (h.v2) xm::launch_qw_sell2(o, xm::EPI_PLAIN, *h.v2, dW, alpha, a, gather_mode, -1, st);
-    else xm::launch_qw_sell(o, xm::EPI_PLAIN, *h.v1, dW, alpha, a, gather_mode, st, dWpad16);
-}
-}  // namespace
-int xm_sell_create3(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
-                    int codec, int64_t row0, int layout, void **handle) {
+int xm_sell_create2(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
+                    int codec, int64_t row0, void **handle) {
     XM_TRY
     require_device();
-    if (!rowptr || !handle || n < 1 || row0 < 0 || (layout != 1 && layout != 2)) throw xm::Error(XM_ERR_ARG, "bad argument");
-    std::unique_ptr<SellHandle> h(new SellHandle());
-    if (layout == 2) h->v2.reset(new xm::Sell2Matrix(rowptr, colidx, blocks, n, ncols, slabs, lmax > 0 ? lmax : 32, nullptr, codec, row0));
-    else h->v1.reset(new xm::SellMatrix(rowptr, colidx, blocks, n, ncols, slabs, lmax > 0 ? lmax : 64, nullptr, codec, row0));
-    *handle = h.release();
+    if (!rowptr || !handle || n < 1 || row0 < 0) throw xm::Error(XM_ERR_ARG, "bad argument");
+    *handle = new xm::SellMatrix(rowptr, colidx, blocks, n, ncols, slabs, lmax > 0 ? lmax : 64, nullptr, codec, row0);
     return XM_OK;
     XM_CATCH
 }
 int xm_sell_create(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
                    void **handle) {
-    return xm_sell_create3(rowptr, colidx, blocks, n, ncols, slabs, lmax, 0, 0, 1, handle);
-}
-int xm_sell_create2(const int64_t *rowptr, const int32_t *colidx, const double *blocks, int64_t n, int64_t ncols, int slabs, int lmax,
-                    int codec, int64_t row0, void **handle) {
-    return xm_sell_create3(rowptr, colidx, blocks, n, ncols, slabs, lmax, codec, row0, 1, handle);
+    return xm_sell_create2(rowptr, colidx, blocks, n, ncols, slabs, lmax, 0, 0, handle);
 }
 int xm_sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt[9]) {
     XM_TRY
@@ -645,44 +479,18 @@ int xm_sell_quat_roundtrip(const double block[9], double quat[4], double rebuilt
     return XM_OK;
     XM_CATCH
 }
-void xm_sell_destroy(void *handle) { delete static_cast<SellHandle *>(handle); }
-int xm_qw_sell(void *handle, int o, const double *dW, double *dOut, double alpha, int gather_mode, void *stream) {
-    XM_TRY
-    if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
-    SellHandle &m = *static_cast<SellHandle *>(handle);
-    sell_product(m, o, dW, alpha, plain_args(m.nloc(), dOut), gather_mode, (hipStream_t)stream);
-    return XM_OK;
-    XM_CATCH
-}
+void xm_sell_destroy(void *handle) { delete static_cast<xm::SellMatrix *>(handle); }
 int xm_qw_sell_padded(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, double alpha, int gather_mode, void *stream) {
     XM_TRY
     if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
-    SellHandle &m = *static_cast<SellHandle *>(handle);
-    sell_product(m, o, dW, alpha, plain_args(m.nloc(), dOut), gather_mode, (hipStream_t)stream, dWpad16);
+    if (gather_mode != 0 && gather_mode != 1) throw xm::Error(XM_ERR_ARG, "gather_mode must be 0 or 1");
+    xm::SellMatrix &m = *static_cast<xm::SellMatrix *>(handle);
+    xm::launch_qw_sell(o, xm::EPI_PLAIN, m, dW, alpha, plain_args(m.nloc(), dOut), gather_mode, (hipStream_t)stream, dWpad16);
     return XM_OK;
     XM_CATCH
 }
-int xm_qw_sell_time(void *handle, int o, const double *dW, double *dOut, int gather_mode, int reps, double *ms_avg) {
-    return xm_qw_sell_time_padded(handle, o, dW, nullptr, dOut, gather_mode, reps, ms_avg);
-}
-int xm_qw_sell_time_padded(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, int gather_mode, int reps, double *ms_avg) {
-    XM_TRY
-    if (!handle) throw xm::Error(XM_ERR_ARG, "null handle");
-    SellHandle &m = *static_cast<SellHandle *>(handle);
-    hipEvent_t e0, e1;
-    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
-    const xm::CamArgs a = plain_args(m.nloc(), dOut);
-    for (int i = 0; i < 3; ++i) sell_product(m, o, dW, 1.0, a, gather_mode, nullptr, dWpad16);
-    XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < reps; ++i) sell_product(m, o, dW, 1.0, a, gather_mode, nullptr, dWpad16);
-    XM_HIP_CHECK(hipEventRecord(e1, nullptr));
-    XM_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (ms_avg) *ms_avg = (double)ms / reps;
-    return XM_OK;
-    XM_CATCH
+int xm_qw_sell(void *handle, int o, const double *dW, double *dOut, double alpha, int gather_mode, void *stream) {
+    return xm_qw_sell_padded(handle, o, dW, nullptr, dOut, alpha, gather_mode, stream);
 }
 
 // symmetric r x r eigen-decomposition (cyclic Jacobi), ascending; V columns = eigenvectors (col-major)
@@ -718,10 +526,12 @@ static void jacobi_eig(int r, std::vector<double> &A, std::vector<double> &V, st
     for (int i = 0; i < r; ++i) w[(size_t)i] = A[i + (size_t)i * r];
 }
 
-int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, double *rot, double *scale, int *n_negative_det) {
-    XM_TRY
+}  // extern "C"
+// variant: kernel form of the per-camera projection (launch_recover_project); reps > 0 and ms_avg: that launch timed with HIP events
+void xm::recover_rotations(int64_t n, int r, const double *R, const double *s, double *rot, double *scale, int *n_negative_det, int variant,
+                           int reps, double *ms_avg) {
     require_device();
-    if (n < 1 || r < 3 || r > 16 || !R || !s || !rot || !scale) throw xm::Error(XM_ERR_ARG, "bad argument");
+    if (n < 1 || r < 3 || r > 16 || !R || !s || !rot || !scale || variant < 0 || variant > 1) throw xm::Error(XM_ERR_ARG, "bad argument");
     const int64_t m = 3 * n;
     xm::DevBuf<double> dR, ds, dV, drot, dscale, dparts;
     xm::DevBuf<int> dneg;
@@ -749,13 +559,33 @@ int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, dou
         for (int c = 0; c < 3; ++c) for (int k = 0; k < r; ++k) V[k + (size_t)c * r] = Ev[k + (size_t)idx[(size_t)c] * r];
     }
     XM_HIP_CHECK(hipMemcpy(dV.p, V.data(), V.size() * sizeof(double), hipMemcpyHostToDevice));
-    xm::launch_recover_project(n, r, dR.p, ds.p, dV.p, drot.p, dscale.p, dneg.p, nullptr);
+    xm::launch_recover_project(n, r, dR.p, ds.p, dV.p, drot.p, dscale.p, dneg.p, nullptr, variant);
+    if (reps > 0 && ms_avg) {
+        hipEvent_t e0, e1;
+        XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1));
+        XM_HIP_CHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps; ++i) {
+            XM_HIP_CHECK(hipMemsetAsync(dneg.p, 0, sizeof(int), nullptr));
+            xm::launch_recover_project(n, r, dR.p, ds.p, dV.p, drot.p, dscale.p, dneg.p, nullptr, variant);
+        }
+        XM_HIP_CHECK(hipEventRecord(e1, nullptr));
+        XM_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        XM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *ms_avg = (double)ms / reps;
+    }
     int neg = 0;
     XM_HIP_CHECK(hipMemcpy(&neg, dneg.p, sizeof(int), hipMemcpyDeviceToHost));
     if (2 * (int64_t)neg > n) xm::launch_negate(drot.p, 9 * n, nullptr);   // recoversolution.py:60-62 (polar(-M) = -polar(M))
     XM_HIP_CHECK(hipMemcpy(rot, drot.p, (size_t)9 * n * sizeof(double), hipMemcpyDeviceToHost));
     XM_HIP_CHECK(hipMemcpy(scale, dscale.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (n_negative_det) *n_negative_det = neg;
+}
+extern "C" {
+int xm_recover_rotations(int64_t n, int r, const double *R, const double *s, double *rot, double *scale, int *n_negative_det) {
+    XM_TRY
+    xm::recover_rotations(n, r, R, s, rot, scale, n_negative_det, 0, 0, nullptr);
     return XM_OK;
     XM_CATCH
 }
@@ -878,43 +708,3 @@ int xm_symw_use(int T, int t, int u) {
     return xm::symw_use(g, t, u) ? 1 : 0;
 }
 
-// micro-benchmark of ONE rank's share of the multi-rank symmetric window product (xm_symw.h) on this GPU: rank `cam0 / nloc` of `world`,
-// its row strip filled with an arbitrary pattern (timing only).  ms[0] = sweep + column sums, ms[1] = per-camera sum + plain epilogue;
-// bytes = what the sweep streams.  The all-gather between the two is not part of it.
-int xm_qw_symw_time(int64_t ntot, int nloc, int cam0, int o, int world, int reps, double ms[2], int64_t *bytes) {
-    XM_TRY
-    require_device();
-    if (ntot < 2 || nloc < 2 || world < 1 || reps < 1 || !ms) throw xm::Error(XM_ERR_ARG, "bad argument");
-    const int64_t ld = xm::dense_ld(ntot);
-    xm::SymwProduct sp(ntot, nloc, cam0, ld, nullptr);
-    sp.ensure(o, world);
-    xm::DevBuf<double> Q, W, out;
-    Q.alloc((size_t)3 * nloc * (size_t)ld, false);
-    W.alloc((size_t)ld * xm::pitch_of(o) + 16);
-    out.alloc((size_t)3 * nloc * xm::pitch_of(o));
-    XM_HIP_CHECK(hipMemset(Q.p, 0x3c, (size_t)3 * nloc * (size_t)ld * sizeof(double)));   // finite pattern
-    XM_HIP_CHECK(hipDeviceSynchronize());
-    xm::CamArgs a = plain_args(nloc, out.p);
-    a.cam0 = cam0;
-    hipEvent_t e0, e1, e2;
-    XM_HIP_CHECK(hipEventCreate(&e0)); XM_HIP_CHECK(hipEventCreate(&e1)); XM_HIP_CHECK(hipEventCreate(&e2));
-    const int rank = cam0 / nloc;
-    for (int i = 0; i < 2; ++i) { sp.sweep(o, Q.p, W.p, nullptr, rank, nullptr); sp.reduce(o, xm::EPI_PLAIN, 1.0, a, world, nullptr); }
-    float t_sw = 0, t_rd = 0;
-    for (int i = 0; i < reps; ++i) {
-        XM_HIP_CHECK(hipEventRecord(e0, nullptr));
-        sp.sweep(o, Q.p, W.p, nullptr, rank, nullptr);
-        XM_HIP_CHECK(hipEventRecord(e1, nullptr));
-        sp.reduce(o, xm::EPI_PLAIN, 1.0, a, world, nullptr);
-        XM_HIP_CHECK(hipEventRecord(e2, nullptr));
-        XM_HIP_CHECK(hipEventSynchronize(e2));
-        float x = 0, y = 0;
-        XM_HIP_CHECK(hipEventElapsedTime(&x, e0, e1)); XM_HIP_CHECK(hipEventElapsedTime(&y, e1, e2));
-        t_sw += x; t_rd += y;
-    }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
-    ms[0] = t_sw / reps; ms[1] = t_rd / reps;
-    if (bytes) *bytes = sp.stream_bytes();
-    return XM_OK;
-    XM_CATCH
-}

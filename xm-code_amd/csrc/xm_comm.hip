@@ -31,44 +31,41 @@ using clk = std::chrono::steady_clock;
 static double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
 
 // ------------------------------------------------------------------------------------------------------------------
-// settings: caller's xm_tuning_t, else the XM_* environment (experiments), else the defaults.  Read once per context.
+// settings: the caller's xm_tuning_t, else the defaults.  Resolved once per context; no kernel or layout is selected through the
+// environment (the only variable read here is XM_WATCHDOG_S, for callers of the file surface, which has no tuning argument).
 // ------------------------------------------------------------------------------------------------------------------
-static bool env_has(const char *k) { const char *e = std::getenv(k); return e && *e; }
-static long long env_ll(const char *k, long long d) { const char *e = std::getenv(k); return (e && *e) ? std::atoll(e) : d; }
-static double env_f(const char *k, double d) { const char *e = std::getenv(k); return (e && *e) ? std::atof(e) : d; }
-
 Settings Settings::resolve(const xm_tuning_t *t) {
     Settings s;
     xm_tuning_t z;
     std::memset(&z, 0, sizeof(z));
     if (t) z = *t;
-    // tri-state switches: field != 0 wins, else the environment (XM_X=1 force, XM_X=0 off), else auto
-    auto tri = [](int field, const char *env) { if (field != 0) return field > 0 ? 1 : -1; if (!env_has(env)) return 0; return env_ll(env, 0) != 0 ? 1 : -1; };
-    s.sym = tri(z.sym, "XM_SYM");
-    s.sym_min_rows = z.sym_min_rows > 0 ? z.sym_min_rows : env_ll("XM_SYM_MIN_ROWS", 6144);
-    s.sell = tri(z.sell, "XM_BSR_SELL");
-    s.sell_slabs = z.sell_slabs > 0 ? z.sell_slabs : (int)env_ll("XM_SELL_SLABS", 4);
-    s.sell_lmax = z.sell_lmax > 0 ? z.sell_lmax : (int)env_ll("XM_SELL_LMAX", 64);
-    // tuning field: 0 auto (= 2) | 1 one record per lane | 2 element-per-lane + LDS transposition | 3 sector windows through LDS-DMA (o = 3; else 2);
-    // XM_SELL_GATHER names the kernel's mode directly (0 | 1 | 2)
-    s.sell_gather = z.sell_gather > 0 ? z.sell_gather - 1 : (int)env_ll("XM_SELL_GATHER", 1);
-    s.sell_codec = z.sell_codec > 0 ? z.sell_codec : (int)env_ll("XM_SELL_CODEC", 0);
-    s.sell_layout = z.sell_layout > 0 ? z.sell_layout : (int)env_ll("XM_SELL_LAYOUT", 0);
-    s.sell_kmax = z.sell_kmax > 0 ? z.sell_kmax : (int)env_ll("XM_SELL_KMAX", 32);
-    s.sell_wpad = tri(z.sell_wpad, "XM_SELL_WPAD");
-    s.sell_pipe = (int)env_ll("XM_SELL2_PIPE", -1);
-    s.overlap = (z.overlap < 0) ? -1 : ((env_has("XM_OVERLAP") && env_ll("XM_OVERLAP", 1) == 0) ? -1 : 0);
-    s.overlap_min_mb = z.overlap_min_mb > 0 ? (double)z.overlap_min_mb : env_f("XM_OVERLAP_MIN_MB", 64.0);
-    s.cert_dense_rows = z.cert_dense_rows > 0 ? z.cert_dense_rows : env_ll("XM_CERT_DENSE_ROWS", 384);
-    s.lanczos_mmax = z.lanczos_mmax > 0 ? z.lanczos_mmax : (int)env_ll("XM_LANCZOS_MMAX", 400);
-    s.lanczos_restarts = z.lanczos_restarts > 0 ? z.lanczos_restarts : (int)env_ll("XM_LANCZOS_RESTARTS", 12);
-    s.watchdog_s = z.watchdog_s > 0 ? (double)z.watchdog_s : env_f("XM_WATCHDOG_S", 600.0);
-    s.balance = z.balance != 0 ? z.balance : (int)env_ll("XM_BALANCE", 0);
-    s.exchange = z.exchange != 0 ? z.exchange : (int)env_ll("XM_EXCHANGE", 0);
-    s.split_k = z.split_k != 0 ? z.split_k : (int)env_ll("XM_SPLIT_K", 0);
-    s.debug_drop_finalize = env_ll("XM_DEBUG_DROP_FINALIZE", -1);
-    s.debug_peer_mute = (int)env_ll("XM_DEBUG_PEER_MUTE", 0);
-    s.exchange_lite = (int)env_ll("XM_EXCHANGE_LITE", 1);
+    auto tri = [](int field) { return field > 0 ? 1 : (field < 0 ? -1 : 0); };
+    s.sym = tri(z.sym);
+    s.sym_min_rows = z.sym_min_rows > 0 ? z.sym_min_rows : 6144;
+    s.sell = tri(z.sell);
+    s.sell_slabs = z.sell_slabs > 0 ? z.sell_slabs : 4;
+    s.sell_lmax = z.sell_lmax > 0 ? z.sell_lmax : 64;
+    if (z.sell_gather < 0 || z.sell_gather > 2) throw Error(XM_ERR_ARG, "xm_tuning_t.sell_gather must be 0 (default), 1 (a record per lane) or 2 (LDS-transposed)");
+    s.sell_gather = (z.sell_gather == 1) ? 0 : 1;   // the kernels' mode: 0 a record per lane | 1 LDS-transposed (default)
+    if (z.sell_codec < 0 || z.sell_codec > 2) throw Error(XM_ERR_ARG, "xm_tuning_t.sell_codec must be 0, 1 or 2");
+    s.sell_codec = z.sell_codec;
+    s.sell_wpad = tri(z.sell_wpad);
+    s.overlap = (z.overlap < 0) ? -1 : 0;
+    s.overlap_min_mb = z.overlap_min_mb > 0 ? (double)z.overlap_min_mb : (z.overlap_min_mb < 0 ? 0.0 : 64.0);
+    s.cert_dense_rows = z.cert_dense_rows > 0 ? z.cert_dense_rows : 384;
+    s.lanczos_mmax = z.lanczos_mmax > 0 ? z.lanczos_mmax : 400;
+    s.lanczos_restarts = z.lanczos_restarts > 0 ? z.lanczos_restarts : 12;
+    if (z.watchdog_s > 0) s.watchdog_s = (double)z.watchdog_s;
+    else if (const char *e = std::getenv("XM_WATCHDOG_S")) { const double v = std::atof(e); if (v > 0) s.watchdog_s = v; }
+    s.balance = z.balance;
+    if (z.exchange < 0 || z.exchange > 3) throw Error(XM_ERR_ARG, "xm_tuning_t.exchange must be 0..3");
+    s.exchange = z.exchange;
+    s.split_k = z.split_k;
+    s.exchange_lite = z.exchange_fence ? 0 : 1;
+    s.schur_host_assembly = z.schur_host_assembly != 0;
+    s.schur_trace = z.schur_trace != 0;
+    s.debug_drop_finalize = z.debug_drop_finalize > 0 ? z.debug_drop_finalize : -1;
+    s.debug_peer_mute = z.debug_peer_mute;
     return s;
 }
 
@@ -394,6 +391,7 @@ struct IpcPeerGroup : PeerGroup {
     int me = 0;
     double limit = 120.0;
     void *mapped[2][kMaxPeers] = {};
+    unsigned long long seg_ino = 0, seg_dev = 0;   // identity of the mapped segment (ranks > 0: to notice that rank 0 has replaced the name since)
     int kind() const override { return 4; }
     ~IpcPeerGroup() override {
         for (int k = 0; k < 2; ++k)
@@ -412,6 +410,30 @@ struct IpcPeerGroup : PeerGroup {
             std::this_thread::yield();
         }
         return sh->aborted.load() == 0;   // also for the rank whose arrival completed the count: an abort is everybody's
+    }
+    // The FIRST barrier of a group.  A rank > 0 that opened the name before rank 0 had replaced a segment left by an earlier job of the same
+    // name (its stamp still fresh: a quick re-run after a crash) sits in the OLD segment, where rank 0 never arrives.  While it waits it
+    // looks the name up again: another inode under it means exactly that.  1 met | 0 failed / timed out | -1 stale segment mapped
+    int rendezvous(unsigned long long &mine) {
+        sh->arrive.fetch_add(1, std::memory_order_acq_rel);
+        const unsigned long long target = (++mine) * (unsigned long long)world;
+        const auto t0 = clk::now();
+        auto t_look = t0;
+        while (sh->arrive.load(std::memory_order_acquire) < target) {
+            if (sh->aborted.load() || since(t0) > limit) return 0;
+            if (me != 0 && since(t_look) > 0.02) {
+                t_look = clk::now();
+                const int fd = shm_open(name.c_str(), O_RDWR, 0600);
+                if (fd >= 0) {
+                    struct stat sb;
+                    const bool other = fstat(fd, &sb) == 0 && ((unsigned long long)sb.st_ino != seg_ino || (unsigned long long)sb.st_dev != seg_dev);
+                    close(fd);
+                    if (other) return -1;
+                }
+            }
+            std::this_thread::yield();
+        }
+        return sh->aborted.load() == 0 ? 1 : 0;
     }
     void barrier(unsigned long long &mine, const char *what) override {
         if (!barrier_nothrow(mine))
@@ -470,7 +492,7 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PeerPtrs pp, const doubl
     const size_t stride = (size_t)gridDim.x * 256;
     // Payload through write-through (system-scope) stores: each is acknowledged by its destination before s_waitcnt vmcnt(0) lets the
     // wave go on and leaves nothing in this device's L2, so the hand-off needs no release fence (a fence writes back the whole L2 of the
-    // XCD; measured on the fused tCG exchange: 6 us per iteration).  pp.lite == 0 keeps the fence form (XM_EXCHANGE_LITE=0).
+    // XCD; measured on the fused tCG exchange: 6 us per iteration).  pp.lite == 0 keeps the fence form (xm_tuning_t.exchange_fence).
     for (int p = 0; p < pp.world; ++p) {
         if (p == pp.rank) continue;
         double *dst = pp.stage[p] + slot_off + (size_t)pp.rank * count;
@@ -543,7 +565,8 @@ struct PeerComm : Comm {
     void *parena[kMaxPeers] = {};      // every rank's arena / exchange buffer as THIS process addresses it
     void *pxbuf[kMaxPeers] = {};
     int plain_reads = 0;               // self-test: see peer_wait_kernel
-    int lite = 1;                      // write-through payload stores instead of a release fence (XM_EXCHANGE_LITE=0: fence form)
+    int lite = 1;                      // write-through payload stores instead of a release fence (set_exchange_fence: fence form)
+    void set_exchange_fence(bool on) override { lite = on ? 0 : 1; }
     std::shared_ptr<Comm> keep;        // a library communicator created beside this one (xm_comm_init): destroyed with it
     int kind() const override { return g->kind(); }
     bool peer() const override { return true; }
@@ -556,7 +579,6 @@ struct PeerComm : Comm {
 
     PeerComm(const std::shared_ptr<PeerGroup> &grp, int r, unsigned long long hb0 = 0) : g(grp), hb(hb0) {
         rank = r; world = grp->world; forced = true;
-        { const char *e = std::getenv("XM_EXCHANGE_LITE"); if (e && *e == '0') lite = 0; }
         XM_HIP_CHECK(hipHostMalloc((void **)&herr, 64, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(herr, 0, 64);
         XM_HIP_CHECK(hipHostGetDevicePointer((void **)&herr_dev, herr, 0));
@@ -716,6 +738,7 @@ std::shared_ptr<IpcPeerGroup> ipc_group_open(int rank, int world, int device, co
     // completely sized segment whose stamp is recent (a stale one is dropped and re-opened until rank 0 has replaced it).
     auto wall_ns = [] { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count(); };
     void *p = MAP_FAILED;
+    unsigned long long ino = 0, dev = 0;
     if (rank == 0) {
         (void)shm_unlink(name);
         const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
@@ -736,7 +759,7 @@ std::shared_ptr<IpcPeerGroup> ipc_group_open(int rank, int world, int device, co
                     void *q = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
                     if (q != MAP_FAILED) {
                         const unsigned long long st = static_cast<IpcShared *>(q)->stamp.load(std::memory_order_acquire), now = wall_ns();
-                        if (st != 0 && now - st < fresh) { p = q; close(fd); break; }
+                        if (st != 0 && now - st < fresh) { p = q; ino = (unsigned long long)sb.st_ino; dev = (unsigned long long)sb.st_dev; close(fd); break; }
                         munmap(q, sizeof(IpcShared));
                     }
                 }
@@ -749,6 +772,7 @@ std::shared_ptr<IpcPeerGroup> ipc_group_open(int rank, int world, int device, co
     auto g = std::make_shared<IpcPeerGroup>();
     g->sh = static_cast<IpcShared *>(p);   // a fresh segment is zero-filled
     g->name = name; g->me = rank; g->world = world; g->limit = limit;
+    g->seg_ino = ino; g->seg_dev = dev;
     for (int r = 0; r < world; ++r) g->device[r] = (r == rank) ? device : -1;
     if (spin_seconds > 0) g->spin_seconds = spin_seconds;
     {   // which physical GPU this rank drives (two processes of a 1-GPU test box share one)
@@ -839,8 +863,15 @@ std::shared_ptr<PeerComm> ipc_comm_try(int rank, int world, int device, const ch
         return nullptr;
     };
     try {
-        g = ipc_group_open(rank, world, device, name, limit, 10.0);   // shorter device-side waits while the transport is on probation
-        if (!g->barrier_nothrow(hb) || g->sh->failed.load()) return give_up("not every rank reached the rendezvous segment (ranks on several nodes?)");
+        const auto t_open = clk::now();
+        for (;;) {
+            g = ipc_group_open(rank, world, device, name, limit, 10.0);   // shorter device-side waits while the transport is on probation
+            hb = 0;
+            const int met = g->rendezvous(hb);
+            if (met == -1 && since(t_open) < limit) { g.reset(); continue; }   // a stale segment of an earlier job of this name: open the name again
+            if (met != 1 || g->sh->failed.load()) return give_up("not every rank reached the rendezvous segment (ranks on several nodes?)");
+            break;
+        }
         c = std::make_shared<PeerComm>(g, rank, hb);
         // the tCG exchange buffer is exported and mapped HERE, once, at its full size: a handle that a peer cannot open must end in the
         // collective fallback below, not in the middle of a solve

@@ -121,14 +121,15 @@ void launch_qw_dense_split(int o, int epi, const double *Q, int64_t ld, const do
 int qw_dense_tile_cols();
 int qw_dense_split_k(int nloc, int64_t ld);   // column split the small-strip policy picks for `nloc` cameras (1 = none)
 int bsr_grid(int nloc);   // workgroups (= partial sums per epilogue slot) of the BSR3 kernels
-int sym_groups(int nloc);
-int sym_variant();   // 1: vertical sweep (also instantiated for the rank-1 certificate operator)
 size_t sym_prow_count(int nloc, int64_t ld, int o);
 size_t sym_pcol_count(int nloc, int64_t ld, int o);
 void symv_plan_get(int nloc, int64_t ld, int out[4]);   // K, Kf, ysplit, nchunks of the vertical-sweep symmetric product
 void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,
                    double *Pcol, hipStream_t st);
 void launch_asym(const double *Q, int64_t ld, int64_t m, double *out, int grid, hipStream_t st);
+// exact symmetry check of a row-partitioned matrix: this strip's (rows row0 .. row0 + nrows of the m x m matrix) share of a sum modulo 2^64
+// that vanishes over all strips iff the matrix is symmetric (xm_kernels.hip: symhash_kernel); out: 2 * grid words
+void launch_symhash(const double *Q, int64_t ld, int64_t row0, int64_t nrows, int64_t m, unsigned long long *out, int grid, hipStream_t st);
 
 // layout helpers
 void launch_transpose_pad(const double *src_colmajor, int64_t lds, int64_t rows, int64_t cols, double *dst, int64_t ldd,
@@ -159,8 +160,9 @@ void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *Qs
                          double *Lam, double *dz, double *parts, hipStream_t st);
 // solution recovery
 void launch_recover_gram(int64_t n, int r, const double *R, const double *s, double *parts, int grid, hipStream_t st);
+// variant 0: one thread per camera (default) | 1: one wavefront per camera, cross-lane reductions (north_star's form; measured alternative)
 void launch_recover_project(int64_t n, int r, const double *R, const double *s, const double *V, double *rot, double *scale, int *negcount,
-                            hipStream_t st);
+                            hipStream_t st, int variant = 0);
 void launch_negate(double *x, int64_t len, hipStream_t st);
 // small vector kernels used by Lanczos
 int dots_multi_segments(int64_t len);

@@ -207,7 +207,7 @@ static void gemm_sub(int m, int n, int k, const double *A, int64_t lda, int ta, 
 // lower triangle is computed -- both substitutions then touch the columns [0, i + b) of block row i only, half the flops of the full
 // solves with the identity.  spd_inverse_layout() writes the full symmetric matrix in the dense kernel's layout from it.
 // Returns false when A is not positive definite.
-bool spd_inverse_device(int n, double *A, double *X, hipStream_t st) {
+bool spd_inverse_device(int n, double *A, double *X, hipStream_t st, bool trace) {
     if (n <= 0) return true;
     const int64_t ld = n;
     DevBuf<int> info;
@@ -223,7 +223,6 @@ bool spd_inverse_device(int n, double *A, double *X, hipStream_t st) {
         }
     }
     check_launch("spd_inverse(cholesky)");
-    static const bool trace = [] { const char *e = std::getenv("XM_SCHUR_TRACE"); return e && *e == '1'; }();
     auto t0 = std::chrono::steady_clock::now();
     int h = 0;
     XM_HIP_CHECK(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -308,212 +308,8 @@ __global__ __launch_bounds__(256) void qw_dense_ks_kernel(const double *__restri
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Half-traffic product for SYMMETRIC dense Q (single GPU, o <= 5).  Only the upper block triangle is read: a workgroup of 8
-// wavefronts owns 8 consecutive cameras (24 rows) and sweeps the column tiles from its diagonal block to the right.  Every Q
-// fragment is used twice: y_rows += Q_tile * w_cols (accumulated in registers over the sweep, as in the full kernel) and
-// y_cols += Q_tile^T * w_rows (per-lane column sums need no cross-lane step; the 8 wavefronts' sums are added in LDS in a
-// fixed order and written as one partial per (workgroup, column)).  sym_reduce_kernel then adds, per camera, the row result
-// and the column partials of the workgroups above it — in a fixed order, no atomics — and runs the same fused epilogue.
-// Traffic: half of Q + o/24 of it written and read back as partials (12.5 % at o = 3).  Workgroups are dispatched heaviest
-// first (block 0 sweeps every tile), which balances the triangular work over the CUs.
-// ----------------------------------------------------------------------------------------------------------------
-constexpr int kSymTile = 128;
-constexpr int kSymChunk = 6;   // column tiles per workgroup: the triangular sweep is cut into equal pieces for load balance
-
-// WV wavefronts of CPW cameras each (G = WV * CPW cameras = 3 G rows per workgroup).  The column partials are written once per
-// (workgroup row group, column): Pcol traffic is (n / G) * 3n * o doubles each way, i.e. o / (3 G) of the half matrix, and the
-// per-tile barrier + LDS exchange is amortised over CPW times more FMAs.  Measured, 13.5 GB matrix, o = 3 (general kernel 2000 us):
-// WV x CPW = 8 x 1 (round 1) 1620-1780 us | 8 x 2 1730 | 8 x 4 1540 (217 VGPRs: ONE workgroup per CU) | 4 x 2 1557 | 4 x 4 1352 us
-// (two workgroups per CU); at Venice size 4 x 4 takes 31.0 us against 33.8 us for the general kernel.
-template <int O, bool NT, int CPW, int WV>
-__global__ __launch_bounds__(64 * WV) void qw_sym_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc,
-                                                      const TcgScal *__restrict__ scal, double *__restrict__ Prow,
-                                                      double *__restrict__ Pcol) {
-    constexpr int OP = pitch_of(O);
-    constexpr int TILE = kSymTile;
-    constexpr int TILE2 = TILE * OP / 2;   // double2 elements of one W tile (<= 320 < 512 threads)
-    constexpr int G = WV * CPW;            // cameras per workgroup
-    constexpr int NTH = 64 * WV;           // threads
-    constexpr int NWS = (TILE2 + NTH - 1) / NTH;   // staging registers (double2) per thread
-    if (scal != nullptr) {
-        if (scal->status != 0) return;
-    }
-    const int b = blockIdx.y, cx = blockIdx.x;
-    const int64_t col_lo = (int64_t)3 * G * b, col_hi = col_lo + 3 * G;   // the group's diagonal block spans [col_lo, col_hi)
-    const int ntiles = (int)((ld + TILE - 1) / TILE);
-    const int t0 = (int)(col_lo / TILE);
-    const int tb = (cx * kSymChunk > t0) ? cx * kSymChunk : t0;
-    const int te = ((cx + 1) * kSymChunk < ntiles) ? (cx + 1) * kSymChunk : ntiles;
-    if (tb >= te) return;   // chunk entirely left of the diagonal (uniform exit, before any barrier)
-    __shared__ __attribute__((aligned(16))) double wt[2][TILE * OP];
-    __shared__ __attribute__((aligned(16))) double cs[2][WV][TILE * O];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int camw = b * G + wave * CPW;   // first camera of this wavefront
-    // this wavefront's rows of W (wave-uniform): operand of the transposed product
-    double wr[CPW][3][O];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c)
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < O; ++k) wr[c][r][k] = (camw + c < nloc) ? W[((size_t)(camw + c) * 3 + r) * OP + k] : 0.0;
-
-    double acc[CPW][3][O];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c)
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < O; ++k) acc[c][r][k] = 0.0;
-
-    double2 q1[CPW][3];   // Q fragments of the next tile (CPW = 1 keeps two tiles in flight through q2)
-    double2 q2[(CPW == 1) ? 1 : 1][3];
-    double2 ws[NWS];
-    auto load_q = [&](double2 (&dst)[3], int c, int t) {
-        const int64_t col = (int64_t)t * TILE;
-        if (camw + c < nloc && t < te) {
-            const double *q0p = Q + (size_t)(camw + c) * 3 * (size_t)ld + 2 * lane;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double2 *qp = reinterpret_cast<const double2 *>(q0p + (size_t)r * ld + col);
-                if (NT) dst[r] = make_double2(__builtin_nontemporal_load(&qp->x), __builtin_nontemporal_load(&qp->y));
-                else dst[r] = *qp;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) dst[r] = make_double2(0.0, 0.0);
-        }
-    };
-    auto load_w = [&](int t) {
-        const double2 *src = reinterpret_cast<const double2 *>(W + (size_t)t * TILE * OP);
-#pragma unroll
-        for (int i = 0; i < NWS; ++i) ws[i] = ((int)threadIdx.x + i * NTH < TILE2) ? src[threadIdx.x + i * NTH] : make_double2(0.0, 0.0);
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NWS; ++i)
-            if ((int)threadIdx.x + i * NTH < TILE2) reinterpret_cast<double2 *>(wt[buf])[threadIdx.x + i * NTH] = ws[i];
-    };
-
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) load_q(q1[c], c, tb);
-    if (CPW == 1) load_q(q2[0], 0, tb + 1);
-    load_w(tb);
-    store_w(tb & 1);
-    __syncthreads();
-    for (int t = tb; t < te; ++t) {
-        double2 q[CPW][3];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) q[c][r] = q1[c][r];
-        if (CPW == 1) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) q1[0][r] = q2[0][r];
-            load_q(q2[0], 0, t + 2);
-        } else {
-#pragma unroll
-            for (int c = 0; c < CPW; ++c) load_q(q1[c], c, t + 1);
-        }
-        const bool more = (t + 1 < te);
-        if (more) load_w(t + 1);
-        const int64_t c2 = (int64_t)t * TILE + 2 * lane;            // this lane's two columns: c2, c2+1 (same class: bounds are even)
-        const double mrow = (c2 >= col_lo) ? 1.0 : 0.0;             // left of the diagonal block: belongs to a workgroup above
-        const double mcol = (c2 >= col_hi) ? 1.0 : 0.0;             // inside the diagonal block: used one way only
-        const double2 *wp = reinterpret_cast<const double2 *>(wt[t & 1]) + (size_t)lane * OP;
-        double wv[2 * OP];
-#pragma unroll
-        for (int j = 0; j < OP; ++j) {
-            const double2 tt = wp[j];
-            wv[2 * j] = tt.x;
-            wv[2 * j + 1] = tt.y;
-        }
-        double cxs[O], cys[O];
-#pragma unroll
-        for (int k = 0; k < O; ++k) { cxs[k] = 0.0; cys[k] = 0.0; }
-#pragma unroll
-        for (int c = 0; c < CPW; ++c)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double qx = q[c][r].x * mrow, qy = q[c][r].y * mrow;
-#pragma unroll
-                for (int k = 0; k < O; ++k) {
-                    acc[c][r][k] += qx * wv[k] + qy * wv[OP + k];
-                    cxs[k] += qx * wr[c][r][k];
-                    cys[k] += qy * wr[c][r][k];
-                }
-            }
-        double *cw = cs[t & 1][wave] + (size_t)(2 * lane) * O;
-#pragma unroll
-        for (int k = 0; k < O; ++k) { cw[k] = cxs[k] * mcol; cw[O + k] = cys[k] * mcol; }
-        if (more) store_w((t + 1) & 1);
-        __syncthreads();
-        // fixed-order sum over the 8 wavefronts -> one partial per (workgroup row group, column, k)
-        for (int i = threadIdx.x; i < TILE * O; i += NTH) {
-            double sum = 0.0;
-#pragma unroll
-            for (int w8 = 0; w8 < WV; ++w8) sum += cs[t & 1][w8][i];
-            Pcol[((size_t)b * (size_t)ld + (size_t)t * TILE) * O + i] = sum;
-        }
-    }
-    // row results of this chunk: wave reduction, lane k keeps column k, raw sums (alpha is applied by the reducer)
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        double *pr = Prow + (((size_t)b * gridDim.x + cx) * G + wave * CPW + c) * 3 * O;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < O; ++k) {
-                const double tsum = wave_sum(acc[c][r][k]);
-                if (lane == k) pr[r * O + k] = tsum;
-            }
-    }
-}
-
-// second half of the symmetric product: y_j = sum_chunks Prow[group(j)][chunk][j] + sum_{b < group(j)} Pcol[b][rows of j]
-// (fixed order, no atomics), then the fused epilogue.  G = cameras per row group of the first kernel.
-template <int O, int EPI>
-__global__ __launch_bounds__(256) void sym_reduce_kernel(const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t ld,
-                                                          int nchunks, int G, double alpha, CamArgs a) {
-    if (EPI == EPI_HESS) {
-        if (a.scal->status != 0) return;
-    }
-    __shared__ double red[kQwWaves][3];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cam = blockIdx.x * kQwWaves + wave;
-    const bool active = cam < a.nloc;
-    EpiOps eops;
-    epi_prefetch<O, EPI>(eops, cam, lane, active, a);
-    double acc[3][O];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
-    if (active) {
-        const int g = cam / G, w = cam - g * G;
-        for (int bb = lane; bb < g; bb += 64) {
-            const double *p = Pcol + ((size_t)bb * (size_t)ld + (size_t)cam * 3) * O;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
-        }
-        const int c0 = (int)(((int64_t)3 * G * g / kSymTile) / kSymChunk);   // first chunk that holds tiles of this row group
-        for (int cx = c0 + lane; cx < nchunks; cx += 64) {
-            const double *p = Prow + (((size_t)g * nchunks + cx) * G + w) * 3 * O;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
-        }
-    }
-    qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// Vertical-sweep variant of the symmetric product (XM_SYM_VARIANT=1).  The horizontal sweep above keeps the ROW sums in registers
-// and flushes one column partial per (16-camera row group, column): o / (3 G) of the half matrix written and read back, and
-// a workgroup barrier + LDS exchange per tile.  Here a WAVEFRONT owns a strip of 256 columns (lane: 2 + 2 adjacent columns, W of its
+// Half-traffic product for SYMMETRIC dense Q (single GPU, o <= 5): only the upper block triangle is read, every Q fragment is used
+// twice.  A WAVEFRONT owns a strip of 256 columns (lane: 2 + 2 adjacent columns, W of its
 // columns in registers for the whole sweep) and walks DOWN it in steps of two cameras (6 rows x 256 columns = 12 KB per step):
 //   column direction  y_cols += Q_step^T w_rows : per-lane accumulators that live in registers for the whole chunk of K steps,
 //                     written ONCE per chunk (w_rows is wave-uniform: scalar loads);
@@ -1043,7 +839,7 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
         const double g = rgR[i], gs = rgs[cam];
         rR[i] = g; pR[i] = -g; vR[i] = 0.0; HvR[i] = 0.0;
         const double wv = s[cam] * (-g) + (-gs) * R[i];
-        Wloc[i] = wv;
+        if (Wloc) Wloc[i] = wv;   // (nullptr: the products of this tCG read the padded copy only, Context::run_tcg)
         if (Wpad) Wpad[(size_t)cam * 16 + (i - (int64_t)cam * (3 * OP))] = wv;   // copy at a 128-byte record pitch for the sliced-ELL gather (xm_sell.h)
         if (i % (3 * OP) == 0) { rs[cam] = gs; ps[cam] = -gs; vs[cam] = 0.0; Hvs[cam] = 0.0; }
     }
@@ -1218,7 +1014,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
                 pR[i] = pn;
                 if (!Afull) {
                     const double wv = sv * pn + psn * Rv;
-                    Wloc[i] = wv;
+                    if (Wloc) Wloc[i] = wv;
                     if (Wpad) Wpad[(size_t)camf * 16 + (i - (int64_t)camf * (3 * OP))] = wv;
                 }
                 if (own0) ps_next[camf] = psn;
@@ -1244,7 +1040,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
                 pR[i] = pn;
                 if (!Afull) {
                     const double wv = s[cam] * pn + psn * R[i];
-                    Wloc[i] = wv;
+                    if (Wloc) Wloc[i] = wv;
                     if (Wpad) Wpad[(size_t)cam * 16 + (i - (int64_t)cam * (3 * OP))] = wv;
                 }
                 if (own) ps_next[cam] = psn;
@@ -1711,16 +1507,87 @@ __device__ __forceinline__ double det3(const double (&M)[3][3]) {
     return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
            M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
 }
+// Orthogonal polar factor U V^T of ANY 3x3 matrix through its SVD by one-sided (Hestenes) Jacobi rotations: the columns of A = X V are
+// made orthogonal, their norms are the singular values, U = the normalised columns.  A rank-deficient block (a camera whose rows of
+// the recovered factor are dependent or zero -- the reference's numpy SVD, utils/recoversolution.py:65-86, still returns an orthogonal
+// U V^T there) gets its missing left vectors from cross products / the coordinate axes, so the result is always orthogonal; the zero
+// matrix maps to the identity.
+__device__ __forceinline__ void polar3_svd(double (&X)[3][3]) {
+    double A[3][3], V[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) { A[a][b] = X[a][b]; V[a][b] = (a == b) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int k = 0; k < 3; ++k) { al += A[k][p] * A[k][p]; be += A[k][q] * A[k][q]; ga += A[k][p] * A[k][q]; }
+                if (ga == 0.0 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+                off += fabs(ga);
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int k = 0; k < 3; ++k) {
+                    const double ap = A[k][p], aq = A[k][q];
+                    A[k][p] = c * ap - sn * aq; A[k][q] = sn * ap + c * aq;
+                    const double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = c * vp - sn * vq; V[k][q] = sn * vp + c * vq;
+                }
+            }
+        if (off == 0.0) break;
+    }
+    double sg[3], smax = 0.0;
+    for (int j = 0; j < 3; ++j) { sg[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]); smax = fmax(smax, sg[j]); }
+    double U[3][3];
+    bool have[3];
+    int nh = 0;
+    for (int j = 0; j < 3; ++j) {
+        have[j] = smax > 0.0 && sg[j] > 1e-13 * smax;
+        if (have[j]) { for (int k = 0; k < 3; ++k) U[k][j] = A[k][j] / sg[j]; ++nh; }
+    }
+    if (nh == 0) { for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) X[a][b] = (a == b) ? 1.0 : 0.0; return; }
+    if (nh == 1) {   // one direction known: a second one orthogonal to it from the coordinate axis it is least aligned with
+        int j0 = have[0] ? 0 : (have[1] ? 1 : 2), j1 = (j0 + 1) % 3;
+        int ax = 0;
+        for (int k = 1; k < 3; ++k) if (fabs(U[k][j0]) < fabs(U[ax][j0])) ax = k;
+        double e[3] = {0.0, 0.0, 0.0};
+        e[ax] = 1.0;
+        const double d = U[ax][j0];
+        double nn = 0.0;
+        for (int k = 0; k < 3; ++k) { e[k] -= d * U[k][j0]; nn += e[k] * e[k]; }
+        nn = sqrt(nn);
+        for (int k = 0; k < 3; ++k) U[k][j1] = e[k] / nn;
+        have[j1] = true;
+    }
+    for (int j = 0; j < 3; ++j)
+        if (!have[j]) {   // the third direction: cross product of the other two, oriented so that det(U) = det(V) (U V^T is then a rotation)
+            const int p = (j + 1) % 3, q = (j + 2) % 3;
+            U[0][j] = U[1][p] * U[2][q] - U[2][p] * U[1][q];
+            U[1][j] = U[2][p] * U[0][q] - U[0][p] * U[2][q];
+            U[2][j] = U[0][p] * U[1][q] - U[1][p] * U[0][q];
+            if (det3(V) < 0.0) for (int k = 0; k < 3; ++k) U[k][j] = -U[k][j];
+        }
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) X[a][b] = U[a][0] * V[b][0] + U[a][1] * V[b][1] + U[a][2] * V[b][2];
+}
+// The blocks of a recovered solution are within round-off of a rotation times a scale: the scaled Newton iteration X <- (g X + X^{-T}/g)/2
+// reaches the polar factor in 3-4 steps.  Anything it cannot handle -- a singular or numerically rank-deficient block, a non-finite
+// cofactor, no convergence -- goes through the SVD above.
 __device__ __forceinline__ void polar3(double (&X)[3][3]) {
+    double X0[3][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) X0[a][b] = X[a][b];
+    bool ok = false;
     for (int it = 0; it < 30; ++it) {
         const double d = det3(X);
-        if (d == 0.0) return;
+        double nx = 0.0;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) nx += X[a][b] * X[a][b];
+        if (!(fabs(d) > 1e-10 * nx * sqrt(nx))) break;   // singular / rank-deficient (or NaN): not Newton's business
         double C[3][3];   // cofactor matrix: X^{-T} = C / det
         C[0][0] = X[1][1] * X[2][2] - X[1][2] * X[2][1]; C[0][1] = X[1][2] * X[2][0] - X[1][0] * X[2][2]; C[0][2] = X[1][0] * X[2][1] - X[1][1] * X[2][0];
         C[1][0] = X[0][2] * X[2][1] - X[0][1] * X[2][2]; C[1][1] = X[0][0] * X[2][2] - X[0][2] * X[2][0]; C[1][2] = X[0][1] * X[2][0] - X[0][0] * X[2][1];
         C[2][0] = X[0][1] * X[1][2] - X[0][2] * X[1][1]; C[2][1] = X[0][2] * X[1][0] - X[0][0] * X[1][2]; C[2][2] = X[0][0] * X[1][1] - X[0][1] * X[1][0];
-        double nx = 0.0, nc = 0.0;
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { nx += X[a][b] * X[a][b]; nc += C[a][b] * C[a][b]; }
+        double nc = 0.0;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) nc += C[a][b] * C[a][b];
         const double g = sqrt(sqrt(nc) / fabs(d) / sqrt(nx));   // Frobenius scaling: g = (|X^{-1}|_F / |X|_F)^(1/2)
         double delta = 0.0;
         for (int a = 0; a < 3; ++a)
@@ -1729,7 +1596,11 @@ __device__ __forceinline__ void polar3(double (&X)[3][3]) {
                 delta += (y - X[a][b]) * (y - X[a][b]);
                 X[a][b] = y;
             }
-        if (delta < 1e-31) return;
+        if (delta < 1e-31) { ok = true; break; }
+    }
+    if (!ok) {
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { const double v = X0[a][b]; X[a][b] = (v == v && fabs(v) < 1e300) ? v : 0.0; }
+        polar3_svd(X);
     }
 }
 
@@ -1758,14 +1629,69 @@ __global__ __launch_bounds__(256) void recover_project_kernel(int64_t n, int r, 
         }
     const double sc = sqrt(nb) / sqrt(3.0);           // recoversolution.py:40
     double X[3][3];                                     // X = (B_0/s_0) * (B_i^T / s_i)   (recoversolution.py:41-47)
+    const double den = s0 * sc;                         // a camera whose block vanished (scale 0): X = 0, the projection returns the identity
     for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) X[a][b] = (B0[a][0] * B[b][0] + B0[a][1] * B[b][1] + B0[a][2] * B[b][2]) / (s0 * sc);
+        for (int b = 0; b < 3; ++b) X[a][b] = (den > 0.0) ? (B0[a][0] * B[b][0] + B0[a][1] * B[b][1] + B0[a][2] * B[b][2]) / den : 0.0;
     polar3(X);
     const bool neg = det3(X) < 0.0;
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) rot[a + 3 * (3 * cam + b)] = X[a][b];
     scale[cam] = sc;
     if (neg) atomicAdd(negcount, 1);
+}
+// The same projection with ONE WAVEFRONT PER CAMERA and cross-lane reductions -- the form BASELINE.json's north_star names for the 3x3
+// SVD ("one wavefront per camera ... with warp-shuffle reductions").  Lane e < 9 owns entry (e / 3, e % 3) of every 3x3 matrix; products
+// across entries come through shuffles (ds_bpermute), sums over entries through the DPP wave reduction.  55 of 64 lanes carry no work:
+// measured beside the thread-per-camera kernel by scripts/kbench_recover.py (profiles/r05_kbench_recover.txt), which is why the thread
+// form stays the default.  Rank-deficient blocks take the same polar3 fallback (every lane gathers the block and runs it redundantly).
+__global__ __launch_bounds__(256) void recover_project_wave_kernel(int64_t n, int r, const double *__restrict__ R, const double *__restrict__ s,
+                                                                    const double *__restrict__ V, double *rot, double *scale, int *negcount) {
+    const int64_t m = 3 * n;
+    const int lane = threadIdx.x & 63;
+    const int64_t cam = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cam >= n) return;   // wave-uniform
+    const int e = lane % 9, a = e / 3, c = e % 3;
+    const bool on = lane < 9;
+    double b0 = 0.0, bi = 0.0;   // entry (a, c) of B_0 and of B_cam
+    for (int k = 0; k < r; ++k) {
+        const double v = V[k + c * r];
+        b0 += s[0] * R[a + (int64_t)k * m] * v;
+        bi += s[cam] * R[3 * cam + a + (int64_t)k * m] * v;
+    }
+    const double s0 = sqrt(wave_sum(on ? b0 * b0 : 0.0)) / sqrt(3.0);
+    const double sc = sqrt(wave_sum(on ? bi * bi : 0.0)) / sqrt(3.0);
+    const double den = s0 * sc;
+    // X[a][c] = sum_j B0[a][j] B[c][j] / den : row a of B_0 (lanes 3a..3a+2), row c of B (lanes 3c..3c+2)
+    double x = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) x += __shfl(b0, 3 * a + j, 64) * __shfl(bi, 3 * c + j, 64);
+    x = (den > 0.0) ? x / den : 0.0;
+    const int a1 = (a + 1) % 3, a2 = (a + 2) % 3, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+    bool ok = false;
+    const double x_in = x;
+    for (int it = 0; it < 30; ++it) {
+        // cofactor of entry (a, c) by the cyclic formula; det = sum over row 0 of X .* C; norms over the nine entries
+        const double cf = __shfl(x, 3 * a1 + c1, 64) * __shfl(x, 3 * a2 + c2, 64) - __shfl(x, 3 * a1 + c2, 64) * __shfl(x, 3 * a2 + c1, 64);
+        const double d = wave_sum((lane < 3) ? x * cf : 0.0);
+        const double nx = wave_sum(on ? x * x : 0.0), nc = wave_sum(on ? cf * cf : 0.0);
+        if (!(fabs(d) > 1e-10 * nx * sqrt(nx))) break;
+        const double g = sqrt(sqrt(nc) / fabs(d) / sqrt(nx));
+        const double y = 0.5 * (g * x + cf / (d * g));
+        const double delta = wave_sum(on ? (y - x) * (y - x) : 0.0);
+        x = y;
+        if (delta < 1e-31) { ok = true; break; }
+    }
+    if (!ok) {   // wave-uniform: rank-deficient block -> SVD, run redundantly by every lane on the gathered block
+        double X[3][3];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { const double v = __shfl(x_in, q, 64); X[q / 3][q % 3] = (v == v && fabs(v) < 1e300) ? v : 0.0; }
+        polar3_svd(X);
+        x = X[a][c];
+    }
+    const double cf = __shfl(x, 3 * a1 + c1, 64) * __shfl(x, 3 * a2 + c2, 64) - __shfl(x, 3 * a1 + c2, 64) * __shfl(x, 3 * a2 + c1, 64);
+    const double d = wave_sum((lane < 3) ? x * cf : 0.0);
+    if (on) rot[a + 3 * (3 * cam + c)] = x;
+    if (lane == 0) { scale[cam] = sc; if (d < 0.0) atomicAdd(negcount, 1); }
 }
 __global__ __launch_bounds__(256) void negate_kernel(double *x, int64_t len) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) x[i] = -x[i];
@@ -1908,18 +1834,8 @@ int flat_grid(int64_t elems) {
 }
 
 
-static bool qw_stream_nt(int nloc, int64_t ld) {   // per-GPU Q beyond the Infinity Cache -> non-temporal stream (XM_QW_NT=0|1 overrides)
-    static const int force = [] { const char *e = std::getenv("XM_QW_NT"); return e ? std::atoi(e) : -1; }();
-    if (force >= 0) return force != 0;
+static bool qw_stream_nt(int nloc, int64_t ld) {   // per-GPU Q beyond the Infinity Cache -> non-temporal stream (a matrix that fits keeps the default policy: nt costs 33.6 -> 36.8 us at Venice size)
     return (size_t)nloc * 3 * (size_t)ld * sizeof(double) > (size_t)240 << 20;
-}
-static int qw_nsub() {  // tuning knob: XM_QW_NSUB=2|4 (tile = 256 / 512 columns)
-    static int v = [] {
-        const char *e = std::getenv("XM_QW_NSUB");
-        const int x = e ? std::atoi(e) : kQwNsub;
-        return (x == 4) ? 4 : 2;
-    }();
-    return v;
 }
 template <int O, int NSUB, bool NT>
 static void qw_dense_epi2(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
@@ -1987,41 +1903,17 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
         if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2, true>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
         else hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2, false>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
-    } else if (qw_nsub() == 4) {
-        XM_DISPATCH_O(o, (qw_dense_epi<O_, 4>(epi, Q, ld, W, alpha, a, st)));
     } else {
-        XM_DISPATCH_O(o, (qw_dense_epi<O_, 2>(epi, Q, ld, W, alpha, a, st)));
+        XM_DISPATCH_O(o, (qw_dense_epi<O_, kQwNsub>(epi, Q, ld, W, alpha, a, st)));
     }
     check_launch("qw_dense");
 }
 
-// XM_BSR_VARIANT = 2 (blocks AND the gathered rows of W staged through LDS; o <= 6) | 1 (blocks only) | 0 (direct loads)
-static int bsr_variant() {
-    const char *e = std::getenv("XM_BSR_VARIANT");
-    return (e && *e >= '0' && *e <= '2') ? (*e - '0') : 2;
-}
-// shape of the symmetric kernel's workgroup: XM_SYM_CPW = cameras per wavefront (1 | 2 | 4), XM_SYM_WAVES = wavefronts (4 | 8)
-int sym_cpw() {
-    static const int v = [] { const char *e = std::getenv("XM_SYM_CPW"); const int x = (e && *e) ? std::atoi(e) : 4; return (x == 1 || x == 2) ? x : 4; }();
-    return v;
-}
-int sym_waves() {
-    static const int v = [] { const char *e = std::getenv("XM_SYM_WAVES"); const int x = (e && *e) ? std::atoi(e) : 4; return (x == 8) ? 8 : 4; }();
-    return v;
-}
-int sym_variant() {   // 1 (default): vertical sweep (column sums in registers) | 0: horizontal sweep (row sums in registers; round 1)
-    static const int v = [] { const char *e = std::getenv("XM_SYM_VARIANT"); return (e && *e) ? std::atoi(e) : 1; }();
-    return v;
-}
-int sym_groups(int nloc) { const int G = sym_waves() * sym_cpw(); return (nloc + G - 1) / G; }
-int sym_chunks(int64_t ld) { const int nt = (int)((ld + kSymTile - 1) / kSymTile); return (nt + kSymChunk - 1) / kSymChunk; }
 // vertical sweep: steps (two cameras) per chunk.  A long chunk amortises the column flush and shortens the reducer's lists
 // (n / (2 K) column partials per camera), a short one yields more wavefronts and a shorter serial chain per wavefront; the
 // optimum grows like the square root of the triangle's step count T (measured best K, o = 3: T = 9.3 k (Venice size) 8,
-// 49 k (n = 4096) 16, 197 k (n = 8192) 32, 550 k (n = 13682) 64) -> K = sqrt(T) / 13, 2 <= K <= 64.  XM_SYMV_K overrides.
+// 49 k (n = 4096) 16, 197 k (n = 8192) 32, 550 k (n = 13682) 64) -> K = sqrt(T) / 13, 2 <= K <= 64.
 int symv_k(int nloc, int64_t ld) {
-    static const int fixed = [] { const char *e = std::getenv("XM_SYMV_K"); return (e && *e) ? std::atoi(e) : 0; }();
-    if (fixed > 0) return fixed;
     const int64_t nsteps = (nloc + 1) / 2, nstrips = (ld + kSvStrip - 1) / kSvStrip;
     int64_t total = 0;
     for (int64_t s = 0; s < nstrips; ++s) total += std::min<int64_t>(nsteps, (s * kSvStrip + kSvStrip + 5) / 6);
@@ -2029,10 +1921,7 @@ int symv_k(int nloc, int64_t ld) {
     if (k > 48) k = 64;   // 13.5 GB: 48 -> 1 190 us, 64 -> 1 147 us, 128 -> 1 265 us
     return (int)std::min<int64_t>(64, std::max<int64_t>(2, k));
 }
-size_t sym_prow_count(int nloc, int64_t ld, int o) {
-    if (sym_variant() == 1) return (size_t)((ld + kSvStrip - 1) / kSvStrip) * 6 * (size_t)((nloc + 1) / 2) * o;
-    return (size_t)sym_groups(nloc) * sym_chunks(ld) * sym_waves() * sym_cpw() * 3 * o;
-}
+size_t sym_prow_count(int nloc, int64_t ld, int o) { return (size_t)((ld + kSvStrip - 1) / kSvStrip) * 6 * (size_t)((nloc + 1) / 2) * o; }
 // The launch's tail: workgroups are dispatched strip group by strip group (left to right) and a chunk of K = 64 steps is a quarter
 // of a millisecond at 13.5 GB with only ~4.5 chunks per resident workgroup, so with equal chunks the last "round" runs part empty.
 // The strip groups dispatched last (the rightmost 13 %, a quarter of the work) are cut four times finer -- guided self-scheduling by
@@ -2045,8 +1934,7 @@ static SymvPlan symv_plan(int nloc, int64_t ld) {
     SymvPlan p;
     p.K = symv_k(nloc, ld);
     const int nsteps = (nloc + 1) / 2, ngy = (int)(((ld + kSvStrip - 1) / kSvStrip + 3) / 4);
-    static const int fine = [] { const char *e = std::getenv("XM_SYMV_TAIL"); return (e && *e) ? std::atoi(e) : 1; }();
-    if (fine && p.K >= 16 && ngy >= 8) {
+    if (p.K >= 16 && ngy >= 8) {
         p.Kf = p.K / 4;
         p.ysplit = (int)(0.866 * ngy);          // work grows linearly with the strip index: the last 13 % of the groups hold 25 % of it
     } else {
@@ -2059,10 +1947,7 @@ void symv_plan_get(int nloc, int64_t ld, int out[4]) {   // host-only view of th
     const SymvPlan p = symv_plan(nloc, ld);
     out[0] = p.K; out[1] = p.Kf; out[2] = p.ysplit; out[3] = p.nchunks;
 }
-size_t sym_pcol_count(int nloc, int64_t ld, int o) {
-    if (sym_variant() == 1) return (size_t)symv_plan(nloc, ld).nchunks * (size_t)ld * o;
-    return (size_t)sym_groups(nloc) * (size_t)ld * o;
-}
+size_t sym_pcol_count(int nloc, int64_t ld, int o) { return (size_t)symv_plan(nloc, ld).nchunks * (size_t)ld * o; }
 
 template <int O>
 static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
@@ -2085,50 +1970,53 @@ static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, d
     }
 }
 
-template <int O>
-static void qw_sym_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
-                       hipStream_t st) {
-    const int nch = sym_chunks(ld);
-    const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
-    const dim3 gs(nch, sym_groups(a.nloc));
-    const bool nt = qw_stream_nt(a.nloc, ld);
-    const int cpw = sym_cpw(), wv = sym_waves(), G = wv * cpw;
-#define XM_SYM_LAUNCH(C, V)                                                                                                                \
-    if (nt) hipLaunchKernelGGL((qw_sym_kernel<O, true, C, V>), gs, dim3(64 * V), 0, st, Q, ld, W, a.nloc, sc, Prow, Pcol);                 \
-    else hipLaunchKernelGGL((qw_sym_kernel<O, false, C, V>), gs, dim3(64 * V), 0, st, Q, ld, W, a.nloc, sc, Prow, Pcol);
-    if (wv == 8) { if (cpw == 1) { XM_SYM_LAUNCH(1, 8) } else if (cpw == 2) { XM_SYM_LAUNCH(2, 8) } else { XM_SYM_LAUNCH(4, 8) } }
-    else { if (cpw == 1) { XM_SYM_LAUNCH(1, 4) } else if (cpw == 2) { XM_SYM_LAUNCH(2, 4) } else { XM_SYM_LAUNCH(4, 4) } }
-#undef XM_SYM_LAUNCH
-    const dim3 g(qw_grid(a.nloc)), b(256);
-    switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nch, G, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nch, G, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((sym_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nch, G, alpha, a); break;
-        default: throw Error(-2, "bad epilogue");
-    }
-}
-// symmetric half-traffic product (o in 3..5); Prow: sym_prow_count() doubles, Pcol: sym_groups(nloc) * ld * o doubles
+// symmetric half-traffic product (o in 1, 3..5); Prow: sym_prow_count() doubles, Pcol: sym_pcol_count() doubles
 void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,
                    double *Pcol, hipStream_t st) {
     if (a.nloc <= 0) return;
-    if (sym_variant() == 1) {
-        switch (o) {
-            case 1: qw_symv_epi<1>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-            case 3: qw_symv_epi<3>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-            case 4: qw_symv_epi<4>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-            case 5: qw_symv_epi<5>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-            default: throw Error(-2, "symmetric product is instantiated for o = 3..5");
-        }
-        check_launch("qw_symv");
-        return;
-    }
     switch (o) {
-        case 3: qw_sym_epi<3>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-        case 4: qw_sym_epi<4>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-        case 5: qw_sym_epi<5>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-        default: throw Error(-2, "symmetric product is instantiated for o = 3..5");
+        case 1: qw_symv_epi<1>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+        case 3: qw_symv_epi<3>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+        case 4: qw_symv_epi<4>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+        case 5: qw_symv_epi<5>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+        default: throw Error(-2, "symmetric product is instantiated for o = 1, 3..5");
     }
-    check_launch("qw_sym");
+    check_launch("qw_symv");
+}
+// EXACT symmetry of a matrix that is spread over several ranks as row strips (no rank sees an entry and its mirror image): every rank sums
+//     g(i, j) * f(i, j) * bits(Q[i][j])   modulo 2^64 over its strip,   g = +1 above the diagonal, -1 below, 0 on it,
+// with f a 64-bit hash of the UNORDERED pair {i, j} and bits() the IEEE pattern (-0 counted as +0).  Integer arithmetic modulo 2^64 is
+// associative and commutative, so the strips' sums add up -- in any order, exactly -- to sum_{i<j} f(i,j) (bits(Q_ij) - bits(Q_ji)): zero for
+// a symmetric matrix, non-zero for any other one except with probability ~2^-64 per differing pair.  out[2 b] = workgroup b's sum,
+// out[2 b + 1] = 1 when it met a NaN (never symmetric, like launch_asym).
+__global__ __launch_bounds__(256) void symhash_kernel(const double *__restrict__ Q, int64_t ld, int64_t row0, int64_t nrows, int64_t m,
+                                                       unsigned long long *out) {
+    __shared__ unsigned long long sh[2][4];
+    unsigned long long acc = 0ull, bad = 0ull;
+    const int64_t total = nrows * m;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t lr = e / m, c = e - lr * m, r = row0 + lr;
+        if (r >= m || r == c) continue;
+        const double v = Q[lr * ld + c];
+        if (v != v) bad = 1ull;
+        unsigned long long b = (v == 0.0) ? 0ull : (unsigned long long)__double_as_longlong(v);
+        unsigned long long z = (unsigned long long)((r < c) ? r : c) * 0x9E3779B97F4A7C15ull + (unsigned long long)((r < c) ? c : r);   // splitmix64 of the pair
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        const unsigned long long t = (z | 1ull) * b;
+        acc += (r < c) ? t : (0ull - t);
+    }
+    // wavefront / workgroup sums in integer arithmetic: order-independent
+    for (int off = 32; off > 0; off >>= 1) { acc += __shfl_xor(acc, off, 64); bad |= __shfl_xor(bad, off, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = acc; sh[1][threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        out[2 * blockIdx.x + 1] = sh[1][0] | sh[1][1] | sh[1][2] | sh[1][3];
+    }
+}
+void launch_symhash(const double *Q, int64_t ld, int64_t row0, int64_t nrows, int64_t m, unsigned long long *out, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(symhash_kernel, dim3(grid), dim3(256), 0, st, Q, ld, row0, nrows, m, out);
+    check_launch("symhash");
 }
 void launch_asym(const double *Q, int64_t ld, int64_t m, double *out, int grid, hipStream_t st) {
     hipLaunchKernelGGL(asym_kernel, dim3(grid), dim3(256), 0, st, Q, ld, m, out);
@@ -2152,18 +2040,20 @@ void launch_qw_bsr3(int o, int epi, const int64_t *rp, const int32_t *ci, const 
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
         hipLaunchKernelGGL((qw_bsr3_kernel<1, EPI_CERT, 0>), dim3((a.nloc + kBsrRows - 1) / kBsrRows), dim3(256), 0, st, rp, ci, bl, W, alpha, a);
-    } else if (bsr_variant() == 2 && o <= 6) {
+    } else {
+        // o <= 6: blocks AND the gathered records of W staged through LDS (VAR 2); above that the records no longer fit: blocks only (VAR 1)
         switch (o) {
             case 3: qw_bsr3_epi<3, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
             case 4: qw_bsr3_epi<4, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
             case 5: qw_bsr3_epi<5, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
             case 6: qw_bsr3_epi<6, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
-            default: XM_DISPATCH_O(o, (qw_bsr3_epi<O_, 1>(epi, rp, ci, bl, W, alpha, a, st)));
+            case 1: qw_bsr3_epi<1, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
+            case 7: qw_bsr3_epi<7, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
+            case 8: qw_bsr3_epi<8, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
+            case 9: qw_bsr3_epi<9, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
+            case 10: qw_bsr3_epi<10, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
+            default: throw Error(-2, "rank o must be 1 or 3..10, got " + std::to_string(o));
         }
-    } else if (bsr_variant() >= 1) {
-        XM_DISPATCH_O(o, (qw_bsr3_epi<O_, 1>(epi, rp, ci, bl, W, alpha, a, st)));
-    } else {
-        XM_DISPATCH_O(o, (qw_bsr3_epi<O_, 0>(epi, rp, ci, bl, W, alpha, a, st)));
     }
     check_launch("qw_bsr3");
 }
@@ -2238,8 +2128,9 @@ void launch_recover_gram(int64_t n, int r, const double *R, const double *s, dou
     check_launch("recover_gram");
 }
 void launch_recover_project(int64_t n, int r, const double *R, const double *s, const double *V, double *rot, double *scale, int *negcount,
-                            hipStream_t st) {
-    hipLaunchKernelGGL(recover_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, r, R, s, V, rot, scale, negcount);
+                            hipStream_t st, int variant) {
+    if (variant == 1) hipLaunchKernelGGL(recover_project_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, r, R, s, V, rot, scale, negcount);
+    else hipLaunchKernelGGL(recover_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, r, R, s, V, rot, scale, negcount);
     check_launch("recover_project");
 }
 void launch_negate(double *x, int64_t len, hipStream_t st) {

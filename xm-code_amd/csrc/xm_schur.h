@@ -28,11 +28,17 @@ constexpr int64_t kSchurMaxCams = 40000;   // (N-1)^2 inverse + workspace = 3 x 
 
 // A (device, column-major n x n, lower triangle read) -> Cholesky factor; X <- the LOWER triangle of A^-1 (above the diagonal: scratch).
 // false: not positive definite
-bool spd_inverse_device(int n, double *A, double *X, hipStream_t st);
+bool spd_inverse_device(int n, double *A, double *X, hipStream_t st, bool trace = false);   // trace: phase times on stderr
 // dst (row-major n x n, leading dimension ldd) <- the full symmetric inverse from X's lower triangle
 void spd_inverse_layout(int n, const double *X, double *dst, int64_t ldd, hipStream_t st);
 // A (device, column-major n x n) -= q * u u^T  (u: device, n doubles)
 void rank1_sub_device(int n, double *A, const double *u, double q, hipStream_t st);
+
+struct SchurSettings {          // from xm_tuning_t (Settings::resolve)
+    bool host_assembly = false; // assemble the reduced camera Laplacian on the host (the reference's route, utils/creatematrix.py:137-260; tests)
+    int64_t sym_min_rows = 6144; // VT^-1 is applied with the half-traffic symmetric kernel from this many rows on
+    bool trace = false;         // set-up phase times on stderr (scripts/kbench_schur.py)
+};
 
 class SchurOp {
 public:
@@ -41,7 +47,7 @@ public:
     // the landmark kernels, multiplies its own rows of VT^-1 only and all-gathers x_cam; the last kernel runs for the rank's cameras
     // (CamArgs.nloc / cam0)
     SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *cam, const int32_t *lm, const double *p, const double *w,
-            hipStream_t st, Comm *comm = nullptr);
+            hipStream_t st, Comm *comm = nullptr, const SchurSettings &cfg = SchurSettings());
     // Y = alpha * Q * W for all n cameras (W: camera records of 3 * pitch_of(o) doubles), same CamArgs / epilogue contract and
     // per-workgroup partial sums (grid qw_grid(n)) as launch_qw_dense
     void product(int o, int epi, const double *W, double alpha, const CamArgs &a, hipStream_t st);
@@ -88,6 +94,7 @@ private:
     DevBuf<int64_t> pos_c_dev_, dpos_l_dev_;
     DevBuf<double> w_in_, q2_;
     bool dup_pairs_ = false;
+    SchurSettings cfg_;
     std::vector<int64_t> hub_lm_, hub_obs_ptr_, hub_obs_;
     void set_weights_device(const double *w, hipStream_t st);
 };

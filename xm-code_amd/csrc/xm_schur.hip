@@ -333,7 +333,8 @@ __global__ __launch_bounds__(64) void schur_vt_rows_kernel(int64_t mr, int64_t c
 // host: factors from the observation list (utils/creatematrix.py:62-175, restated on the observation level)
 // ------------------------------------------------------------------------------------------------------------------
 SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *cam, const int32_t *lm, const double *p, const double *w,
-                 hipStream_t st, Comm *comm) {
+                 hipStream_t st, Comm *comm, const SchurSettings &cfg) {
+    cfg_ = cfg;
     comm_ = (comm && comm->active()) ? comm : nullptr;
     world_ = comm_ ? comm_->world : 1;
     rank_ = comm_ ? comm_->rank : 0;
@@ -411,8 +412,7 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
                 if (seen[(size_t)b] == l) { dup_pairs_ = true; break; }
                 seen[(size_t)b] = l;
             }
-        static const bool force_host = [] { const char *e = std::getenv("XM_SCHUR_HOST_ASSEMBLY"); return e && *e == '1'; }();
-        if (force_host) dup_pairs_ = true;
+        if (cfg_.host_assembly) dup_pairs_ = true;
     }
     hub_lm_.clear(); hub_obs_ptr_.assign(1, 0); hub_obs_.clear();   // heavy landmarks: their observations (input indices), for the rank-1 terms
     {
@@ -448,7 +448,7 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
     if (!w) throw Error(XM_ERR_ARG, "matrix-free Q: null weights");
     if (!dup_pairs_) { set_weights_device(w, st); return; }
     const int64_t N = n_, M = m_, nobs = nobs_;
-    static const bool trace = [] { const char *e = std::getenv("XM_SCHUR_TRACE"); return e && *e == '1'; }();   // set-up phase times on stderr
+    const bool trace = cfg_.trace;   // set-up phase times on stderr
     auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -535,7 +535,7 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
         }
         XM_HIP_CHECK(hipStreamSynchronize(st));
         lap("hub rank-1 terms (device)");
-        if (!spd_inverse_device((int)mr, tmp.p, inv.p, st))
+        if (!spd_inverse_device((int)mr, tmp.p, inv.p, st, cfg_.trace))
             throw Error(XM_ERR_ARG, "matrix-free Q: the reduced camera Laplacian is not positive definite (observation graph not connected?)");
         lap("SPD inverse (device)");
         spd_inverse_layout((int)mr, inv.p, vtinv_.p, ldv_, st);
@@ -548,7 +548,7 @@ void SchurOp::set_weights(const double *w, hipStream_t st) {
 // needed 0.2 + 0.3 s for them at 13 682 cameras and 0.18 s to ship the 1.5 GB matrix), hub landmarks as rank-1 terms, inverse, layout.
 void SchurOp::set_weights_device(const double *w, hipStream_t st) {
     const int64_t N = n_, M = m_, nobs = nobs_;
-    static const bool trace = [] { const char *e = std::getenv("XM_SCHUR_TRACE"); return e && *e == '1'; }();
+    const bool trace = cfg_.trace;
     auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -613,7 +613,7 @@ void SchurOp::set_weights_device(const double *w, hipStream_t st) {
         }
     }
     lap("hub rank-1 terms (device)");
-    if (!spd_inverse_device((int)mr, tmp.p, inv.p, st))
+    if (!spd_inverse_device((int)mr, tmp.p, inv.p, st, cfg_.trace))
         throw Error(XM_ERR_ARG, "matrix-free Q: the reduced camera Laplacian is not positive definite (observation graph not connected?)");
     lap("SPD inverse (device)");
     spd_inverse_layout((int)mr, inv.p, vtinv_.p, ldv_, st);
@@ -693,10 +693,9 @@ void SchurOp::ensure(int o) {
     h_.alloc((size_t)m_ * OP); xl_.alloc((size_t)m_ * OP);
     r_.alloc((size_t)ldv_ * OP + 2);            // product input of the dense kernel: ldv rows, zero beyond N-1
     xc_.alloc((size_t)3 * nred_pad_ * OP + 2);
-    // VT^-1 is symmetric: above XM_SCHUR_SYM_MIN_ROWS rows (default 6144, the threshold of the dense solver) the chain applies it with
-    // the half-traffic kernel (upper triangle only; o = 3, 4)
-    static const int64_t sym_min = [] { const char *e = std::getenv("XM_SCHUR_SYM_MIN_ROWS"); return (e && *e) ? (int64_t)std::atoll(e) : (int64_t)6144; }();
-    vt_sym_ = 3 * nred_ >= sym_min;
+    // VT^-1 is symmetric: from xm_tuning_t.sym_min_rows rows on (default 6144, the threshold of the dense solver) the chain applies it
+    // with the half-traffic kernel (upper triangle only; o = 3, 4)
+    vt_sym_ = 3 * nred_ >= cfg_.sym_min_rows;
     if (vt_sym_ && o >= 3) {
         const int os = std::min(o, 4);
         sym_prow_.alloc(sym_prow_count((int)nred_, ldv_, os));

@@ -77,10 +77,10 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
     }
     out.pptr[(size_t)nloc] = slot;
     out.nparts = slot;
-    // Where a partial result is STORED: XM_SELL_SLOTS=0 at its list position (row-major: the lanes of a slice scatter 72-byte records
-    // over the whole array), 1 (default) at slice * 64 + lane (the 64 records of a slice are one contiguous 4.6 KB run, written once, by
-    // one wavefront; the per-camera sum then looks its records up through ridx).
-    static const bool slice_order = [] { const char *e = std::getenv("XM_SELL_SLOTS"); return !(e && *e == '0'); }();
+    // A partial result is STORED at slice * 64 + lane: the 64 records of a slice are one contiguous 4.6 KB run, written once, by one
+    // wavefront; the per-camera sum looks its records up through ridx.  (Storing at the list position -- the lanes of a slice scatter
+    // 72-byte records over the whole array -- cost the main launch 20 instead of 9 us at 100 k cameras, HISTORY.md section 2.5.)
+    constexpr bool slice_order = true;
     out.ridx.assign((size_t)std::max<int64_t>(slot, 1), 0);
     // per slab: stable counting sort by length (descending), then slices of 64
     out.slab_start.assign((size_t)S + 1, 0);
@@ -225,10 +225,7 @@ SellMatrix::SellMatrix(const int64_t *rowptr, const int32_t *colidx, const doubl
     max_list_ = 0;
     for (int64_t r = 0; r < nloc; ++r) max_list_ = std::max<int64_t>(max_list_, h.pptr[(size_t)r + 1] - h.pptr[(size_t)r]);
     nloc_ = nloc; nparts_ = h.nstore; nsteps_ = h.nsteps; nslices_ = h.nslices; S_ = S;
-    {   // XM_SELL_CSTORE=0 keeps the per-lane 72-byte record stores (needs the slice-order slots)
-        const char *e = std::getenv("XM_SELL_CSTORE");
-        coalesced_ = h.slice_order && !(e && *e == '0');
-    }
+    coalesced_ = h.slice_order;
     const int64_t b0 = rowptr[0], nb = rowptr[nloc] - b0;
     slice_off_.alloc(h.slice_off.size(), false);
     slab_start_.alloc(h.slab_start.size(), false);
@@ -297,8 +294,7 @@ SellArgs SellMatrix::args() const {
     a.diag = (codec_ == SELL_CODEC_QUAT) ? diag_.p : nullptr;
     a.row0 = row0_;
     a.wstride = 0;   // set per rank by the launcher (wstride(o))
-    static const bool wt = [] { const char *e = std::getenv("XM_SELL_WT"); return e && *e == '1'; }();   // experiment: write-through partial stores
-    a.coalesced_store = coalesced_ ? (wt ? 2 : 1) : 0;
+    a.coalesced_store = coalesced_ ? 1 : 0;
     return a;
 }
 
@@ -323,37 +319,22 @@ typedef double d2a __attribute__((ext_vector_type(2)));               // 16-byte
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));   // pair at 8-byte alignment (records of W)
 typedef int i2a __attribute__((ext_vector_type(2)));
 
-// gather mode 4: instruction I of a step's sector-window fetch (o = 3).  Lane group g = lane >> 3 takes record 8 g + I (its column sits in
-// lane (lane & 0x38) | I: one ds_swizzle in bit-mask mode) and lane (lane & 7) loads 16 bytes of the record's 128-byte window of two
-// 64-byte-aligned sectors: a quad reads exactly one aligned sector, so a record costs exactly two cache accesses.
-// MEASURED (profiles/r04_pmc_sell_gather_accesses.txt, r04_kbench_sell_gather4.txt): 13.76 M vector-L1 accesses per product instead of
-// 16.14 M, the SAME 8.66 M requests to the L2 and the same duration (82.0-82.2 against 82.8-83.8 us; banded graph 70.6 against 62.1) --
-// the product is not bound by the access count.  What the counters of the default kernel say (r04_pmc_sell_diag2_memory_path.json): the
-// vector L1 waits for L2 data in 61 % of its active cycles with on average 74 lines outstanding per CU (8.66 M requests x 388 cycles /
-// 178 k cycles / 256 CUs) -- 1.54 M stream lines at ~1 380 cycles (HBM) hold 63 % of those slots, 7.1 M gathered lines at ~173 cycles
-// (L2 hits) the rest; L2 tag stalls, TLB misses and request-path stalls are ~0.  Resident wavefronts (LDS halved, o = 4 / 5 at three
-// instead of two workgroups per CU) and the L1 policy of the gathered lines (sc1, sc0 sc1) change the duration by < 2 %
-// (r04_kbench_sell_lds_occ.txt, r04_kbench_sell_cache_policy.txt; nt on the gather evicts W from the L2: 123-128 us), and a kernel
-// that only LOADS (no codec, LDS or FMA work) takes the same 81-82 us (r04_kbench_sell_loads_only.txt): the duration follows the number
-// of LINES requested times their latency.  What does shorten it is fewer lines per record: W at a 128-byte record pitch (Wpad16 of
-// launch_qw_sell) -- 5.09 M instead of 7.1 M gathered lines, main launch 72.8 -> 63.6 us.
-template <int I>
-__device__ __forceinline__ d2a sell_window_load(int j, const double *__restrict__ W, int piece) {
-    const int jr = __builtin_amdgcn_ds_swizzle(j, 0x18 | (I << 5));
-    const unsigned boff = ((((unsigned)jr * 9u) & ~7u) + 2u * (unsigned)piece) * 8u;   // 32-bit byte offset + uniform base
-    return *reinterpret_cast<const d2a *>(reinterpret_cast<const char *>(W) + boff);
-}
-
+// What bounds the gather (profiles/r04_pmc_sell_diag2_memory_path.json, r04_pmc_sell_gather_accesses.txt): the vector L1 waits for L2 data
+// in 61 % of its active cycles with on average 74 lines outstanding per CU -- 1.54 M stream lines at ~1 380 cycles (HBM) hold 63 % of
+// those slots, 7.1 M gathered lines at ~173 cycles (L2 hits) the rest; a kernel that only LOADS takes the same 81-82 us
+// (r04_kbench_sell_loads_only.txt).  The duration follows the LINES requested times their latency, so what shortens it is fewer lines per
+// record: W at a 128-byte record pitch (Wpad16 of launch_qw_sell) -- 5.09 M instead of 7.1 M gathered lines, main launch 72.8 -> 63.6 us.
+// Sector-window gathers (through LDS-DMA, or into registers), 8-byte element fetches, cache-policy bits on the gathered lines and a
+// one-launch chunk-tiled layout were all measured slower or equal and are gone from the sources (HISTORY.md, "Round 4").
 template <int O, int GM, int NQ = 9>
 struct SellBuf {   // one pipeline stage: two steps of blocks and the two gathered records of W
     static constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2;
     d2a q[NQ];
     double w[2][(GM == 0) ? REC : 1];
     d2u raw[2][(GM == 1) ? NPR : 1];
-    d2a win[2][(GM == 4) ? 8 : 1];
 };
 
-template <int O, int GM, int ABL = 0, int PIPE = 0, int CODEC = 0>   // PIPE 1: block loads run one pair ahead.  ABL: ablation bits for timing experiments (1 no block loads, 2 no gather, 4 no partial store, 8 loads only: no codec / LDS / FMA work).  CODEC: SELL_CODEC_*
+template <int O, int GM, int PIPE = 0, int CODEC = 0>   // GM 0: a record of W per lane | 1: records fetched element-per-lane, transposed through LDS.  PIPE 1: block loads run one pair ahead.  CODEC: SELL_CODEC_*
 __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
                                              double *__restrict__ parts) {
     constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2, RECP = (REC + 1) & ~1;
@@ -364,7 +345,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     // ONE transposition buffer per wavefront (the two steps of a pair go through it one after the other; transpose1 ends with a wavefront
     // fence): 20 KB per workgroup at o = 3, 32 KB at o = 4 / 5 -- with one buffer per step (40 / 64 KB) the LDS, not the registers, capped
     // the resident workgroups per CU (o = 4 / 5: two)
-    __shared__ __attribute__((aligned(16))) double lds[(GM == 4) ? 4 * 8 * 130 : (GM != 0) ? 4 * 64 * RECP : 2];
+    __shared__ __attribute__((aligned(16))) double lds[(GM != 0) ? 4 * 64 * RECP : 2];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int per = 8 / m.S;
     const int x = blockIdx.x & 7, bi = blockIdx.x >> 3;
@@ -377,7 +358,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     const bool tail = (w & 1) != 0;
     const int32_t *cb = m.cols + off * 64;
     const double *bb = m.blk + off * (64 * NQ);
-    double *L = lds + ((GM == 4) ? wave * 8 * 130 : (GM != 0) ? wave * 64 * RECP : 0);
+    double *L = lds + ((GM != 0) ? wave * 64 * RECP : 0);
 
     double acc[3][O];
 #pragma unroll
@@ -389,10 +370,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     auto load_blk = [&](int p, d2a (&q)[NQ]) {
         const d2a *b = reinterpret_cast<const d2a *>(bb) + (size_t)p * (64 * NQ) + lane;
 #pragma unroll
-        for (int e = 0; e < NQ; ++e) {
-            if constexpr (ABL & 1) { q[e] = d2a{(double)(lane + e), (double)(p - e)}; asm volatile("" : "+v"(q[e])); }
-            else q[e] = __builtin_nontemporal_load(b + e * 64);
-        }
+        for (int e = 0; e < NQ; ++e) q[e] = __builtin_nontemporal_load(b + e * 64);
     };
     // stored planes of one pair -> the two 3x3 blocks (codec 0: the planes ARE the blocks; quaternion codec: -R(q), 23 flops each)
     auto expand = [&](const d2a (&q)[NQ], double (&q0)[9], double (&q1)[9]) {
@@ -446,27 +424,6 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    // GM 4 (o = 3, native stride, W 64-byte aligned): aligned sector windows, two cache accesses per record (modes 1 / 3: ~2.5)
-    auto gather4 = [&](int j, d2a (&win)[8]) {
-        const int piece = lane & 7;
-        win[0] = sell_window_load<0>(j, W, piece); win[1] = sell_window_load<1>(j, W, piece);
-        win[2] = sell_window_load<2>(j, W, piece); win[3] = sell_window_load<3>(j, W, piece);
-        win[4] = sell_window_load<4>(j, W, piece); win[5] = sell_window_load<5>(j, W, piece);
-        win[6] = sell_window_load<6>(j, W, piece); win[7] = sell_window_load<7>(j, W, piece);
-    };
-    auto transpose4 = [&](const d2a (&win)[8], double *Ls, int j, double (&wv)[REC]) {
-        // instruction slabs of 64 x 16 bytes + 16 bytes of skew; record r = lane sits in slab (r & 7) at lane group (r >> 3), and starts
-        // (column mod 8) doubles into its window ((column * 9) mod 8 == column mod 8)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<d2a *>(Ls + i * 130 + lane * 2) = win[i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const double *src = Ls + (lane & 7) * 130 + (lane >> 3) * 16 + (j & 7);
-#pragma unroll
-        for (int e = 0; e < REC; ++e) wv[e] = src[e];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
     auto fma_step = [&](const double (&q)[9], const double (&wv)[REC]) {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -475,19 +432,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
                 acc[r][k] = fma(q[3 * r + 2], wv[2 * OP + k], fma(q[3 * r + 1], wv[OP + k], fma(q[3 * r], wv[k], acc[r][k])));
     };
     auto gather_pair = [&](const i2a j, SellBuf<O, GM, NQ> &B) {
-        if constexpr (ABL & 2) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if constexpr (GM == 0) {
-#pragma unroll
-                    for (int i = 0; i < REC; ++i) { B.w[h][i] = (double)(h ? j.y : j.x) + i; asm volatile("" : "+v"(B.w[h][i])); }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NPR; ++i) { B.raw[h][i] = d2u{(double)(h ? j.y : j.x), (double)i}; asm volatile("" : "+v"(B.raw[h][i])); }
-                }
-            }
-        } else if constexpr (GM == 0) { gather0(j.x, B.w[0]); gather0(j.y, B.w[1]); }
-        else if constexpr (GM == 4) { gather4(j.x, B.win[0]); gather4(j.y, B.win[1]); }
+        if constexpr (GM == 0) { gather0(j.x, B.w[0]); gather0(j.y, B.w[1]); }
         else { gather1(j.x, B.raw[0]); gather1(j.y, B.raw[1]); }
     };
 
@@ -514,12 +459,6 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             if constexpr (GM == 0) {
                 fma_step(q0, A.w[0]);
                 fma_step(q1, A.w[1]);
-            } else if constexpr (GM == 4) {
-                double w0[REC];
-                transpose4(A.win[0], L, jc.x, w0);
-                fma_step(q0, w0);
-                transpose4(A.win[1], L, jc.y, w0);
-                fma_step(q1, w0);
             } else {
                 double w0[REC];
                 transpose1(A.raw[0], L, w0);
@@ -555,26 +494,11 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             gather_pair(jc, A);
             __builtin_amdgcn_sched_barrier(0);   // every load of the pair is in flight before the first FMA (the scheduler would
                                                  // otherwise trickle them to save registers: 4-5 dependent round trips per pair)
-            if constexpr ((ABL & 8) != 0 && GM == 1) {   // traffic only: every loaded value is consumed by one add (no codec, LDS or FMA work)
-#pragma unroll
-                for (int e = 0; e < NQ; ++e) acc[0][0] += A.q[e].x + A.q[e].y;
-#pragma unroll
-                for (int i = 0; i < NPR; ++i) acc[1][0] += (A.raw[0][i].x + A.raw[0][i].y) + (A.raw[1][i].x + A.raw[1][i].y);
-                asm volatile("" : "+v"(jn.x), "+v"(jn.y));
-                jc = jn;
-                continue;
-            }
             double q0[9], q1[9];
             expand(A.q, q0, q1);
             if constexpr (GM == 0) {
                 fma_step(q0, A.w[0]);
                 fma_step(q1, A.w[1]);
-            } else if constexpr (GM == 4) {
-                double w0[REC];
-                transpose4(A.win[0], L, jc.x, w0);
-                fma_step(q0, w0);
-                transpose4(A.win[1], L, jc.y, w0);
-                fma_step(q1, w0);
             } else {
                 double w0[REC];
                 transpose1(A.raw[0], L, w0);
@@ -605,12 +529,6 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             double wt[REC];
             gather0(jt, wt);
             fma_step(qt, wt);
-        } else if constexpr (GM == 4) {
-            d2a wint[8];
-            double w0[REC];
-            gather4(jt, wint);
-            transpose4(wint, L, jt, w0);
-            fma_step(qt, w0);
         } else {
             d2u rawt[NPR];
             double w0[REC];
@@ -619,7 +537,7 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
             fma_step(qt, w0);
         }
     }
-    if constexpr (GM != 0 && !(ABL & 4)) {
+    if constexpr (GM != 0) {
         if (m.coalesced_store) {
             // the 64 records of the slice are one contiguous run of 64 * 3 * O doubles (slot = slice * 64 + lane): transposed through
             // LDS and written with lane-consecutive 16-byte stores (5 fully coalesced instructions at o = 3) instead of 3 * O
@@ -636,193 +554,10 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
 #pragma unroll
             for (int i = 0; i < (TOT2 + 63) / 64; ++i) {
                 const int idx = i * 64 + lane;
-                if (idx < TOT2) {
-                    // write-through: nothing of the partial results is left dirty in the L2 for the end of the launch to write back
-                    if (m.coalesced_store == 2) { const d2a v = l2[idx]; asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o2 + idx), "v"(v) : "memory"); }
-                    else o2[idx] = l2[idx];
-                }
+                if (idx < TOT2) o2[idx] = l2[idx];
             }
             return;
         }
-    }
-    const int slot = m.pslot[(size_t)c * 64 + lane];
-    if constexpr (ABL & 4) {
-        double t = 0.0;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < O; ++k) t += acc[r][k];
-        if (t == 1.2345e-300) parts[0] = t;   // keeps the accumulators alive
-    } else if (slot >= 0) {
-        double *o = parts + (size_t)slot * 3 * O;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < O; ++k) o[r * O + k] = acc[r][k];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Gather mode 2 (o = 3): SECTOR WINDOWS THROUGH LDS-DMA.  MEASURED SLOWER than mode 1 (profiles/r04_kbench_sell_gather2.txt: 100 k cameras
-// 88.2 against 82.8 us with the view-graph codec, 115.0 against 110.5 with full blocks, banded graph 76.2 against 61.8) and therefore not the
-// default; kept selectable because it is the exact "two accesses per record" form.  The idea: what bounds modes 0 / 1 is the texture data path of the gather (PMC,
-// profiles/r04_pmc_sell_diag_layout1.json: TD busy 78 % of the launch, 16.1 M 64-byte cache accesses per product = 2.47 per gathered
-// record): the lanes that fetch one 72-byte record sit in two different quads of a load instruction, and the unit coalesces inside a
-// quad, so a record costs 2.5-3 accesses for the 2 sectors it occupies.  Here a record (always inside ONE 128-byte window of two aligned
-// sectors: the stride is 72 = 64 + 8 bytes and W is 64-byte aligned) is fetched by EIGHT lanes = two quads that each read one whole
-// aligned sector -- exactly 2 accesses per record -- with global_load_lds_dwordx4: the data lands in LDS at lane * 16 bytes, i.e. already
-// record after record (no VGPRs, no ds_write instruction), and lane L picks its 9 doubles at offset (column & 7) of its window.
-// One step of 64 records = 8 such instructions (instruction i takes record 8 g + i in lane group g: the column index comes from lane
-// (g << 3 | i) with ONE ds_swizzle).  The windows of step k + 1 are in flight while the FMAs of step k run; one 8.1 KB buffer per
-// wavefront (the instruction slabs are skewed by 16 bytes so that lanes with equal window offsets do not meet on one bank).
-// ------------------------------------------------------------------------------------------------------------------
-// instruction I of a step's window fetch: lane group g = lane >> 3 takes record 8 g + I, whose column sits in lane (lane & 0x38) | I
-template <int I>
-__device__ __forceinline__ void sell_fetch_window(int j, const double *__restrict__ W, int piece, double *slab0) {
-    const int jr = __builtin_amdgcn_ds_swizzle(j, 0x18 | (I << 5));   // bit-mask mode inside each half of the wavefront: and 0x18, or I
-    const double *win = W + (((size_t)jr * 9) & ~(size_t)7) + 2 * piece;
-    __builtin_amdgcn_global_load_lds(win, (__attribute__((address_space(3))) void *)(slab0 + I * 130), 16, 0, 0);
-}
-
-template <int CODEC>
-__device__ __forceinline__ void qw_sell_body_g2(const SellArgs &m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
-                                                double *__restrict__ parts) {
-    constexpr int O = 3, REC = 9, NV = 9;
-    constexpr int NQ = (CODEC == SELL_CODEC_QUAT) ? 4 : 9;
-    constexpr int SLAB = 130;            // doubles per instruction slab: 64 lanes x 16 bytes + 16 bytes of skew
-    constexpr int TW = 8 * SLAB;         // per wavefront
-    if (scal != nullptr) {
-        if (scal->status != 0) return;
-    }
-    __shared__ __attribute__((aligned(16))) double lds[4 * TW];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int per = 8 / m.S;
-    const int x = blockIdx.x & 7, bi = blockIdx.x >> 3;
-    const int slab = x / per, sub = x - slab * per;
-    const int c = m.slab_start[slab] + (bi * per + sub) * 4 + wave;
-    if (c >= m.slab_start[slab + 1]) return;   // wave-uniform
-    const int64_t off = m.slice_off[c];
-    const int w = (int)(m.slice_off[c + 1] - off);
-    const int np = w >> 1;
-    const bool tail = (w & 1) != 0;
-    const int32_t *cb = m.cols + off * 64;
-    const double *bb = m.blk + off * (64 * NQ);
-    double *T = lds + wave * TW;
-    const int piece = lane & 7;
-    // where this lane's own record starts inside its slab: record r = lane sits in slab (r & 7), lane group (r >> 3)
-    const double *mine = T + (lane & 7) * SLAB + (lane >> 3) * 16;
-
-    double acc[3][O];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
-
-    auto load_cols = [&](int p) -> i2a { return __builtin_nontemporal_load(reinterpret_cast<const i2a *>(cb) + (size_t)p * 64 + lane); };
-    auto load_blk = [&](int p, d2a (&q)[NQ]) {
-        const d2a *b = reinterpret_cast<const d2a *>(bb) + (size_t)p * (64 * NQ) + lane;
-#pragma unroll
-        for (int e = 0; e < NQ; ++e) q[e] = __builtin_nontemporal_load(b + e * 64);
-    };
-    // the 64 windows of one step -> LDS (8 instructions; nothing lands in registers)
-    auto fetch = [&](int j) {
-        sell_fetch_window<0>(j, W, piece, T); sell_fetch_window<1>(j, W, piece, T); sell_fetch_window<2>(j, W, piece, T);
-        sell_fetch_window<3>(j, W, piece, T); sell_fetch_window<4>(j, W, piece, T); sell_fetch_window<5>(j, W, piece, T);
-        sell_fetch_window<6>(j, W, piece, T); sell_fetch_window<7>(j, W, piece, T);
-    };
-    auto landed = [&]() {   // every window (and every block load issued before) has arrived; the LDS reads below may not move above this
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto take = [&](int j, double (&wv)[REC]) {
-        const double *src = mine + (j & 7);   // (column * 9) mod 8 == column mod 8: the record's offset inside its window, in doubles
-#pragma unroll
-        for (int e = 0; e < REC; ++e) wv[e] = src[e];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads have been SERVED before the next windows are requested into the same buffer
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();   // everybody has its record: the buffer may be refilled
-    };
-    auto fma_step = [&](const double (&q)[9], const double (&wv)[REC]) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < O; ++k)
-                acc[r][k] = fma(q[3 * r + 2], wv[2 * O + k], fma(q[3 * r + 1], wv[O + k], fma(q[3 * r], wv[k], acc[r][k])));
-    };
-    auto expand_x = [&](const d2a (&q)[NQ], double (&q0)[9]) {
-        if constexpr (CODEC == SELL_CODEC_QUAT) quat_to_block(q[0].x, q[1].x, q[2].x, q[3].x, q0);
-        else {
-#pragma unroll
-            for (int e = 0; e < 9; ++e) q0[e] = q[e].x;
-        }
-    };
-    auto expand_y = [&](const d2a (&q)[NQ], double (&q1)[9]) {
-        if constexpr (CODEC == SELL_CODEC_QUAT) quat_to_block(q[0].y, q[1].y, q[2].y, q[3].y, q1);
-        else {
-#pragma unroll
-            for (int e = 0; e < 9; ++e) q1[e] = q[e].y;
-        }
-    };
-    int jt = 0;
-    if (tail) jt = __builtin_nontemporal_load(cb + (size_t)np * 128 + lane);
-    if (np > 0) {
-        d2a q[NQ];
-        i2a jc = load_cols(0);
-        load_blk(0, q);
-        fetch(jc.x);
-        for (int p = 0; p < np; ++p) {
-            const bool more = (p + 1 < np);
-            i2a jn = load_cols(more ? p + 1 : p);   // clamped, unconditional
-            double qe[9], wv[REC];
-            landed();                 // step 2p (and the pair's blocks)
-            take(jc.x, wv);
-            fetch(jc.y);              // step 2p + 1 travels while step 2p is multiplied
-            expand_x(q, qe);
-            fma_step(qe, wv);
-            landed();                 // step 2p + 1 (and jn)
-            take(jc.y, wv);
-            expand_y(q, qe);          // the stored pair is consumed: its registers take the next pair's blocks
-            if (more) { load_blk(p + 1, q); fetch(jn.x); }
-            else if (tail) fetch(jt);
-            fma_step(qe, wv);
-            jc = jn;
-        }
-    } else if (tail) {
-        fetch(jt);
-    }
-    if (tail) {
-        double qt[9], wv[REC];
-        const double *b = bb + (size_t)np * (128 * NQ) + lane;
-        if constexpr (CODEC == SELL_CODEC_QUAT) {
-            double t4[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t4[e] = __builtin_nontemporal_load(b + e * 64);
-            quat_to_block(t4[0], t4[1], t4[2], t4[3], qt);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 9; ++e) qt[e] = __builtin_nontemporal_load(b + e * 64);
-        }
-        landed();
-        take(jt, wv);
-        fma_step(qt, wv);
-    }
-    if (m.coalesced_store) {   // as in the other modes: one contiguous run of 64 x 9 doubles per slice, through LDS
-        constexpr int TOT2 = 64 * NV / 2;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < O; ++k) T[lane * NV + r * O + k] = acc[r][k];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        d2a *o2 = reinterpret_cast<d2a *>(parts + (size_t)c * 64 * NV);
-        const d2a *l2 = reinterpret_cast<const d2a *>(T);
-#pragma unroll
-        for (int i = 0; i < (TOT2 + 63) / 64; ++i) {
-            const int idx = i * 64 + lane;
-            if (idx < TOT2) o2[idx] = l2[idx];
-        }
-        return;
     }
     const int slot = m.pslot[(size_t)c * 64 + lane];
     if (slot >= 0) {
@@ -833,31 +568,19 @@ __device__ __forceinline__ void qw_sell_body_g2(const SellArgs &m, const double 
             for (int k = 0; k < O; ++k) o[r * O + k] = acc[r][k];
     }
 }
-template <int CODEC>
-__global__ __launch_bounds__(256) void qw_sell_g2_kernel(SellArgs m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
-                                                          double *__restrict__ parts) {
-    qw_sell_body_g2<CODEC>(m, W, scal, parts);
-}
 
-template <int O, int GM, int ABL = 0, int PIPE = 0, int CODEC = 0>
+template <int O, int GM, int PIPE = 0, int CODEC = 0>
 __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
                                                        double *__restrict__ parts) {
-    qw_sell_body<O, GM, ABL, PIPE, CODEC>(m, W, scal, parts);
+    qw_sell_body<O, GM, PIPE, CODEC>(m, W, scal, parts);
 }
-// quaternion codec compiled for FOUR wavefronts per SIMD (the blocks of a pair are 16 registers instead of 36)
-template <int O, int GM, int PIPE>
+// quaternion codec at o = 3 compiled for FOUR wavefronts per SIMD (the blocks of a pair are 16 registers instead of 36), no software pipeline:
+// 81.9 us against 82.4 (two wavefronts, no pipeline) / 84.2 (block loads one pair ahead) at 100 k cameras (profiles/r03_kbench_sell.txt)
+template <int GM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void qw_sell_kernel_q_occ4(SellArgs m, const double *__restrict__ W,
                                                                                                       const TcgScal *__restrict__ scal,
                                                                                                       double *__restrict__ parts) {
-    qw_sell_body<O, GM, 0, PIPE, SELL_CODEC_QUAT>(m, W, scal, parts);
-}
-// the same body compiled for FOUR wavefronts per SIMD (<= 128 VGPRs; XM_SELL_PIPE=2): the product is bound by the bytes a CU keeps
-// in flight (PMC: 64 % of the wave cycles wait on memory, ~6 wavefronts resident per CU), not by issue slots
-template <int O, int GM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void qw_sell_kernel_occ4(SellArgs m, const double *__restrict__ W,
-                                                                                                    const TcgScal *__restrict__ scal,
-                                                                                                    double *__restrict__ parts) {
-    qw_sell_body<O, GM, 0, 0>(m, W, scal, parts);
+    qw_sell_body<3, GM, 0, SELL_CODEC_QUAT>(m, W, scal, parts);
 }
 
 // per camera: partial results added in list order (fixed -> bit-reproducible), then the common tail of the Q*W kernels
@@ -897,7 +620,10 @@ __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restr
 #pragma unroll
                 for (int k = 0; k < O; ++k) acc[r][k] += v[r * O + k];
         }
-        if (diag != nullptr && gl == GW - 1) {   // quaternion codec: the diagonal block d * I was left out of the slices (last lane: it has the fewest list entries)
+        // quaternion codec: the diagonal block d * I was left out of the slices.  Inside the single-rank tCG (Hessian epilogue, no exchange
+        // image) the term is added after the group sum from the epilogue's own operands (W_i = s_i p_i + ps_i R_i: no read of W, 7.2 MB per
+        // product at 100 k cameras); everywhere else the last lane (it has the fewest list entries) reads the camera's record of W
+        if (diag != nullptr && !(EPI == EPI_HESS && a.Bout == nullptr) && gl == GW - 1) {
             constexpr int OPW = pitch_of(O);
             const double d = diag[cam];
             const double *w = W + (size_t)(row0 + cam) * wstride;
@@ -905,6 +631,26 @@ __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restr
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int k = 0; k < O; ++k) acc[r][k] = fma(d, w[r * OPW + k], acc[r][k]);
+        }
+    }
+    if constexpr (EPI == EPI_HESS) {
+        if (diag != nullptr && a.Bout == nullptr) {
+            Col3 h;
+            h.v[0] = h.v[1] = h.v[2] = 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    const double t = group_sum<GW>(acc[r][k]);
+                    if (gl == k) h.v[r] = t;
+                }
+            if (active && gl < O) {
+                const double d = diag[cam];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) h.v[r] = alpha * fma(d, eops.s * eops.P.v[r] + eops.ps * eops.R.v[r], h.v[r]);
+            }
+            qw_tail<O, EPI, GW, NSLOT>(cam, gl, slot, active, h, a, eops, red);
+            return;
         }
     }
     qw_finish<O, EPI, GW, NSLOT>(cam, gl, slot, active, acc, alpha, a, eops, red);
@@ -933,70 +679,22 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
     if (padded) { sa.wstride = 16; W = Wpad16; }
     if (m.grid() > 0) {
         const dim3 g(m.grid()), b(256);
-        static const int abl = [] { const char *e = std::getenv("XM_SELL_ABLATE"); return (e && *e) ? std::atoi(e) : 0; }();   // timing experiments only
-        if constexpr (O == 3) {
-            if (abl != 0 && !quat) {
-#define XM_ABL_CASE(G, A) if (gm == G && abl == A) hipLaunchKernelGGL((qw_sell_kernel<3, G, A>), g, b, 0, st, sa, W, sc, parts);
-                XM_ABL_CASE(0, 1) XM_ABL_CASE(0, 2) XM_ABL_CASE(0, 3) XM_ABL_CASE(0, 4) XM_ABL_CASE(0, 6) XM_ABL_CASE(0, 7)
-                XM_ABL_CASE(1, 1) XM_ABL_CASE(1, 2) XM_ABL_CASE(1, 4)
-#undef XM_ABL_CASE
-            }
-            if (abl != 0 && quat) {
-#define XM_ABL_CASE(G, A) if (gm == G && abl == A) hipLaunchKernelGGL((qw_sell_kernel<3, G, A, 0, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
-                XM_ABL_CASE(1, 1) XM_ABL_CASE(1, 2) XM_ABL_CASE(1, 4) XM_ABL_CASE(1, 6) XM_ABL_CASE(1, 8) XM_ABL_CASE(1, 12)
-#undef XM_ABL_CASE
-            }
-        }
-        // block loads one pair ahead: worth 2-3 us at o = 3 with full blocks; beyond that the second block buffer costs the occupancy
-        // (o = 5: 256 VGPRs).  Quaternion codec: a pair of blocks is 16 registers, the second buffer is cheap at every rank.
-        if (gm != 0 && (uint64_t)m.ncols() * (uint64_t)sa.wstride * 8u >= (1ull << 32)) gm = 0;   // modes 1-3 address W with 32-bit byte offsets
-        if (gm == 2 && (O != 3 || sa.wstride != 9 || (reinterpret_cast<uintptr_t>(W) & 63) != 0)) gm = 1;   // sector windows: o = 3, native stride, W 64-byte aligned
-        if constexpr (O == 3) {
-            if (gm == 2 && abl == 0) {
-                if (quat) hipLaunchKernelGGL((qw_sell_g2_kernel<SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
-                else hipLaunchKernelGGL((qw_sell_g2_kernel<SELL_CODEC_FULL>), g, b, 0, st, sa, W, sc, parts);
-            }
-        }
-        static const int pipe_env = [] { const char *e = std::getenv("XM_SELL_PIPE"); return (e && *e) ? std::atoi(e) : -1; }();
-        // measured at 100 k cameras, o = 3 (profiles/r03_kbench_sell.txt): full blocks 111.4 / 111.3 / 110.5 us for pipe 0 / 1 / 2; quaternion
-        // codec 82.4 / 84.2 / 204.8 (spills) / 81.9 us for pipe 0 / 1 / 2 / 3 -> 3 (four wavefronts per SIMD, no software pipeline)
-        const int pipe = (pipe_env >= 0) ? pipe_env : (quat ? (O == 3 ? 3 : 0) : (O == 3 ? 1 : 0));
-        if (gm == 4 && !(O == 3 && quat && pipe == 3)) gm = 1;   // compiled for the view-graph codec at o = 3
-        if (gm == 4 && (sa.wstride != 9 || (reinterpret_cast<uintptr_t>(W) & 63) != 0)) gm = 1;   // sector windows: native stride, W 64-byte aligned   // aligned element fetch: compiled for the view-graph codec at o = 3
-        if (gm == 2 && abl == 0) {
-        } else if (abl == 0 || O != 3) {
-            if (quat) {
-                bool launched = false;
-                if constexpr (O == 3) {   // the four-wavefront variants exist at o = 3 only (o = 4, 5 cannot reach that occupancy)
-                    if (pipe == 2) {          // four wavefronts per SIMD, block loads one pair ahead
-                        if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 1, 1>), g, b, 0, st, sa, W, sc, parts);
-                        else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 0, 1>), g, b, 0, st, sa, W, sc, parts);
-                        launched = true;
-                    } else if (pipe == 3) {   // four wavefronts per SIMD, no software pipeline
-                        if (gm == 4) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 4, 0>), g, b, 0, st, sa, W, sc, parts);
-                        else if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 1, 0>), g, b, 0, st, sa, W, sc, parts);
-                        else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<3, 0, 0>), g, b, 0, st, sa, W, sc, parts);
-                        launched = true;
-                    }
-                }
-                if (launched) {
-                } else if (pipe == 1) {
-                    if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, 0, 1, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
-                    else hipLaunchKernelGGL((qw_sell_kernel<O, 0, 0, 1, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
-                } else {
-                    if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, 0, 0, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
-                    else hipLaunchKernelGGL((qw_sell_kernel<O, 0, 0, 0, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
-                }
-            } else if (pipe == 2 && O == 3) {
-                if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_occ4<3, 1>), g, b, 0, st, sa, W, sc, parts);
-                else hipLaunchKernelGGL((qw_sell_kernel_occ4<3, 0>), g, b, 0, st, sa, W, sc, parts);
-            } else if (pipe == 1) {
-                if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, 0, 1>), g, b, 0, st, sa, W, sc, parts);
-                else hipLaunchKernelGGL((qw_sell_kernel<O, 0, 0, 1>), g, b, 0, st, sa, W, sc, parts);
+        if (gm != 0 && (uint64_t)m.ncols() * (uint64_t)sa.wstride * 8u >= (1ull << 32)) gm = 0;   // mode 1 addresses W with 32-bit byte offsets
+        // Kernel variant by codec and rank (measured at 100 k cameras, profiles/r03_kbench_sell.txt).  Full blocks: the block loads run one
+        // pair ahead at o = 3 (worth 2-3 us); beyond that the second block buffer costs the occupancy (o = 5: 256 VGPRs).  Quaternion
+        // codec: four wavefronts per SIMD without software pipeline at o = 3, the plain body at o = 4, 5.
+        if (quat) {
+            if constexpr (O == 3) {
+                if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<1>), g, b, 0, st, sa, W, sc, parts);
+                else hipLaunchKernelGGL((qw_sell_kernel_q_occ4<0>), g, b, 0, st, sa, W, sc, parts);
             } else {
-                if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1>), g, b, 0, st, sa, W, sc, parts);
-                else hipLaunchKernelGGL((qw_sell_kernel<O, 0>), g, b, 0, st, sa, W, sc, parts);
+                if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, 0, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
+                else hipLaunchKernelGGL((qw_sell_kernel<O, 0, 0, SELL_CODEC_QUAT>), g, b, 0, st, sa, W, sc, parts);
             }
+        } else {
+            constexpr int PIPE = (O == 3) ? 1 : 0;
+            if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel<O, 1, PIPE>), g, b, 0, st, sa, W, sc, parts);
+            else hipLaunchKernelGGL((qw_sell_kernel<O, 0, PIPE>), g, b, 0, st, sa, W, sc, parts);
         }
     }
     const dim3 g(m.reduce_grid(O, a.nloc)), b(256);
@@ -1019,7 +717,7 @@ void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha
         SellArgs sa = m.args();
         sa.wstride = 3;
         if (m.grid() > 0) {
-            if (m.codec() == SELL_CODEC_QUAT) hipLaunchKernelGGL((qw_sell_kernel<1, 0, 0, 0, SELL_CODEC_QUAT>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
+            if (m.codec() == SELL_CODEC_QUAT) hipLaunchKernelGGL((qw_sell_kernel<1, 0, 0, SELL_CODEC_QUAT>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
             else hipLaunchKernelGGL((qw_sell_kernel<1, 0>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
         }
         if (m.reduce_gw(1) == 4) hipLaunchKernelGGL((sell_reduce_kernel<1, EPI_CERT, 4>), dim3(m.reduce_grid(1, a.nloc)), dim3(256), 0, st, sa.pptr, sa.ridx, parts, alpha, a, sa.diag, W, sa.row0, sa.wstride);

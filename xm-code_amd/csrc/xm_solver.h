@@ -13,29 +13,27 @@
 
 namespace xm {
 
-// ---- settings resolved ONCE at context creation (xm_tuning_t of the caller, else the XM_* environment, else the defaults) ----------------
+// ---- settings resolved ONCE at context creation (xm_tuning_t of the caller, else the defaults) ----------------------------------------
 struct Settings {
     int sym = 0;                 // 0 auto | 1 force | -1 off
     int64_t sym_min_rows = 6144;
     int sell = 0;                // 0 auto | 1 force | -1 off
-    int sell_slabs = 4, sell_lmax = 64, sell_gather = 1;   // sell_gather: kernel gather mode (0 record per lane | 1 LDS-transposed, the default | 2 sector windows through LDS-DMA at o = 3: measured slower | 4 sector windows into registers, codec + o = 3: equal on random graphs, slower on banded ones)
+    int sell_slabs = 4, sell_lmax = 64, sell_gather = 1;   // sell_gather: the kernels' gather mode (0 a record of W per lane | 1 records fetched element-per-lane and transposed through LDS, the default)
     int sell_codec = 0;          // 0 auto | 1 full | 2 quaternion
-    int sell_layout = 0;         // 0 auto (chunk-tiled where it applies) | 1 sorted virtual rows, two launches (xm_sell.h) | 2 chunk-tiled, one launch (xm_sell2.h)
     int sell_wpad = 0;           // the tCG keeps a copy of W at a 128-byte record pitch for the sliced-ELL gather (single rank, o = 3..5): 0 when the
-                                 // column pattern says it pays (SellMatrix::padded_pays) | 1 always | -1 never (XM_SELL_WPAD=1 | 0)
-    int sell_kmax = 32;          // chunk-tiled layout: most steps of a slice
-    int sell_pipe = -1;          // chunk-tiled layout: -1 default | 0 single-buffered | 1 block loads one pair ahead (XM_SELL2_PIPE)
+                                 // column pattern says it pays (SellMatrix::padded_pays) | 1 always | -1 never
     int overlap = 0;             // 0 auto | -1 off
     double overlap_min_mb = 64.0;
     int64_t cert_dense_rows = 384;
     int lanczos_mmax = 400, lanczos_restarts = 12;
     double watchdog_s = 600.0;
     int balance = 0;             // 0 by stored blocks | 1 equal camera ranges
-    int exchange = 0;            // 0 auto | 1 RCCL | 2 peer writes
+    int exchange = 0;            // xm_tuning_t.exchange: 0 auto | 1 an all-gather between the launches | 2 direct peer writes | 3 RCCL
     int split_k = 0;             // 0 auto (multi-rank small strips) | -1 off | 2..8 forced
-    long long debug_drop_finalize = -1;   // XM_DEBUG_DROP_FINALIZE (tests)
-    int debug_peer_mute = 0;              // XM_DEBUG_PEER_MUTE=1 (tests): rank 1 never publishes its tCG epoch -> the peers' bounded wait must expire
-    int exchange_lite = 1;                // XM_EXCHANGE_LITE=0: the fused tCG exchange pushes with plain stores + a system-scope release fence instead of write-through stores
+    long long debug_drop_finalize = -1;   // tests: this outer iteration loses its result kernel
+    int debug_peer_mute = 0;              // tests: rank 1 never publishes its tCG epoch -> the peers' bounded wait must expire
+    int exchange_lite = 1;                // 0 (xm_tuning_t.exchange_fence): the fused tCG exchange pushes with plain stores + a system-scope release fence instead of write-through stores
+    bool schur_host_assembly = false, schur_trace = false;   // matrix-free storage (xm_schur.h: SchurSettings)
     static Settings resolve(const xm_tuning_t *t);
 };
 
@@ -71,6 +69,7 @@ struct Comm {
     // kernel holds its hardware queue, and the queues of eight ranks' pushes and waits are more than the device keeps active at once --
     // the collectives are then synchronised through the host and the tCG exchange is not fused into cg_step
     virtual bool device_waits() const { return true; }
+    virtual void set_exchange_fence(bool on) { (void)on; }   // peer transports: release fence instead of write-through stores in the collectives
     std::string fallback_note;   // why a faster transport was given up for this one (empty: first choice)
     void note(const char *what, double a, double b);   // XM_COMM_TRACE debugging aid
 private:
@@ -122,10 +121,12 @@ struct DevBuf {
 };
 
 void partition_cuts(int64_t n, int world, const int64_t *weights, std::vector<int64_t> &cuts);   // xm_solver.hip
+// solution recovery behind xm_recover_rotations (xm_capi.hip); variant 1 = the wavefront-per-camera projection kernel, timed when reps > 0
+void recover_rotations(int64_t n, int r, const double *R, const double *s, double *rot, double *scale, int *n_negative_det, int variant,
+                       int reps, double *ms_avg);
 int64_t equal_range_len(int64_t n, int world);   // cameras per rank of the equal partition (even for world > 1)
 
 class SellMatrix;   // xm_sell.h
-class Sell2Matrix;  // xm_sell2.h
 class SymwProduct;  // xm_symw.h
 class SchurOp;      // xm_schur.h
 
@@ -152,6 +153,7 @@ public:
     explicit Context(const xm_problem_t &prob, std::shared_ptr<Comm> comm = nullptr);
     int rank() const { return comm_->rank; }
     int comm_kind() const { return comm_->active() ? comm_->kind() : 0; }
+    int product_kind(int o) const;   // XM_PRODUCT_* (include/xm_amd.h): the kernel that serves a tCG product of rank o
     bool sell_wpad_on() const { return wpad_on_; }   // the sliced-ELL gather of the current rank's tCG reads W at the 128-byte record pitch
     const std::string &fallback_note() const { return comm_->fallback_note; }
     int world() const { return comm_->world; }
@@ -193,7 +195,6 @@ private:
     DevBuf<double> blocks_;
     int64_t nb_loc_ = 0;
     std::unique_ptr<SellMatrix> sell_;   // large block-sparse Q: sliced-ELL layout (xm_sell.h); the CSR arrays stay for the fallback kernels
-    std::unique_ptr<Sell2Matrix> sell2_; // the same in the chunk-tiled layout: product + epilogue in one launch (xm_sell2.h); at most one of the two exists
     int sell_gm_ = 0;
     std::unique_ptr<SchurOp> schur_;     // XM_STORAGE_SCHUR: matrix-free Q (xm_schur.h)
     // XM^2 edge description (attach_edges)
@@ -298,6 +299,7 @@ public:
     Team &operator=(const Team &) = delete;
     int world() const;
     int comm_kind() const;                       // Comm::kind() of the ranks' communicators
+    int product_kind(int o) const;               // of rank 0's context
     const std::string &fallback_note() const;    // why the direct peer exchange was given up (empty: it was not)
     void solve(const xm_options_t &opt, xm_result_t &res);
     void attach_edges(int64_t ne, const int32_t *ei, const int32_t *ej, const double *M);

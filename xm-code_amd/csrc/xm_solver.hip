@@ -11,7 +11,6 @@
 //    per inner iteration, Dense/transpose.h:7-22).
 #include "xm_solver.h"
 #include "xm_sell.h"
-#include "xm_sell2.h"
 #include "xm_symw.h"
 #include "xm_schur.h"
 
@@ -87,6 +86,7 @@ void Context::ensure_pinned(size_t doubles) {
 Context::Context(const xm_problem_t &prob, std::shared_ptr<Comm> comm) {
     comm_ = comm ? std::move(comm) : default_comm();
     cfg_ = Settings::resolve(prob.tuning);
+    if (!cfg_.exchange_lite) comm_->set_exchange_fence(true);
     try {
         init(prob);
     } catch (...) {   // a later allocation failed (e.g. the 13.5 GB slab): release what the destructor would have released
@@ -320,22 +320,20 @@ void Context::init(const xm_problem_t &prob_in) {
         // Large problems: sliced-ELL over per-XCD column slabs (xm_sell.h).  Below ~1M blocks per GPU the product is in the
         // launch-latency regime (13 us at 13682 cameras) and the one-launch CSR kernel stays.  View-graph storage compresses the
         // stream with the quaternion codec (36 instead of 76 bytes per stored block).  Settings: sell, sell_slabs, sell_lmax,
-        // sell_gather, sell_codec (XM_BSR_SELL, XM_SELL_SLABS, XM_SELL_LMAX, XM_SELL_GATHER, XM_SELL_CODEC).
+        // sell_gather, sell_codec (xm_tuning_t).
         if (cfg_.sell == 1 || (cfg_.sell == 0 && nb_loc_ >= 1000000)) {
             sell_gm_ = cfg_.sell_gather;
             const int codec = (cfg_.sell_codec == 2 || (cfg_.sell_codec == 0 && viewgraph)) ? SELL_CODEC_QUAT : SELL_CODEC_FULL;
-            // layout: sorted virtual rows + a second launch for the per-camera sum (xm_sell.h) unless the chunk-tiled one-launch layout
-            // (xm_sell2.h) is asked for -- measured at 100 k cameras, o = 3, view-graph codec (profiles/r04_kbench_sell2.txt): 82.3 us
-            // in two launches against 90.3 us in one; both spend their time in the texture data path of the gather (PMC: TD busy 78 %),
-            // and the one-launch form pays 50 % more VALU and 25 % more LDS instructions for its row-end logic
-            const bool tiled = cfg_.sell_layout == 2 && ntot_ < kSell2MaxCols;
-            if (tiled) sell2_.reset(new Sell2Matrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_kmax, st_, codec, cam0_));
-            else sell_.reset(new SellMatrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_lmax, st_, codec, cam0_));
+            // layout: sorted virtual rows + a second launch for the per-camera sum (xm_sell.h).  A chunk-tiled ONE-launch layout was measured
+            // in round 4 (profiles/r04_kbench_sell2.txt: 90.3 us against 82.3 us in two launches at 100 k cameras) and removed in round 5.
+            sell_.reset(new SellMatrix(rp.data(), ci.data(), prob.blocks + b0 * 9, nloc_, ntot_, cfg_.sell_slabs, cfg_.sell_lmax, st_, codec, cam0_));
         }
     } else if (storage_ == XM_STORAGE_SCHUR) {
         // several ranks (round 4): every rank builds the factors from the whole observation list; the rows of VT^-1 and the cameras of the
         // last kernel of the chain are partitioned (xm_schur.h)
-        schur_.reset(new SchurOp(n_, prob.n_landmarks, prob.nobs, prob.obs_cam, prob.obs_lm, prob.obs_p, prob.obs_w, st_, comm_.get()));
+        SchurSettings sc;
+        sc.host_assembly = cfg_.schur_host_assembly; sc.sym_min_rows = cfg_.sym_min_rows; sc.trace = cfg_.schur_trace;
+        schur_.reset(new SchurOp(n_, prob.n_landmarks, prob.nobs, prob.obs_cam, prob.obs_lm, prob.obs_p, prob.obs_w, st_, comm_.get(), sc));
         w_cur_.assign(prob.obs_w, prob.obs_w + prob.nobs);
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
@@ -373,8 +371,10 @@ void Context::init(const xm_problem_t &prob_in) {
         }
     }
     // Several ranks: every rank streams half of its row strip through a cyclic half window (xm_symw.h) -- the upper triangle cut into row
-    // strips would leave rank 0 with almost its whole strip.  Whether Q is symmetric cannot be seen from one strip: the ranks multiply one
-    // random vector both ways (general kernel / window product) and take the window product only if all of them agree to 1e-9.
+    // strips would leave rank 0 with almost its whole strip.  Whether Q is symmetric cannot be seen from one strip.  The policy is the
+    // single-GPU one: automatic (sym = 0) only for an EXACTLY symmetric matrix -- an order-independent checksum modulo 2^64 over the
+    // strips (launch_symhash), all-gathered; forced (sym = 1) when a random vector multiplied both ways (general kernel / window
+    // product) agrees to 1e-9 on every rank.
     symw_.reset();
     if (storage_ == XM_STORAGE_DENSE && world > 1 && comm_->active() && cfg_.sym != -1 && (nloc_ % 2) == 0 &&
         (cfg_.sym == 1 || 3 * n_ >= cfg_.sym_min_rows)) {
@@ -420,6 +420,27 @@ void Context::init(const xm_problem_t &prob_in) {
         for (int r = 0; r < world; ++r) { dall = std::max(dall, rep[(size_t)2 * r]); yall = std::max(yall, rep[(size_t)2 * r + 1]); }
         q_asym_ = dall; q_max_ = yall;
         if (!(dall <= 1e-9 * yall)) symw_.reset();   // identical decision on every rank (identical gathered numbers)
+        if (symw_ && cfg_.sym != 1) {
+            // automatic mode: exact symmetry, as on one GPU (there: launch_asym == 0).  The strips' checksums travel as bit patterns.
+            const int grid = 1024;
+            DevBuf<unsigned long long> hsh;
+            hsh.alloc((size_t)2 * grid);
+            launch_symhash(dQ_, ld_, 3 * (int64_t)cam0_, 3 * (int64_t)nloc_, 3 * ntot_, hsh.p, grid, st_);
+            std::vector<unsigned long long> hh((size_t)2 * grid);
+            XM_HIP_CHECK(hipMemcpyAsync(hh.data(), hsh.p, hh.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st_));
+            XM_HIP_CHECK(hipStreamSynchronize(st_));
+            unsigned long long mine2[2] = {0ull, 0ull};
+            for (int b = 0; b < grid; ++b) { mine2[0] += hh[(size_t)2 * b]; mine2[1] |= hh[(size_t)2 * b + 1]; }
+            static_assert(sizeof(unsigned long long) == sizeof(double), "checksums travel through the double all-gather");
+            XM_HIP_CHECK(hipMemcpyAsync(repd.p + (size_t)rank * 2, mine2, sizeof(mine2), hipMemcpyHostToDevice, st_));
+            comm_->allgather(repd.p, 2, st_);
+            std::vector<unsigned long long> all((size_t)world * 2);
+            XM_HIP_CHECK(hipMemcpyAsync(all.data(), repd.p, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st_));
+            XM_HIP_CHECK(hipStreamSynchronize(st_));
+            unsigned long long tot = 0ull, bad2 = 0ull;
+            for (int r = 0; r < world; ++r) { tot += all[(size_t)2 * r]; bad2 |= all[(size_t)2 * r + 1]; }
+            if (tot != 0ull || bad2 != 0ull) symw_.reset();   // identical on every rank
+        }
         comm_->host_barrier();
     }
     XM_HIP_CHECK(hipHostMalloc((void **)&hstat_, 256, hipHostMallocMapped | hipHostMallocCoherent));
@@ -505,7 +526,6 @@ void Context::setup_rank(int o) {
     // the whole device, and with several ranks of one process on one device ("virtual devices") a free between two collectives waits for
     // a peer's spinning wait kernel that waits for this rank's next push (8 virtual ranks ran into exactly that at the first o = 4 product)
     if (sell_ && sell_supports(o)) (void)sell_->parts(o);
-    if (sell2_ && Sell2Matrix::supports(o, ntot_)) (void)sell2_->args(o);
     // pinned staging: partial sums, a whole replicated point (download_point) and a Lanczos vector
     ensure_pinned(std::max<size_t>((size_t)2 * nA_ + (size_t)nB_ + partsM_.count + 64, (size_t)ld_ * OP_ + (size_t)ntot_ + 1024));
     if (comm_->active()) comm_->host_barrier();   // nobody enqueues the next collective while somebody is still freeing
@@ -553,7 +573,6 @@ void Context::download_point(std::vector<double> &R_cm, std::vector<double> &s_e
 
 // workgroups of the product kernels == number of per-workgroup partial sums per epilogue slot
 int Context::prod_grid() const {
-    if (storage_ == XM_STORAGE_BSR3 && sell2_ && Sell2Matrix::supports(o_, ntot_)) return sell2_->nchunks();
     if (storage_ == XM_STORAGE_BSR3 && sell_ && sell_supports(o_)) return sell_->reduce_grid(o_, nloc_);
     return (storage_ == XM_STORAGE_BSR3) ? bsr_grid(nloc_) : qw_grid(nloc_);   // dense and matrix-free: one wavefront per camera
 }
@@ -615,8 +634,6 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
         else launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
     } else if (storage_ == XM_STORAGE_SCHUR) {
         schur_->product(o, epi, W_.p, alpha, a, st_);
-    } else if (sell2_ && Sell2Matrix::supports(o, ntot_)) {
-        launch_qw_sell2(o, epi, *sell2_, W_.p, alpha, a, sell_gm_, cfg_.sell_pipe, st_);
     } else if (sell_ && sell_supports(o)) {
         // inside the tCG the kernels that write W keep a copy at the 128-byte record pitch (run_tcg): the gather reads that one
         launch_qw_sell(o, epi, *sell_, W_.p, alpha, a, sell_gm_, st_, (epi == EPI_HESS && o == o_) ? wpad() : nullptr);
@@ -624,6 +641,13 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
         launch_qw_bsr3(o, epi, rowptr_.p, colidx_.p, blocks_.p, W_.p, alpha, a, st_);
     }
     if (res_) res_->qw_products++;
+}
+
+int Context::product_kind(int o) const {
+    if (storage_ == XM_STORAGE_SCHUR) return XM_PRODUCT_SCHUR;
+    if (storage_ == XM_STORAGE_DENSE) return ((symw_ || sym_ok_) && o >= 3 && o <= sym_max_o_) ? XM_PRODUCT_DENSE_SYM : XM_PRODUCT_DENSE;
+    if (sell_ && sell_supports(o)) return sell_->codec() == SELL_CODEC_QUAT ? XM_PRODUCT_SELL_QUAT : XM_PRODUCT_SELL;
+    return XM_PRODUCT_BSR3;
 }
 
 // multi-rank symmetric Q: sweep of this rank's half window, all-gather of the ranks' column sums, per-camera sum + epilogue (xm_symw.h)
@@ -766,7 +790,10 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     const bool profile = (opt_->flags & XM_FLAG_PROFILE_QW) != 0;
     const int nA_loc = prod_grid(), nB_loc = tcg_blocks();
     const int rank = comm_->rank;
-    double *Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
+    // with the padded copy on (single rank, sliced ELL) nothing reads the native-pitch product input inside the tCG: the main launch
+    // gathers from the copy and the second launch rebuilds the diagonal term from its own operands -- the kernels skip those 7.2 MB of
+    // stores per iteration at 100 k cameras
+    double *Wloc = wpad() ? nullptr : W_.p + (size_t)cam0_ * 3 * OP_;
     const PointState &P = ps_[cur_];
     if (comm_->active()) comm_->note("tcg_start", rr, delta);
     *hstat_ = ~0ull;
@@ -1160,10 +1187,9 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 // w = S v_j : the product input is v_j itself (pitch 1); output rows land in w at this rank's offset
                 a.Wloc = vj + (size_t)cam0_ * 3;
                 a.out = w.p + (size_t)cam0_ * 3;
-                if (storage_ == XM_STORAGE_DENSE && sym_ok_ && Pcol_.p && sym_variant() == 1) launch_qw_sym(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, Prow_.p, Pcol_.p, st_);
+                if (storage_ == XM_STORAGE_DENSE && sym_ok_ && Pcol_.p) launch_qw_sym(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, Prow_.p, Pcol_.p, st_);
                 else if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
                 else if (storage_ == XM_STORAGE_SCHUR) schur_->product(1, EPI_CERT, vj, 1.0, a, st_);
-                else if (sell2_) launch_qw_sell2(1, EPI_CERT, *sell2_, vj, 1.0, a, 0, 0, st_);
                 else if (sell_) launch_qw_sell(1, EPI_CERT, *sell_, vj, 1.0, a, 0, st_);
                 else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_);
                 res_->qw_products++;
@@ -1489,7 +1515,6 @@ void Context::set_edge_weights(const double *w) {
     launch_edge_write(dense, ne_, ei_.p, ej_.p, eM_.p, ew_.p, cam0_, nloc_, inc_ptr_.p, inc_edge_.p, pos_ij_.p, pos_ji_.p, pos_d_.p,
                       dense ? nullptr : blocks_.p, dense ? dQ_ : nullptr, ld_, st_);
     if (sell_) sell_->refill(colidx_.p, blocks_.p, st_);   // the sliced-ELL copy follows the CSR values
-    if (sell2_) sell2_->refill(colidx_.p, blocks_.p, st_);
     XM_HIP_CHECK(hipStreamSynchronize(st_));
 }
 
@@ -1598,7 +1623,7 @@ void Context::solve(const xm_options_t &opt, xm_result_t &res) {
     else if (storage_ == XM_STORAGE_SCHUR) res.qw_bytes = schur_->bytes_per_product(of);
     else res.qw_bytes = 76LL * nb_loc_ + 4LL * (n_ + 1) + 2LL * 8 * 3 * n_ * of;
     res.qw_stream_bytes = (storage_ == XM_STORAGE_DENSE) ? (symw_ ? symw_->stream_bytes() : (res.sym_product ? 4LL : 8LL) * (3 * n_) * (3 * n_))
-                          : (storage_ == XM_STORAGE_BSR3) ? ((sell2_ && Sell2Matrix::supports(of, ntot_)) ? sell2_->stream_bytes() : (sell_ && sell_supports(of)) ? sell_->stream_bytes() : 76LL * nb_loc_) : 0;
+                          : (storage_ == XM_STORAGE_BSR3) ? ((sell_ && sell_supports(of)) ? sell_->stream_bytes() : 76LL * nb_loc_) : 0;
     res.n_gpus = comm_->world;
     res.exchange = !comm_->active() ? 0 : (xchg_.world > 1 ? 2 : 1);
     res.seconds = secs_since(t0);

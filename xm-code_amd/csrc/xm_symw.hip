@@ -260,8 +260,7 @@ __global__ __launch_bounds__(256) void symw_reduce_kernel(SymwGeom g, const doub
 // host: the per-rank object
 // ------------------------------------------------------------------------------------------------------------------
 SymwProduct::SymwProduct(int64_t ntot, int nloc, int cam0, int64_t ld, hipStream_t st) : ntot_(ntot), ld_(ld), nloc_(nloc) {
-    static const int kfix = [] { const char *e = std::getenv("XM_SYMW_K"); return (e && *e) ? std::atoi(e) : 0; }();
-    symw_plan_build(ntot, nloc, cam0, kfix, plan_);
+    symw_plan_build(ntot, nloc, cam0, 0, plan_);
     if (ld < (int64_t)6 * plan_.g.T || (ld % 128) != 0) throw Error(-2, "symmetric window product: bad leading dimension");
     items_.alloc(std::max<size_t>(plan_.items.size(), 1), false);
     strip_ptr_.alloc(plan_.strip_ptr.size(), false);

@@ -114,7 +114,7 @@ Team::Team(const xm_problem_t &prob, int n_gpus, int gpu_map) : p_(new Impl) {
     // Transport ladder.  (1) direct peer writes (xm_comm.hip: PeerComm): every rank maps the peers' fine-grained arenas and the transport
     // has to pass its self-test -- all-gathers with known contents through both read paths -- on THIS machine before a solver relies on
     // it.  (2) RCCL, one communicator per host thread (the library's own transport over xGMI; one all-gather per tCG iteration instead
-    // of the fused exchange).  (3) XM_ERR_COMM naming both reasons.  XM_EXCHANGE=3 / xm_tuning_t.exchange = 3 asks for (2) directly
+    // of the fused exchange).  (3) XM_ERR_COMM naming both reasons.  xm_tuning_t.exchange = 3 asks for (2) directly
     // (exchange = 1 keeps the peer transport and only takes the exchange out of the tCG kernel).
     // device-side waits give up after min(watchdog / 3, 30 s): long enough for a peer that lags, short enough not to look hung, and well
     // before the host-side watchdog of the rank that waits (so that the failure is reported as what it is: XM_ERR_COMM)
@@ -131,7 +131,10 @@ Team::Team(const xm_problem_t &prob, int n_gpus, int gpu_map) : p_(new Impl) {
             t.kind = 3;
         } catch (const std::exception &e) {
             why_peer = e.what();
+            int dev_keep = 0;
+            (void)hipGetDevice(&dev_keep);   // the caller's current device survives the clean-up (later xm_dev_alloc / torch work on this thread)
             for (int r = 0; r < n_gpus; ++r) { (void)hipSetDevice(t.device[(size_t)r]); (void)hipDeviceSynchronize(); t.comm[(size_t)r].reset(); }
+            (void)hipSetDevice(dev_keep);
             t.group.reset();
             { std::lock_guard<std::mutex> lk(t.mu); t.broken = false; }
         }
@@ -170,6 +173,8 @@ void Team::shutdown() {
     t.cv_job.notify_all();
     for (auto &th : t.th) if (th.joinable()) th.join();
     t.th.clear();
+    int dev_keep = 0;
+    (void)hipGetDevice(&dev_keep);   // restored below: the caller's thread keeps its current device
     // contexts before communicators (a Context frees device memory its communicator's peers may still address: drain first)
     for (size_t r = 0; r < t.ctx.size(); ++r) {
         if (!t.ctx[r]) continue;
@@ -178,12 +183,14 @@ void Team::shutdown() {
     }
     for (size_t r = 0; r < t.ctx.size(); ++r) { (void)hipSetDevice(t.device[r]); t.ctx[r].reset(); }
     for (size_t r = 0; r < t.comm.size(); ++r) { (void)hipSetDevice(t.device[r]); t.comm[r].reset(); }
+    (void)hipSetDevice(dev_keep);
 }
 
 Team::~Team() { shutdown(); }
 
 int Team::world() const { return p_->world; }
 int Team::comm_kind() const { return p_->kind; }
+int Team::product_kind(int o) const { return p_->ctx[0] ? p_->ctx[0]->product_kind(o) : 0; }
 const std::string &Team::fallback_note() const { return p_->fallback; }
 
 void Team::solve(const xm_options_t &opt, xm_result_t &res) {

@@ -26,11 +26,15 @@ FLAG_WARM_R = 16
 EXPORTS = [
     "xm_last_error", "xm_version", "xm_abi_revision", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
     "xm_ctx_destroy", "xm_dense_ld", "xm_dev_count", "xm_dev_alloc", "xm_dev_free", "xm_dev_h2d", "xm_dev_d2h",
-    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_dense_sym_time", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_retract_variant", "xm_qw_dense_time", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_peer_allgather_bench", "xm_qw_bsr3_time", "xm_recover_rotations",
+    "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_init_ipc", "xm_comm_finalize", "xm_partition", "xm_partition_blocks",
-    "xm_symv_plan", "xm_sell_layout", "xm_sell_locality", "xm_sell_create", "xm_sell_create2", "xm_sell_create3", "xm_sell2_layout", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_time", "xm_qw_sell_padded", "xm_qw_sell_time_padded",
-    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport", "xm_ctx_sell_wpad", "xm_symw_plan", "xm_symw_use", "xm_qw_symw_time",
+    "xm_symv_plan", "xm_sell_layout", "xm_sell_locality", "xm_sell_create", "xm_sell_create2", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_padded",
+    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport", "xm_ctx_sell_wpad", "xm_ctx_product_kind", "xm_symw_plan", "xm_symw_use",
 ]
+# include/xm_bench.h: timing hooks of the micro-benchmarks (same library, not part of the product ABI)
+BENCH_EXPORTS = ["xm_bench_last_error", "xm_qw_dense_time", "xm_qw_dense_sym_time", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_qw_bsr3_time", "xm_qw_sell_time",
+                 "xm_retract_variant", "xm_recover_rotations_variant", "xm_peer_allgather_bench", "xm_qw_symw_time"]
+PRODUCT_KINDS = {0: "dense", 1: "dense_sym", 2: "bsr3", 3: "sell", 4: "sell_quat", 5: "schur"}
 
 
 class XmError(RuntimeError):
@@ -40,7 +44,8 @@ class XmError(RuntimeError):
 class Tuning(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("sym", "sym_min_rows", "sell", "sell_slabs", "sell_lmax", "sell_gather", "sell_codec", "overlap",
                                          "overlap_min_mb", "cert_dense_rows", "lanczos_mmax", "lanczos_restarts", "watchdog_s", "balance",
-                                         "exchange", "split_k", "sell_layout", "sell_kmax", "sell_wpad")] + [("reserved", C.c_int32 * 1)]
+                                         "exchange", "split_k", "sell_wpad", "exchange_fence", "schur_host_assembly", "schur_trace",
+                                         "schur_solver", "schur_dense_max", "debug_drop_finalize", "debug_peer_mute")] + [("reserved", C.c_int32 * 4)]
 
 
 class Problem(C.Structure):
@@ -111,6 +116,8 @@ def lib():
         L.xm_ctx_recover_tp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_ctx_transport.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.xm_ctx_sell_wpad.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.xm_ctx_product_kind.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.xm_bench_last_error.restype = C.c_char_p
         L.xm_symw_plan.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.xm_symw_use.argtypes = [C.c_int, C.c_int, C.c_int]
         L.xm_qw_symw_time.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
@@ -140,6 +147,7 @@ def lib():
         L.xm_qw_bsr3_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                       C.POINTER(C.c_double)]
         L.xm_recover_rotations.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.xm_recover_rotations_variant.argtypes = L.xm_recover_rotations.argtypes + [C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.xm_comm_unique_id.argtypes = [C.c_char_p]
         L.xm_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.xm_comm_init_shm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
@@ -150,22 +158,20 @@ def lib():
         L.xm_sell_locality.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.xm_sell_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.xm_sell_create2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]
-        L.xm_sell_create3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
-        L.xm_sell2_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p] + [C.c_void_p] * 8
         L.xm_sell_quat_roundtrip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_sell_destroy.argtypes = [C.c_void_p]
         L.xm_sell_destroy.restype = None
         L.xm_qw_sell.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
-        L.xm_qw_sell_time.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.xm_qw_sell_padded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
-        L.xm_qw_sell_time_padded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.xm_qw_sell_time.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
 
 def _chk(rc):
     if rc != 0:
-        raise XmError(f"xm_amd error {rc}: {lib().xm_last_error().decode()}")
+        msg = lib().xm_last_error().decode() or lib().xm_bench_last_error().decode()   # the timing hooks keep their own message (xm_bench.h)
+        raise XmError(f"xm_amd error {rc}: {msg}")
 
 
 def device_count():
@@ -368,42 +374,22 @@ def symw_plan(ntot, nloc, cam0, K=0):
     return out
 
 
-def sell2_layout(rowptr, colidx, ncols=None, slabs=4, kmax=32):
-    """host-side description of the chunk-tiled sliced-ELL layout (xm_sell2.h) -- no GPU involved; used by the CPU tests"""
-    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
-    n = rowptr.size - 1
-    ncols = n if ncols is None else ncols
-    sizes = np.zeros(4, dtype=np.int64)
-    args = (rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), n, ncols, slabs, kmax)
-    _chk(lib().xm_sell2_layout(*args, sizes.ctypes.data_as(C.c_void_p), *([None] * 8)))
-    nsl, nst, ntl, nch = (int(x) for x in sizes)
-    out = dict(nslices=nsl, nsteps=nst, ntiles=ntl, nchunks=nch, slabs=slabs,
-               slice_off=np.zeros(nsl + 1, dtype=np.int64), slab_start=np.zeros(slabs + 1, dtype=np.int32),
-               slice_chunk=np.zeros(max(nsl, 1), dtype=np.int32), slice_tile=np.zeros(max(nsl, 1), dtype=np.int32),
-               tile_ptr=np.zeros(nch + 1, dtype=np.int32), kind=np.zeros(max(nst, 1), dtype=np.uint8),
-               src=np.zeros(max(nst, 1) * 64, dtype=np.int64), lane_meta=np.zeros(max(nsl, 1) * 64, dtype=np.int32))
-    _chk(lib().xm_sell2_layout(*args, sizes.ctypes.data_as(C.c_void_p),
-                               *(out[k].ctypes.data_as(C.c_void_p) for k in ("slice_off", "slab_start", "slice_chunk", "slice_tile", "tile_ptr",
-                                                                             "kind", "src", "lane_meta"))))
-    return out
-
-
 class SellMatrix:
     """3x3-block sparse Q in the sliced-ELL device layout (xm_sell_create); product through xm_qw_sell"""
 
-    def __init__(self, rowptr, colidx, blocks, ncols=None, slabs=4, lmax=0, codec=0, row0=0, layout=1):
-        """codec 1 = view-graph codec (quaternion per off-diagonal block, scalar per diagonal block); layout 1 = two launches per product
-        (xm_sell.h), 2 = chunk-tiled, one launch per product (xm_sell2.h)"""
+    def __init__(self, rowptr, colidx, blocks, ncols=None, slabs=4, lmax=0, codec=0, row0=0):
+        """codec 1 = view-graph codec (quaternion per off-diagonal block, scalar per diagonal block)"""
         require_gpu()
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); colidx = np.ascontiguousarray(colidx, dtype=np.int32)
         blocks = np.ascontiguousarray(blocks, dtype=np.float64)
         self.n = rowptr.size - 1
         self.h = C.c_void_p()
-        _chk(lib().xm_sell_create3(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
-                                   self.n, self.n if ncols is None else ncols, slabs, lmax, codec, row0, layout, C.byref(self.h)))
+        _chk(lib().xm_sell_create2(rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
+                                   self.n, self.n if ncols is None else ncols, slabs, lmax, codec, row0, C.byref(self.h)))
 
-    def qw(self, W, alpha=1.0, gather=0, padded=False):
-        """padded=True: the input is also handed over at a record pitch of 16 doubles (xm_qw_sell_padded; o = 3..5, layout 1)"""
+    def qw(self, W, alpha=1.0, gather=1, padded=False):
+        """gather: 0 a record of W per lane | 1 LDS-transposed (the solver's default).  padded=True: the input is also handed over at a
+        record pitch of 16 doubles (xm_qw_sell_padded; o = 3..5)"""
         W = np.asarray(W, dtype=np.float64)
         o = W.shape[1]
         dW = DevArray(to_rm(W)); dO = DevArray(nbytes=3 * self.n * pitch_of(o) * 8)
@@ -444,15 +430,20 @@ def retract(R, s, D, ds, t, polar=False):
     return out
 
 
-def recover_rotations(R, s):
-    """anchored O(3) rotations (3 x 3n) and scales of a solution (R: 3n x r, s: n) through xm_recover_rotations"""
+def recover_rotations(R, s, variant=None, reps=0):
+    """anchored O(3) rotations (3 x 3n) and scales of a solution (R: 3n x r, s: n) through xm_recover_rotations.  variant (xm_bench.h): 0 the
+    default kernel, 1 one wavefront per camera; with reps > 0 a fourth value is returned: average ms of the projection launch"""
     require_gpu()
     R = np.asfortranarray(np.asarray(R, dtype=np.float64)); s = np.ascontiguousarray(np.asarray(s, dtype=np.float64).reshape(-1))
     n, r = s.size, R.shape[1]
     rot = np.zeros((3, 3 * n), order="F"); sc = np.zeros(n); neg = C.c_int(0)
-    _chk(lib().xm_recover_rotations(n, r, R.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
-                                    rot.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), C.byref(neg)))
-    return np.ascontiguousarray(rot), sc, neg.value
+    args = (n, r, R.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), rot.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), C.byref(neg))
+    if variant is None:
+        _chk(lib().xm_recover_rotations(*args))
+        return np.ascontiguousarray(rot), sc, neg.value
+    ms = C.c_double(0.0)
+    _chk(lib().xm_recover_rotations_variant(*args, int(variant), int(reps), C.byref(ms)))
+    return (np.ascontiguousarray(rot), sc, neg.value) + ((ms.value,) if reps > 0 else ())
 
 
 # ------------------------------------------------------------------------------------------------ context API
@@ -522,6 +513,12 @@ class Context:
         k = C.c_int(0); buf = C.create_string_buffer(512)
         _chk(lib().xm_ctx_transport(self.h, C.byref(k), buf, 512))
         return k.value, self.TRANSPORTS.get(k.value, "?"), buf.value.decode()
+
+    def product_kind(self, o=3):
+        """name of the kernel family that serves a tCG product of rank o (xm_ctx_product_kind)"""
+        k = C.c_int(0)
+        _chk(lib().xm_ctx_product_kind(self.h, int(o), C.byref(k)))
+        return PRODUCT_KINDS.get(k.value, "?")
 
     def sell_wpad(self):
         """True when the tCG of the last solved rank read its product input at the 128-byte record pitch (xm_ctx_sell_wpad)"""
@@ -633,8 +630,8 @@ class Context:
             pass
 
 
-def solve_dense(Q, max_rank, tol, lam, **kw):
-    ctx = Context(Q=Q)
+def solve_dense(Q, max_rank, tol, lam, tuning=None, **kw):
+    ctx = Context(Q=Q, tuning=tuning)
     try:
         return ctx.solve(max_rank, tol, lam, **kw)
     finally:
