@@ -194,12 +194,13 @@ def parity_vs_recorded_oracle(workload_name, R, s, primal):
                                         "not re-run here: %.0f s" % (c.get("threads"), c.get("seconds", 0.0))}
 
 
-def host_l3_reachable_bytes():
-    """last-level cache the threads of this process can reach: the distinct L3 slices (sysfs cache/index3, told apart by their shared_cpu_list)
-    of the CPUs in the affinity mask.  None when sysfs does not say."""
+def host_l3_reachable_bytes(threads):
+    """last-level cache the OpenMP team of the host leg can reach: the distinct L3 slices (sysfs cache/index3, told apart by their
+    shared_cpu_list) of the CPUs the process may run on; `threads` threads spread over the slices (OMP_PROC_BIND=spread) reach at most one
+    slice each.  None when sysfs does not say."""
     try:
-        cpus = sorted(os.sched_getaffinity(0))
-        seen, total = set(), 0
+        cpus = sorted(_FULL_AFFINITY if _FULL_AFFINITY is not None else os.sched_getaffinity(0))
+        seen, sizes = set(), []
         for c in cpus:
             base = "/sys/devices/system/cpu/cpu%d/cache/index3/" % c
             shared = open(base + "shared_cpu_list").read().strip()
@@ -207,8 +208,9 @@ def host_l3_reachable_bytes():
                 continue
             seen.add(shared)
             sz = open(base + "size").read().strip()
-            total += int(sz[:-1]) * (1 << 10 if sz[-1] in "Kk" else 1 << 20) if sz[-1] in "KkMm" else int(sz)
-        return total or None
+            sizes.append(int(sz[:-1]) * (1 << 10 if sz[-1] in "Kk" else 1 << 20) if sz[-1] in "KkMm" else int(sz))
+        sizes.sort(reverse=True)
+        return sum(sizes[:max(1, threads)]) or None
     except Exception:
         return None
 
@@ -245,7 +247,7 @@ def cpu_baseline(Q, wl, budget_s, bsr=None):
 def _residency(matrix_bytes, threads):
     """where the host product's matrix can live: compared with the L3 the bound threads reach (not with a constant) -- a block-CSR matrix a
     little below the total L3 streamed by 16 threads with a random gather is a DRAM rate, a dense matrix spread over all slices is not"""
-    l3 = host_l3_reachable_bytes()
+    l3 = host_l3_reachable_bytes(threads)
     if l3 is None:
         return dict(residency=None, residency_note="L3 size not readable from sysfs; qw_host_GBs is whatever the host delivers at this size", matrix_MB=matrix_bytes / 1e6)
     fits = matrix_bytes <= 0.6 * l3      # room for the vectors and the other ways
@@ -414,8 +416,32 @@ def _init_ranks(rank, world, local, dist, reinit=False):
             xmamd._chk(xmamd.lib().xm_comm_init(rank, world, local, box[0], None))
 
 
-def _rccl_leg(args, wl, tl, Q, tkw, team, world, rank, retr, torch, dist, barrier):
+def _rccl_leg(args, wl, tl, Q, tkw, team, world, rank, retr, torch, dist, barrier, out):
+    """the headline workload again through the RCCL rung of the transport ladder.  The headline is already measured: whatever happens here
+    -- a refusal, an exception, a collective that never returns -- must not cost it.  A timer prints the line as it stands (with the leg
+    marked) and ends the process with status 0 if the leg has not finished after XM_BENCH_RCCL_LEG_S seconds (default 240; every rank
+    runs the same timer, so the job ends together)."""
+    import threading
     _PHASE[0] = "RCCL leg"
+    limit = float(os.environ.get("XM_BENCH_RCCL_LEG_S", "240"))
+
+    def give_up():
+        if rank == 0:
+            out["rccl_leg"] = {"error": "no result after %.0f s; the lines above it stand" % limit}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    timer = threading.Timer(limit, give_up)
+    timer.daemon = True
+    timer.start()
+    try:
+        return _rccl_leg_body(args, wl, tl, Q, tkw, team, world, rank, retr, torch, dist, barrier)
+    except Exception as e:      # not only XmError: nothing raised here may lose the line
+        return {"refused": "exchange: rccl -> refused (%s: %s)" % (type(e).__name__, str(e)[:400]), "communicator_world": world * team}
+    finally:
+        timer.cancel()
+
+
+def _rccl_leg_body(args, wl, tl, Q, tkw, team, world, rank, retr, torch, dist, barrier):
     try:
         if team > 1:
             kw = dict(tkw); kw["tuning"] = dict(kw.get("tuning") or {}, exchange=3)
@@ -559,12 +585,6 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                              "per-rank Q is %.0f MB, beyond the 256 MB Infinity Cache: HBM-bound" % (alg_bytes / 1e6))},
     }
     ctx.close()
-    if ngp > 1 and args.exchange == "auto" and not args.no_rccl_leg:
-        # north_star prescribes "an RCCL all-gather of Y over xGMI each iteration"; the library's default is the direct peer exchange.  One
-        # driver run yields both curves: the same workload again with the RCCL rung of the ladder forced (xm_tuning_t.exchange = 3 in the
-        # single-process mode; XM_COMM_PEER=0 + a fresh xm_comm_init with one process per GPU).  A refusal (RCCL does not put two ranks
-        # on one device: the virtual-device dry run) is reported, not raised.
-        out["rccl_leg"] = _rccl_leg(args, wl, tl, Q, tkw, team, world, rank, retr, torch, dist, barrier)
     if not args.no_rome and args.workload == "venice1778":
         # BASELINE.json north_star: "end-to-end solve of a Rome-scale (>= 10k-camera) Q reported as iters/s and wall-clock at
         # 1, 2, 4 and 8 GPUs" — a secondary leg at every N (same rules: warmup, barrier-bracketed, max over ranks); the headline
@@ -656,6 +676,16 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
             out["cpu_baseline"]["recorded_wallclock_to_kkt_s"] = par["cpu_wallclock_to_kkt_s"]       # ANOTHER machine and thread count than `value`:
             out["cpu_baseline"]["recorded_wallclock_to_kkt_threads"] = par["cpu_threads"]            # see kkt_pair for a same-node pair
             out["cpu_baseline"]["recorded_wallclock_to_kkt_provenance"] = par["cpu_wallclock_provenance"]
+    if ngp > 1 and args.exchange == "auto" and not args.no_rccl_leg:
+        # north_star prescribes "an RCCL all-gather of Y over xGMI each iteration"; the library's default is the direct peer exchange.  One
+        # driver run yields both curves: the same workload again with the RCCL rung of the ladder forced (xm_tuning_t.exchange = 3 in the
+        # single-process mode; XM_COMM_PEER=0 + a fresh xm_comm_init with one process per GPU).  A refusal (RCCL does not put two ranks
+        # on one device: the virtual-device dry run) is reported, not raised.
+        # LAST of the communicating legs: in the one-process-per-GPU launch it replaces the process-level communicator.
+        if os.environ.get("XM_BENCH_SHM") == "1" or os.environ.get("XM_BENCH_IPC") == "1":
+            out["rccl_leg"] = {"skipped": "debugging transport selected by XM_BENCH_SHM / XM_BENCH_IPC: no RCCL communicator in this run"}
+        else:
+            out["rccl_leg"] = _rccl_leg(args, wl, tl, Q, tkw, team, world, rank, retr, torch, dist, barrier, out)
     if world > 1:
         xmamd.lib().xm_comm_finalize()
         # Replica throughput: what N GPUs deliver on N INDEPENDENT Venice-size scenes (no data-path communication; the row

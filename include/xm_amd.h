@@ -74,7 +74,7 @@ typedef struct xm_ctx xm_ctx_t;
                                   each rank builds only its own camera rows (a >= 10k-camera Q never exists on the host) */
 #define XM_STORAGE_VIEWGRAPH 4 /* the north_star workload described by its EDGE LIST: Q = sum_e w_e G_e over view-graph edges e = (i, j), Q_ii += w_e I,
                                   Q_jj += w_e I, Q_ij = -w_e M_e, Q_ji = Q_ij^T with M_e the measured relative rotation (what xm_ctx_attach_edges takes).
-                                  Stored as 3x3-block CSR; with >= 1 M blocks per GPU the products stream the compressed sliced-ELL copy
+                                  Stored as 3x3-block CSR; with >= 1.5 M blocks per GPU (xm_tuning_t.sell) the products stream the compressed sliced-ELL copy
                                   (quaternion per off-diagonal block, one double per diagonal block: 36 B per stored block instead of 76,
                                   xm-code_amd/csrc/xm_sell.h).  The edges are attached for the XM^2 calls at creation. */
 #define XM_STORAGE_SCHUR 3     /* MATRIX-FREE: Q is never formed.  The problem is the observation list the reference's
@@ -282,6 +282,11 @@ int xm_ctx_xm2_round(xm_ctx_t *ctx, const double *R, const double *s, int r, con
  * N^2).  rot: 3 x 3n column-major and scale: n as returned by xm_recover_rotations; t: 3 x n column-major (t[:, 0] = 0, the
  * anchor), p: 3 x n_landmarks column-major.  Uses the context's CURRENT observation weights. */
 int xm_ctx_recover_tp(xm_ctx_t *ctx, const double *rot, const double *scale, double *t, double *p);
+/* XM_STORAGE_SCHUR: how the reduced camera Laplacian VT = Q2_bar - V3_bar Q3^-1 V3_bar^T (utils/creatematrix.py:150-166) is applied inside a
+ * product -- *uses_cg = 0: through its dense inverse (set-up O(N^3), 8 (N-1)^2 bytes; up to xm_tuning_t.schur_dense_max cameras), 1: by
+ * preconditioned CG on the matrix-free VT (no N^2 array) -- and, for the CG form, stats = {products so far, inner CG iterations
+ * so far, products that stopped at the iteration cap instead of at the tolerance 1e-13} and the relative residual of the last product. */
+int xm_ctx_schur_info(xm_ctx_t *ctx, int *uses_cg, int64_t stats[3], double *last_relres);
 
 /* ================================================================== 3. kernel-level entry points (device pointers) */
 /* device memory helpers so that callers need no other GPU runtime */

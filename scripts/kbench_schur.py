@@ -1,13 +1,19 @@
-"""matrix-free Q (XM_STORAGE_SCHUR) on synthetic SfM scenes: set-up time, product time, solve; python scripts/kbench_schur.py N M views"""
+"""matrix-free Q (XM_STORAGE_SCHUR) on synthetic SfM scenes: set-up time, product time, solve;
+   python scripts/kbench_schur.py N M views [--product-only] [--solver 1|2] [--trace]      solver: 1 dense inverse of the reduced camera Laplacian, 2 CG form"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "xm-code_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, xmamd, xm_testlib as tl
 N, M, views = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 PRODUCT_ONLY = "--product-only" in sys.argv      # for rocprofv3 --kernel-trace: 20 products, no solve
+TN = {}
+if "--solver" in sys.argv:
+    TN["schur_solver"] = int(sys.argv[sys.argv.index("--solver") + 1])
+if "--trace" in sys.argv:
+    TN["schur_trace"] = 1
 S = tl.gen_scene(N, M, views, seed=N)
 nobs = S["cam"].size
-t0 = time.time(); ctx = xmamd.Context(obs=(S["cam"], S["lm"], S["p"], S["w"])); t_setup = time.time() - t0
+t0 = time.time(); ctx = xmamd.Context(obs=(S["cam"], S["lm"], S["p"], S["w"]), tuning=TN or None); t_setup = time.time() - t0
 rng = np.random.default_rng(0)
 W = rng.standard_normal((3 * N, 3))
 Y = ctx.qw(W)
@@ -17,9 +23,10 @@ if N <= 4000:
 U = rng.standard_normal((3 * N, 3))
 print(f"symmetry <U,QW> vs <QU,W>: {abs(np.sum(U * Y) - np.sum(ctx.qw(U) * W)) / abs(np.sum(U * Y)):.2e}")
 if PRODUCT_ONLY:
+    t0 = time.time()
     for _ in range(20):
         ctx.qw(W)
-    print(f"N={N} landmarks={S['m']} observations={nobs}: set-up {t_setup:.2f} s, 20 products done")
+    print(f"N={N} landmarks={S['m']} observations={nobs}: set-up {t_setup:.2f} s, 20 products done in {(time.time() - t0) * 50:.2f} ms each (host to host), {ctx.schur_info()}")
     ctx.close(); sys.exit(0)
 # XM_KB_LAM: scale regulariser (default 0; "auto" = the data term's own diagonal scale sum w |p|^2 / (3 N)).  With lam = 0 or the
 # reference's heuristic lam = observations / cameras (which presumes points of norm ~1; these have norm ~10) the iteration count grows with
@@ -34,8 +41,9 @@ rot, _ = tl.recover_rotations(R, s)
 Rs = S["R_star"]
 gt = np.concatenate([Rs[0].T @ Rs[k] for k in range(N)], axis=1)
 gt2 = np.concatenate([Rs[0] @ Rs[k].T for k in range(N)], axis=1)
-print(f"N={N} landmarks={S['m']} observations={nobs}: set-up {t_setup:.2f} s (VT assembled on the host, inverted on the device), "
+si = ctx.schur_info()
+print(f"N={N} landmarks={S['m']} observations={nobs}: set-up {t_setup:.2f} s ({'CG form: no VT' if si['cg'] else 'VT assembled and inverted on the device'}), {si}, "
       f"lam {lam:.0f}, solve {t_solve*1e3:.1f} ms rank {i['rank']} status {i['status']} tcg {i['tcg_iters']} ({i['tcg_iters']/max(i['tr_seconds'],1e-9):.0f} it/s), "
-      f"Hessian product (5 kernels + dense VT^-1) {qw_us:.1f} us; algorithmic bytes matrix-free {i['qw_bytes']/1e6:.0f} MB vs dense Q {72.0*N*N/1e6:.0f} MB; "
+      f"Hessian product (whole chain) {qw_us:.1f} us; algorithmic bytes matrix-free {i['qw_bytes']/1e6:.0f} MB vs dense Q {72.0*N*N/1e6:.0f} MB; "
       f"rotations vs planted: {min(tl.rel_fro(rot, gt), tl.rel_fro(rot, gt2)):.3e}")
 ctx.close()

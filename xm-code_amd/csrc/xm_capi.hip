@@ -265,6 +265,17 @@ int xm_ctx_recover_tp(xm_ctx_t *ctx, const double *rot, const double *scale, dou
     return XM_OK;
     XM_CATCH
 }
+int xm_ctx_schur_info(xm_ctx_t *ctx, int *uses_cg, int64_t stats[3], double *last_relres) {
+    XM_TRY
+    if (!ctx || !ctx->impl || !uses_cg) throw xm::Error(XM_ERR_ARG, "xm_ctx_schur_info: single-GPU context and a non-null output needed");
+    int64_t st[3] = {0, 0, 0};
+    double rr = 0.0;
+    *uses_cg = ctx->impl->schur_info(st, &rr) ? 1 : 0;
+    if (stats) { stats[0] = st[0]; stats[1] = st[1]; stats[2] = st[2]; }
+    if (last_relres) *last_relres = rr;
+    return XM_OK;
+    XM_CATCH
+}
 int xm_ctx_set_edge_weights(xm_ctx_t *ctx, const double *w) {
     XM_TRY
     if (!ctx) throw xm::Error(XM_ERR_ARG, "null argument");

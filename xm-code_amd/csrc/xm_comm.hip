@@ -64,6 +64,9 @@ Settings Settings::resolve(const xm_tuning_t *t) {
     s.exchange_lite = z.exchange_fence ? 0 : 1;
     s.schur_host_assembly = z.schur_host_assembly != 0;
     s.schur_trace = z.schur_trace != 0;
+    if (z.schur_solver < 0 || z.schur_solver > 2) throw Error(XM_ERR_ARG, "xm_tuning_t.schur_solver must be 0, 1 or 2");
+    s.schur_solver = z.schur_solver;
+    if (z.schur_dense_max > 0) s.schur_dense_max = z.schur_dense_max;
     s.debug_drop_finalize = z.debug_drop_finalize > 0 ? z.debug_drop_finalize : -1;
     s.debug_peer_mute = z.debug_peer_mute;
     return s;

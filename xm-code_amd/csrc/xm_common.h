@@ -45,8 +45,24 @@ struct TcgScal {
     double delta;     // trust-region radius
     double gradnorm;  // sqrt(rdotr[0])                                     (trustregion.h:485)
     double last_step; // alpha or tau of the last iteration (diagnostics)
-    int32_t status;   // 0 running | 1 negative curvature | 2 boundary | 3 norm tolerance | 5 rdotr<1e-15 | 6 max iterations
+    int32_t status;   // 0 running | 1 negative curvature | 2 boundary | 3 norm tolerance | 5 rdotr<1e-15 | 6 max iterations | 7 a peer never arrived
+                      // | 9 dormant: a speculatively enqueued tCG whose outer iteration did not go the predicted way (SpecCtl)
     int32_t iter;     // inner iteration index i (== completed iterations)
+    int32_t seq;      // which truncated-CG run of this context this is (travels in the host-mapped progress word: a word of an earlier run is stale)
+    int32_t pad_;
+};
+
+// Hand-over between the end of an outer iteration and a SPECULATIVELY enqueued start of the next truncated CG (single GPU): outer_finalize_kernel
+// evaluates the trust-region update (trustregion.h:680-708) with the same formulas the host uses and, when the step is accepted and no stop test
+// fires, lets the tcg_init / product / cg_step launches that are already in the queue behind it run -- the GPU does not idle through the host
+// round trip (result word over PCIe, host arithmetic, three launches).  The host stays the authority: it takes the same decision from the same
+// numbers and ADOPTS the running tCG only if `go` was set and the radius agrees bit for bit; otherwise the speculative launches were no-ops
+// (status 9) or are overwritten by a regular start.
+struct SpecCtl {
+    int32_t go;       // 1: accepted, continue -- the queued tcg_init may start from the candidate point
+    int32_t pad_;
+    double rr;        // <rg,rg> of the accepted point
+    double delta;     // radius after the update
 };
 
 // Everything the fused epilogues / per-camera kernels need.  All pointers are device pointers; matrices are
@@ -142,7 +158,8 @@ int flat_grid(int64_t elems);
 void launch_scale_rows(int o, int nloc, const double *R, const double *s, double *Wloc, hipStream_t st);
 void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, const double *R, const double *s, double *rR,
                      double *rs, double *pR, double *ps, double *vR, double *vs, double *HvR, double *Hvs, double *Wloc,
-                     TcgScal *scal0, double rr, double delta, unsigned long long *hstat, hipStream_t st, double *Wpad = nullptr);
+                     TcgScal *scal0, double rr, double delta, unsigned long long *hstat, hipStream_t st, double *Wpad = nullptr, int seq = 0,
+                     const SpecCtl *spec = nullptr);   // spec: start only if spec->go, with spec->rr / spec->delta (else leave scal0 dormant)
 void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *parts, int nA_loc, int nB_loc, int world,
                     const double *HpR, const double *Hps, const double *R, const double *s, double *pR,
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
@@ -150,8 +167,10 @@ void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next
                     double *Wfull, int grouping, const struct PeerXchg &xchg, hipStream_t st, double *Wpad = nullptr);   // Wpad: single-rank only
 void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs,
                         const double *rgR, const double *rgs, const double *s, double *parts, hipStream_t st);
+// trust-region numbers of the iteration that ends (what the host holds when it enqueues this launch); spec_out: see SpecCtl (nullptr: none)
+struct OuterArgs { double loss, delta, delta_bar, gradtol; int shrink_count, last_iter; };
 void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,
-                           unsigned long long seq, int grouping, hipStream_t st);
+                           unsigned long long seq, int grouping, hipStream_t st, const OuterArgs *oa = nullptr, SpecCtl *spec_out = nullptr);
 // polar: 0 the reference's Gram-Schmidt retraction, one thread per camera | 1 polar retraction (XM_RETRACT_POLAR) | 2 Gram-Schmidt with a quad
 // of lanes per camera (measured alternative, scripts/kbench_retract.py)
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,

@@ -90,6 +90,46 @@ __device__ __forceinline__ void sum_partials256_x4(const double *p0, const doubl
     for (int k = 0; k < 4; ++k) out[k] = (sh16[k * 4] + sh16[k * 4 + 1]) + (sh16[k * 4 + 2] + sh16[k * 4 + 3]);
 }
 
+// The same sums with the first kPre rounds of loads ISSUED EARLY by the caller (sum_partials_prefetch, before it waits for anything else):
+// the values are added in exactly the order of sum_partials256_x4, so the results are bit-identical.  cg_step_kernel reads its scalar
+// block and these partial sums from memory the previous launch wrote on another XCD (an L2 miss each): requested together they cost one
+// round trip instead of two.
+constexpr int kPre = 2;
+struct PartialsPre { double v[4][kPre]; };
+__device__ __forceinline__ void sum_partials_prefetch(const double *p0, const double *p1, const double *p2, int count, const double *p3, int count3,
+                                                      PartialsPre &pre, int grp) {
+#pragma unroll
+    for (int r = 0; r < kPre; ++r) {
+        const int i = threadIdx.x + 256 * r;
+        const int j = (i < count) ? sum_perm(i, count, grp) : 0, j3 = (i < count3) ? sum_perm(i, count3, grp) : 0;
+        pre.v[0][r] = (i < count) ? p0[j] : 0.0; pre.v[1][r] = (i < count) ? p1[j] : 0.0; pre.v[2][r] = (i < count) ? p2[j] : 0.0;
+        pre.v[3][r] = (i < count3) ? p3[j3] : 0.0;
+    }
+}
+__device__ __forceinline__ void sum_partials256_x4_pre(const double *p0, const double *p1, const double *p2, int count, const double *p3,
+                                                       int count3, bool use3, const PartialsPre &pre, double *sh16, double (&out)[4], int grp = 0) {
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < kPre; ++r) {
+        const int i = threadIdx.x + 256 * r;
+        if (i < count) { v[0] += pre.v[0][r]; v[1] += pre.v[1][r]; v[2] += pre.v[2][r]; }
+        if (use3 && i < count3) v[3] += pre.v[3][r];
+    }
+    for (int i = threadIdx.x + 256 * kPre; i < count; i += 256) { const int j = sum_perm(i, count, grp); v[0] += p0[j]; v[1] += p1[j]; v[2] += p2[j]; }
+    if (use3)
+        for (int i = threadIdx.x + 256 * kPre; i < count3; i += 256) v[3] += p3[sum_perm(i, count3, grp)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh16[k * 4 + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (sh16[k * 4] + sh16[k * 4 + 1]) + (sh16[k * 4 + 2] + sh16[k * 4 + 3]);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // fused epilogues, column-distributed: after the wave reduction lane k (< O) owns column k of the camera's 3 x O
 // block; every 3-vector below is "that column".  Reductions over k are wave_sum()s with lanes >= O contributing 0,

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "xm_common.h"
@@ -576,9 +577,6 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
                                                        const double *__restrict__ blocks, const double *__restrict__ W,
                                                        double alpha, CamArgs a) {
     constexpr int OP = pitch_of(O);
-    if (EPI == EPI_HESS) {
-        if (a.scal->status != 0) return;
-    }
     constexpr int REC = 3 * OP;                                   // doubles of one camera's rows of W
     constexpr int SW = (VAR == 2 && REC > 9) ? REC : 9;           // LDS doubles per lane (blocks and W share the window)
     __shared__ double red[kBsrRows][3];
@@ -594,6 +592,9 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
     int64_t b0 = 0, b1 = 0;
     if (active) { b0 = rowptr[cam]; b1 = rowptr[cam + 1]; }
+    if (EPI == EPI_HESS) {   // the tCG's status word (written by the previous cg_step on another XCD: an L2 miss) travels WITH the row pointers:
+        if (a.scal->status != 0) return;   // the dependent chain of this latency-bound kernel is one round trip shorter
+    }
     // the four groups of a wavefront loop together (wave-level trip count = the longest of their rows)
     int64_t span = b1 - b0;
     span = max(span, (int64_t)__shfl_xor((long long)span, 16, 64));
@@ -789,8 +790,8 @@ __global__ void dense_from_bsr_kernel(const int64_t *__restrict__ rowptr, const 
 // ----------------------------------------------------------------------------------------------------------------
 // flat kernels (grid-stride over the nloc*3*OP elements; the row -> camera map is idx / (3*OP))
 // ----------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long pack_stat(int iter, int status) {
-    return ((unsigned long long)(unsigned)iter << 8) | (unsigned long long)(unsigned)(status & 0xff);
+__device__ __forceinline__ unsigned long long pack_stat(int seq, int iter, int status) {   // [seq : 32 | iter : 24 | status : 8]
+    return ((unsigned long long)(unsigned)seq << 32) | ((unsigned long long)((unsigned)iter & 0xffffffu) << 8) | (unsigned long long)(unsigned)(status & 0xff);
 }
 __device__ __forceinline__ void publish_host(unsigned long long *hstat, unsigned long long v) {
     if (hstat) __hip_atomic_store(hstat, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the word is its own payload
@@ -831,9 +832,16 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
                                                         const double *__restrict__ R, const double *__restrict__ s,
                                                         double *rR, double *rs, double *pR, double *ps, double *vR, double *vs,
                                                         double *HvR, double *Hvs, double *Wloc, TcgScal *scal0, double rr,
-                                                        double delta, unsigned long long *hstat, double *Wpad) {
+                                                        double delta, unsigned long long *hstat, double *Wpad, int seq, const SpecCtl *spec) {
     constexpr int OP = pitch_of(O);
     const int64_t total = (int64_t)nloc * 3 * OP;
+    if (spec != nullptr) {   // speculative start (enqueued behind outer_finalize_kernel before the host knew the outcome)
+        if (!spec->go) {     // not this way: the product / cg_step launches queued behind find a dormant state and return
+            if (blockIdx.x == 0 && threadIdx.x == 0) { TcgScal sc = *scal0; sc.status = 9; sc.seq = seq; *scal0 = sc; }
+            return;
+        }
+        rr = spec->rr; delta = spec->delta;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int cam = (int)(i / (3 * OP));
         const double g = rgR[i], gs = rgs[cam];
@@ -846,9 +854,9 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         TcgScal sc;
         sc.rr = rr; sc.vv = 0.0; sc.vp = 0.0; sc.pp = rr; sc.delta = delta; sc.gradnorm = sqrt(rr); sc.last_step = 0.0;
-        sc.status = 0; sc.iter = 0;
+        sc.status = 0; sc.iter = 0; sc.seq = seq; sc.pad_ = 0;
         *scal0 = sc;
-        publish_host(hstat, pack_stat(0, 0));
+        publish_host(hstat, pack_stat(seq, 0, 0));
     }
 }
 
@@ -883,6 +891,12 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
     double hp = 0, pv = 0, vv0 = 0, hv = 0, rv = 0, Rv = 0, hs = 0, psv = 0, rsv = 0, sv = 1, vsv = 0, hvs = 0;
     if (in0) { hp = HpR[i]; pv = pR[i]; vv0 = vR[i]; hv = HvR[i]; rv = rR[i]; Rv = R[i]; hs = Hps[camf]; psv = ps_cur[camf]; rsv = rs_cur[camf]; sv = s[camf]; }
     if (own0) { vsv = vs[camf]; hvs = Hvs[camf]; }
+    // ... and so are the first rounds of rank 0's partial sums (single GPU: all of them up to 512 workgroups): scalar block and partial sums
+    // were written by the previous launches on other XCDs -- one memory round trip for both instead of two in a row
+    // (not with the fused peer exchange: there the peers' chunks arrive DURING this launch)
+    const bool can_pre = x.world <= 1;
+    PartialsPre pre;
+    if (can_pre) sum_partials_prefetch(parts + b_off, parts + b_off + nA_loc, parts + b_off + 2 * nA_loc, nA_loc, parts + b_off + 3 * nA_loc, nB_loc, pre, grp);
     const TcgScal sc0 = *scal_cur;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (sc0.status != 0) {
@@ -963,7 +977,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
             if (lead) {
                 TcgScal nx = sc0; nx.status = 7;
                 *scal_next = nx;
-                publish_host(hstat, pack_stat(nx.iter, nx.status));
+                publish_host(hstat, pack_stat(nx.seq, nx.iter, nx.status));
             }
             return;
         }
@@ -977,7 +991,8 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
     for (int r = 0; r < world; ++r) {
         const double *pa = parts + (size_t)r * chunk + b_off;
         double t[4];
-        sum_partials256_x4(pa, pa + nA_loc, pa + 2 * nA_loc, nA_loc, pa + 3 * nA_loc, (sc0.iter > 0) ? nB_loc : 0, sh16, t, grp);
+        if (r == 0 && can_pre) sum_partials256_x4_pre(pa, pa + nA_loc, pa + 2 * nA_loc, nA_loc, pa + 3 * nA_loc, nB_loc, sc0.iter > 0, pre, sh16, t, grp);
+        else sum_partials256_x4(pa, pa + nA_loc, pa + 2 * nA_loc, nA_loc, pa + 3 * nA_loc, (sc0.iter > 0) ? nB_loc : 0, sh16, t, grp);
         pHp += t[0]; rHp += t[1]; HpHp += t[2];
         if (sc0.iter > 0) rr_prev += t[3];
     }
@@ -988,7 +1003,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
         if (lead) {
             TcgScal nx = sc; nx.status = 5; nx.last_step = 0.0;
             *scal_next = nx;
-            publish_host(hstat, pack_stat(nx.iter, nx.status));
+            publish_host(hstat, pack_stat(nx.seq, nx.iter, nx.status));
         }
         return;
     }
@@ -1088,7 +1103,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
             }
         }
         *scal_next = nx;
-        publish_host(hstat, pack_stat(nx.iter, nx.status));
+        publish_host(hstat, pack_stat(nx.seq, nx.iter, nx.status));
     }
 }
 
@@ -1119,7 +1134,8 @@ __global__ __launch_bounds__(256) void model_value_kernel(int nloc, const double
 // is written last.  Replaces three device-to-host copies and a stream synchronisation per outer iteration.
 __global__ __launch_bounds__(256) void outer_finalize_kernel(const double *__restrict__ partsA, int nA_loc, int world,
                                                               const double *__restrict__ partsM, int nM,
-                                                              const TcgScal *__restrict__ scal, double *hres, unsigned long long seq, int grp) {
+                                                              const TcgScal *__restrict__ scal, double *hres, unsigned long long seq, int grp,
+                                                              OuterArgs oa, SpecCtl *spec_out) {
     __shared__ double sh[4];
     double f = 0.0, rr = 0.0;
     for (int r = 0; r < world; ++r) {   // same grouping as the host-side summation it replaces: rank by rank
@@ -1134,6 +1150,29 @@ __global__ __launch_bounds__(256) void outer_finalize_kernel(const double *__res
         __hip_atomic_store(hres + 2, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(hres + 3, (double)sc.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(hres + 4, (double)sc.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (spec_out != nullptr) {
+            // the trust-region update of trustregion.h:680-708, with the formulas (and the order) of Context::trust_region
+            const int endreason = (sc.status == 0) ? 6 : sc.status;
+            double delta = oa.delta;
+            int shrink = oa.shrink_count;
+            bool go = (m < 0.0) && endreason != 7;
+            if (go) {
+                const double rou = (f - oa.loss) / m;
+                if (rou < 0.25) { delta *= 0.25; shrink++; }
+                else if (rou > 0.75 && endreason <= 2) { delta = fmin(delta * 2, oa.delta_bar); shrink = 0; }
+                else shrink = 0;
+                bool stop_delta = false;
+                if (shrink > 3) { delta *= 1e-3; shrink = 0; if (delta < 1e-20) stop_delta = true; }
+                const bool reject = (f > oa.loss || rou < 0.1);
+                // continue only on the plain path: accepted, no stop test of the next iteration's top fires (:527-543)
+                go = !stop_delta && !reject && endreason != 5 && !(sqrt(rr) < oa.gradtol) && !oa.last_iter;
+            }
+            SpecCtl sp;
+            sp.go = go ? 1 : 0; sp.pad_ = 0; sp.rr = rr; sp.delta = delta;
+            *spec_out = sp;
+            __hip_atomic_store(hres + 6, go ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(hres + 7, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         __atomic_thread_fence(__ATOMIC_SEQ_CST);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(hres + 5), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2076,9 +2115,9 @@ void launch_scale_rows(int o, int nloc, const double *R, const double *s, double
 }
 void launch_tcg_init(int o, int nloc, const double *rgR, const double *rgs, const double *R, const double *s, double *rR, double *rs,
                      double *pR, double *ps, double *vR, double *vs, double *HvR, double *Hvs, double *Wloc, TcgScal *scal0,
-                     double rr, double delta, unsigned long long *hstat, hipStream_t st, double *Wpad) {
+                     double rr, double delta, unsigned long long *hstat, hipStream_t st, double *Wpad, int seq, const SpecCtl *spec) {
     XM_DISPATCH_O(o, hipLaunchKernelGGL((tcg_init_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
-                                        nloc, rgR, rgs, R, s, rR, rs, pR, ps, vR, vs, HvR, Hvs, Wloc, scal0, rr, delta, hstat, Wpad));
+                                        nloc, rgR, rgs, R, s, rR, rs, pR, ps, vR, vs, HvR, Hvs, Wloc, scal0, rr, delta, hstat, Wpad, seq, spec));
     check_launch("tcg_init");
 }
 void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next, const double *parts, int nA_loc, int nB_loc, int world,
@@ -2099,8 +2138,11 @@ void launch_model_value(int o, int nloc, const double *vR, const double *vs, con
     check_launch("model_value");
 }
 void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,
-                           unsigned long long seq, int grouping, hipStream_t st) {
-    hipLaunchKernelGGL(outer_finalize_kernel, dim3(1), dim3(256), 0, st, partsA, nA_loc, world, partsM, nM, scal, hres, seq, grouping);
+                           unsigned long long seq, int grouping, hipStream_t st, const OuterArgs *oa, SpecCtl *spec_out) {
+    OuterArgs z;
+    std::memset(&z, 0, sizeof(z));
+    hipLaunchKernelGGL(outer_finalize_kernel, dim3(1), dim3(256), 0, st, partsA, nA_loc, world, partsM, nM, scal, hres, seq, grouping, oa ? *oa : z,
+                       (oa != nullptr) ? spec_out : (SpecCtl *)nullptr);
     check_launch("outer_finalize");
 }
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
@@ -2137,7 +2179,9 @@ void launch_negate(double *x, int64_t len, hipStream_t st) {
     hipLaunchKernelGGL(negate_kernel, dim3(flat_grid(len)), dim3(256), 0, st, x, len);
     check_launch("negate");
 }
-int dots_multi_segments(int64_t len) { return (int)std::min<int64_t>(64, std::max<int64_t>(1, len / 16384)); }
+// segments of ~4096 elements (16 strided steps per thread): with 16384 the 41 k-element Lanczos vectors of the Final-13682 certificate were two
+// segments per column -- 66 workgroups walking 80 steps each, 21 us per call, three calls per Lanczos step (profiles/r05_trace_summary_rome_bsr.txt)
+int dots_multi_segments(int64_t len) { return (int)std::min<int64_t>(64, std::max<int64_t>(1, len / 4096)); }
 // scratch: m * dots_multi_segments(len) doubles (may be null when that is 1 segment: short vectors keep the single-kernel sum)
 void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *c, double *scratch, hipStream_t st) {
     if (m <= 0) return;

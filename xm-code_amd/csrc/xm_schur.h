@@ -38,7 +38,10 @@ struct SchurSettings {          // from xm_tuning_t (Settings::resolve)
     bool host_assembly = false; // assemble the reduced camera Laplacian on the host (the reference's route, utils/creatematrix.py:137-260; tests)
     int64_t sym_min_rows = 6144; // VT^-1 is applied with the half-traffic symmetric kernel from this many rows on
     bool trace = false;         // set-up phase times on stderr (scripts/kbench_schur.py)
+    int solver = 0;             // reduced camera system inside the product: 0 by size (dense inverse up to dense_max cameras, CG above) | 1 dense inverse | 2 preconditioned CG
+    int64_t dense_max = 20000;  // (the dense inverse costs 8 (N-1)^2 bytes -- 3.2 GB here -- and an O(N^3) set-up; the CG form nothing but the observation lists)
 };
+struct SchurLm;                 // xm_schur.hip
 
 class SchurOp {
 public:
@@ -61,6 +64,10 @@ public:
     int64_t n_landmarks() const { return m_; }
     int64_t nobs() const { return nobs_; }
     int64_t bytes_per_product(int o) const;
+    // CG form of the reduced camera system: statistics since construction (products, inner iterations, products that hit the iteration cap)
+    // and the relative residual of the last one
+    bool uses_pcg() const { return pcg_; }
+    void pcg_stats(int64_t out[3], double *relres) const { out[0] = pcg_products_; out[1] = pcg_iters_total_; out[2] = pcg_unconverged_; if (relres) *relres = pcg_last_relres_; }
 
 private:
     int64_t n_ = 0, m_ = 0, nobs_ = 0, nred_ = 0, ldv_ = 0;   // nred = cameras of the padded (N-1) system / 3
@@ -97,6 +104,19 @@ private:
     SchurSettings cfg_;
     std::vector<int64_t> hub_lm_, hub_obs_ptr_, hub_obs_;
     void set_weights_device(const double *w, hipStream_t st);
+    // preconditioned CG on the matrix-free reduced camera Laplacian (cfg.solver; xm_schur.hip)
+    bool pcg_ = false;
+    DevBuf<double> pcg_dinv_, pcg_r_, pcg_p_, pcg_ap_, pcg_parts_;
+    DevBuf<int32_t> pcg_state_;
+    struct PcgState *pcg_host_ = nullptr;   // pinned copy of the device state word
+    int pcg_grid_ = 1, pcg_last_iters_ = 24, pcg_max_iters_ = 1000;
+    double pcg_tol_ = 1e-13, pcg_last_relres_ = 0.0;
+    int64_t pcg_products_ = 0, pcg_iters_total_ = 0, pcg_unconverged_ = 0;
+    template <int O> void pcg_solve(const SchurLm &L, const struct TcgScal *sc, hipStream_t st);
+public:
+    ~SchurOp();
+    SchurOp(const SchurOp &) = delete;
+    SchurOp &operator=(const SchurOp &) = delete;
 };
 
 }  // namespace xm

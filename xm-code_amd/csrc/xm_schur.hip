@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -228,6 +229,235 @@ __global__ __launch_bounds__(256) void schur_cam_y_kernel(int64_t n, int64_t nob
     qw_finish<O, EPI, 64, kQwWaves>(lcam, gl, slot, active, acc, alpha, a, eops, red);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The reduced camera Laplacian WITHOUT its inverse ("a sparse Cholesky of the reduced Laplacian" -- here: no factorisation at
+// all).  x_cam = VT^-1 r is solved per product by preconditioned CG on  VT = Q2_bar - V3_bar Q3^-1 V3_bar^T  applied matrix-free through the
+// two observation lists (by landmark: y_l = (1/Q3_l) sum w x_cam; by camera: (VT x)_i = Q2_i x_i - sum w y_l -- the kernels of the chain
+// itself), Jacobi preconditioner diag(VT), the o columns of the right-hand side advanced together with their own alpha / beta.  No
+// (N-1)^2 array exists: memory and set-up are O(observations); the dense inverse costs 8 (N-1)^2 bytes (1.5 GB at 13 682 cameras, 80 GB
+// at 100 k) and an O(N^3) factorisation.  Every scalar is a fixed-order sum of per-workgroup partial sums that each workgroup adds up
+// itself (as cg_step_kernel does): no atomics, no grid barrier, bit-reproducible.  Launches per iteration: direction, landmark pass,
+// camera pass (+ <p, VT p> partials), update (+ <r, z>, |r|^2 partials).
+// ------------------------------------------------------------------------------------------------------------------
+struct PcgState {             // device-resident; written by workgroup 0 of the kernel that decides
+    int32_t done;             // 1: every column reached the tolerance (or the tCG launch this product belongs to is a no-op)
+    int32_t iters;            // iterations performed
+    double relres;            // max over the columns of |r| / |b| when it stopped
+};
+struct PcgArgs {
+    int n1;                   // N - 1 unknowns per column
+    int grid;                 // workgroups of the flat kernels == partial sums per column
+    double tol2;              // (relative residual)^2 to reach
+    const double *b;          // right-hand side r_ (pitch OP)
+    const double *dinv;       // 1 / diag(VT), n1
+    const double *q2;         // Q2 per camera (index cam)
+    double *x, *r, *p, *Ap;   // pitch OP, n1 records
+    double *prz[2], *prr, *pbb;   // per-workgroup partial sums of <r,z> (by iteration parity), |r|^2, |b|^2: grid * O each (column-major: [k][workgroup])
+    double *ppap;             // the same of <p, VT p> from the camera pass: cam_grid * O
+    int cam_grid;
+    PcgState *st;
+};
+template <int O>
+__device__ __forceinline__ void pcg_sums(const double *parts, int grid, double (&out)[O], double *sh) {
+#pragma unroll
+    for (int k = 0; k < O; ++k) out[k] = sum_partials256(parts + (size_t)k * grid, grid, sh);
+}
+template <int O>
+__device__ __forceinline__ void pcg_store_partials(const double (&acc)[O], double *parts, int grid, double *sh) {
+#pragma unroll
+    for (int k = 0; k < O; ++k) {
+        const double t = block_sum256(acc[k], sh);
+        if (threadIdx.x == 0) parts[(size_t)k * grid + blockIdx.x] = t;
+    }
+}
+// x = 0, r = b, p = z = dinv .* r; partials of <r, z> (parity 0) and |b|^2
+template <int O>
+__global__ __launch_bounds__(256) void pcg_init_kernel(PcgArgs a, const TcgScal *__restrict__ scal) {
+    constexpr int OP = pitch_of(O);
+    __shared__ double sh[4];
+    if (scal != nullptr && scal->status != 0) {   // a launch enqueued past the end of the tCG: nothing to solve
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->done = 1; a.st->iters = 0; a.st->relres = 0.0; }
+        return;
+    }
+    double rz[O], bb[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) rz[k] = bb[k] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n1; i += gridDim.x * 256) {
+        const double di = a.dinv[i];
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            const double v = a.b[(size_t)i * OP + k], z = di * v;
+            a.x[(size_t)i * OP + k] = 0.0; a.r[(size_t)i * OP + k] = v; a.p[(size_t)i * OP + k] = z;
+            rz[k] += v * z; bb[k] += v * v;
+        }
+    }
+    pcg_store_partials<O>(rz, a.prz[0], a.grid, sh);
+    pcg_store_partials<O>(bb, a.pbb, a.grid, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->done = 0; a.st->iters = 0; a.st->relres = 1.0; }
+}
+// iteration it >= 1: beta = <r,z>_new / <r,z>_old per column, p = z + beta p; decides whether the previous update reached the tolerance
+template <int O>
+__global__ __launch_bounds__(256) void pcg_dir_kernel(PcgArgs a, int it) {
+    constexpr int OP = pitch_of(O);
+    __shared__ double sh[4];
+    __shared__ int was_done;
+    if (threadIdx.x == 0) was_done = a.st->done;   // ONE read per workgroup: workgroup 0 may set the flag while later workgroups start
+    __syncthreads();
+    if (was_done) return;
+    double rzn[O], rzo[O], rr[O], bb[O];
+    pcg_sums<O>(a.prz[it & 1], a.grid, rzn, sh);
+    pcg_sums<O>(a.prz[(it & 1) ^ 1], a.grid, rzo, sh);
+    pcg_sums<O>(a.prr, a.grid, rr, sh);
+    pcg_sums<O>(a.pbb, a.grid, bb, sh);
+    bool conv = true;
+    double worst = 0.0;
+#pragma unroll
+    for (int k = 0; k < O; ++k) {
+        const double q = (bb[k] > 0.0) ? rr[k] / bb[k] : 0.0;
+        worst = fmax(worst, q);
+        if (!(q <= a.tol2)) conv = false;
+    }
+    if (conv) {   // identical decision in every workgroup (identical sums); workgroup 0 publishes it for the launches behind this one.  The
+                  // flag is written only AFTER every workgroup has read it above: all of them read st->done before this store can matter,
+                  // because a workgroup that sees done == 1 here returns exactly as one that computes conv itself
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->done = 1; a.st->iters = it; a.st->relres = sqrt(worst); }
+        return;
+    }
+    double beta[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) beta[k] = (rzo[k] > 0.0) ? rzn[k] / rzo[k] : 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n1; i += gridDim.x * 256) {
+        const double di = a.dinv[i];
+#pragma unroll
+        for (int k = 0; k < O; ++k) a.p[(size_t)i * OP + k] = di * a.r[(size_t)i * OP + k] + beta[k] * a.p[(size_t)i * OP + k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->iters = it; a.st->relres = sqrt(worst); }
+}
+// y_l = (1/Q3_l) sum_{obs of l} w p_cam   (the anchor camera 0 is not an unknown)
+template <int O>
+__global__ __launch_bounds__(kSchurHeavyThreads) void pcg_lm_kernel(SchurLm L, const double *__restrict__ q3inv, const double *__restrict__ pv,
+                                                                  const PcgState *__restrict__ st, double *__restrict__ y) {
+    constexpr int OP = pitch_of(O);
+    if (st->done) return;
+    const bool heavy = (int64_t)blockIdx.x < L.nheavy;
+    int64_t l, e, e_end, step;
+    if (heavy) {
+        l = blockIdx.x; e = L.ptr[l] + threadIdx.x; e_end = L.ptr[l + 1]; step = kSchurHeavyThreads;
+    } else {
+        const int64_t t = ((int64_t)blockIdx.x - L.nheavy) * kSchurHeavyThreads + threadIdx.x;
+        l = L.nheavy + t;
+        if (l >= L.m) return;
+        e = L.gbase[t >> 6] + (t & 63); e_end = e + (int64_t)64 * L.deg[l]; step = 64;
+    }
+    double acc[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) acc[k] = 0.0;
+    for (; e < e_end; e += step) {
+        const int i = L.cam[e];
+        if (i == 0) continue;
+        const double w = L.w[e];
+        double xi[O];
+        load_rec<O>(pv + (size_t)(i - 1) * OP, xi);
+#pragma unroll
+        for (int k = 0; k < O; ++k) acc[k] += w * xi[k];
+    }
+    const double qi = q3inv[l];
+    if (heavy) {
+        if (!heavy_block_sum<O>(acc)) return;
+    }
+#pragma unroll
+    for (int k = 0; k < O; ++k) y[(size_t)l * OP + k] = acc[k] * qi;
+}
+// Ap_i = Q2_i p_i - sum_{obs of i} w y_l, one wavefront per camera 1..N-1; per-workgroup partials of <p, Ap>
+template <int O>
+__global__ __launch_bounds__(256) void pcg_cam_kernel(int n, const int64_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_lm,
+                                                       const double *__restrict__ cam_w, const double *__restrict__ y, PcgArgs a) {
+    constexpr int OP = pitch_of(O);
+    __shared__ double red[kQwWaves][O];
+    if (a.st->done) return;
+    const int gl = threadIdx.x & 63, wv = threadIdx.x >> 6, cam = blockIdx.x * kQwWaves + wv;
+    double acc[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) acc[k] = 0.0;
+    const bool on = cam < n && cam >= 1;
+    if (on)
+        for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 64) {
+            const double w = cam_w[e];
+            double yl[O];
+            load_rec<O>(y + (size_t)cam_lm[e] * OP, yl);
+#pragma unroll
+            for (int k = 0; k < O; ++k) acc[k] += w * yl[k];
+        }
+#pragma unroll
+    for (int k = 0; k < O; ++k) acc[k] = wave_sum(acc[k]);
+    if (gl == 0) {
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            double pap = 0.0;
+            if (on) {
+                const double pk = a.p[(size_t)(cam - 1) * OP + k];
+                const double v = a.q2[cam] * pk - acc[k];
+                a.Ap[(size_t)(cam - 1) * OP + k] = v;
+                pap = pk * v;
+            }
+            red[wv][k] = pap;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < kQwWaves; ++q) t += red[q][k];
+            a.ppap[(size_t)k * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+// alpha = <r,z> / <p,Ap> per column; x += alpha p, r -= alpha Ap; partials of the new <r,z> (other parity) and |r|^2
+template <int O>
+__global__ __launch_bounds__(256) void pcg_upd_kernel(PcgArgs a, int it) {
+    constexpr int OP = pitch_of(O);
+    __shared__ double sh[4];
+    if (a.st->done) return;
+    double rz[O], pap[O], alpha[O];
+    pcg_sums<O>(a.prz[it & 1], a.grid, rz, sh);
+    pcg_sums<O>(a.ppap, a.cam_grid, pap, sh);
+#pragma unroll
+    for (int k = 0; k < O; ++k) alpha[k] = (pap[k] > 0.0 && rz[k] > 0.0) ? rz[k] / pap[k] : 0.0;
+    double rzn[O], rr[O];
+#pragma unroll
+    for (int k = 0; k < O; ++k) rzn[k] = rr[k] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n1; i += gridDim.x * 256) {
+        const double di = a.dinv[i];
+#pragma unroll
+        for (int k = 0; k < O; ++k) {
+            const size_t j = (size_t)i * OP + k;
+            a.x[j] += alpha[k] * a.p[j];
+            const double rn = a.r[j] - alpha[k] * a.Ap[j];
+            a.r[j] = rn;
+            rzn[k] += rn * rn * di; rr[k] += rn * rn;
+        }
+    }
+    pcg_store_partials<O>(rzn, a.prz[(it & 1) ^ 1], a.grid, sh);
+    pcg_store_partials<O>(rr, a.prr, a.grid, sh);
+}
+// 1 / diag(VT):  diag_i = Q2_i - sum_{obs of i} w^2 / Q3_l   (one wavefront per camera; set-up)
+__global__ __launch_bounds__(256) void pcg_diag_kernel(int n, const int64_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_lm,
+                                                        const double *__restrict__ cam_w, const double *__restrict__ q3inv,
+                                                        const double *__restrict__ q2, double *__restrict__ dinv) {
+    const int gl = threadIdx.x & 63, cam = blockIdx.x * kQwWaves + (threadIdx.x >> 6);
+    double acc = 0.0;
+    if (cam < n && cam >= 1)
+        for (int64_t e = cam_ptr[cam] + gl; e < cam_ptr[cam + 1]; e += 64) { const double w = cam_w[e]; acc += w * w * q3inv[cam_lm[e]]; }
+    acc = wave_sum(acc);
+    if (cam < n && cam >= 1 && gl == 0) {
+        const double d = q2[cam] - acc;
+        dinv[cam - 1] = (d > 0.0) ? 1.0 / d : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // device: everything that depends on the weights (round 4; the host version below stays as the fall-back for observation lists that name
 // a (camera, landmark) pair twice).  utils/creatematrix.py:62-175 restated on the observation level.
@@ -339,7 +569,11 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     world_ = comm_ ? comm_->world : 1;
     rank_ = comm_ ? comm_->rank : 0;
     if (n < 1 || n_landmarks < 1 || nobs < 1 || !cam || !lm || !p || !w) throw Error(XM_ERR_ARG, "matrix-free Q: bad observation list");
-    if (n > kSchurMaxCams) throw Error(XM_ERR_ARG, "matrix-free Q: more than " + std::to_string(kSchurMaxCams) + " cameras");
+    // how VT^-1 is applied: the dense inverse (fast products, 8 (N-1)^2 bytes and an O(N^3) set-up) up to cfg.dense_max cameras, above that
+    // preconditioned CG inside every product (no (N-1)^2 array at all); cfg.solver forces one of the two
+    pcg_ = cfg.solver == 2 || (cfg.solver == 0 && n > cfg.dense_max);
+    if (pcg_ && comm_) throw Error(XM_ERR_ARG, "matrix-free Q: the CG form of the reduced camera system runs on one GPU (row-partitioned contexts use the dense inverse)");
+    if (!pcg_ && n > kSchurMaxCams) throw Error(XM_ERR_ARG, "matrix-free Q: more than " + std::to_string(kSchurMaxCams) + " cameras need the CG form (xm_tuning_t.schur_solver)");
     n_ = n; m_ = n_landmarks; nobs_ = nobs;
     const int64_t N = n, M = n_landmarks;
     // ---- structure (fixed for the life of the context): observation lists by camera and by landmark, input order inside each
@@ -436,8 +670,19 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     // (the set-up is replicated) but multiplies only its own rows, and the ranks all-gather x_cam
     nred_loc_ = (nred_ + world_ - 1) / world_;
     nred_pad_ = nred_loc_ * world_;
-    vtinv_.alloc((size_t)3 * nred_pad_ * (size_t)ldv_);
+    if (pcg_) {
+        dup_pairs_ = false;   // (the host assembly exists for VT; a pair named twice only makes the Jacobi diagonal approximate)
+        pcg_dinv_.alloc((size_t)std::max<int64_t>(mr, 1));
+        XM_HIP_CHECK(hipHostMalloc((void **)&pcg_host_, sizeof(PcgState), hipHostMallocDefault));
+        pcg_state_.alloc(sizeof(PcgState) / sizeof(int32_t) + 2);
+    } else {
+        vtinv_.alloc((size_t)3 * nred_pad_ * (size_t)ldv_);
+    }
     set_weights(w, st);
+}
+
+SchurOp::~SchurOp() {
+    if (pcg_host_) (void)hipHostFree(pcg_host_);
 }
 
 // Everything that depends on the weights (utils/creatematrix.py:62-175 restated on the observation level): Q1, c (= V1), Q3, the
@@ -574,6 +819,18 @@ void SchurOp::set_weights_device(const double *w, hipStream_t st) {
     lap("weights, Q1, c, Q2, 1/Q3 (device)");
     const int64_t mr = N - 1;
     if (mr <= 0) { XM_HIP_CHECK(hipStreamSynchronize(st)); return; }
+    if (pcg_) {   // no VT, no inverse: the Jacobi diagonal is all the CG form needs
+        hipLaunchKernelGGL(pcg_diag_kernel, dim3((unsigned)((N + kQwWaves - 1) / kQwWaves)), dim3(256), 0, st, (int)N, cam_ptr_.p, cam_lm_.p, cam_w_.p,
+                           q3inv_.p, q2_.p, pcg_dinv_.p);
+        check_launch("schur set-up (Jacobi diagonal)");
+        std::vector<double> hd((size_t)mr);
+        XM_HIP_CHECK(hipMemcpyAsync(hd.data(), pcg_dinv_.p, (size_t)mr * sizeof(double), hipMemcpyDeviceToHost, st));
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        for (double d : hd)
+            if (!(d > 0.0) || !std::isfinite(d)) throw Error(XM_ERR_ARG, "matrix-free Q: a camera has no weight on the reduced camera Laplacian's diagonal (camera without observations?)");
+        lap("Jacobi diagonal (device)");
+        return;
+    }
     DevBuf<double> tmp, inv;
     tmp.alloc((size_t)mr * mr, false); inv.alloc((size_t)mr * mr, false);
     constexpr int64_t kColsPerPass = 16384;   // 128 KB of LDS per wavefront (one workgroup per CU; gfx950 has 160 KB)
@@ -693,9 +950,15 @@ void SchurOp::ensure(int o) {
     h_.alloc((size_t)m_ * OP); xl_.alloc((size_t)m_ * OP);
     r_.alloc((size_t)ldv_ * OP + 2);            // product input of the dense kernel: ldv rows, zero beyond N-1
     xc_.alloc((size_t)3 * nred_pad_ * OP + 2);
+    if (pcg_) {
+        const size_t v = (size_t)std::max<int64_t>(n_ - 1, 1) * OP + 2;
+        pcg_r_.alloc(v); pcg_p_.alloc(v); pcg_ap_.alloc(v);
+        pcg_grid_ = flat_grid(std::max<int64_t>(n_ - 1, 1));
+        pcg_parts_.alloc(((size_t)4 * pcg_grid_ + (size_t)qw_grid((int)n_)) * (size_t)o + 16);
+    }
     // VT^-1 is symmetric: from xm_tuning_t.sym_min_rows rows on (default 6144, the threshold of the dense solver) the chain applies it
     // with the half-traffic kernel (upper triangle only; o = 3, 4)
-    vt_sym_ = 3 * nred_ >= cfg_.sym_min_rows;
+    vt_sym_ = !pcg_ && 3 * nred_ >= cfg_.sym_min_rows;
     if (vt_sym_ && o >= 3) {
         const int os = std::min(o, 4);
         sym_prow_.alloc(sym_prow_count((int)nred_, ldv_, os));
@@ -706,7 +969,9 @@ void SchurOp::ensure(int o) {
 
 int64_t SchurOp::bytes_per_product(int o) const {
     // observation arrays are streamed twice by camera (w, landmark index; w, p, landmark index) and twice by landmark, VT^{-1} once
-    return nobs_ * (8 + 4) + nobs_ * (8 + 24 + 4) + nobs_ * (8 + 24 + 4) + nobs_ * (8 + 4) + 8 * (n_ - 1) * (n_ - 1) + 2LL * 8 * 3 * n_ * o;
+    // CG form: every iteration streams both observation lists once more (w + index each way); counted with the iterations of the last product
+    const int64_t inner = pcg_ ? (int64_t)std::max(1, pcg_last_iters_) * (2 * nobs_ * (8 + 4)) : 8 * (n_ - 1) * (n_ - 1);
+    return nobs_ * (8 + 4) + nobs_ * (8 + 24 + 4) + nobs_ * (8 + 24 + 4) + nobs_ * (8 + 4) + inner + 2LL * 8 * 3 * n_ * o;
 }
 
 template <int O>
@@ -714,14 +979,16 @@ static void schur_product_o(int epi, int64_t n, int64_t nobs, const SchurLm &L, 
                             const double *Q1,
                             const double *c, const double *q3inv, const double *vtinv, int64_t nred, int64_t ldv, double *h, double *r,
                             double *xc, double *xl, const double *W, double alpha, const CamArgs &a, double *sym_prow, double *sym_pcol, hipStream_t st,
-                            Comm *comm, int64_t nred_loc) {
+                            Comm *comm, int64_t nred_loc, const std::function<void(const TcgScal *)> &solve_pcg) {
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
     const int64_t nheavy = L.nheavy, nlight = L.m - L.nheavy;
     const dim3 b(256), gc(qw_grid((int)n)), gy(qw_grid(a.nloc));
     const dim3 glm((unsigned)(nheavy + (nlight + kSchurHeavyThreads - 1) / kSchurHeavyThreads)), blm(kSchurHeavyThreads);
     hipLaunchKernelGGL((schur_lm_h_kernel<O>), glm, blm, 0, st, L, q3inv, W, sc, h);
     hipLaunchKernelGGL((schur_cam_r_kernel<O>), gc, b, 0, st, (int)n, cam_ptr, cam_lm, cam_w, c, W, h, sc, r);
-    if (n > 1) {
+    if (n > 1 && solve_pcg) {
+        solve_pcg(sc);   // x_cam by preconditioned CG on the matrix-free reduced camera Laplacian (SchurOp::pcg_solve)
+    } else if (n > 1) {
         constexpr int OPc = pitch_of(O);
         CamArgs pa;
         std::memset(&pa, 0, sizeof(pa));
@@ -758,10 +1025,59 @@ void SchurOp::product(int o, int epi, const double *W, double alpha, const CamAr
     }
     SchurLm L;
     L.m = m_; L.nheavy = nheavy_; L.total = ltotal_; L.ptr = lm_ptr_.p; L.gbase = gbase_.p; L.deg = ldeg_.p; L.cam = lm_cam_.p; L.w = lm_w_.p; L.p = lm_p_.p;
+    std::function<void(const TcgScal *)> pcg;
+    if (pcg_) pcg = [&](const TcgScal *sc) { XM_DISPATCH_O(o, (pcg_solve<O_>(L, sc, st))); };
     XM_DISPATCH_O(o, (schur_product_o<O_>(epi, n_, nobs_, L, cam_ptr_.p, cam_lm_.p, cam_w_.p, cam_p_.p, Q1_.p,
                                          c_.p, q3inv_.p, vtinv_.p, nred_, ldv_, h_.p, r_.p, xc_.p, xl_.p, W, alpha, a, (vt_sym_ && !comm_) ? sym_prow_.p : (double *)nullptr, sym_pcol_.p, st,
-                                         comm_, nred_loc_)));
+                                         comm_, nred_loc_, pcg)));
     check_launch("schur_product");
+}
+
+// x_cam = VT^-1 r by preconditioned CG (kernels above).  The iterations are enqueued in batches without looking at the device: as many as
+// the previous product needed (+ 2), then the host reads the state word and tops up in steps of 8 -- one host round trip per product in
+// the steady state, where consecutive right-hand sides of a truncated CG need the same number of iterations to within a few.
+template <int O>
+void SchurOp::pcg_solve(const SchurLm &L, const TcgScal *sc, hipStream_t st) {
+    constexpr int OP = pitch_of(O);
+    const int n1 = (int)(n_ - 1);
+    PcgArgs a;
+    a.n1 = n1; a.grid = pcg_grid_; a.tol2 = pcg_tol_ * pcg_tol_;
+    a.b = r_.p; a.dinv = pcg_dinv_.p; a.q2 = q2_.p;
+    a.x = xc_.p; a.r = pcg_r_.p; a.p = pcg_p_.p; a.Ap = pcg_ap_.p;
+    const size_t seg = (size_t)pcg_grid_ * O;
+    a.prz[0] = pcg_parts_.p; a.prz[1] = pcg_parts_.p + seg; a.prr = pcg_parts_.p + 2 * seg; a.pbb = pcg_parts_.p + 3 * seg;
+    a.ppap = pcg_parts_.p + 4 * seg; a.cam_grid = qw_grid((int)n_);
+    a.st = reinterpret_cast<PcgState *>(pcg_state_.p);
+    const dim3 b(256), gf(pcg_grid_), gc(a.cam_grid);
+    const int64_t nlight = L.m - L.nheavy;
+    const dim3 glm((unsigned)(L.nheavy + (nlight + kSchurHeavyThreads - 1) / kSchurHeavyThreads)), blm(kSchurHeavyThreads);
+    hipLaunchKernelGGL((pcg_init_kernel<O>), gf, b, 0, st, a, sc);
+    int it = 0;
+    auto enqueue = [&](int upto) {
+        for (; it < upto; ++it) {
+            if (it > 0) hipLaunchKernelGGL((pcg_dir_kernel<O>), gf, b, 0, st, a, it);
+            hipLaunchKernelGGL((pcg_lm_kernel<O>), glm, blm, 0, st, L, q3inv_.p, (const double *)a.p, (const PcgState *)a.st, xl_.p);
+            hipLaunchKernelGGL((pcg_cam_kernel<O>), gc, b, 0, st, (int)n_, cam_ptr_.p, cam_lm_.p, cam_w_.p, (const double *)xl_.p, a);
+            hipLaunchKernelGGL((pcg_upd_kernel<O>), gf, b, 0, st, a, it);
+        }
+        hipLaunchKernelGGL((pcg_dir_kernel<O>), gf, b, 0, st, a, it);   // the convergence test of the last update (no-op once done); it is not advanced:
+                                                                       // a following batch repeats this launch as its first direction update
+    };
+    int target = std::min(pcg_max_iters_, std::max(4, pcg_last_iters_ + 2));
+    for (;;) {
+        enqueue(target);
+        check_launch("schur_pcg");
+        XM_HIP_CHECK(hipMemcpyAsync(pcg_host_, a.st, sizeof(PcgState), hipMemcpyDeviceToHost, st));
+        XM_HIP_CHECK(hipStreamSynchronize(st));
+        if (pcg_host_->done || target >= pcg_max_iters_) break;
+        target = std::min(pcg_max_iters_, target + 8);
+    }
+    if (pcg_host_->done && pcg_host_->iters > 0) pcg_last_iters_ = pcg_host_->iters;
+    pcg_last_relres_ = pcg_host_->relres;
+    pcg_products_++;
+    pcg_iters_total_ += pcg_host_->done ? pcg_host_->iters : target;
+    if (!pcg_host_->done) pcg_unconverged_++;
+    (void)OP;
 }
 
 }  // namespace xm

@@ -339,9 +339,6 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
                                              double *__restrict__ parts) {
     constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2, RECP = (REC + 1) & ~1;
     constexpr int NQ = (CODEC == SELL_CODEC_QUAT) ? 4 : 9;   // doubles per stored block
-    if (scal != nullptr) {
-        if (scal->status != 0) return;
-    }
     // ONE transposition buffer per wavefront (the two steps of a pair go through it one after the other; transpose1 ends with a wavefront
     // fence): 20 KB per workgroup at o = 3, 32 KB at o = 4 / 5 -- with one buffer per step (40 / 64 KB) the LDS, not the registers, capped
     // the resident workgroups per CU (o = 4 / 5: two)
@@ -354,6 +351,9 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     if (c >= m.slab_start[slab + 1]) return;   // wave-uniform
     const int64_t off = m.slice_off[c];
     const int w = (int)(m.slice_off[c + 1] - off);
+    if (scal != nullptr) {   // the tCG's status word (an L2 miss: written by the previous cg_step) is waited for only after the slice look-ups
+        if (scal->status != 0) return;   // have been requested
+    }
     const int np = w >> 1;
     const bool tail = (w & 1) != 0;
     const int32_t *cb = m.cols + off * 64;

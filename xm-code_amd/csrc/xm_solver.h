@@ -34,6 +34,8 @@ struct Settings {
     int debug_peer_mute = 0;              // tests: rank 1 never publishes its tCG epoch -> the peers' bounded wait must expire
     int exchange_lite = 1;                // 0 (xm_tuning_t.exchange_fence): the fused tCG exchange pushes with plain stores + a system-scope release fence instead of write-through stores
     bool schur_host_assembly = false, schur_trace = false;   // matrix-free storage (xm_schur.h: SchurSettings)
+    int schur_solver = 0;                 // 0 by size | 1 dense inverse of the reduced camera Laplacian | 2 preconditioned CG inside the product
+    int64_t schur_dense_max = 20000;
     static Settings resolve(const xm_tuning_t *t);
 };
 
@@ -176,6 +178,7 @@ public:
     double xm2_filter(const double *rot, const double *scale, double pct, int64_t *removed, double *w_out);
     const std::vector<double> &weights() const { return w_cur_; }
     int64_t n_landmarks() const;
+    bool schur_info(int64_t out[3], double *relres) const;   // matrix-free storage with the CG form: products, inner iterations, products at the cap
 
 private:
     // ---- problem ------------------------------------------------------------------------------------------------
@@ -278,7 +281,12 @@ private:
     bool overlap_applies() const;
     void eval_point(int state, const double *Rp, const double *sp, double &f, double &rr);
     double sum_parts(const double *dparts, int count);
-    int run_tcg(double rr, double delta, TcgScal &fin);
+    int run_tcg(double rr, double delta, TcgScal &fin, int adopted = 0);   // adopted: iterations of THIS tCG already enqueued speculatively (enqueue_spec_tcg)
+    int enqueue_spec_tcg();      // single GPU: tcg_init + the first iteration(s) of the next tCG from the CANDIDATE point, gated on the device (SpecCtl)
+    void tcg_enqueue_iteration(int i, bool profile);   // one iteration = Hessian product (+ exchange) + cg_step
+    bool spec_applies() const;
+    DevBuf<SpecCtl> spec_;
+    unsigned int tcg_seq_ = 0;   // sequence number of the current truncated-CG run (TcgScal.seq, progress word)
     volatile double *wait_outer_result();
     bool stream_idle(std::chrono::steady_clock::time_point t_wait, const char *what);   // true: drained; throws on a device error / watchdog
     bool agree_any(bool local);

@@ -317,11 +317,13 @@ void Context::init(const xm_problem_t &prob_in) {
             XM_HIP_CHECK(hipMemcpy(colidx_.p, ci.data(), (size_t)nb_loc_ * sizeof(int32_t), hipMemcpyHostToDevice));
             XM_HIP_CHECK(hipMemcpy(blocks_.p, prob.blocks + b0 * 9, (size_t)nb_loc_ * 9 * sizeof(double), hipMemcpyHostToDevice));
         }
-        // Large problems: sliced-ELL over per-XCD column slabs (xm_sell.h).  Below ~1M blocks per GPU the product is in the
-        // launch-latency regime (13 us at 13682 cameras) and the one-launch CSR kernel stays.  View-graph storage compresses the
+        // Large problems: sliced-ELL over per-XCD column slabs (xm_sell.h).  Below ~1.5 M blocks per GPU the product is in the
+        // launch-latency regime and the one-launch CSR kernel wins -- measured (profiles/r05_kbench_sell_crossover.txt, o = 3, us):
+        // 425 k blocks CSR 13.2 / sliced ELL 23.0, 929 k blocks 25.5 / 32.0, 2.05 M blocks 53.1 / 46.8; inside the solve at 425 k blocks
+        // (Hessian epilogue, HIP events) 20.4 / 28.9 and 22.4 k / 18.3 k tCG iterations per second (r05_bench_rome_bsr*.json).  View-graph storage compresses the
         // stream with the quaternion codec (36 instead of 76 bytes per stored block).  Settings: sell, sell_slabs, sell_lmax,
         // sell_gather, sell_codec (xm_tuning_t).
-        if (cfg_.sell == 1 || (cfg_.sell == 0 && nb_loc_ >= 1000000)) {
+        if (cfg_.sell == 1 || (cfg_.sell == 0 && nb_loc_ >= kSellMinBlocks)) {
             sell_gm_ = cfg_.sell_gather;
             const int codec = (cfg_.sell_codec == 2 || (cfg_.sell_codec == 0 && viewgraph)) ? SELL_CODEC_QUAT : SELL_CODEC_FULL;
             // layout: sorted virtual rows + a second launch for the per-camera sum (xm_sell.h).  A chunk-tiled ONE-launch layout was measured
@@ -333,6 +335,7 @@ void Context::init(const xm_problem_t &prob_in) {
         // last kernel of the chain are partitioned (xm_schur.h)
         SchurSettings sc;
         sc.host_assembly = cfg_.schur_host_assembly; sc.sym_min_rows = cfg_.sym_min_rows; sc.trace = cfg_.schur_trace;
+        sc.solver = cfg_.schur_solver; sc.dense_max = cfg_.schur_dense_max;
         schur_.reset(new SchurOp(n_, prob.n_landmarks, prob.nobs, prob.obs_cam, prob.obs_lm, prob.obs_p, prob.obs_w, st_, comm_.get(), sc));
         w_cur_.assign(prob.obs_w, prob.obs_w + prob.nobs);
     } else {
@@ -522,6 +525,7 @@ void Context::setup_rank(int o) {
         Pstrip_.alloc(mat);
     }
     scal_.alloc(2);
+    spec_.alloc(1);
     // the sliced-ELL product's partial-result buffer grows with o: (re)allocate it HERE, between the two barriers -- hipFree synchronises
     // the whole device, and with several ranks of one process on one device ("virtual devices") a free between two collectives waits for
     // a peer's spinning wait kernel that waits for this rank's next push (8 virtual ranks ran into exactly that at the first o = 4 product)
@@ -785,21 +789,82 @@ void Context::finish_profile() {
 // ------------------------------------------------------------------------------------------------------------------
 // truncated CG (trustregion.h:559-664): enqueue-ahead with a host-mapped progress word, no host sync per iteration
 // ------------------------------------------------------------------------------------------------------------------
-int Context::run_tcg(double rr, double delta, TcgScal &fin) {
-    const bool stepped = (opt_->flags & XM_FLAG_HOST_STEPPED) != 0;
-    const bool profile = (opt_->flags & XM_FLAG_PROFILE_QW) != 0;
+// one tCG iteration on the stream: the Hessian product of iteration i, the lockstep all-gather when the exchange is not fused, cg_step
+void Context::tcg_enqueue_iteration(int i, bool profile) {
     const int nA_loc = prod_grid(), nB_loc = tcg_blocks();
     const int rank = comm_->rank;
+    const bool fused = xchg_.world > 1;
+    const bool lockstep = comm_->active() && !fused;
+    double *Wloc = wpad() ? nullptr : W_.p + (size_t)cam0_ * 3 * OP_;   // (see run_tcg)
+    const int par = i & 1;
+    CamArgs a = cam_args(cur_);
+    a.scal = scal_.p + par;
+    a.ps = par ? psB_.p : psA_.p;
+    a.rs = par ? rsB_.p : rs_.p;
+    // tCG partial sums travel in ONE all-gather per iteration: chunk = [Hessian-epilogue partials of this iteration |
+    // |r|^2 partials the previous cg_step left in this parity's buffer]
+    // and, with more than one rank, in front of them this rank's rows of the image of Hp (see cg_step_kernel): the product
+    // input of the next iteration then follows from replicated data and needs no all-gather of its own.
+    const size_t mat = (size_t)nloc_ * 3 * OP_;
+    const size_t b_off = comm_->active() ? mat : 0;
+    const size_t chunk = b_off + (size_t)3 * nA_loc + nB_loc;
+    double *pB = fused ? partsB_peer_ : partsB_.p;
+    double *pcur = pB + (size_t)par * chunk * comm_->world, *pnext = pB + (size_t)(par ^ 1) * chunk * comm_->world;
+    a.partials = pcur + (size_t)rank * chunk + b_off;
+    a.Bout = comm_->active() ? pcur + (size_t)rank * chunk : nullptr;
+    const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
+    if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
+    product(EPI_HESS, o_, 2.0, a);
+    if (timed) { XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].second, st_)); ev_used_++; }
+    hess_launches_++;
+    if (lockstep) comm_->allgather(pcur, chunk, st_);
+    launch_cg_step(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), pcur, nA_loc, nB_loc, comm_->world, HpR_.p, Hps_.p, R_.p,
+                   s_.p, pR_.p, par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, rR_.p,
+                   par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pnext + (size_t)rank * chunk + b_off + 3 * nA_loc, hstat_dev_,
+                   (int)b_off, (int64_t)mat, comm_->active() ? Afull_.p : nullptr, W_.p, grouping_, xchg_, st_, wpad());
+}
+
+// May the start of the next truncated CG be enqueued behind outer_finalize_kernel before the host knows how the outer iteration ended?
+// One GPU, run-ahead polling (not the host-stepped debugging mode), and no product that synchronises with the host inside the tCG.
+bool Context::spec_applies() const {
+    return !comm_->active() && opt_ && !(opt_->flags & XM_FLAG_HOST_STEPPED) && storage_ != XM_STORAGE_SCHUR && cfg_.debug_drop_finalize < 0;
+}
+
+// The host's view is switched to "the candidate was accepted" (R / s swapped, the candidate's gradient state current) for the duration of the
+// enqueue: the launches carry the pointers of that world.  tcg_init starts only if the device reached the same verdict (SpecCtl.go), else it
+// leaves the scalar block dormant and the iteration(s) behind it return at once.  Returns the iterations enqueued.
+int Context::enqueue_spec_tcg() {
+    std::swap(R_.p, Rc_.p);
+    std::swap(s_.p, sc_.p);
+    cur_ ^= 1;
+    const PointState &P = ps_[cur_];
+    double *Wloc = wpad() ? nullptr : W_.p + (size_t)cam0_ * 3 * OP_;
+    ++tcg_seq_;
+    launch_tcg_init(o_, nloc_, P.rgR.p, P.rgs.p, R_.p, s_.p, rR_.p, rs_.p, pR_.p, psA_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, Wloc,
+                    scal_.p, 0.0, 0.0, hstat_dev_, st_, wpad(), (int)tcg_seq_, spec_.p);
+    const int n_spec = 2;
+    for (int i = 0; i < n_spec; ++i) tcg_enqueue_iteration(i, false);   // (not sampled by the HIP-event profile: they may turn out dormant)
+    std::swap(R_.p, Rc_.p);
+    std::swap(s_.p, sc_.p);
+    cur_ ^= 1;
+    return n_spec;
+}
+
+int Context::run_tcg(double rr, double delta, TcgScal &fin, int adopted) {
+    const bool stepped = (opt_->flags & XM_FLAG_HOST_STEPPED) != 0;
+    const bool profile = (opt_->flags & XM_FLAG_PROFILE_QW) != 0;
     // with the padded copy on (single rank, sliced ELL) nothing reads the native-pitch product input inside the tCG: the main launch
     // gathers from the copy and the second launch rebuilds the diagonal term from its own operands -- the kernels skip those 7.2 MB of
     // stores per iteration at 100 k cameras
     double *Wloc = wpad() ? nullptr : W_.p + (size_t)cam0_ * 3 * OP_;
     const PointState &P = ps_[cur_];
     if (comm_->active()) comm_->note("tcg_start", rr, delta);
-    *hstat_ = ~0ull;
-    launch_tcg_init(o_, nloc_, P.rgR.p, P.rgs.p, R_.p, s_.p, rR_.p, rs_.p, pR_.p, psA_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, Wloc,
-                    scal_.p, rr, delta, hstat_dev_, st_, wpad());
-    gather_W();
+    if (adopted == 0) {
+        ++tcg_seq_;
+        launch_tcg_init(o_, nloc_, P.rgR.p, P.rgs.p, R_.p, s_.p, rR_.p, rs_.p, pR_.p, psA_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, Wloc,
+                        scal_.p, rr, delta, hstat_dev_, st_, wpad(), (int)tcg_seq_);
+        gather_W();
+    }
     // Iterations in flight ahead of the last one seen finished; the excess become no-op launches.  With a communicator the
     // loop must issue the SAME number of collectives on every rank although ranks poll at different moments: iteration j is
     // enqueued only once iteration j-2 is confirmed (so nobody can be past T+1 when the tCG ends in iteration T) and every
@@ -812,35 +877,8 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
     const bool lockstep = comm_->active() && !fused;
     const int run_ahead = lockstep ? 2 : 3;
     int fin_status = 0, fin_iter = 0;
-    int it = 0;  // iterations enqueued
-    auto enqueue = [&](int i) {
-        const int par = i & 1;
-        CamArgs a = cam_args(cur_);
-        a.scal = scal_.p + par;
-        a.ps = par ? psB_.p : psA_.p;
-        a.rs = par ? rsB_.p : rs_.p;
-        // tCG partial sums travel in ONE all-gather per iteration: chunk = [Hessian-epilogue partials of this iteration |
-        // |r|^2 partials the previous cg_step left in this parity's buffer]
-        // and, with more than one rank, in front of them this rank's rows of the image of Hp (see cg_step_kernel): the product
-        // input of the next iteration then follows from replicated data and needs no all-gather of its own.
-        const size_t mat = (size_t)nloc_ * 3 * OP_;
-        const size_t b_off = comm_->active() ? mat : 0;
-        const size_t chunk = b_off + (size_t)3 * nA_loc + nB_loc;
-        double *pB = fused ? partsB_peer_ : partsB_.p;
-        double *pcur = pB + (size_t)par * chunk * comm_->world, *pnext = pB + (size_t)(par ^ 1) * chunk * comm_->world;
-        a.partials = pcur + (size_t)rank * chunk + b_off;
-        a.Bout = comm_->active() ? pcur + (size_t)rank * chunk : nullptr;
-        const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
-        if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
-        product(EPI_HESS, o_, 2.0, a);
-        if (timed) { XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].second, st_)); ev_used_++; }
-        hess_launches_++;
-        if (lockstep) comm_->allgather(pcur, chunk, st_);
-        launch_cg_step(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), pcur, nA_loc, nB_loc, comm_->world, HpR_.p, Hps_.p, R_.p,
-                       s_.p, pR_.p, par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, rR_.p,
-                       par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pnext + (size_t)rank * chunk + b_off + 3 * nA_loc, hstat_dev_,
-                       (int)b_off, (int64_t)mat, comm_->active() ? Afull_.p : nullptr, W_.p, grouping_, xchg_, st_, wpad());
-    };
+    int it = adopted;  // iterations enqueued
+    auto enqueue = [&](int i) { tcg_enqueue_iteration(i, profile); };
     auto read_scal = [&](int par) {
         TcgScal sc;
         to_host(&sc, scal_.p + par, sizeof(TcgScal));
@@ -853,6 +891,8 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
             enqueue(it++);
         }
     } else {
+        // progress word = [run : 32 | iteration : 24 | status : 8], written by tcg_init and every cg_step of THIS run (TcgScal.seq): a word
+        // of an earlier run -- the previous tCG's last one, until this run's tcg_init has executed -- is not progress of this one
         volatile unsigned long long *hs = hstat_;
         auto last_progress = clk::now();
         auto last_change = last_progress;   // watchdog reference: the progress word last moved here
@@ -860,9 +900,9 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
         for (;;) {
             const unsigned long long v = *hs;
             if (v != seen) { seen = v; last_progress = clk::now(); last_change = last_progress; }
-            const bool valid = (v != ~0ull);
+            const bool valid = (unsigned int)(v >> 32) == tcg_seq_;
             const int status = valid ? (int)(v & 0xff) : 0;
-            const int done = valid ? (int)(v >> 8) : 0;
+            const int done = valid ? (int)((v >> 8) & 0xffffff) : 0;
             if (status != 0) { fin_status = status; fin_iter = done; break; }
             if (it < kMaxInner && it - done < run_ahead) { enqueue(it++); continue; }
             __builtin_ia32_pause();
@@ -873,7 +913,7 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin) {
                     TcgScal sc = read_scal(it & 1);
                     if (sc.status != 0) { fin_status = sc.status; fin_iter = sc.iter; break; }
                     if (it >= kMaxInner) { fin_status = 6; fin_iter = kMaxInner; break; }
-                    *hstat_ = ((unsigned long long)(unsigned)sc.iter << 8);
+                    *hstat_ = ((unsigned long long)tcg_seq_ << 32) | ((unsigned long long)(unsigned)sc.iter << 8);
                     if (it - sc.iter >= run_ahead) enqueue(it++);  // cannot happen, but never stall
                 }
                 last_progress = clk::now();
@@ -949,6 +989,7 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
     double loss = f;
 
     int endreason = 6, trstatus = 4, shrink_count = 0, inner_print = 1, k = 0;
+    int adopted = 0;   // iterations of the NEXT truncated CG that are already running (enqueue_spec_tcg), adopted by the decision below
     long long totalite = 0;
     int stop_reason = 14;
     const auto start = clk::now();
@@ -975,7 +1016,8 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         endreason = 6; trstatus = 4;
 
         TcgScal fin;
-        const int enq = run_tcg(rr, delta, fin);
+        const int enq = run_tcg(rr, delta, fin, adopted);
+        adopted = 0;
 
         // model decrease, retraction and the candidate's cost/gradient are enqueued right behind the tCG and fetched with
         // ONE synchronisation (trustregion.h:667-678 needs four blocking reads + a sync here)
@@ -997,12 +1039,19 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         // XM_DEBUG_DROP_FINALIZE=k (tests): the k-th outer iteration "loses" its result kernel, as a failed launch would: the host
         // must come back with XM_ERR_HIP from wait_outer_result() instead of spinning on a sequence word that never arrives
         const long long drop_at = cfg_.debug_drop_finalize;
+        // Single GPU: the result kernel also evaluates the trust-region update and, when the step is accepted and the solve goes on, releases
+        // the start of the NEXT truncated CG, enqueued right behind it (SpecCtl): the GPU works through the host's round trip
+        const bool spec = spec_applies();
+        const OuterArgs oa = {loss, delta, delta_bar, gradtol, shrink_count, (k + 1 >= kMaxOuter) ? 1 : 0};
         if (drop_at >= 0 && (long long)outer_seq_ + 1 == drop_at) ++outer_seq_;
         else
         launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, nB_loc * comm_->world, scal_.p + (enq & 1),
-                              reinterpret_cast<double *>(hstat_dev_) + 8, ++outer_seq_, grouping_, st_);
+                              reinterpret_cast<double *>(hstat_dev_) + 8, ++outer_seq_, grouping_, st_, spec ? &oa : nullptr, spec_.p);
+        const int n_spec = spec ? enqueue_spec_tcg() : 0;
         volatile double *hres = wait_outer_result();
         double f_new = hres[0], rr_new = hres[1], loss_qu = hres[2];
+        const bool spec_go = spec && hres[6] != 0.0;
+        const double spec_delta = hres[7];
         fin.status = (int)hres[3];
         fin.iter = (int)hres[4];
         if (fin.status == 7) { comm_->check_device_error(); throw Error(XM_ERR_COMM, "peer exchange: a rank did not arrive inside the truncated CG"); }
@@ -1030,6 +1079,8 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
             if (stop_delta) { stop_reason = 13; break; }  // the reference leaves the new point in place but reports loss[k]
             loss = f_new;
             rr = rr_new;
+            // the device came to the same verdict from the same numbers: the tCG it has started from this point IS the next one
+            if (spec_go && std::memcmp(&spec_delta, &delta, sizeof(double)) == 0) adopted = n_spec;
         } else {
             trstatus = 3;  // keep point, state, loss and rr
         }
@@ -1500,6 +1551,11 @@ void Context::recover_tp(const double *rot, const double *scale, double *t, doub
     schur_->recover_tp(rot, scale, t, p, st_);
 }
 int64_t Context::n_landmarks() const { return schur_ ? schur_->n_landmarks() : 0; }
+bool Context::schur_info(int64_t out[3], double *relres) const {
+    if (!schur_ || !schur_->uses_pcg()) return false;
+    schur_->pcg_stats(out, relres);
+    return true;
+}
 
 void Context::set_edge_weights(const double *w) {
     if (storage_ == XM_STORAGE_SCHUR) {

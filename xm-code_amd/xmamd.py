@@ -29,7 +29,7 @@ EXPORTS = [
     "xm_dev_sync", "xm_dense_upload", "xm_dense_from_bsr3", "xm_qw_dense", "xm_qw_dense_sym", "xm_qw_bsr3", "xm_retract", "xm_retract_polar", "xm_recover_rotations",
     "xm_comm_unique_id", "xm_comm_init", "xm_comm_init_shm", "xm_comm_init_ipc", "xm_comm_finalize", "xm_partition", "xm_partition_blocks",
     "xm_symv_plan", "xm_sell_layout", "xm_sell_locality", "xm_sell_create", "xm_sell_create2", "xm_sell_quat_roundtrip", "xm_sell_destroy", "xm_qw_sell", "xm_qw_sell_padded",
-    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport", "xm_ctx_sell_wpad", "xm_ctx_product_kind", "xm_symw_plan", "xm_symw_use",
+    "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_schur_info", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport", "xm_ctx_sell_wpad", "xm_ctx_product_kind", "xm_symw_plan", "xm_symw_use",
 ]
 # include/xm_bench.h: timing hooks of the micro-benchmarks (same library, not part of the product ABI)
 BENCH_EXPORTS = ["xm_bench_last_error", "xm_qw_dense_time", "xm_qw_dense_sym_time", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_qw_bsr3_time", "xm_qw_sell_time",
@@ -115,6 +115,7 @@ def lib():
         L.xm_ctx_xm2_round.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Options), C.POINTER(Xm2Info), C.POINTER(Result)]
         L.xm_ctx_recover_tp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xm_ctx_transport.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+        L.xm_ctx_schur_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_double)]
         L.xm_ctx_sell_wpad.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.xm_ctx_product_kind.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.xm_bench_last_error.restype = C.c_char_p
@@ -519,6 +520,12 @@ class Context:
         k = C.c_int(0)
         _chk(lib().xm_ctx_product_kind(self.h, int(o), C.byref(k)))
         return PRODUCT_KINDS.get(k.value, "?")
+
+    def schur_info(self):
+        """matrix-free contexts: dict(cg=bool, products, inner_iters, capped, last_relres) (xm_ctx_schur_info)"""
+        u = C.c_int(0); st = (C.c_int64 * 3)(); rr = C.c_double(0.0)
+        _chk(lib().xm_ctx_schur_info(self.h, C.byref(u), st, C.byref(rr)))
+        return dict(cg=bool(u.value), products=int(st[0]), inner_iters=int(st[1]), capped=int(st[2]), last_relres=rr.value)
 
     def sell_wpad(self):
         """True when the tCG of the last solved rank read its product input at the 128-byte record pitch (xm_ctx_sell_wpad)"""
