@@ -165,8 +165,6 @@ void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next
                     const double *ps_cur, double *ps_next, double *vR, double *vs, double *HvR, double *Hvs, double *rR, const double *rs_cur,
                     double *rs_next, double *Wloc, double *partsB_out, unsigned long long *hstat, int b_off, int64_t mat, double *Afull,
                     double *Wfull, int grouping, const struct PeerXchg &xchg, hipStream_t st, double *Wpad = nullptr);   // Wpad: single-rank only
-void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs,
-                        const double *rgR, const double *rgs, const double *s, double *parts, hipStream_t st);
 // trust-region numbers of the iteration that ends (what the host holds when it enqueues this launch); spec_out: see SpecCtl (nullptr: none)
 struct OuterArgs { double loss, delta, delta_bar, gradtol; int shrink_count, last_iter; };
 void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,
@@ -175,6 +173,12 @@ void launch_outer_finalize(const double *partsA, int nA_loc, int world, const do
 // of lanes per camera (measured alternative, scripts/kbench_retract.py)
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
                     double *Rout, double *sout, double *Wloc, hipStream_t st, int polar = 0);
+// the retraction of an outer iteration's step (vR, vs) with the model decrease of that step fused in (parts: retract_grid(nloc) partial sums, the
+// sum trustregion.h:667-668 takes) and, if Wpad is given, the product input also at the 128-byte record pitch (xm_sell.h)
+int retract_grid(int nloc);
+void launch_retract_model(int o, int nloc, int cam0, const double *R, const double *s, const double *vR, const double *vs, double *Rout, double *sout,
+                          double *Wloc, double *Wpad, const double *HvR, const double *Hvs, const double *rgR, const double *rgs, double *parts,
+                          hipStream_t st, int polar);
 void launch_cert_prepare(int o, int nloc, int cam0, double lam, const double *QsR, const double *R, const double *s,
                          double *Lam, double *dz, double *parts, hipStream_t st);
 // solution recovery

@@ -94,7 +94,7 @@ __device__ __forceinline__ void sum_partials256_x4(const double *p0, const doubl
 // the values are added in exactly the order of sum_partials256_x4, so the results are bit-identical.  cg_step_kernel reads its scalar
 // block and these partial sums from memory the previous launch wrote on another XCD (an L2 miss each): requested together they cost one
 // round trip instead of two.
-constexpr int kPre = 2;
+constexpr int kPre = 4;   // covers 1024 workgroups: every partial sum of a problem in the latency regime
 struct PartialsPre { double v[4][kPre]; };
 __device__ __forceinline__ void sum_partials_prefetch(const double *p0, const double *p1, const double *p2, int count, const double *p3, int count3,
                                                       PartialsPre &pre, int grp) {

@@ -572,7 +572,10 @@ __global__ __launch_bounds__(256) void asym_kernel(const double *__restrict__ Q,
 // The row sums and the whole fused epilogue run inside the 16-lane row with four DPP steps per reduction.
 // ----------------------------------------------------------------------------------------------------------------
 
-template <int O, int EPI, int VAR>
+// EARLY: the epilogue's operands are requested at the start instead of after the gather phase.  They cost ~50 VGPRs through the main loop --
+// rows in flight, which is what a large matrix needs -- but a small one (a few workgroups per CU: the launch-latency regime this kernel
+// serves since the sliced-ELL layout took the large matrices over) is bound by its chain of dependent round trips, and this removes one.
+template <int O, int EPI, int VAR, bool EARLY = false>
 __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                                        const double *__restrict__ blocks, const double *__restrict__ W,
                                                        double alpha, CamArgs a) {
@@ -592,6 +595,8 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
     int64_t b0 = 0, b1 = 0;
     if (active) { b0 = rowptr[cam]; b1 = rowptr[cam + 1]; }
+    EpiOps eops;
+    if constexpr (EARLY) epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
     if (EPI == EPI_HESS) {   // the tCG's status word (written by the previous cg_step on another XCD: an L2 miss) travels WITH the row pointers:
         if (a.scal->status != 0) return;   // the dependent chain of this latency-bound kernel is one round trip shorter
     }
@@ -748,9 +753,8 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // epilogue operands are fetched only now: holding ~40 more VGPRs through the gather phase would cost rows in flight
-    EpiOps eops;
-    epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
+    // epilogue operands are fetched only now (unless EARLY): holding ~40 more VGPRs through the gather phase would cost rows in flight
+    if constexpr (!EARLY) epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
     qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red);
 }
 
@@ -1107,28 +1111,6 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
     }
 }
 
-// model decrease  m = <v,Hv>/2 + <v,rg>  in the product metric (trustregion.h:667-668)
-template <int O>
-__global__ __launch_bounds__(256) void model_value_kernel(int nloc, const double *__restrict__ vR, const double *__restrict__ vs,
-                                                           const double *__restrict__ HvR, const double *__restrict__ Hvs,
-                                                           const double *__restrict__ rgR, const double *__restrict__ rgs,
-                                                           const double *__restrict__ s, double *parts) {
-    constexpr int OP = pitch_of(O);
-    __shared__ double sh[4];
-    const int64_t total = (int64_t)nloc * 3 * OP;
-    double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        acc += vR[i] * (0.5 * HvR[i] + rgR[i]);
-        if (i % (3 * OP) == 0) {
-            const int cam = (int)(i / (3 * OP));
-            const double vsds = vs[cam] / (s[cam] * s[cam]);
-            acc += vsds * (0.5 * Hvs[cam] + rgs[cam]);
-        }
-    }
-    const double tot = block_sum256(acc, sh);
-    if (threadIdx.x == 0) parts[blockIdx.x] = tot;
-}
-
 // End of an outer iteration: one 256-thread block adds the gathered partial sums in their fixed order and hands
 // {f_new, <g,g>_new, model value, tCG exit status, inner iterations} to the host through mapped memory; the sequence word
 // is written last.  Replaces three device-to-host copies and a stream synchronisation per outer iteration.
@@ -1230,19 +1212,41 @@ __device__ __forceinline__ void polar_rows(double (&X)[3][O]) {
     }
 }
 
-template <int O, int POLAR>
+// MV: the same launch also delivers the model decrease of the step D = v it retracts, m = <v,Hv>/2 + <v,rg> in the product metric
+// (trustregion.h:667-668): this camera's share, summed per workgroup into mv.parts[blockIdx.x] (fixed order: threads, then the DPP tree).
+// The step is in registers anyway; a launch of its own (model_value_kernel: 4.5-8 us per outer iteration) reads it a second time.
+// Wpad: the product input also at the 128-byte record pitch of the sliced-ELL gather (xm_sell.h), as tcg_init / cg_step write it.
+struct ModelArgs { const double *HvR, *Hvs, *rgR, *rgs; double *parts; };
+template <int O, int POLAR, bool MV = false>
 __global__ __launch_bounds__(256) void retract_kernel(int nloc, int cam0, const double *__restrict__ R, const double *__restrict__ s,
                                                        const double *__restrict__ D, const double *__restrict__ ds, double t,
-                                                       double *Rout, double *sout, double *Wloc) {
+                                                       double *Rout, double *sout, double *Wloc, double *Wpad, ModelArgs mv) {
     constexpr int OP = pitch_of(O);
+    __shared__ double sh_mv[4];
     const int cam = blockIdx.x * 256 + threadIdx.x;
-    if (cam >= nloc) return;
-    const size_t base = (size_t)cam * 3 * OP;
+    const bool live = cam < nloc;
+    if constexpr (!MV) {
+        if (!live) return;
+    }
+    const size_t base = (size_t)(live ? cam : 0) * 3 * OP;
     double q[3][O];
+    double macc = 0.0;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int k = 0; k < O; ++k) q[r][k] = R[base + r * OP + k] + t * D[base + r * OP + k];
+        for (int k = 0; k < O; ++k) {
+            const double d = D[base + r * OP + k];
+            q[r][k] = R[base + r * OP + k] + t * d;
+            if constexpr (MV) macc += d * (0.5 * mv.HvR[base + r * OP + k] + mv.rgR[base + r * OP + k]);
+        }
+    if constexpr (MV) {
+        const int c = live ? cam : 0;
+        const double vsds = ds[c] / (s[c] * s[c]);
+        macc += vsds * (0.5 * mv.Hvs[c] + mv.rgs[c]);
+        const double tot = block_sum256(live ? macc : 0.0, sh_mv);
+        if (threadIdx.x == 0) mv.parts[blockIdx.x] = tot;
+        if (!live) return;
+    }
     if constexpr (POLAR) {
         polar_rows<O>(q);
     } else {
@@ -1273,6 +1277,7 @@ __global__ __launch_bounds__(256) void retract_kernel(int nloc, int cam0, const 
         for (int k = 0; k < O; ++k) {
             Rout[base + r * OP + k] = q[r][k];
             if (Wloc) Wloc[base + r * OP + k] = sn * q[r][k];
+            if (Wpad) Wpad[(size_t)cam * 16 + r * OP + k] = sn * q[r][k];
         }
         if (OP > O) { Rout[base + r * OP + O] = 0.0; if (Wloc) Wloc[base + r * OP + O] = 0.0; }
     }
@@ -2066,6 +2071,12 @@ template <int O, int VAR>
 static void qw_bsr3_epi(int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, double alpha,
                         const CamArgs &a, hipStream_t st) {
     const dim3 g((a.nloc + kBsrRows - 1) / kBsrRows), b(256);
+    if constexpr (VAR == 2) {
+        if (g.x <= 1024) {   // at most four workgroups per CU: latency regime, epilogue operands requested up front (qw_bsr3_kernel: EARLY)
+            if (epi == EPI_GRAD) { hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD, VAR, true>), g, b, 0, st, rp, ci, bl, W, alpha, a); return; }
+            if (epi == EPI_HESS) { hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_HESS, VAR, true>), g, b, 0, st, rp, ci, bl, W, alpha, a); return; }
+        }
+    }
     switch (epi) {
         case EPI_PLAIN: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_PLAIN, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
         case EPI_GRAD: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
@@ -2131,12 +2142,6 @@ void launch_cg_step(int o, int nloc, const TcgScal *scal_cur, TcgScal *scal_next
                                         vs, HvR, Hvs, rR, rs_cur, rs_next, Wloc, partsB_out, hstat, b_off, mat, Afull, Wfull, grouping, xchg, Wpad));
     check_launch("cg_step");
 }
-void launch_model_value(int o, int nloc, const double *vR, const double *vs, const double *HvR, const double *Hvs, const double *rgR,
-                        const double *rgs, const double *s, double *parts, hipStream_t st) {
-    XM_DISPATCH_O(o, hipLaunchKernelGGL((model_value_kernel<O_>), dim3(flat_grid((int64_t)nloc * 3 * pitch_of(O_))), dim3(256), 0, st,
-                                        nloc, vR, vs, HvR, Hvs, rgR, rgs, s, parts));
-    check_launch("model_value");
-}
 void launch_outer_finalize(const double *partsA, int nA_loc, int world, const double *partsM, int nM, const TcgScal *scal, double *hres,
                            unsigned long long seq, int grouping, hipStream_t st, const OuterArgs *oa, SpecCtl *spec_out) {
     OuterArgs z;
@@ -2145,17 +2150,29 @@ void launch_outer_finalize(const double *partsA, int nA_loc, int world, const do
                        (oa != nullptr) ? spec_out : (SpecCtl *)nullptr);
     check_launch("outer_finalize");
 }
+int retract_grid(int nloc) { return (nloc + 255) / 256; }
+// the outer iteration's retraction: + model decrease of the step (partial sums parts[retract_grid(nloc)]) + the padded copy of the product input
+void launch_retract_model(int o, int nloc, int cam0, const double *R, const double *s, const double *vR, const double *vs, double *Rout, double *sout,
+                          double *Wloc, double *Wpad, const double *HvR, const double *Hvs, const double *rgR, const double *rgs, double *parts,
+                          hipStream_t st, int polar) {
+    const ModelArgs mv = {HvR, Hvs, rgR, rgs, parts};
+    const dim3 g(retract_grid(nloc)), b(256);
+    if (polar) { XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 1, true>), g, b, 0, st, nloc, cam0, R, s, vR, vs, 1.0, Rout, sout, Wloc, Wpad, mv)); }
+    else { XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 0, true>), g, b, 0, st, nloc, cam0, R, s, vR, vs, 1.0, Rout, sout, Wloc, Wpad, mv)); }
+    check_launch("retract_model");
+}
 void launch_retract(int o, int nloc, int cam0, const double *R, const double *s, const double *D, const double *ds, double t,
                     double *Rout, double *sout, double *Wloc, hipStream_t st, int polar) {
+    const ModelArgs mv = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (polar == 2) {   // the quad-per-camera form of the MGS-QR retraction (measured alternative)
         XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_quad_kernel<O_>), dim3((nloc + 63) / 64), dim3(256), 0, st, nloc, cam0, R, s, D, ds, t,
                                             Rout, sout, Wloc));
     } else if (polar) {
         XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 1>), dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, R, s, D, ds, t,
-                                            Rout, sout, Wloc));
+                                            Rout, sout, Wloc, (double *)nullptr, mv));
     } else {
         XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 0>), dim3((nloc + 255) / 256), dim3(256), 0, st, nloc, cam0, R, s, D, ds, t,
-                                            Rout, sout, Wloc));
+                                            Rout, sout, Wloc, (double *)nullptr, mv));
     }
     check_launch("retract");
 }

@@ -99,6 +99,7 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t count = 0;
+    size_t capacity = 0;   // elements allocated (>= count): ensure() reuses the allocation
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -107,10 +108,12 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         count = 0;
+        capacity = 0;
     }
     void alloc(size_t n, bool zero = true) {
         release();
         count = n;
+        capacity = n ? n : 1;
         XM_HIP_CHECK(hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)));
         if (zero) {
             // hipMemset runs on the NULL stream and may return before it has executed; the solver works on its own NON-BLOCKING
@@ -119,6 +122,19 @@ struct DevBuf {
             XM_HIP_CHECK(hipMemset(p, 0, (n ? n : 1) * sizeof(T)));
             XM_HIP_CHECK(hipStreamSynchronize(nullptr));
         }
+    }
+    // n zero-filled elements for work on stream `st`: the allocation is kept when it is large enough (a memset enqueued on `st`, no
+    // hipFree / hipMalloc / device synchronisation -- a staircase solve sets its workspace up once per rank level, ~45 buffers each
+    // time); `reserve` (>= n) is what a NEW allocation is sized for, so that later rank levels fit
+    void ensure(size_t n, hipStream_t st, size_t reserve = 0) {
+        if (p && n <= capacity) {
+            count = n;
+            XM_HIP_CHECK(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(T), st));
+            return;
+        }
+        const size_t want = std::max(n, reserve);
+        alloc(want);
+        count = n;
     }
 };
 
@@ -228,6 +244,7 @@ private:
     DevBuf<double> wpad_;   // sliced-ELL storage, single rank, o = 3..5: the tCG's product input at a record pitch of 16 doubles (Settings.sell_wpad)
     double *wpad() const { return (wpad_.p && wpad_on_) ? wpad_.p : nullptr; }
     bool wpad_on_ = false;   // for the current rank (setup_rank)
+    const double *wpad_next_ = nullptr;   // set by the outer iteration's retraction: the NEXT gradient product finds its input in the padded copy too
     PointState ps_[2];
     int cur_ = 0;
     DevBuf<double> rR_, rs_, rsB_, pR_, psA_, psB_, vR_, vs_, HvR_, Hvs_, HpR_, Hps_;

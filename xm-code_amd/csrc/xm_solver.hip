@@ -470,19 +470,23 @@ void Context::setup_rank(int o) {
     OP_ = pitch_of(o);
     const size_t mat = (size_t)nloc_ * 3 * OP_, vec = (size_t)nloc_;
     const int world = comm_->world;
-    for (DevBuf<double> *b : {&R_, &Rc_, &D_, &rR_, &pR_, &vR_, &HvR_, &HpR_}) b->alloc(mat);
-    for (DevBuf<double> *b : {&s_, &sc_, &rs_, &rsB_, &psA_, &psB_, &vs_, &Hvs_, &Hps_}) b->alloc(vec);
+    // grow-only workspace: sized once for the highest rank this solve can reach (the pitch grows with the rank), reused by every later
+    // rank level and every later solve of the context
+    const int o_top = std::max(o, (int)std::min<unsigned>(opt_ ? opt_->max_rank : 0u, (unsigned)kMaxRank));
+    const size_t mat_top = (size_t)nloc_ * 3 * pitch_of(o_top);
+    for (DevBuf<double> *b : {&R_, &Rc_, &D_, &rR_, &pR_, &vR_, &HvR_, &HpR_}) b->ensure(mat, st_, mat_top);
+    for (DevBuf<double> *b : {&s_, &sc_, &rs_, &rsB_, &psA_, &psB_, &vs_, &Hvs_, &Hps_}) b->ensure(vec, st_);
     for (int k = 0; k < 2; ++k) {
-        ps_[k].G.alloc(mat); ps_[k].rgR.alloc(mat); ps_[k].egs.alloc(vec); ps_[k].rgs.alloc(vec); ps_[k].S0.alloc(vec * 9);
+        ps_[k].G.ensure(mat, st_, mat_top); ps_[k].rgR.ensure(mat, st_, mat_top); ps_[k].egs.ensure(vec, st_); ps_[k].rgs.ensure(vec, st_); ps_[k].S0.ensure(vec * 9, st_);
     }
     cur_ = 0;
     wpad_on_ = sell_ && cfg_.sell_wpad >= 0 && !comm_->active() && sell_supports(o) && o >= 3 && 3 * OP_ <= 16 && (cfg_.sell_wpad == 1 || sell_->padded_pays(o));
     if (wpad_on_ && !wpad_.p) wpad_.alloc((size_t)ntot_ * 16 + 16);   // zero-filled: the pad is never written
-    W_.alloc((size_t)ld_ * OP_ + 16);   // + slack: the sector-window gather of the sliced-ELL product reads whole 64-byte sectors around a record
+    W_.ensure((size_t)ld_ * OP_ + 16, st_, (size_t)ld_ * pitch_of(o_top) + 16);   // + slack: the sector-window gather of the sliced-ELL product reads whole 64-byte sectors around a record
     const int nA_loc = prod_grid(), nB_loc = tcg_blocks();
     nA_ = nA_loc * world;
     nB_ = nB_loc * world;
-    partsA_.alloc((size_t)3 * nA_);
+    partsA_.ensure((size_t)3 * nA_, st_);
     // tCG exchange buffers: two parity buffers of world chunks [rows of the image of Hp (multi-rank only) | 3*nA_loc | nB_loc]
     const size_t b_off = comm_->active() ? mat : 0;
     const size_t pb = (size_t)2 * (b_off * world + 3 * nA_ + nB_);
@@ -496,10 +500,10 @@ void Context::setup_rank(int o) {
     } else {
         xchg_ = PeerXchg();
         partsB_peer_ = nullptr;
-        partsB_.alloc(pb);
+        partsB_.ensure(pb, st_, (size_t)2 * ((comm_->active() ? mat_top : 0) * world + 3 * nA_ + nB_));
     }
-    if (comm_->active()) Afull_.alloc(mat * world); else Afull_.release();
-    partsM_.alloc((size_t)std::max(std::max(nB_, flat_grid((int64_t)mat) * world), 2 * ((nloc_ + 255) / 256) * world));
+    if (comm_->active()) Afull_.ensure(mat * world, st_, mat_top * world); else Afull_.release();
+    partsM_.ensure((size_t)std::max(std::max(nB_, flat_grid((int64_t)mat_top) * world), 2 * ((nloc_ + 255) / 256) * world), st_);
     if (sym_ok_ && o >= 3 && o <= sym_max_o_) {
         Prow_.alloc(sym_prow_count(nloc_, ld_, o));
         Pcol_.alloc(sym_pcol_count(nloc_, ld_, o), false);
@@ -524,8 +528,8 @@ void Context::setup_rank(int o) {
         }
         Pstrip_.alloc(mat);
     }
-    scal_.alloc(2);
-    spec_.alloc(1);
+    scal_.ensure(2, st_);
+    spec_.ensure(1, st_);
     // the sliced-ELL product's partial-result buffer grows with o: (re)allocate it HERE, between the two barriers -- hipFree synchronises
     // the whole device, and with several ranks of one process on one device ("virtual devices") a free between two collectives waits for
     // a peer's spinning wait kernel that waits for this rank's next push (8 virtual ranks ran into exactly that at the first o = 4 product)
@@ -640,7 +644,9 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
         schur_->product(o, epi, W_.p, alpha, a, st_);
     } else if (sell_ && sell_supports(o)) {
         // inside the tCG the kernels that write W keep a copy at the 128-byte record pitch (run_tcg): the gather reads that one
-        launch_qw_sell(o, epi, *sell_, W_.p, alpha, a, sell_gm_, st_, (epi == EPI_HESS && o == o_) ? wpad() : nullptr);
+        const double *wp = (epi == EPI_HESS && o == o_) ? wpad() : ((epi == EPI_GRAD && o == o_) ? wpad_next_ : nullptr);
+        wpad_next_ = nullptr;
+        launch_qw_sell(o, epi, *sell_, W_.p, alpha, a, sell_gm_, st_, wp);
     } else {
         launch_qw_bsr3(o, epi, rowptr_.p, colidx_.p, blocks_.p, W_.p, alpha, a, st_);
     }
@@ -1021,13 +1027,16 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
 
         // model decrease, retraction and the candidate's cost/gradient are enqueued right behind the tCG and fetched with
         // ONE synchronisation (trustregion.h:667-678 needs four blocking reads + a sync here)
-        const int nB_loc = flat_grid((int64_t)nloc_ * 3 * OP_);
         const int nA_loc = prod_grid();
         const PointState &P = ps_[cur_];
-        launch_model_value(o, nloc_, vR_.p, vs_.p, HvR_.p, Hvs_.p, P.rgR.p, P.rgs.p, s_.p, partsM_.p + (size_t)comm_->rank * nB_loc, st_);
+        // the step's model decrease comes out of the retraction launch (the anchor's scale part of the step is zero by construction, as in
+        // the flat kernel this replaces); the quad-per-camera form of the retraction is a micro-benchmark alternative only
+        const int nB_loc = retract_grid(nloc_);
+        launch_retract_model(o, nloc_, cam0_, R_.p, s_.p, vR_.p, vs_.p, Rc_.p, sc_.p, Wloc, wpad(), HvR_.p, Hvs_.p, P.rgR.p, P.rgs.p,
+                             partsM_.p + (size_t)comm_->rank * nB_loc, st_, retraction_ == XM_RETRACT_POLAR ? 1 : 0);
         if (comm_->active()) comm_->allgather(partsM_.p, (size_t)nB_loc, st_);
-        launch_retract(o, nloc_, cam0_, R_.p, s_.p, vR_.p, vs_.p, 1.0, Rc_.p, sc_.p, Wloc, st_, retraction_);
         gather_W();
+        wpad_next_ = wpad();   // the gradient product below may gather from the padded copy the retraction has just written
         {
             CamArgs a = cam_args(cur_ ^ 1);
             a.R = Rc_.p;
