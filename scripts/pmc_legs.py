@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """HBM-side traffic (rocprofv3 --pmc FETCH_SIZE, own pass) and traced duration (rocprofv3 --kernel-trace, own pass) of the dominant kernels
 of bench.py's legs, stamped with the hash of the sources they were measured on -- what bench.py quotes as roofline.traffic / roofline_hbm.traffic.
-Run on the GPU box:   python scripts/pmc_legs.py <tag> [leg ...]      legs: venice hbm13682 rome_dense vg100k_vg vg100k_bsr
+Run on the GPU box:   python scripts/pmc_legs.py <tag> [leg ...]      legs: venice hbm13682 rome_dense rome_bsr vg100k_vg vg100k_bsr
 Writes gpurun_out/<tag>_pmc_fetch_<leg>.json (copy them into profiles/)."""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 LEGS = {
-    # leg: (bench.py arguments, {role: substring(s) of the kernel name}, what)
+    # leg: (bench.py arguments, {role: substring(s) of the kernel name -- ALL of a list, or ANY of the alternatives of a list of lists}, what)
     "venice": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-hbm-check", "--no-rome"],
                {"hess": ["qw_dense_kernel<", ", 2, 2, "]}, "Hessian launches of the headline solve (qw_dense_kernel<o, EPI_HESS>)"),
     "hbm13682": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-rome"],
@@ -15,11 +15,14 @@ LEGS = {
     "rome_dense": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-hbm-check"],
                    {"main": ["qw_symv_kernel<3"], "reduce": ["symv_reduce_kernel<3, 2"]},
                    "rome_scale_dense leg: Hessian products of the 13.5 GB dense Q through the half-traffic symmetric path (main + reduce launch)"),
+    "rome_bsr": (["--workload", "final13682", "--storage", "bsr", "--steps", "1", "--warmup", "0", "--no-hbm-check", "--cpu-seconds", "0"],
+                 {"hess": ["qw_bsr3_kernel<3, 2, 2"]},
+                 "Hessian launches of the Final-13682-size solve in 3x3-block CSR storage (qw_bsr3_kernel<3, EPI_HESS>; 34 MB: cache-resident, latency regime)"),
     "vg100k_vg": (["--workload", "vg100k", "--storage", "vg", "--steps", "1", "--warmup", "0", "--no-rome", "--no-hbm-check", "--cpu-seconds", "0"],
-                  {"main": ["qw_sell", "<3"], "reduce": ["sell_reduce_kernel<3, 2"]},
+                  {"main": ["qw_sell_kernel_q_occ4<"], "reduce": ["sell_reduce_kernel<3, 2"]},
                   "Hessian products of the 100k-camera solve, view-graph storage (sliced-ELL main launch + per-camera sum / epilogue launch)"),
     "vg100k_bsr": (["--workload", "vg100k", "--storage", "bsr", "--steps", "1", "--warmup", "0", "--no-rome", "--no-hbm-check", "--cpu-seconds", "0"],
-                   {"main": ["qw_sell", "<3"], "reduce": ["sell_reduce_kernel<3, 2"]},
+                   {"main": ["qw_sell_kernel<3, "], "reduce": ["sell_reduce_kernel<3, 2"]},
                    "Hessian products of the 100k-camera solve, 3x3-block CSR storage (sliced-ELL copy with full blocks)"),
 }
 

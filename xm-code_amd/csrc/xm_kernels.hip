@@ -572,10 +572,7 @@ __global__ __launch_bounds__(256) void asym_kernel(const double *__restrict__ Q,
 // The row sums and the whole fused epilogue run inside the 16-lane row with four DPP steps per reduction.
 // ----------------------------------------------------------------------------------------------------------------
 
-// EARLY: the epilogue's operands are requested at the start instead of after the gather phase.  They cost ~50 VGPRs through the main loop --
-// rows in flight, which is what a large matrix needs -- but a small one (a few workgroups per CU: the launch-latency regime this kernel
-// serves since the sliced-ELL layout took the large matrices over) is bound by its chain of dependent round trips, and this removes one.
-template <int O, int EPI, int VAR, bool EARLY = false>
+template <int O, int EPI, int VAR>
 __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                                        const double *__restrict__ blocks, const double *__restrict__ W,
                                                        double alpha, CamArgs a) {
@@ -595,8 +592,6 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
     int64_t b0 = 0, b1 = 0;
     if (active) { b0 = rowptr[cam]; b1 = rowptr[cam + 1]; }
-    EpiOps eops;
-    if constexpr (EARLY) epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
     if (EPI == EPI_HESS) {   // the tCG's status word (written by the previous cg_step on another XCD: an L2 miss) travels WITH the row pointers:
         if (a.scal->status != 0) return;   // the dependent chain of this latency-bound kernel is one round trip shorter
     }
@@ -753,8 +748,11 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // epilogue operands are fetched only now (unless EARLY): holding ~40 more VGPRs through the gather phase would cost rows in flight
-    if constexpr (!EARLY) epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
+    // epilogue operands are fetched only now: holding ~50 more VGPRs through the gather phase costs rows in flight -- also in the latency
+    // regime (13 682 cameras, 856 workgroups): requested up front they save a round trip but drop the kernel from three to two wavefronts per
+    // SIMD, 22.5 against 20.3 us per Hessian product and 31.3 against 28.8 ms per solve on one box (profiles/r05_ab_rome.txt, lib_x)
+    EpiOps eops;
+    epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
     qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red);
 }
 
@@ -2071,12 +2069,6 @@ template <int O, int VAR>
 static void qw_bsr3_epi(int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, double alpha,
                         const CamArgs &a, hipStream_t st) {
     const dim3 g((a.nloc + kBsrRows - 1) / kBsrRows), b(256);
-    if constexpr (VAR == 2) {
-        if (g.x <= 1024) {   // at most four workgroups per CU: latency regime, epilogue operands requested up front (qw_bsr3_kernel: EARLY)
-            if (epi == EPI_GRAD) { hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD, VAR, true>), g, b, 0, st, rp, ci, bl, W, alpha, a); return; }
-            if (epi == EPI_HESS) { hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_HESS, VAR, true>), g, b, 0, st, rp, ci, bl, W, alpha, a); return; }
-        }
-    }
     switch (epi) {
         case EPI_PLAIN: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_PLAIN, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
         case EPI_GRAD: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;

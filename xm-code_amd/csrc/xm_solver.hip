@@ -848,7 +848,10 @@ int Context::enqueue_spec_tcg() {
     ++tcg_seq_;
     launch_tcg_init(o_, nloc_, P.rgR.p, P.rgs.p, R_.p, s_.p, rR_.p, rs_.p, pR_.p, psA_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, Wloc,
                     scal_.p, 0.0, 0.0, hstat_dev_, st_, wpad(), (int)tcg_seq_, spec_.p);
-    const int n_spec = 2;
+    // ONE iteration behind tcg_init, and a run-ahead of two in run_tcg: measured against 2 / 3 on one box at Final-13682 size in block CSR
+    // (profiles/r05_ab_rome.txt: 27.8 against 28.8 ms per solve; fewer launches that turn out to be no-ops when the tCG ends after ~5
+    // iterations) and equal at Venice size
+    const int n_spec = 1;
     for (int i = 0; i < n_spec; ++i) tcg_enqueue_iteration(i, false);   // (not sampled by the HIP-event profile: they may turn out dormant)
     std::swap(R_.p, Rc_.p);
     std::swap(s_.p, sc_.p);
@@ -881,7 +884,8 @@ int Context::run_tcg(double rr, double delta, TcgScal &fin, int adopted) {
     const bool fused = xchg_.world > 1;
     if (fused) xchg_.epoch_base = (++tcg_runs_) << 12;
     const bool lockstep = comm_->active() && !fused;
-    const int run_ahead = lockstep ? 2 : 3;
+    // (single GPU: two iterations ahead, three for the smallest problems, whose iteration is shorter than the host's two launches)
+    const int run_ahead = (lockstep || prod_grid() >= 64) ? 2 : 3;
     int fin_status = 0, fin_iter = 0;
     int it = adopted;  // iterations enqueued
     auto enqueue = [&](int i) { tcg_enqueue_iteration(i, profile); };

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libxm_amd.so")
+LIB_PATH = os.environ.get("XMAMD_LIB") or os.path.join(_HERE, "lib", "libxm_amd.so")   # XMAMD_LIB: a development aid of this binding (A/B builds)
 MODULE_DIR = os.path.join(_HERE, "build")      # holds XM.cpython-*.so (the reference's module name)
 
 STORAGE_DENSE, STORAGE_BSR3 = 0, 1
