@@ -19,7 +19,7 @@ for o in os_:
     ms = C.c_double()
     xmamd._chk(L.xm_qw_dense_time(dq.ptr, n, o, dW.ptr, dO.ptr, 200 if n < 5000 else 20, C.byref(ms)))
     by = 8.0 * (3 * n) ** 2 + 2 * 8 * 3 * n * o
-    print(f"n={n} o={o} NSUB={os.environ.get('XM_QW_NSUB','2')}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s algorithmic  ({by/1e6:.1f} MB)")
+    print(f"n={n} o={o} {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s algorithmic  ({by/1e6:.1f} MB)")
     if 3 <= o <= 5:
         xmamd._chk(L.xm_qw_dense_sym_time(dq.ptr, n, o, dW.ptr, dO.ptr, 200 if n < 5000 else 20, C.byref(ms)))
         print(f"n={n} o={o} SYM (upper triangle only): {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s of full-storage algorithmic bytes")
