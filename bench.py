@@ -282,13 +282,29 @@ def kkt_pair(tl, xmamd_mod, budget_s):
             "note": "same process, same node, same Q and options, same stop rule (|grad| < tol, then the certificate's acceptance rule, checkeig.h:349-368)"}
 
 
+_JSON_FD = [1]
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries loaded during the run write there too (RCCL's "Librccl path : ..." banner sits in
+    libc's buffer until the process exits, i.e. AFTER the line): from here on file descriptor 1 is stderr for everybody, and the JSON line
+    alone goes to the launcher's stdout through a private duplicate."""
+    sys.stdout.flush()
+    _JSON_FD[0] = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _emit(obj):
+    os.write(_JSON_FD[0], (json.dumps(obj) + "\n").encode())
+
+
 def _error_line(ngp, args, workload_desc, msg):
     """the ONE JSON line of a run that could not produce its measurement (transport ladder ended in XM_ERR_COMM, a solve failed, a peer
     rank died, the watchdog fired): whoever launched this learns why instead of finding nothing"""
-    print(json.dumps({"metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
+    _emit(dict({"metric": "BM iters/sec (tCG Hessian-vector iterations per second; ms_per_step = wall-clock-to-KKT of one staircase solve)",
                       "value": None, "unit": "tCG iters/s", "n_gpus": ngp, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
                       "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": workload_desc}, "transport": None, "fallback": None, "error": msg}), flush=True)
+                      "config": {"workload": workload_desc}, "transport": None, "fallback": None, "error": msg}))
 
 
 _PHASE = ["start"]     # where the run is: named in the watchdog's / the signal handler's error line
@@ -337,6 +353,7 @@ def main():
     ap.add_argument("--no-rccl-leg", action="store_true", help="skip the second (RCCL) leg of a multi-GPU run")
     ap.add_argument("--sell", default="auto", choices=["auto", "on", "off"], help="sliced-ELL copy of block-sparse storage (xm_tuning_t.sell)")
     args = ap.parse_args()
+    _claim_stdout()
 
     import torch
     import torch.distributed as dist
@@ -428,7 +445,7 @@ def _rccl_leg(args, wl, tl, Q, tkw, team, world, rank, retr, torch, dist, barrie
     def give_up():
         if rank == 0:
             out["rccl_leg"] = {"error": "no result after %.0f s; the lines above it stand" % limit}
-            print(json.dumps(out), flush=True)
+            _emit(out)
         os._exit(0)
     timer = threading.Timer(limit, give_up)
     timer.daemon = True
@@ -709,7 +726,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                                "steps": max(1, args.steps), "ms_per_step": float(tm[0]) / max(1, args.steps) * 1e3}
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        _emit(out)
 
 
 if __name__ == "__main__":

@@ -6,6 +6,9 @@ tag = sys.argv[1]
 P = os.path.join(R, "profiles")
 n = 0
 for f in sorted(glob.glob(os.path.join(R, "gpurun_out", tag + "_*"))):
+    base = os.path.basename(f)[len(tag) + 1:].rsplit(".", 1)[0]
+    if base.rsplit("_", 1)[-1] in ("a", "b", "c", "d") or "_traced" in base or base in ("load_time_plain", "rome_trace"):
+        continue          # numbered probe outputs of the development calls; what they showed is in HISTORY.md
     if os.path.isfile(f) and os.path.getsize(f) > 0 and not f.endswith(".err"):
         shutil.copy(f, os.path.join(P, os.path.basename(f))); n += 1
 print(n, "files copied into profiles/")
@@ -50,7 +53,7 @@ for name in ("bench_venice1778.json", "bench_vg100k_vg.json", "bench_vg100k_bsr.
     ev = f"{r['avg_launch_ms'] * 1e3:.1f}" if r.get("avg_launch_ms") else "—"
     tus = r.get("traced_avg_launch_us")
     tu = f"{tus:.1f}" if tus else "—"
-    tf = f"{alg / tus / 1e6 / r.get('peak', 8000.0):.3f}" if (alg and tus) else "—"
+    tf = f"{alg / tus / 1e3 / r.get('peak', 8000.0):.3f}" if (alg and tus) else "—"
     out.append(f"| `{tag}_{name}` | {g(b, 'config', 'workload')} ×{b.get('n_gpus')} | {g(b, 'value', fmt='{:.0f}')} | {g(b, 'ms_per_step', fmt='{:.1f}')} | "
                f"{g(r, 'kernel')} | {ev} / {g(r, 'frac', fmt='{:.3f}')} | {tu} / {tf} | {ratio} | {g(b, 'transport')} |")
 b = load("bench_venice1778.json")

@@ -1,11 +1,23 @@
 #!/bin/bash
-# Evidence run of a round on the GPU box (through gpurun):   bash scripts/gpu_evidence.sh <tag> [quick]
+# Evidence run of a round on the GPU box (through gpurun):   bash scripts/gpu_evidence.sh <tag> [quick|schur]
 # whole GPU suite + smoke, the multi-rank tests three more times (hard gates), PMC traffic + traced durations of every bench leg (stamped with the
 # hash of the sources: bench.py quotes them only while it matches), the bench lines, rocprofv3 kernel statistics of the three solves, the
 # micro-benchmarks.  Everything lands in gpurun_out/<tag>_*; scripts/collect_profiles.py <tag> copies it into profiles/.
+# "quick" skips the micro-benchmarks, "schur" runs only the matrix-free section (per-kernel time and traffic of its product in both forms).
 TAG=${1:-r05}; QUICK=$2
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; O=$R/gpurun_out
+schur_section() {
+  # Final-13682-size scene (6.4 M observations), lam at the data term's scale (certifies at rank 3-4): the whole solve once per form ...
+  XM_KB_LAM=auto timeout 600 python scripts/kbench_schur.py 13682 800000 8 --trace > $O/${TAG}_kbench_schur_final_dense.txt 2>&1
+  XM_KB_LAM=auto timeout 600 python scripts/kbench_schur.py 13682 800000 8 --solver 2 --trace > $O/${TAG}_kbench_schur_final_cg.txt 2>&1
+  # ... and 20 products under the kernel trace and under FETCH_SIZE: where the time and the bytes of the factor chain go
+  timeout 900 python scripts/pmc_kernels.py ${TAG}_kernels_schur_final_dense -- python scripts/kbench_schur.py 13682 800000 8 --product-only > /dev/null 2>&1
+  timeout 900 python scripts/pmc_kernels.py ${TAG}_kernels_schur_final_cg -- python scripts/kbench_schur.py 13682 800000 8 --solver 2 --product-only > /dev/null 2>&1
+  timeout 600 python scripts/kbench_schur.py 50000 1500000 6 --product-only > $O/${TAG}_kbench_schur_50k.txt 2>&1
+  timeout 900 python scripts/kbench_schur.py 100000 3000000 6 --product-only > $O/${TAG}_kbench_schur_100k.txt 2>&1
+}
+if [ "$QUICK" = schur ]; then schur_section; ls $O | grep -c $TAG; exit 0; fi
 timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rf 2>&1 | tail -8 | cut -c1-300 > $O/${TAG}_pytest_gpu.txt
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | grep -v amdgpu.ids | tail -4 > $O/${TAG}_smoke.txt
 : > $O/${TAG}_pytest_multi_x3.txt
@@ -41,4 +53,5 @@ cd $R
  python scripts/kbench_sell.py 100000 50 --o 3 4 5 --slabs 4 --gather 1 --codec 0 1 --no-csr --padded
  python scripts/kbench_sell.py 100000 50 --o 3 --band --codec 1 --no-csr) > $O/${TAG}_kbench_sell.txt 2>&1
 python scripts/kbench_symw.py 13682 --worlds 2 8 > $O/${TAG}_kbench_symw.txt 2>&1
+schur_section
 ls -la $O | grep $TAG | wc -l

@@ -1,5 +1,5 @@
 """Per-kernel register / LDS / scratch figures of one HIP source, from hipcc's own resource remarks (no GPU needed):
-   python scripts/kernel_resources.py xm-code_amd/csrc/xm_sell2.hip [name filter]"""
+   python scripts/kernel_resources.py xm-code_amd/csrc/xm_sell.hip [name filter]"""
 import re, subprocess, sys
 src = sys.argv[1]; filt = sys.argv[2] if len(sys.argv) > 2 else ""
 out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/dev/null",

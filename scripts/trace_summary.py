@@ -19,3 +19,18 @@ for r in rows:
 print(f"window: {len(rows)} launches, span {(t1 - t0) / 1e6:.3f} ms, kernel time {busy / 1e6:.3f} ms = {busy / (t1 - t0):.3f} of the span")
 for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{t / 1e3:10.1f} us total {c:7d} calls {t / c / 1e3:8.2f} us avg  {100.0 * t / (t1 - t0):5.1f} % of span  {k}")
+
+# idle time in front of each kernel name: the gap between the end of the previous launch (by start order) and this launch's start --
+# kernel boundaries, no-op launches' dispatch and host round trips all show here
+gaps = collections.defaultdict(lambda: [0, 0])
+prev_end = None
+for r in rows:
+    st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if prev_end is not None and st > prev_end:
+        k = r["Kernel_Name"][:110]
+        gaps[k][0] += 1; gaps[k][1] += st - prev_end
+    prev_end = en if prev_end is None else max(prev_end, en)
+tot = sum(v[1] for v in gaps.values())
+print(f"\nidle {tot / 1e6:.3f} ms = {tot / (t1 - t0):.3f} of the span, by the kernel that follows the gap:")
+for k, (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
+    print(f"{t / 1e3:10.1f} us total {c:7d} gaps {t / c / 1e3:8.2f} us avg  {k}")
