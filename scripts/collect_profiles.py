@@ -7,7 +7,7 @@ P = os.path.join(R, "profiles")
 n = 0
 for f in sorted(glob.glob(os.path.join(R, "gpurun_out", tag + "_*"))):
     base = os.path.basename(f)[len(tag) + 1:].rsplit(".", 1)[0]
-    if base.rsplit("_", 1)[-1] in ("a", "b", "c", "d") or "_traced" in base or base in ("load_time_plain", "rome_trace"):
+    if base.rsplit("_", 1)[-1] in ("a", "b", "c", "d") or "_traced" in base or base in ("load_time_plain", "rome_trace", "compress_probe"):
         continue          # numbered probe outputs of the development calls; what they showed is in HISTORY.md
     if os.path.isfile(f) and os.path.getsize(f) > 0 and not f.endswith(".err"):
         shutil.copy(f, os.path.join(P, os.path.basename(f))); n += 1
