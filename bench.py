@@ -352,6 +352,8 @@ def main():
                          "With auto and --gpus N > 1 a second, RCCL-timed leg follows the default one (rccl_leg)")
     ap.add_argument("--no-rccl-leg", action="store_true", help="skip the second (RCCL) leg of a multi-GPU run")
     ap.add_argument("--sell", default="auto", choices=["auto", "on", "off"], help="sliced-ELL copy of block-sparse storage (xm_tuning_t.sell)")
+    ap.add_argument("--sym-min-rows", type=int, default=0, help="rows (3n) from which an exactly symmetric dense Q is multiplied by the half-traffic "
+                    "kernel (xm_tuning_t.sym_min_rows; 0 = the library's measured default)")
     args = ap.parse_args()
     _claim_stdout()
 
@@ -378,6 +380,8 @@ def main():
         tn["exchange"] = {"peer": 2, "rccl": 3}[args.exchange]
     if args.sell != "auto":
         tn["sell"] = 1 if args.sell == "on" else -1
+    if args.sym_min_rows:
+        tn["sym_min_rows"] = args.sym_min_rows
     if tn:
         tkw["tuning"] = tn
     if args.exchange == "rccl" and world > 1:
@@ -594,7 +598,10 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                   "tr_seconds": last["tr_seconds"], "cert_seconds": last["cert_seconds"], "setup_gen_s": gen_s,
                   "tcg_iters_by_step": [i["tcg_iters"] for i in infos], "exchange": last.get("exchange")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_source, "traced_avg_launch_us": traced_us, "kernel": kname + (" via the half-traffic symmetric path (qw_sym_kernel + sym_reduce_kernel; bytes counted at FULL storage, SURVEY 8d)" if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
+                     "traffic": traffic, "traffic_source": traffic_source, "traced_avg_launch_us": traced_us, "kernel": kname + ("; Q is exactly symmetric and has >= 5120 rows: the rank-3 / rank-4 stages multiply it through the half-traffic pair "
+                                                "qw_symv_kernel + symv_reduce_kernel<o, EPI_HESS> (one product = both launches, upper triangle streamed once), rank 5 through "
+                                                "qw_dense_kernel; achieved / frac count the FULL-storage bytes of SURVEY 8d per product, traffic is what the counters saw"
+                                                if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); " + (
                              "per-rank Q is %.0f MB, inside the 256 MB Infinity Cache: the figure is cache-assisted, see roofline_hbm for the "

@@ -8,8 +8,12 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 LEGS = {
     # leg: (bench.py arguments, {role: substring(s) of the kernel name -- ALL of a list, or ANY of the alternatives of a list of lists}, what)
-    "venice": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-hbm-check", "--no-rome"],
-               {"hess": ["qw_dense_kernel<", ", 2, 2, "]}, "Hessian launches of the headline solve (qw_dense_kernel<o, EPI_HESS>)"),
+    # the headline solve multiplies an exactly symmetric Q of 5334 rows through the half-traffic pair at rank 3 / 4 and through the general kernel
+    # at rank 5 (xm_solver.h: sym_rows): per_product = the launch-count-weighted mean of the two kinds of product (MIX below)
+    "venice": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-hbm-check", "--no-rome", "--no-kkt-pair"],
+               {"hess": ["qw_dense_kernel<", ", 2, 2, "], "main": ["qw_symv_kernel<"], "reduce": ["symv_reduce_kernel<", ", 2>"]},
+               "Hessian products of the headline solve: qw_symv_kernel + symv_reduce_kernel<o, EPI_HESS> at rank 3 / 4 (half-traffic symmetric pair; "
+               "the main launch also serves the few gradient products), qw_dense_kernel<5, EPI_HESS> at rank 5"),
     "hbm13682": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-rome"],
                  {"plain": ["qw_dense_kernel<3, 0, 2, true"]}, "roofline_hbm leg: qw_dense_kernel<3, EPI_PLAIN> on the 13.5 GB matrix (non-temporal stream)"),
     "rome_dense": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-hbm-check"],
@@ -25,6 +29,8 @@ LEGS = {
                    {"main": ["qw_sell_kernel<3, "], "reduce": ["sell_reduce_kernel<3, 2"]},
                    "Hessian products of the 100k-camera solve, 3x3-block CSR storage (sliced-ELL copy with full blocks)"),
 }
+
+MIX = {"venice": [("general kernel", ["hess"], "hess"), ("symmetric pair", ["main", "reduce"], "reduce")]}
 
 
 def run(tag, leg):
@@ -62,9 +68,22 @@ def run(tag, leg):
                 out.setdefault(role, {})["traced_avg_us_real"] = sum(real) / len(real) / 1e3
                 out[role]["traced_real_launches"] = len(real)
         shutil.rmtree(d, ignore_errors=True)
-    tot = [out[r]["hbm_side_bytes_per_real_launch"] for r in roles if r in out and "hbm_side_bytes_per_real_launch" in out[r]]
-    dur = [out[r]["traced_avg_us_real"] for r in roles if r in out and "traced_avg_us_real" in out[r]]
-    out["per_product"] = {"hbm_side_bytes": sum(tot) if len(tot) == len(roles) else None, "traced_us": sum(dur) if len(dur) == len(roles) else None}
+    if leg in MIX:
+        # alternatives of one product: (roles whose launches add up to it, the role whose real launches count the products of that kind)
+        num_b = num_t = den = 0.0
+        kinds = {}
+        for name, rs, counter in MIX[leg]:
+            if not all(r in out and "hbm_side_bytes_per_real_launch" in out[r] and "traced_avg_us_real" in out[r] for r in rs):
+                continue          # a kind that did not occur in this run (e.g. no rank-5 stage)
+            b = sum(out[r]["hbm_side_bytes_per_real_launch"] for r in rs); t = sum(out[r]["traced_avg_us_real"] for r in rs)
+            k = out[counter]["real_launches"]
+            kinds[name] = {"products": k, "hbm_side_bytes": b, "traced_us": t}
+            num_b += k * b; num_t += k * t; den += k
+        out["per_product"] = {"hbm_side_bytes": num_b / den if den else None, "traced_us": num_t / den if den else None, "kinds": kinds}
+    else:
+        tot = [out[r]["hbm_side_bytes_per_real_launch"] for r in roles if r in out and "hbm_side_bytes_per_real_launch" in out[r]]
+        dur = [out[r]["traced_avg_us_real"] for r in roles if r in out and "traced_avg_us_real" in out[r]]
+        out["per_product"] = {"hbm_side_bytes": sum(tot) if len(tot) == len(roles) else None, "traced_us": sum(dur) if len(dur) == len(roles) else None}
     import bench
     out["source_sha256"] = bench.source_sha256()   # bench.py quotes this profile only while the sources are the ones it was measured on
     out["correction"] = "x1024 (KB) x2 (gfx950: 128-byte requests tallied at 64 B, MI355X_MICROARCH.md HBM section); FETCH_SIZE counts Infinity-Cache hits too"

@@ -41,7 +41,7 @@ Settings Settings::resolve(const xm_tuning_t *t) {
     if (t) z = *t;
     auto tri = [](int field) { return field > 0 ? 1 : (field < 0 ? -1 : 0); };
     s.sym = tri(z.sym);
-    s.sym_min_rows = z.sym_min_rows > 0 ? z.sym_min_rows : 6144;
+    s.sym_min_rows = z.sym_min_rows > 0 ? z.sym_min_rows : 0;   // 0: the measured default of the path that asks (Settings::sym_rows)
     s.sell = tri(z.sell);
     s.sell_slabs = z.sell_slabs > 0 ? z.sell_slabs : 4;
     s.sell_lmax = z.sell_lmax > 0 ? z.sell_lmax : 64;

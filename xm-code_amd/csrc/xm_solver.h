@@ -16,7 +16,12 @@ namespace xm {
 // ---- settings resolved ONCE at context creation (xm_tuning_t of the caller, else the defaults) ----------------------------------------
 struct Settings {
     int sym = 0;                 // 0 auto | 1 force | -1 off
-    int64_t sym_min_rows = 6144;
+    int64_t sym_min_rows = 0;    // 0 = the measured default: sym_rows()
+    // Rows (3n) from which an exactly symmetric dense Q goes through the half-traffic kernels.  One GPU: the two-launch symmetric product
+    // overtakes the general kernel between 1536 and 1778 cameras (profiles/r05_kbench_dense_sym_crossover.txt, us, general / symmetric:
+    // n = 1536 o = 3 26.6 / 27.7, o = 4 28.2 / 31.4; n = 1778 33.8 / 30.2, 34.9 / 34.2; n = 2048 49.0 / 41.8, 48.9 / 45.8) -> 5120 rows;
+    // in the Venice-1778 solve 230 -> 220 ms.  Several ranks (cyclic half window, xm_symw.h): measured at Final-13682 size only -> 6144.
+    int64_t sym_rows(int world) const { return sym_min_rows > 0 ? sym_min_rows : (world <= 1 ? 5120 : 6144); }
     int sell = 0;                // 0 auto | 1 force | -1 off
     int sell_slabs = 4, sell_lmax = 64, sell_gather = 1;   // sell_gather: the kernels' gather mode (0 a record of W per lane | 1 records fetched element-per-lane and transposed through LDS, the default)
     int sell_codec = 0;          // 0 auto | 1 full | 2 quaternion

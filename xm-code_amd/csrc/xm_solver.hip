@@ -334,15 +334,15 @@ void Context::init(const xm_problem_t &prob_in) {
         // several ranks (round 4): every rank builds the factors from the whole observation list; the rows of VT^-1 and the cameras of the
         // last kernel of the chain are partitioned (xm_schur.h)
         SchurSettings sc;
-        sc.host_assembly = cfg_.schur_host_assembly; sc.sym_min_rows = cfg_.sym_min_rows; sc.trace = cfg_.schur_trace;
+        sc.host_assembly = cfg_.schur_host_assembly; sc.sym_min_rows = cfg_.sym_rows(1); sc.trace = cfg_.schur_trace;
         sc.solver = cfg_.schur_solver; sc.dense_max = cfg_.schur_dense_max;
         schur_.reset(new SchurOp(n_, prob.n_landmarks, prob.nobs, prob.obs_cam, prob.obs_lm, prob.obs_p, prob.obs_w, st_, comm_.get(), sc));
         w_cur_.assign(prob.obs_w, prob.obs_w + prob.nobs);
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
     }
-    // Symmetric half-traffic product: dense, Q exactly symmetric.  It pays when the product is truly HBM bound (measured: 13682
-    // cameras 2017 -> 1147 us at o = 3) and not at Venice size.  Settings.sym: auto = on for 3n >= sym_min_rows and o <= 4; 1 forces
+    // Symmetric half-traffic product: dense, Q exactly symmetric.  It pays from ~1700 cameras on (Settings::sym_rows: measured cross-over;
+    // 13682 cameras 2017 -> 1147 us at o = 3, 1778 cameras 33.8 -> 30.2 us).  Settings.sym: auto = on for 3n >= sym_rows() and o <= 4; 1 forces
     // it for every size (o <= 5, 1e-9 relative asymmetry accepted); -1 disables it.  Single rank only: the kernel sweeps the upper
     // triangle of the WHOLE matrix (a rank's row strip is a rectangle).
     sym_ok_ = false;
@@ -350,7 +350,7 @@ void Context::init(const xm_problem_t &prob_in) {
     {
         const bool force = cfg_.sym == 1, off = cfg_.sym == -1;
         if (force) sym_max_o_ = 5;
-        if (storage_ == XM_STORAGE_DENSE && world == 1 && !off && (force || 3 * n_ >= cfg_.sym_min_rows)) {
+        if (storage_ == XM_STORAGE_DENSE && world == 1 && !off && (force || 3 * n_ >= cfg_.sym_rows(1))) {
             const int grid = 2048;
             DevBuf<double> d;
             d.alloc((size_t)2 * grid);
@@ -380,7 +380,7 @@ void Context::init(const xm_problem_t &prob_in) {
     // product) agrees to 1e-9 on every rank.
     symw_.reset();
     if (storage_ == XM_STORAGE_DENSE && world > 1 && comm_->active() && cfg_.sym != -1 && (nloc_ % 2) == 0 &&
-        (cfg_.sym == 1 || 3 * n_ >= cfg_.sym_min_rows)) {
+        (cfg_.sym == 1 || 3 * n_ >= cfg_.sym_rows(world))) {
         sym_max_o_ = (cfg_.sym == 1) ? 5 : 4;
         symw_.reset(new SymwProduct(ntot_, nloc_, cam0_, ld_, st_));
         comm_->reserve(symw_csum_count(ntot_, sym_max_o_) * (size_t)world + 4096);
