@@ -603,6 +603,9 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                                                 "qw_dense_kernel; achieved / frac count the FULL-storage bytes of SURVEY 8d per product, traffic is what the counters saw"
                                                 if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
+                     # what really moved, next to the contract's algorithmic figure: counter bytes per product / traced duration per product
+                     "streamed": ({"bytes_per_product": traffic, "GBs": traffic / (traced_us * 1e-6) / 1e9, "frac": traffic / (traced_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                   "traced_frac_algorithmic": alg_bytes / (traced_us * 1e-6) / 1e9 / HBM_PEAK_GBS} if (traffic and traced_us) else None),
                      "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); " + (
                              "per-rank Q is %.0f MB, inside the 256 MB Infinity Cache: the figure is cache-assisted, see roofline_hbm for the "
                              "HBM-bound run of the same kernel" % (alg_bytes / 1e6) if alg_bytes < 250e6 else

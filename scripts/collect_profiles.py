@@ -55,7 +55,7 @@ for name in ("bench_venice1778.json", "bench_vg100k_vg.json", "bench_vg100k_bsr.
     tu = f"{tus:.1f}" if tus else "—"
     tf = f"{alg / tus / 1e3 / r.get('peak', 8000.0):.3f}" if (alg and tus) else "—"
     out.append(f"| `{tag}_{name}` | {g(b, 'config', 'workload')} ×{b.get('n_gpus')} | {g(b, 'value', fmt='{:.0f}')} | {g(b, 'ms_per_step', fmt='{:.1f}')} | "
-               f"{g(r, 'kernel')} | {ev} / {g(r, 'frac', fmt='{:.3f}')} | {tu} / {tf} | {ratio} | {g(b, 'transport')} |")
+               f"{g(r, 'kernel')[:70]} | {ev} / {g(r, 'frac', fmt='{:.3f}')} | {tu} / {tf} | {ratio} | {g(b, 'transport')} |")
 b = load("bench_venice1778.json")
 if b:
     out += ["", "## legs of the headline line (`%s_bench_venice1778.json`)" % tag, ""]
