@@ -328,9 +328,6 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
                                                        const TcgScal *__restrict__ scal, double *__restrict__ Prow,
                                                        double *__restrict__ Pcol) {
     constexpr int OP = pitch_of(O), V = 6 * O;
-    if (scal != nullptr) {
-        if (scal->status != 0) return;
-    }
     __shared__ __attribute__((aligned(16))) double lds[4][V * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = blockIdx.y * 4 + wave, ch = blockIdx.x;
@@ -444,6 +441,11 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
 
     double2 qA[6][2], qB[6][2];
     load_q(jb, qA);
+    // the tCG's status word (written by the previous launch on another XCD: an L2 miss) is looked at only now, with the columns of W and the
+    // first step of Q already requested: one round trip at the head of every wavefront instead of two
+    if (scal != nullptr) {
+        if (scal->status != 0) return;
+    }
     int j = jb;
     for (; j + 1 < je; j += 2) {
         load_q(j + 1, qB);
@@ -469,9 +471,6 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
 template <int O, int EPI>
 __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t ld,
                                                            int nstrips, int Kc, int Kf, int ysplit, double alpha, CamArgs a) {
-    if (EPI == EPI_HESS) {
-        if (a.scal->status != 0) return;
-    }
     __shared__ double red[kQwWaves][3];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cam = blockIdx.x * kQwWaves + wave;
@@ -483,36 +482,56 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restri
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
-    if (active) {
-        const int64_t R = (int64_t)6 * ((a.nloc + 1) >> 1);
-        const int s_lo = (6 * (cam >> 1)) / kSvStrip;
-        const int nrow = nstrips - s_lo;
-        int cnt[3];
+    // A camera adds nrow row-sum records and up to ncol column-sum records (~100 at Venice size), lane i the records i, i + 64, ... in that
+    // order, then the wavefront's fixed DPP tree.  The records of a PAIR of rounds are requested together, the first pair before the
+    // tCG's status word is looked at (the launch is latency-bound: status word, partial sums and epilogue operands were all written by
+    // earlier launches on other XCDs -- one round trip for all of them instead of three in a row).  Loads are unconditional (a lane
+    // without a record re-reads a valid one and selects zero): a predicated load becomes a branch the compiler drains the queue for.
+    const int camc = active ? cam : 0;
+    const int64_t R = (int64_t)6 * ((a.nloc + 1) >> 1);
+    const int s_lo = (6 * (camc >> 1)) / kSvStrip;
+    const int nrow = nstrips - s_lo;
+    int cnt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int c = 3 * camc + r;
+        const int K = ((c / kSvStrip) / 4 >= ysplit) ? Kf : Kc;   // chunk length of the strip group that owns column c
+        cnt[r] = (c >= 6) ? (c - 6) / (6 * K) + 1 : 0;
+    }
+    const int ncol = max(cnt[0], max(cnt[1], cnt[2]));
+    const int tot = active ? nrow + ncol : 0;
+    auto fetch = [&](int i, double (&v)[3][O]) {
+        const int ic = min(i, nrow + ncol - 1);               // nrow >= 1: always a valid record
+        const double *p = (ic < nrow) ? Prow + ((size_t)(s_lo + ic) * (size_t)R + (size_t)camc * 3) * O
+                                      : Pcol + ((size_t)(ic - nrow) * (size_t)ld + (size_t)camc * 3) * O;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < O; ++k) v[r][k] = p[r * O + k];
+    };
+    auto add = [&](int i, const double (&v)[3][O]) {
+        const bool row = i < nrow;
+        const int ch = i - nrow;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const int c = 3 * cam + r;
-            const int K = ((c / kSvStrip) / 4 >= ysplit) ? Kf : Kc;   // chunk length of the strip group that owns column c
-            cnt[r] = (c >= 6) ? (c - 6) / (6 * K) + 1 : 0;
+            const bool ok = (i < tot) && (row || ch < cnt[r]);
+#pragma unroll
+            for (int k = 0; k < O; ++k) acc[r][k] += ok ? v[r][k] : 0.0;
         }
-        const int ncol = max(cnt[0], max(cnt[1], cnt[2]));
-        for (int i = lane; i < nrow + ncol; i += 64) {
-            if (i < nrow) {
-                const double *p = Prow + ((size_t)(s_lo + i) * (size_t)R + (size_t)cam * 3) * O;
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
-            } else {
-                const int ch = i - nrow;
-                const double *p = Pcol + ((size_t)ch * (size_t)ld + (size_t)cam * 3) * O;
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    if (ch < cnt[r]) {
-#pragma unroll
-                        for (int k = 0; k < O; ++k) acc[r][k] += p[r * O + k];
-                    }
-            }
-        }
+    };
+    double va[3][O], vb[3][O];
+    fetch(lane, va);
+    fetch(lane + 64, vb);
+    if (EPI == EPI_HESS) {
+        if (a.scal->status != 0) return;
+    }
+    add(lane, va);
+    add(lane + 64, vb);
+    for (int i = lane + 128; i < tot + lane; i += 128) {      // wave-uniform trip count (i - lane < tot)
+        fetch(i, va);
+        fetch(i + 64, vb);
+        add(i, va);
+        add(i + 64, vb);
     }
     qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }

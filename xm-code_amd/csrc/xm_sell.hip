@@ -597,23 +597,25 @@ __global__ __launch_bounds__(256) void sell_reduce_kernel(const int64_t *__restr
                                                            double alpha, CamArgs a, const double *__restrict__ diag, const double *__restrict__ W,
                                                            int64_t row0, int wstride) {
     constexpr int NSLOT = 256 / GW;
-    if (EPI == EPI_HESS) {
-        if (a.scal->status != 0) return;
-    }
     __shared__ double red[NSLOT][3];
     const int gl = threadIdx.x & (GW - 1), slot = threadIdx.x / GW;
     const int cam = blockIdx.x * NSLOT + slot;
     const bool active = cam < a.nloc;
     EpiOps eops;
     epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
+    // list bounds and epilogue operands are requested BEFORE the tCG's status word is looked at (all of them were written by earlier
+    // launches on other XCDs): status -> bounds -> indices -> partial sums was four round trips in a row, now three
+    const int64_t p0 = active ? pptr[cam] : 0, p1 = active ? pptr[cam + 1] : 0;
+    if (EPI == EPI_HESS) {
+        if (a.scal->status != 0) return;
+    }
     double acc[3][O];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
     if (active) {
-        const int64_t p1 = pptr[cam + 1];
-        for (int64_t p = pptr[cam] + gl; p < p1; p += GW) {   // fixed order: lane gl takes list entries gl, gl + GW, ...
+        for (int64_t p = p0 + gl; p < p1; p += GW) {   // fixed order: lane gl takes list entries gl, gl + GW, ...
             const double *v = parts + (size_t)ridx[p] * 3 * O;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
