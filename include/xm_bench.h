@@ -17,6 +17,14 @@ const char *xm_bench_last_error(void);
 int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
 /* the half-traffic symmetric product (xm_qw_dense_sym), scratch allocated once */
 int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
+/* micro-benchmark settings of the symmetric sweep: k > 0 overrides the chunk length of the plan (0 = the plan's own; set it BEFORE a context
+ * or a timing call sizes its partial-result buffers); alternate = 0: xm_qw_dense_sym_time sweeps top-down in every launch instead of
+ * alternating the direction between consecutive products as the solver does */
+int xm_bench_symv_k(int k, int alternate);
+/* ONE traced launch of the sweep (o = 3 or 4, top-down): per wavefront `slots` 100 MHz timestamps -- [0] entry, [1] after the status word,
+ * [2 + i] after step i, [slots - 3] loop done, [slots - 2] column sums written, [slots - 1] XCC_ID << 32 | HW_ID; trace_host = NULL: grid and slots only */
+int xm_qw_dense_sym_trace(const double *dq, int64_t n, int o, const double *dW, double *dOut, unsigned long long *trace_host, int64_t trace_cap,
+                          int grid[2], int *slots);
 /* the same for a ROW STRIP of nloc cameras of an n-camera matrix (what one rank of an N-GPU row partition multiplies: dq = 3 nloc rows x
  * xm_dense_ld(n)): the expected per-iteration time of the partitioned solve from measured pieces */
 int xm_qw_dense_strip_time(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);

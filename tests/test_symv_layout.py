@@ -12,35 +12,43 @@ import xmamd
 STRIP = 256
 
 
-def emulate(Q, W, K, Kf, ysplit):
+def emulate(Q, W, K, Kf, ysplit, rev=0):
+    """ysplit counts strip GROUPS of four (the plan's unit); the kernel cuts strips s >= 4 ysplit finer.  A workgroup = one strip x 4 Ks steps,
+    its four wavefronts' column sums are added before the one record per workgroup is written; rev walks every chunk bottom-up."""
     m, o = W.shape
     n = m // 3
     ld = xmamd.dense_ld(n)
     nsteps, nstrips = (n + 1) // 2, (ld + STRIP - 1) // STRIP
     Qp = np.zeros((6 * nsteps, ld)); Qp[:m, :m] = Q
     Wp = np.zeros((max(ld, 6 * nsteps), o)); Wp[:m] = W
-    nch = (nsteps + Kf - 1) // Kf
-    Prow = np.full((nstrips, 6 * nsteps, o), np.nan); Pcol = np.full((nch, ld, o), np.nan)
+    nsc = ((nsteps + Kf - 1) // Kf + 3) // 4
+    Prow = np.full((nstrips, 6 * nsteps, o), np.nan); Pcol = np.full((nsc, ld, o), np.nan)
     for s in range(nstrips):
-        Ks = Kf if s // 4 >= ysplit else K
+        Ks = Kf if s >= 4 * ysplit else K
         c0 = s * STRIP
         cols = np.arange(c0, min(c0 + STRIP, ld))
         jend = min(nsteps, (c0 + STRIP + 5) // 6)
-        for ch in range((jend + Ks - 1) // Ks):
-            acc = np.zeros((cols.size, o))
-            for j in range(ch * Ks, min(ch * Ks + Ks, jend)):
-                rows = np.arange(6 * j, 6 * j + 6)
-                q = Qp[np.ix_(rows, cols)]
-                Prow[s, rows] = (q * (cols >= 6 * j)[None, :]) @ Wp[cols]              # used row-wise from the diagonal block on
-                acc += (q * (cols >= 6 * j + 6)[None, :]).T @ Wp[rows]                 # and column-wise strictly right of it
-            assert np.all(np.isnan(Pcol[ch, cols]))                                     # written once
-            Pcol[ch, cols] = acc
+        for sc in range((jend + 4 * Ks - 1) // (4 * Ks)):
+            tot = np.zeros((cols.size, o))
+            for wave in range(4):
+                jb = (sc * 4 + wave) * Ks; je = min(jb + Ks, jend)
+                acc = np.zeros((cols.size, o))
+                steps = range(jb, je)
+                for j in (reversed(steps) if rev else steps):
+                    rows = np.arange(6 * j, 6 * j + 6)
+                    q = Qp[np.ix_(rows, cols)]
+                    assert np.all(np.isnan(Prow[s, rows]))                                  # written once
+                    Prow[s, rows] = (q * (cols >= 6 * j)[None, :]) @ Wp[cols]              # used row-wise from the diagonal block on
+                    acc += (q * (cols >= 6 * j + 6)[None, :]).T @ Wp[rows]                 # and column-wise strictly right of it
+                tot += acc
+            assert np.all(np.isnan(Pcol[sc, cols]))                                         # written once
+            Pcol[sc, cols] = tot
     Y = np.zeros((m, o))
     for cam in range(n):
         s_lo = (6 * (cam // 2)) // STRIP
         for r in range(3):
             c = 3 * cam + r
-            Kc = Kf if (c // STRIP) // 4 >= ysplit else K
+            Kc = 4 * (Kf if c // STRIP >= 4 * ysplit else K)                                # steps per column-sum record
             cnt = (c - 6) // (6 * Kc) + 1 if c >= 6 else 0
             Y[c] = Prow[s_lo:, c].sum(axis=0) + Pcol[:cnt, c].sum(axis=0)
     assert np.all(np.isfinite(Y))                                                        # everything read had been written
@@ -65,6 +73,8 @@ def test_symv_partition_sums_to_the_product(n, o, plan):
     assert np.abs(Y - ref).max() <= 1e-11 * np.abs(ref).max()
     Ql = Q.copy(); Ql[np.tril_indices(3 * n, -6)] = 1e6            # far enough below the diagonal nothing may be read
     assert np.array_equal(emulate(Ql, W, K, Kf, ysplit), Y)
+    Yr = emulate(Q, W, K, Kf, ysplit, rev=1)                       # the bottom-up sweep reads and writes the same entries
+    assert np.abs(Yr - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
 def test_symv_plan_of_the_benchmark_sizes():

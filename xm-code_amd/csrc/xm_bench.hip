@@ -59,6 +59,7 @@ int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, doubl
     return XM_OK;
     XM_CATCH
 }
+static int g_sym_alternate = 1;
 int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
     XM_TRY
     const int64_t ld = xm::dense_ld(n);
@@ -66,8 +67,37 @@ int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, d
     prow.alloc(xm::sym_prow_count((int)n, ld, o));
     pcol.alloc(xm::sym_pcol_count((int)n, ld, o), false);
     const xm::CamArgs a = plain_args(n, dOut);
-    const double ms = time_launches(3, reps, [&] { xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, prow.p, pcol.p, nullptr); });
+    int it = 0;   // consecutive products alternate the sweep direction as the solver's do (xm_bench_symv_k(k, 0): always top-down)
+    const double ms = time_launches(3, reps, [&] { xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, prow.p, pcol.p, nullptr, g_sym_alternate ? (it++ & 1) : 0); });
     if (ms_avg) *ms_avg = ms;
+    return XM_OK;
+    XM_CATCH
+}
+int xm_bench_symv_k(int k, int alternate) {
+    xm::symv_bench_k(k);
+    g_sym_alternate = alternate;
+    return XM_OK;
+}
+int xm_qw_dense_sym_trace(const double *dq, int64_t n, int o, const double *dW, double *dOut, unsigned long long *trace_host, int64_t trace_cap,
+                          int grid[2], int *slots) {
+    XM_TRY
+    const int64_t ld = xm::dense_ld(n);
+    const xm::CamArgs a = plain_args(n, dOut);
+    xm::launch_qw_sym_traced(o, nullptr, ld, nullptr, a, nullptr, nullptr, nullptr, grid, nullptr);     // grid only
+    *slots = xm::symv_trace_slots();
+    const int64_t need = (int64_t)grid[0] * grid[1] * 4 * *slots;
+    if (trace_host == nullptr) return XM_OK;
+    if (trace_cap < need) throw xm::Error(XM_ERR_ARG, "trace buffer too small");
+    xm::DevBuf<double> prow, pcol;
+    prow.alloc(xm::sym_prow_count((int)n, ld, o));
+    pcol.alloc(xm::sym_pcol_count((int)n, ld, o), false);
+    xm::DevBuf<unsigned long long> tr;
+    tr.alloc((size_t)need);
+    for (int i = 0; i < 3; ++i) xm::launch_qw_sym(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, prow.p, pcol.p, nullptr);   // warm: caches in their steady state
+    XM_HIP_CHECK(hipMemsetAsync(tr.p, 0, (size_t)need * 8, nullptr));
+    xm::launch_qw_sym_traced(o, dq, ld, dW, a, prow.p, pcol.p, tr.p, grid, nullptr);
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    XM_HIP_CHECK(hipMemcpy(trace_host, tr.p, (size_t)need * 8, hipMemcpyDeviceToHost));
     return XM_OK;
     XM_CATCH
 }

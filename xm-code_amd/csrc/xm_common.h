@@ -139,9 +139,13 @@ int qw_dense_split_k(int nloc, int64_t ld);   // column split the small-strip po
 int bsr_grid(int nloc);   // workgroups (= partial sums per epilogue slot) of the BSR3 kernels
 size_t sym_prow_count(int nloc, int64_t ld, int o);
 size_t sym_pcol_count(int nloc, int64_t ld, int o);
+void symv_bench_k(int k);                                  // micro-benchmark override of the chunk length (xm_bench.h)
+int symv_trace_slots();
+void launch_qw_sym_traced(int o, const double *Q, int64_t ld, const double *W, const CamArgs &a, double *Prow, double *Pcol, unsigned long long *trace,
+                          int grid[2], hipStream_t st);
 void symv_plan_get(int nloc, int64_t ld, int out[4]);   // K, Kf, ysplit, nchunks of the vertical-sweep symmetric product
 void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,
-                   double *Pcol, hipStream_t st);
+                   double *Pcol, hipStream_t st, int rev = 0);   // rev: sweep direction, alternated by the caller between consecutive products
 void launch_asym(const double *Q, int64_t ld, int64_t m, double *out, int grid, hipStream_t st);
 // exact symmetry check of a row-partitioned matrix: this strip's (rows row0 .. row0 + nrows of the m x m matrix) share of a sum modulo 2^64
 // that vanishes over all strips iff the matrix is symmetric (xm_kernels.hip: symhash_kernel); out: 2 * grid words

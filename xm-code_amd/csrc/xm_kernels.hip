@@ -310,70 +310,74 @@ __global__ __launch_bounds__(256) void qw_dense_ks_kernel(const double *__restri
 
 // ----------------------------------------------------------------------------------------------------------------
 // Half-traffic product for SYMMETRIC dense Q (single GPU, o <= 5): only the upper block triangle is read, every Q fragment is used
-// twice.  A WAVEFRONT owns a strip of 256 columns (lane: 2 + 2 adjacent columns, W of its
-// columns in registers for the whole sweep) and walks DOWN it in steps of two cameras (6 rows x 256 columns = 12 KB per step):
-//   column direction  y_cols += Q_step^T w_rows : per-lane accumulators that live in registers for the whole chunk of K steps,
-//                     written ONCE per chunk (w_rows is wave-uniform: scalar loads);
+// twice.  A WORKGROUP owns a strip of 256 columns and 4 K consecutive steps of it; each of its four wavefronts (lane: 2 + 2 adjacent
+// columns, W of its columns in registers for the whole sweep) walks K steps of two cameras (6 rows x 256 columns = 12 KB per step):
+//   column direction  y_cols += Q_step^T w_rows : per-lane accumulators that live in registers for the whole chunk; the four
+//                     wavefronts' sums are added in LDS (wavefront order 0..3: fixed) and written ONCE per workgroup;
 //   row direction     y_rows  = Q_step w_cols   : 6 * o per-lane partial sums per step, summed over the 64 lanes through LDS
 //                     (transposed write, 16-lane DPP row sums) and written as 6 * o doubles per step.
-// Partial-result traffic: o / (6 K) + o / 256 of the half matrix each way (K = 32: 3 % at o = 3 against 25 %), no workgroup
-// barrier anywhere (the four wavefronts of a workgroup are independent: four adjacent strips, same rows -> 8 KB contiguous per row).
 // Element (r, c) of step j (rows [6j, 6j+6)): used both ways when c >= 6j + 6, in the row direction only when 6j <= c < 6j + 6
 // (the 6 x 6 diagonal block is read in full), not at all when c < 6j (its mirror image serves it).
+// Round 6 (profiles/r06_kbench_symv.txt; Venice size, o = 3 / 4, pair of launches, us): workgroup on four strips with one chunk each and a
+// select behind every load 29.8 / 34.0 -> workgroup on one strip, column sums combined in LDS (Pcol / 4: ~35 instead of ~100 partial records
+// per camera), loads without a select and a peeled loop so that the next step's twelve requests stay in flight while the current step is
+// multiplied (s_waitcnt vmcnt(12), not 0) 28.1 / 32.5 -> alternating sweep direction (rev) 27.4 / 31.9 -> K = 6 (one residency round of
+// ~420 workgroups) 26.5 / 29.6.  The per-wavefront timestamps (TRACE) say where the time of the launch goes: all wavefronts start within
+// 1 us, the first step completes after ~5-6 us (every wavefront asks for 20 KB at once: 25 MB at the ~7 TB/s the fabric delivers), every
+// further step 2.1-2.5 us (= 7 TB/s over all wavefronts: the loop runs at the chip's saturation), the median wavefront ends at 20 us, the last at 24.
+// The loads carry no select: a row past the end re-reads the last row and meets w_row = 0 in the column direction (its row sums land in
+// rows of Prow nobody reads), the absent second half of the last strip re-reads the first half and meets w_col = 0.
+// TRACE (micro-benchmark only): 100 MHz timestamps per wavefront -- entry, after the status word, after every step, end.
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int kSvStrip = 256;
-
-template <int O, bool NT>
+constexpr int kSvTraceSlots = 24;
+template <int O, bool NT, bool TRACE = false>
 __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc, int Kc, int Kf, int ysplit,
-                                                       const TcgScal *__restrict__ scal, double *__restrict__ Prow,
-                                                       double *__restrict__ Pcol) {
+                                                        const TcgScal *__restrict__ scal, double *__restrict__ Prow,
+                                                        double *__restrict__ Pcol, unsigned long long *__restrict__ trace, int rev) {
     constexpr int OP = pitch_of(O), V = 6 * O;
     __shared__ __attribute__((aligned(16))) double lds[4][V * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = blockIdx.y * 4 + wave, ch = blockIdx.x;
-    const int K = ((int)blockIdx.y >= ysplit) ? Kf : Kc;   // the strip groups dispatched last are cut finer: they are the launch's tail
+    const int s = blockIdx.y, sc = blockIdx.x;
+    unsigned long long *tr = nullptr;
+    if constexpr (TRACE) {
+        tr = trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * kSvTraceSlots;
+        if (lane == 0) {
+            unsigned int hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            tr[0] = wall_clock64();
+            tr[kSvTraceSlots - 1] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+    const int K = (s >= ysplit) ? Kf : Kc;   // the strips dispatched last are cut finer: they are the launch's tail
     const int nsteps = (nloc + 1) >> 1, nrows = 3 * nloc;
     const int64_t c0 = (int64_t)s * kSvStrip;
-    if (c0 >= ld) return;                                        // wave-uniform exits: no workgroup barrier in this kernel
+    if (c0 >= ld) return;                                        // uniform over the workgroup
     int jend = (int)((c0 + kSvStrip + 5) / 6);                   // steps whose rows start above the end of the strip
     if (jend > nsteps) jend = nsteps;
-    const int jb = ch * K;
-    if (jb >= jend) return;
+    if (sc * 4 * K >= jend) return;                              // uniform over the workgroup
+    const int jb = (sc * 4 + wave) * K;                          // this wavefront's chunk [jb, je): may be empty at the foot of the strip
     const int je = (jb + K < jend) ? jb + K : jend;
     const int jfull = (int)(c0 / 6);                             // steps j < jfull lie entirely above the diagonal: no masks
     const bool half1 = c0 + 128 < ld;                            // ld is a multiple of 128: the strip may end after its first half
     const int64_t R = (int64_t)6 * nsteps;
     double *L = lds[wave];
-    const int64_t cA = c0 + 2 * lane;
+    const int64_t cA = c0 + 2 * lane, cB = half1 ? cA + 128 : cA;
 
     double wc[2][2][O], ca[2][2][O];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int k = 0; k < O; ++k) {
-                wc[h][e][k] = (h == 0 || half1) ? W[(size_t)(cA + 128 * h + e) * OP + k] : 0.0;
-                ca[h][e][k] = 0.0;
-            }
 
-    // branch-free loads: rows past the end (odd camera count: three rows of the last step) and the absent second half of the last
-    // strip read a valid address instead and are zeroed by a select
-    const int64_t cB = half1 ? cA + 128 : cA;
     auto load_q = [&](int j, double2 (&q)[6][2]) {
         const int64_t r0 = (int64_t)6 * j;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            const bool ok = r0 + r < nrows;   // wave-uniform
-            const double *row = Q + (size_t)(ok ? r0 + r : nrows - 1) * (size_t)ld;
+            const int64_t rr = (r0 + r < nrows) ? r0 + r : nrows - 1;   // wave-uniform clamp (odd camera count: three rows of the last step)
+            const double *row = Q + (size_t)rr * (size_t)ld;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const double2 *qp = reinterpret_cast<const double2 *>(row + (h ? cB : cA));
-                double2 v;
-                if (NT) v = make_double2(__builtin_nontemporal_load(&qp->x), __builtin_nontemporal_load(&qp->y));
-                else v = *qp;
-                const bool keep = ok && (h == 0 || half1);
-                q[r][h] = make_double2(keep ? v.x : 0.0, keep ? v.y : 0.0);
+                if (NT) q[r][h] = make_double2(__builtin_nontemporal_load(&qp->x), __builtin_nontemporal_load(&qp->y));
+                else q[r][h] = *qp;
             }
         }
     };
@@ -391,9 +395,13 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             double wr[O];
-            const int64_t rw = (r0 + r < nrows) ? r0 + r : nrows - 1;   // rows past the end: Q was zeroed, any finite w will do
+            const bool ok = r0 + r < nrows;                              // wave-uniform: scalar loads, scalar select
+            const int64_t rw = ok ? r0 + r : nrows - 1;
 #pragma unroll
-            for (int k = 0; k < O; ++k) wr[k] = W[(size_t)rw * OP + k];   // wave-uniform: scalar loads
+            for (int k = 0; k < O; ++k) {
+                const double t = W[(size_t)rw * OP + k];
+                wr[k] = ok ? t : 0.0;
+            }
             double qr[2][2], qc[2][2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -422,9 +430,6 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
             const int v = v0 + g;
             double t = 0.0;
             if (v < V) {
-                // (lane jl: elements 4 jl .. 4 jl + 3.  The PMC pass shows 65 % of the LDS cycles of this kernel in bank conflicts from
-                // this pattern; the conflict-free mapping 2 jl / 32 + 2 jl was measured: no faster (LDS is 8 % of the wave cycles), and
-                // it changes the summation grouping, so it was not kept.)
                 const double2 a = *reinterpret_cast<const double2 *>(L + v * 64 + 4 * jl), b = *reinterpret_cast<const double2 *>(L + v * 64 + 4 * jl + 2);
                 t = (a.x + a.y) + (b.x + b.y);
             }
@@ -434,37 +439,76 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
+    int nrun = 0;
     auto run = [&](int j, const double2 (&q)[6][2]) {
         if (j < jfull) step(j, q, std::false_type{});
         else step(j, q, std::true_type{});
+        if constexpr (TRACE) {
+            if (lane == 0 && 2 + nrun < kSvTraceSlots - 3) tr[2 + nrun] = wall_clock64();
+            ++nrun;
+        }
     };
 
     double2 qA[6][2], qB[6][2];
-    load_q(jb, qA);
+    if (jb < je) load_q(rev ? je - 1 : jb, qA);                // wave-uniform
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                const double t = W[(size_t)((h ? cB : cA) + e) * OP + k];   // unconditional request (a predicated one is a branch per element)
+                wc[h][e][k] = (h == 0 || half1) ? t : 0.0;
+                ca[h][e][k] = 0.0;
+            }
     // the tCG's status word (written by the previous launch on another XCD: an L2 miss) is looked at only now, with the columns of W and the
     // first step of Q already requested: one round trip at the head of every wavefront instead of two
     if (scal != nullptr) {
         if (scal->status != 0) return;
     }
-    int j = jb;
-    for (; j + 1 < je; j += 2) {
-        load_q(j + 1, qB);
-        run(j, qA);
-        if (j + 2 < je) load_q(j + 2, qA);
-        run(j + 1, qB);
-    }
-    if (j < je) run(j, qA);
-
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (h == 0 || half1) {
-            double *pc = Pcol + ((size_t)ch * (size_t)ld + (size_t)(cA + 128 * h)) * O;
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int k = 0; k < O; ++k) pc[e * O + k] = ca[h][e][k];
+    if constexpr (TRACE) { if (lane == 0) tr[1] = wall_clock64(); }
+    // rev: the chunk is walked bottom-up (position i <-> step je - 1 - i).  Launches alternate the direction, so that a launch starts with
+    // the steps the previous one ended with: they are still in this XCD's L2 (4 MB; block b runs on XCD b mod 8 in every launch)
+    auto at = [&](int i) { return rev ? je - 1 - i : jb + i; };
+    const int cnt = je - jb;
+    if (cnt > 0) {
+        int i = 0;
+        while (i + 2 < cnt) {          // two more steps follow: both requests below are unconditional
+            load_q(at(i + 1), qB);
+            run(at(i), qA);
+            load_q(at(i + 2), qA);
+            run(at(i + 1), qB);
+            i += 2;
+        }
+        if (i + 1 < cnt) {
+            load_q(at(i + 1), qB);
+            run(at(i), qA);
+            run(at(i + 1), qB);
+        } else {
+            run(at(i), qA);
         }
     }
+    if constexpr (TRACE) { if (lane == 0) tr[kSvTraceSlots - 3] = wall_clock64(); }
+
+    // column sums of the four chunks, added in wavefront order; wavefront h writes the h-th half of the strip (2 O contiguous doubles per lane)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int k = 0; k < O; ++k) L[((h * 2 + e) * O + k) * 64 + lane] = ca[h][e][k];
+    __syncthreads();
+    if (wave < 2 && (wave == 0 || half1)) {
+        double *pc = Pcol + ((size_t)sc * (size_t)ld + (size_t)(cA + 128 * wave)) * O;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                const int idx = ((wave * 2 + e) * O + k) * 64 + lane;
+                pc[e * O + k] = ((lds[0][idx] + lds[1][idx]) + lds[2][idx]) + lds[3][idx];
+            }
+    }
+    if constexpr (TRACE) { if (lane == 0) tr[kSvTraceSlots - 2] = wall_clock64(); }
 }
 
 // second half: y_cam = sum_{strips s >= s_lo} Prow[s][rows of cam] + sum_{chunks above} Pcol[chunk][rows of cam] (fixed order), fused epilogue
@@ -495,7 +539,7 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restri
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int c = 3 * camc + r;
-        const int K = ((c / kSvStrip) / 4 >= ysplit) ? Kf : Kc;   // chunk length of the strip group that owns column c
+        const int K = (c / kSvStrip >= ysplit) ? Kf : Kc;         // steps per column-sum record of the strip that owns column c (ysplit in strips)
         cnt[r] = (c >= 6) ? (c - 6) / (6 * K) + 1 : 0;
     }
     const int ncol = max(cnt[0], max(cnt[1], cnt[2]));
@@ -1970,17 +2014,31 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
     check_launch("qw_dense");
 }
 
-// vertical sweep: steps (two cameras) per chunk.  A long chunk amortises the column flush and shortens the reducer's lists
-// (n / (2 K) column partials per camera), a short one yields more wavefronts and a shorter serial chain per wavefront; the
-// optimum grows like the square root of the triangle's step count T (measured best K, o = 3: T = 9.3 k (Venice size) 8,
-// 49 k (n = 4096) 16, 197 k (n = 8192) 32, 550 k (n = 13682) 64) -> K = sqrt(T) / 13, 2 <= K <= 64.
+// vertical sweep: steps (two cameras) per chunk.  A long chunk amortises the column flush and shortens the reducer's lists, a short one
+// yields more wavefronts and a shorter serial chain per wavefront; the optimum grows like the square root of the triangle's step count T
+// (measured best K, o = 3: T = 21 k (n = 2560) 10-12, 49 k (n = 4096) 16-24, 550 k (n = 13682) 48-64) -> K = sqrt(T) / 13, 2 <= K <= 64.
+// SMALL triangles (Venice size, T = 9.9 k) run in ONE residency round -- every workgroup is on the chip at once, 2 per CU x 256 CUs -- and the
+// launch lasts as long as its longest wavefront: there the shortest chunk whose live workgroups still fit in one round with a margin wins
+// (profiles/r06_kbench_symv.txt, us per pair at o = 3 / 4: K = 5 (503 workgroups: a second round) 30.7 / 36.4, K = 6 (420) 26.5 / 29.6,
+// K = 7 27.0 / 31.4, K = 8 28.5 / 33.6, K = 10 30.3 / 37.1).
+static int64_t symv_live_groups(int64_t nsteps, int64_t nstrips, int64_t k) {
+    int64_t live = 0;
+    for (int64_t s = 0; s < nstrips; ++s) live += (std::min<int64_t>(nsteps, (s * kSvStrip + kSvStrip + 5) / 6) + 4 * k - 1) / (4 * k);
+    return live;
+}
 int symv_k(int nloc, int64_t ld) {
     const int64_t nsteps = (nloc + 1) / 2, nstrips = (ld + kSvStrip - 1) / kSvStrip;
     int64_t total = 0;
     for (int64_t s = 0; s < nstrips; ++s) total += std::min<int64_t>(nsteps, (s * kSvStrip + kSvStrip + 5) / 6);
     int64_t k = (int64_t)(std::sqrt((double)total) / 13.0 + 0.5);
     if (k > 48) k = 64;   // 13.5 GB: 48 -> 1 190 us, 64 -> 1 147 us, 128 -> 1 265 us
-    return (int)std::min<int64_t>(64, std::max<int64_t>(2, k));
+    k = std::min<int64_t>(64, std::max<int64_t>(2, k));
+    if (symv_live_groups(nsteps, nstrips, k) <= 512) {          // one round at the square-root length: shorten the chain while a round with margin still holds everything
+        int64_t ks = 4;
+        while (ks < k && symv_live_groups(nsteps, nstrips, ks) > 440) ++ks;
+        k = ks;
+    }
+    return (int)k;
 }
 size_t sym_prow_count(int nloc, int64_t ld, int o) { return (size_t)((ld + kSvStrip - 1) / kSvStrip) * 6 * (size_t)((nloc + 1) / 2) * o; }
 // The launch's tail: workgroups are dispatched strip group by strip group (left to right) and a chunk of K = 64 steps is a quarter
@@ -1991,9 +2049,11 @@ size_t sym_prow_count(int nloc, int64_t ld, int o) { return (size_t)((ld + kSvSt
 // (a barrier and an atomic per item).  The remaining +-6 % between MI355X boxes for one K (1 145 / 1 290 us) is not scheduling noise
 // of this kind: it repeats on a box.
 struct SymvPlan { int K, Kf, ysplit, nchunks; };
+static int g_symv_k = 0;                                  // micro-benchmark override of the chunk length (xm_bench.h: xm_bench_symv_k)
+void symv_bench_k(int k) { g_symv_k = k; }
 static SymvPlan symv_plan(int nloc, int64_t ld) {
     SymvPlan p;
-    p.K = symv_k(nloc, ld);
+    p.K = g_symv_k > 0 ? g_symv_k : symv_k(nloc, ld);
     const int nsteps = (nloc + 1) / 2, ngy = (int)(((ld + kSvStrip - 1) / kSvStrip + 3) / 4);
     if (p.K >= 16 && ngy >= 8) {
         p.Kf = p.K / 4;
@@ -2012,34 +2072,56 @@ size_t sym_pcol_count(int nloc, int64_t ld, int o) { return (size_t)symv_plan(nl
 
 template <int O>
 static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
-                        hipStream_t st) {
+                        hipStream_t st, int rev, unsigned long long *trace = nullptr) {
     const SymvPlan pl = symv_plan(a.nloc, ld);
     const int nstrips = (int)((ld + kSvStrip - 1) / kSvStrip);
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
-    const dim3 gs(pl.nchunks, (nstrips + 3) / 4);
-    if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, pl.ysplit, sc, Prow, Pcol);
-    else hipLaunchKernelGGL((qw_symv_kernel<O, false>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, pl.ysplit, sc, Prow, Pcol);
+    // the per-camera sum needs: steps per column-sum record (4 K: one record per workgroup), strip from which the finer cut applies
+    const int ys = 4 * pl.ysplit, rK = 4 * pl.K, rKf = 4 * pl.Kf, rys = ys;
+    // odd width: block (x, y) runs on XCD (y * width + x) mod 8 and the live blocks are the small x -- an odd width rotates them over the
+    // XCDs (width 32 at K = 7: 214 ... 139 live wavefronts per XCD and a second dispatch round, 36.4 us; width 33: 27.0 us)
+    const dim3 gs(((pl.nchunks + 3) / 4) | 1, nstrips);
+    if (trace) {
+        if constexpr (O == 3 || O == 4) hipLaunchKernelGGL((qw_symv_kernel<O, false, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, sc, Prow, Pcol, trace, rev);
+    } else if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, sc, Prow, Pcol, trace, rev);
+    else hipLaunchKernelGGL((qw_symv_kernel<O, false>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, sc, Prow, Pcol, trace, rev);
     const dim3 g(qw_grid(a.nloc)), b(256);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nstrips, pl.K, pl.Kf, pl.ysplit, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nstrips, pl.K, pl.Kf, pl.ysplit, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nstrips, pl.K, pl.Kf, pl.ysplit, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break;
         case EPI_CERT:   // certificate operator (rank-1 input): the Lanczos products of a large dense Q at half the traffic too
-            if constexpr (O == 1) { hipLaunchKernelGGL((symv_reduce_kernel<1, EPI_CERT>), g, b, 0, st, Prow, Pcol, ld, nstrips, pl.K, pl.Kf, pl.ysplit, alpha, a); break; }
+            if constexpr (O == 1) { hipLaunchKernelGGL((symv_reduce_kernel<1, EPI_CERT>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break; }
             throw Error(-2, "certificate operator needs o == 1");
         default: throw Error(-2, "bad epilogue");
     }
 }
+int symv_trace_slots() { return kSvTraceSlots; }
+// micro-benchmark: one traced product (o = 3 or 4); trace = [grid.y * grid.x * 4 wavefronts][kSvTraceSlots] timestamps, grid returned
+void launch_qw_sym_traced(int o, const double *Q, int64_t ld, const double *W, const CamArgs &a, double *Prow, double *Pcol, unsigned long long *trace,
+                          int grid[2], hipStream_t st) {
+    const SymvPlan pl = symv_plan(a.nloc, ld);
+    grid[0] = ((pl.nchunks + 3) / 4) | 1; grid[1] = (int)((ld + kSvStrip - 1) / kSvStrip);
+    if (trace == nullptr) return;
+    if (o == 3) qw_symv_epi<3>(EPI_PLAIN, Q, ld, W, 1.0, a, Prow, Pcol, st, 0, trace);
+    else if (o == 4) qw_symv_epi<4>(EPI_PLAIN, Q, ld, W, 1.0, a, Prow, Pcol, st, 0, trace);
+    else throw Error(-2, "traced symmetric product: o = 3 or 4");
+    check_launch("qw_symv traced");
+}
 
-// symmetric half-traffic product (o in 1, 3..5); Prow: sym_prow_count() doubles, Pcol: sym_pcol_count() doubles
+// symmetric half-traffic product (o in 1, 3..5); Prow: sym_prow_count() doubles, Pcol: sym_pcol_count() doubles.  rev (0 / 1): the direction
+// of the sweep inside every chunk.  A launch that starts with the steps the previous launch ended with finds them in the XCDs' L2 (4 MB each:
+// a quarter of a Venice-size sweep; block b runs on XCD b mod 8 in every launch), so callers alternate it between consecutive products --
+// by a number both runs of the same solve agree on (the tCG iteration, the Lanczos step), never by a launch count that run-ahead no-ops would shift:
+// the direction changes the order of the column sums, i.e. the last bits.
 void launch_qw_sym(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow,
-                   double *Pcol, hipStream_t st) {
+                   double *Pcol, hipStream_t st, int rev) {
     if (a.nloc <= 0) return;
     switch (o) {
-        case 1: qw_symv_epi<1>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-        case 3: qw_symv_epi<3>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-        case 4: qw_symv_epi<4>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
-        case 5: qw_symv_epi<5>(epi, Q, ld, W, alpha, a, Prow, Pcol, st); break;
+        case 1: qw_symv_epi<1>(epi, Q, ld, W, alpha, a, Prow, Pcol, st, rev & 1); break;
+        case 3: qw_symv_epi<3>(epi, Q, ld, W, alpha, a, Prow, Pcol, st, rev & 1); break;
+        case 4: qw_symv_epi<4>(epi, Q, ld, W, alpha, a, Prow, Pcol, st, rev & 1); break;
+        case 5: qw_symv_epi<5>(epi, Q, ld, W, alpha, a, Prow, Pcol, st, rev & 1); break;
         default: throw Error(-2, "symmetric product is instantiated for o = 1, 3..5");
     }
     check_launch("qw_symv");

@@ -280,6 +280,7 @@ private:
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
     size_t ev_used_ = 0;
     int64_t hess_launches_ = 0;
+    int sym_rev_ = 1;                    // sweep direction of the next symmetric dense product (launch_qw_sym): tCG iteration parity inside the tCG, 1 elsewhere
     std::vector<float> qw_samples_;
 
     void init(const xm_problem_t &prob);

@@ -638,7 +638,7 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
     }
     if (storage_ == XM_STORAGE_DENSE) {
         if (symw_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT) product_symw(epi, o, alpha, a);
-        else if (sym_ok_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT && Pcol_.p) launch_qw_sym(o, epi, dQ_, ld_, W_.p, alpha, a, Prow_.p, Pcol_.p, st_);
+        else if (sym_ok_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT && Pcol_.p) launch_qw_sym(o, epi, dQ_, ld_, W_.p, alpha, a, Prow_.p, Pcol_.p, st_, sym_rev_);
         else launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
     } else if (storage_ == XM_STORAGE_SCHUR) {
         schur_->product(o, epi, W_.p, alpha, a, st_);
@@ -820,7 +820,9 @@ void Context::tcg_enqueue_iteration(int i, bool profile) {
     a.Bout = comm_->active() ? pcur + (size_t)rank * chunk : nullptr;
     const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
     if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
+    sym_rev_ = par;        // consecutive tCG iterations sweep the symmetric matrix in opposite directions (launch_qw_sym)
     product(EPI_HESS, o_, 2.0, a);
+    sym_rev_ = 1;          // every other product (gradient, cost): bottom-up, the direction iteration 0 of a tCG does not use
     if (timed) { XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].second, st_)); ev_used_++; }
     hess_launches_++;
     if (lockstep) comm_->allgather(pcur, chunk, st_);
@@ -1251,7 +1253,7 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 // w = S v_j : the product input is v_j itself (pitch 1); output rows land in w at this rank's offset
                 a.Wloc = vj + (size_t)cam0_ * 3;
                 a.out = w.p + (size_t)cam0_ * 3;
-                if (storage_ == XM_STORAGE_DENSE && sym_ok_ && Pcol_.p) launch_qw_sym(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, Prow_.p, Pcol_.p, st_);
+                if (storage_ == XM_STORAGE_DENSE && sym_ok_ && Pcol_.p) launch_qw_sym(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, Prow_.p, Pcol_.p, st_, j);
                 else if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
                 else if (storage_ == XM_STORAGE_SCHUR) schur_->product(1, EPI_CERT, vj, 1.0, a, st_);
                 else if (sell_) launch_qw_sell(1, EPI_CERT, *sell_, vj, 1.0, a, 0, st_);
