@@ -18,9 +18,11 @@ int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, doubl
 /* the half-traffic symmetric product (xm_qw_dense_sym), scratch allocated once */
 int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
 /* micro-benchmark settings of the symmetric sweep: k > 0 overrides the chunk length of the plan (0 = the plan's own; set it BEFORE a context
- * or a timing call sizes its partial-result buffers); alternate = 0: xm_qw_dense_sym_time sweeps top-down in every launch instead of
- * alternating the direction between consecutive products as the solver does */
+ * or a timing call sizes its partial-result buffers); alternate = 0: xm_qw_dense_sym_time / xm_qw_dense_time walk the matrix in the same direction in every
+ * launch instead of alternating it between consecutive products as the solver does */
 int xm_bench_symv_k(int k, int alternate);
+/* load policy of the dense stream in the micro-benchmarks: -1 = by size (the product's rule), 0 = default (cacheable), 1 = non-temporal */
+int xm_bench_dense_policy(int nt);
 /* ONE traced launch of the sweep (o = 3 or 4, top-down): per wavefront `slots` 100 MHz timestamps -- [0] entry, [1] after the status word,
  * [2 + i] after step i, [slots - 3] loop done, [slots - 2] column sums written, [slots - 1] XCC_ID << 32 | HW_ID; trace_host = NULL: grid and slots only */
 int xm_qw_dense_sym_trace(const double *dq, int64_t n, int o, const double *dW, double *dOut, unsigned long long *trace_host, int64_t trace_cap,

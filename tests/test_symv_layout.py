@@ -13,22 +13,37 @@ STRIP = 256
 
 
 def emulate(Q, W, K, Kf, ysplit, rev=0):
-    """ysplit counts strip GROUPS of four (the plan's unit); the kernel cuts strips s >= 4 ysplit finer.  A workgroup = one strip x 4 Ks steps,
-    its four wavefronts' column sums are added before the one record per workgroup is written; rev walks every chunk bottom-up."""
+    """ysplit counts ROWS of the folded grid (row y = strip y and strip S - 1 - y): the strips of rows >= ysplit are cut finer.  A workgroup =
+    one strip x 4 Ks steps, its four wavefronts' column sums are added before the one record per workgroup is written; rev walks every chunk
+    bottom-up.  The grid is walked as the kernel maps it: block (x, y) -> strip y while x < groups(y), else strip S - 1 - y."""
     m, o = W.shape
     n = m // 3
     ld = xmamd.dense_ld(n)
     nsteps, nstrips = (n + 1) // 2, (ld + STRIP - 1) // STRIP
     Qp = np.zeros((6 * nsteps, ld)); Qp[:m, :m] = Q
     Wp = np.zeros((max(ld, 6 * nsteps), o)); Wp[:m] = W
-    nsc = ((nsteps + Kf - 1) // Kf + 3) // 4
+    nsc = (nsteps + 4 * Kf - 1) // (4 * Kf)
     Prow = np.full((nstrips, 6 * nsteps, o), np.nan); Pcol = np.full((nsc, ld, o), np.nan)
-    for s in range(nstrips):
-        Ks = Kf if s >= 4 * ysplit else K
-        c0 = s * STRIP
-        cols = np.arange(c0, min(c0 + STRIP, ld))
-        jend = min(nsteps, (c0 + STRIP + 5) // 6)
-        for sc in range((jend + 4 * Ks - 1) // (4 * Ks)):
+    def groups(st, k):
+        return (min(nsteps, (st * STRIP + STRIP + 5) // 6) + 4 * k - 1) // (4 * k)
+    gy = (nstrips + 1) // 2
+    gx = max(groups(y, Kf if y >= ysplit else K) + (groups(nstrips - 1 - y, Kf if y >= ysplit else K) if nstrips - 1 - y != y else 0) for y in range(gy))
+    seen = set()
+    for y in range(gy):
+        Ks = Kf if y >= ysplit else K
+        for x in range(gx):
+            s, sc = y, x
+            nA = groups(y, Ks)
+            if sc >= nA:
+                if nstrips - 1 - y == y:
+                    continue
+                s, sc = nstrips - 1 - y, sc - nA
+            c0 = s * STRIP
+            cols = np.arange(c0, min(c0 + STRIP, ld))
+            jend = min(nsteps, (c0 + STRIP + 5) // 6)
+            if sc * 4 * Ks >= jend:
+                continue
+            assert (s, sc) not in seen; seen.add((s, sc))
             tot = np.zeros((cols.size, o))
             for wave in range(4):
                 jb = (sc * 4 + wave) * Ks; je = min(jb + Ks, jend)
@@ -48,7 +63,8 @@ def emulate(Q, W, K, Kf, ysplit, rev=0):
         s_lo = (6 * (cam // 2)) // STRIP
         for r in range(3):
             c = 3 * cam + r
-            Kc = 4 * (Kf if c // STRIP >= 4 * ysplit else K)                                # steps per column-sum record
+            st = c // STRIP
+            Kc = 4 * (Kf if min(st, nstrips - 1 - st) >= ysplit else K)                      # steps per column-sum record
             cnt = (c - 6) // (6 * Kc) + 1 if c >= 6 else 0
             Y[c] = Prow[s_lo:, c].sum(axis=0) + Pcol[:cnt, c].sum(axis=0)
     assert np.all(np.isfinite(Y))                                                        # everything read had been written
@@ -65,7 +81,7 @@ def test_symv_partition_sums_to_the_product(n, o, plan):
         p = (C.c_int32 * 4)()
         assert xmamd.lib().xm_symv_plan(n, p) == 0
         K, Kf, ysplit, nch = (int(x) for x in p)
-        assert 2 <= K <= 64 and 1 <= Kf <= K and nch == ((n + 1) // 2 + Kf - 1) // Kf
+        assert 2 <= K <= 64 and 1 <= Kf <= K and nch == ((n + 1) // 2 + 4 * Kf - 1) // (4 * Kf)
     else:
         K, Kf, ysplit = plan
     Y = emulate(Q, W, K, Kf, ysplit)
@@ -78,7 +94,7 @@ def test_symv_partition_sums_to_the_product(n, o, plan):
 
 
 def test_symv_plan_of_the_benchmark_sizes():
-    for n, kmin, kmax in ((1778, 4, 12), (4096, 12, 24), (8192, 24, 48), (13682, 64, 64)):
+    for n, kmin, kmax in ((1778, 4, 12), (4096, 12, 32), (8192, 16, 48), (13682, 32, 64)):
         p = (C.c_int32 * 4)()
         assert xmamd.lib().xm_symv_plan(n, p) == 0
-        assert kmin <= p[0] <= kmax and (p[1] == p[0] // 4 if p[0] >= 16 else p[1] == p[0])
+        assert kmin <= p[0] <= kmax and p[1] in (p[0], p[0] // 4) and (p[1] == p[0] // 4 if n >= 8192 else p[1] == p[0])

@@ -50,16 +50,21 @@ double time_launches(int warm, int reps, F f) {
 extern "C" {
 const char *xm_bench_last_error(void) { return g_berr.c_str(); }
 
+static int g_sym_alternate = 1;
 int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
     XM_TRY
-    const xm::CamArgs a = plain_args(n, dOut);
+    xm::CamArgs a = plain_args(n, dOut);
     const int64_t ld = xm::dense_ld(n);
-    const double ms = time_launches(3, reps, [&] { xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr); });
+    int it = 0;   // consecutive products alternate the tile direction as the solver's do (xm_bench_symv_k(k, 0): always left to right)
+    const double ms = time_launches(3, reps, [&] { a.rev = g_sym_alternate ? (it++ & 1) : 0; xm::launch_qw_dense(o, xm::EPI_PLAIN, dq, ld, dW, 1.0, a, nullptr); });
     if (ms_avg) *ms_avg = ms;
     return XM_OK;
     XM_CATCH
 }
-static int g_sym_alternate = 1;
+int xm_bench_dense_policy(int nt) {
+    xm::qw_bench_nt(nt);
+    return XM_OK;
+}
 int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg) {
     XM_TRY
     const int64_t ld = xm::dense_ld(n);

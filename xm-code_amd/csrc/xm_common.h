@@ -106,6 +106,8 @@ struct CamArgs {
     int ks;               // 0 / 1: off
     double *ksum;         // ks x nloc x 3 x OP
     unsigned int *kcount; // one per camera group, zero between launches
+    int rev;              // dense product (unsplit): 1 = the column tiles are walked right to left.  Consecutive products alternate it so that a
+                          // launch starts with the tiles the previous one ended with (still in the L2s / the Infinity Cache); see launch_qw_sym
 };
 
 enum Epilogue { EPI_PLAIN = 0, EPI_GRAD = 1, EPI_HESS = 2, EPI_CERT = 3 };
@@ -139,6 +141,7 @@ int qw_dense_split_k(int nloc, int64_t ld);   // column split the small-strip po
 int bsr_grid(int nloc);   // workgroups (= partial sums per epilogue slot) of the BSR3 kernels
 size_t sym_prow_count(int nloc, int64_t ld, int o);
 size_t sym_pcol_count(int nloc, int64_t ld, int o);
+void qw_bench_nt(int nt);                                  // micro-benchmark override of the load policy: -1 by size, 0 default, 1 non-temporal
 void symv_bench_k(int k);                                  // micro-benchmark override of the chunk length (xm_bench.h)
 int symv_trace_slots();
 void launch_qw_sym_traced(int o, const double *Q, int64_t ld, const double *W, const CamArgs &a, double *Prow, double *Pcol, unsigned long long *trace,

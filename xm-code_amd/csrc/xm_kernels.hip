@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
     const int span = SPLIT ? (a.t_hi - a.t_lo) : 0;
     const int ntiles = !SPLIT ? ntiles_all : (a.range_mode == 1 ? span : ntiles_all - span);
     auto tile_at = [&](int i) -> int {
-        if (!SPLIT) return i;
+        if (!SPLIT) return a.rev ? ntiles_all - 1 - i : i;
         return (a.range_mode == 1) ? a.t_lo + i : ((i < a.t_lo) ? i : i + span);
     };
 
@@ -338,7 +338,24 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
     constexpr int OP = pitch_of(O), V = 6 * O;
     __shared__ __attribute__((aligned(16))) double lds[4][V * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = blockIdx.y, sc = blockIdx.x;
+    // The live (strip, group) pairs form a staircase -- strip s has ~ (s + 1) * 42.7 / (4 K) groups -- and block b runs on XCD b mod 8: a grid of
+    // strips x groups is half empty and its live blocks land on the XCDs unevenly (K = 11 at 2 560 cameras: 180 ... 272 live wavefronts per XCD,
+    // one XCD beyond its 64 resident workgroups, a second dispatch round: 66.7 us instead of 48).  FOLDED grid: row y holds strip y and, behind
+    // it, strip S - 1 - y -- every row has about the same number of live blocks, (nearly) every block of the grid is live, and consecutive
+    // blocks are consecutive XCDs.
+    const int nsteps = (nloc + 1) >> 1, nrows = 3 * nloc;
+    const int nstrips = (int)((ld + kSvStrip - 1) / kSvStrip);
+    const int K = ((int)blockIdx.y >= ysplit) ? Kf : Kc;         // the rows dispatched last are cut finer: they are the launch's tail
+    int s = blockIdx.y, sc = blockIdx.x;
+    {
+        int jA = (int)(((int64_t)s * kSvStrip + kSvStrip + 5) / 6);
+        if (jA > nsteps) jA = nsteps;
+        const int nA = (jA + 4 * K - 1) / (4 * K);
+        if (sc >= nA) {
+            if (nstrips - 1 - s == s) return;                    // the middle strip of an odd count has no partner (uniform over the workgroup)
+            s = nstrips - 1 - s; sc -= nA;
+        }
+    }
     unsigned long long *tr = nullptr;
     if constexpr (TRACE) {
         tr = trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * kSvTraceSlots;
@@ -350,10 +367,7 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
             tr[kSvTraceSlots - 1] = ((unsigned long long)xcc << 32) | hw;
         }
     }
-    const int K = (s >= ysplit) ? Kf : Kc;   // the strips dispatched last are cut finer: they are the launch's tail
-    const int nsteps = (nloc + 1) >> 1, nrows = 3 * nloc;
     const int64_t c0 = (int64_t)s * kSvStrip;
-    if (c0 >= ld) return;                                        // uniform over the workgroup
     int jend = (int)((c0 + kSvStrip + 5) / 6);                   // steps whose rows start above the end of the strip
     if (jend > nsteps) jend = nsteps;
     if (sc * 4 * K >= jend) return;                              // uniform over the workgroup
@@ -539,7 +553,8 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restri
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int c = 3 * camc + r;
-        const int K = (c / kSvStrip >= ysplit) ? Kf : Kc;         // steps per column-sum record of the strip that owns column c (ysplit in strips)
+        const int sc_ = c / kSvStrip, row = min(sc_, nstrips - 1 - sc_);   // grid row of the strip that owns column c (folded grid of the sweep)
+        const int K = (row >= ysplit) ? Kf : Kc;                  // steps per column-sum record there
         cnt[r] = (c >= 6) ? (c - 6) / (6 * K) + 1 : 0;
     }
     const int ncol = max(cnt[0], max(cnt[1], cnt[2]));
@@ -1939,7 +1954,10 @@ int flat_grid(int64_t elems) {
 }
 
 
-static bool qw_stream_nt(int nloc, int64_t ld) {   // per-GPU Q beyond the Infinity Cache -> non-temporal stream (a matrix that fits keeps the default policy: nt costs 33.6 -> 36.8 us at Venice size)
+static int g_qw_nt_override = -1;   // micro-benchmark only (xm_bench.h: xm_bench_dense_policy)
+void qw_bench_nt(int nt) { g_qw_nt_override = nt; }
+static bool qw_stream_nt(int nloc, int64_t ld) {
+    if (g_qw_nt_override >= 0) return g_qw_nt_override != 0;   // per-GPU Q beyond the Infinity Cache -> non-temporal stream (a matrix that fits keeps the default policy: nt costs 33.6 -> 36.8 us at Venice size)
     return (size_t)nloc * 3 * (size_t)ld * sizeof(double) > (size_t)240 << 20;
 }
 template <int O, int NSUB, bool NT>
@@ -2014,13 +2032,14 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
     check_launch("qw_dense");
 }
 
-// vertical sweep: steps (two cameras) per chunk.  A long chunk amortises the column flush and shortens the reducer's lists, a short one
-// yields more wavefronts and a shorter serial chain per wavefront; the optimum grows like the square root of the triangle's step count T
-// (measured best K, o = 3: T = 21 k (n = 2560) 10-12, 49 k (n = 4096) 16-24, 550 k (n = 13682) 48-64) -> K = sqrt(T) / 13, 2 <= K <= 64.
-// SMALL triangles (Venice size, T = 9.9 k) run in ONE residency round -- every workgroup is on the chip at once, 2 per CU x 256 CUs -- and the
-// launch lasts as long as its longest wavefront: there the shortest chunk whose live workgroups still fit in one round with a margin wins
-// (profiles/r06_kbench_symv.txt, us per pair at o = 3 / 4: K = 5 (503 workgroups: a second round) 30.7 / 36.4, K = 6 (420) 26.5 / 29.6,
-// K = 7 27.0 / 31.4, K = 8 28.5 / 33.6, K = 10 30.3 / 37.1).
+// vertical sweep: steps (two cameras) per chunk K; a workgroup = 4 K steps of one strip.
+// SMALL triangles run in ONE residency round -- every workgroup on the chip at once, 2 per CU x 256 CUs = 512 -- and the launch lasts as long as
+// its longest wavefront: the shortest chunk whose live workgroups still fit wins, and a plan just beyond one round loses a third
+// (profiles/r06_kbench_symv.txt, us per pair at o = 3, folded grid: Venice size K = 5 (503 workgroups) 26.5, 6 26.9, 7 26.7; n = 2 560: K = 9 (565)
+// 59.6, 10 49.1, 11 48.7, 12 50.1; n = 3 072: 14 77.8, 15 64.7, 16 64.5, 18 67.8; n = 4 096: 17 121.3, 24 138.7, 26 138.0, 28 (one round) 116.7, 32 117.3).
+// LARGE triangles take several rounds: a long chunk amortises the column flush and shortens the reducer's lists, a short one evens out the last
+// round; the optimum grows like the square root of the triangle's step count T (n = 8 192, T = 197 k: K = 24 402 us, 34 437, 48 447; n = 13 682,
+// T = 550 k: 48 1 123, 64 1 149) -> K = sqrt(T) / 18, 2 <= K <= 64, with the rows dispatched last cut four times finer (symv_plan).
 static int64_t symv_live_groups(int64_t nsteps, int64_t nstrips, int64_t k) {
     int64_t live = 0;
     for (int64_t s = 0; s < nstrips; ++s) live += (std::min<int64_t>(nsteps, (s * kSvStrip + kSvStrip + 5) / 6) + 4 * k - 1) / (4 * k);
@@ -2030,12 +2049,11 @@ int symv_k(int nloc, int64_t ld) {
     const int64_t nsteps = (nloc + 1) / 2, nstrips = (ld + kSvStrip - 1) / kSvStrip;
     int64_t total = 0;
     for (int64_t s = 0; s < nstrips; ++s) total += std::min<int64_t>(nsteps, (s * kSvStrip + kSvStrip + 5) / 6);
-    int64_t k = (int64_t)(std::sqrt((double)total) / 13.0 + 0.5);
-    if (k > 48) k = 64;   // 13.5 GB: 48 -> 1 190 us, 64 -> 1 147 us, 128 -> 1 265 us
+    int64_t k = (int64_t)(std::sqrt((double)total) / 18.0 + 0.5);
     k = std::min<int64_t>(64, std::max<int64_t>(2, k));
-    if (symv_live_groups(nsteps, nstrips, k) <= 512) {          // one round at the square-root length: shorten the chain while a round with margin still holds everything
+    if (symv_live_groups(nsteps, nstrips, k) <= 1100) {         // about two rounds or less at the square-root length: make it ONE round
         int64_t ks = 4;
-        while (ks < k && symv_live_groups(nsteps, nstrips, ks) > 440) ++ks;
+        while (symv_live_groups(nsteps, nstrips, ks) > 504) ++ks;
         k = ks;
     }
     return (int)k;
@@ -2048,20 +2066,29 @@ size_t sym_prow_count(int nloc, int64_t ld, int o) { return (size_t)((ld + kSvSt
 // work counter instead (workgroups pulling item numbers) was measured too: no steadier at 13.5 GB and 1.5 x slower at Venice size
 // (a barrier and an atomic per item).  The remaining +-6 % between MI355X boxes for one K (1 145 / 1 290 us) is not scheduling noise
 // of this kind: it repeats on a box.
-struct SymvPlan { int K, Kf, ysplit, nchunks; };
 static int g_symv_k = 0;                                  // micro-benchmark override of the chunk length (xm_bench.h: xm_bench_symv_k)
 void symv_bench_k(int k) { g_symv_k = k; }
+// K: steps per chunk (a wavefront); Kf: the same in the grid rows >= ysplit (dispatched last: cut finer when the sweep takes several residency
+// rounds); nchunks: upper bound of column-sum records per column (sizes Pcol); gx, gy: the folded grid
+struct SymvPlan { int K, Kf, ysplit, nchunks, gx, gy; };
 static SymvPlan symv_plan(int nloc, int64_t ld) {
     SymvPlan p;
     p.K = g_symv_k > 0 ? g_symv_k : symv_k(nloc, ld);
-    const int nsteps = (nloc + 1) / 2, ngy = (int)(((ld + kSvStrip - 1) / kSvStrip + 3) / 4);
-    if (p.K >= 16 && ngy >= 8) {
+    const int nsteps = (nloc + 1) / 2, nstrips = (int)((ld + kSvStrip - 1) / kSvStrip);
+    p.gy = (nstrips + 1) / 2;
+    if (p.K >= 8 && symv_live_groups(nsteps, nstrips, p.K) > 1100) {   // several residency rounds
         p.Kf = p.K / 4;
-        p.ysplit = (int)(0.866 * ngy);          // work grows linearly with the strip index: the last 13 % of the groups hold 25 % of it
+        p.ysplit = (int)(0.75 * p.gy);          // every row of the folded grid holds the same work: the last quarter of it is cut four times finer
     } else {
-        p.Kf = p.K; p.ysplit = ngy;
+        p.Kf = p.K; p.ysplit = p.gy;
     }
-    p.nchunks = (nsteps + p.Kf - 1) / p.Kf;
+    auto groups = [&](int s, int k) { return (int)((std::min<int64_t>(nsteps, ((int64_t)s * kSvStrip + kSvStrip + 5) / 6) + 4 * k - 1) / (4 * k)); };
+    p.gx = 1;
+    for (int y = 0; y < p.gy; ++y) {
+        const int k = (y >= p.ysplit) ? p.Kf : p.K, sb = nstrips - 1 - y;
+        p.gx = std::max(p.gx, groups(y, k) + (sb != y ? groups(sb, k) : 0));
+    }
+    p.nchunks = (nsteps + 4 * p.Kf - 1) / (4 * p.Kf);
     return p;
 }
 void symv_plan_get(int nloc, int64_t ld, int out[4]) {   // host-only view of the plan (CPU test of the index arithmetic)
@@ -2076,11 +2103,9 @@ static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, d
     const SymvPlan pl = symv_plan(a.nloc, ld);
     const int nstrips = (int)((ld + kSvStrip - 1) / kSvStrip);
     const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
-    // the per-camera sum needs: steps per column-sum record (4 K: one record per workgroup), strip from which the finer cut applies
-    const int ys = 4 * pl.ysplit, rK = 4 * pl.K, rKf = 4 * pl.Kf, rys = ys;
-    // odd width: block (x, y) runs on XCD (y * width + x) mod 8 and the live blocks are the small x -- an odd width rotates them over the
-    // XCDs (width 32 at K = 7: 214 ... 139 live wavefronts per XCD and a second dispatch round, 36.4 us; width 33: 27.0 us)
-    const dim3 gs(((pl.nchunks + 3) / 4) | 1, nstrips);
+    // the per-camera sum needs: steps per column-sum record (4 K: one record per workgroup), grid row from which the finer cut applies
+    const int ys = pl.ysplit, rK = 4 * pl.K, rKf = 4 * pl.Kf, rys = ys;
+    const dim3 gs(pl.gx, pl.gy);
     if (trace) {
         if constexpr (O == 3 || O == 4) hipLaunchKernelGGL((qw_symv_kernel<O, false, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, sc, Prow, Pcol, trace, rev);
     } else if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, sc, Prow, Pcol, trace, rev);
@@ -2101,7 +2126,7 @@ int symv_trace_slots() { return kSvTraceSlots; }
 void launch_qw_sym_traced(int o, const double *Q, int64_t ld, const double *W, const CamArgs &a, double *Prow, double *Pcol, unsigned long long *trace,
                           int grid[2], hipStream_t st) {
     const SymvPlan pl = symv_plan(a.nloc, ld);
-    grid[0] = ((pl.nchunks + 3) / 4) | 1; grid[1] = (int)((ld + kSvStrip - 1) / kSvStrip);
+    grid[0] = pl.gx; grid[1] = pl.gy;
     if (trace == nullptr) return;
     if (o == 3) qw_symv_epi<3>(EPI_PLAIN, Q, ld, W, 1.0, a, Prow, Pcol, st, 0, trace);
     else if (o == 4) qw_symv_epi<4>(EPI_PLAIN, Q, ld, W, 1.0, a, Prow, Pcol, st, 0, trace);

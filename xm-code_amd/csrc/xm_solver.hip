@@ -639,7 +639,7 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
     if (storage_ == XM_STORAGE_DENSE) {
         if (symw_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT) product_symw(epi, o, alpha, a);
         else if (sym_ok_ && o == o_ && o >= 3 && o <= sym_max_o_ && epi != EPI_CERT && Pcol_.p) launch_qw_sym(o, epi, dQ_, ld_, W_.p, alpha, a, Prow_.p, Pcol_.p, st_, sym_rev_);
-        else launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, a, st_);
+        else { CamArgs ar = a; ar.rev = sym_rev_; launch_qw_dense(o, epi, dQ_, ld_, W_.p, alpha, ar, st_); }
     } else if (storage_ == XM_STORAGE_SCHUR) {
         schur_->product(o, epi, W_.p, alpha, a, st_);
     } else if (sell_ && sell_supports(o)) {
