@@ -106,6 +106,7 @@ struct CamArgs {
     int ks;               // 0 / 1: off
     double *ksum;         // ks x nloc x 3 x OP
     unsigned int *kcount; // one per camera group, zero between launches
+    int nt_cam0;          // dense product: cameras >= this stream their rows non-temporally (set by the launcher from the size rule, not by callers)
     int rev;              // dense product (unsplit): 1 = the column tiles are walked right to left.  Consecutive products alternate it so that a
                           // launch starts with the tiles the previous one ended with (still in the L2s / the Infinity Cache); see launch_qw_sym
 };

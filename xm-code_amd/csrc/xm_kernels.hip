@@ -32,6 +32,13 @@
 
 namespace xm {
 
+// one 16-byte non-temporal load (global_load_dwordx4 ... nt): streams past the Infinity Cache without displacing what is meant to stay there
+__device__ __forceinline__ double2 nt_load16(const double2 *p) {
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+    return make_double2(v.x, v.y);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // dense Q*W
 // ----------------------------------------------------------------------------------------------------------------
@@ -39,7 +46,7 @@ namespace xm {
 // of tile t+1 (its 3 rows of Q and the workgroup's share of the next W tile) are already in flight; one barrier per tile.
 // SPLIT (separate instantiations, the default ones are untouched): the tile loop runs over a sub-range of the column tiles
 // (CamArgs.range_mode) so that the product can be done in two launches around the all-gather of W.
-template <int O, int EPI, int NSUB, bool NT, bool SPLIT = false>
+template <int O, int EPI, int NSUB, bool SPLIT = false>
 __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict__ Q, int64_t ld,
                                                         const double *__restrict__ W, double alpha, CamArgs a) {
     constexpr int OP = pitch_of(O);
@@ -51,6 +58,7 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cam = blockIdx.x * kQwWaves + wave;   // wave-uniform (scalar): per-camera scalars load through the scalar cache
     const bool active = cam < a.nloc;
+    const bool nt = (int)(blockIdx.x * kQwWaves) >= a.nt_cam0;   // workgroup-uniform load policy of these cameras' rows
     const double *q0 = Q + (size_t)(active ? cam : 0) * 3 * (size_t)ld + 2 * lane;
     const int ntiles_all = (int)((ld + TILE - 1) / TILE);
     // tile sequence: i-th tile of this launch (identity unless SPLIT)
@@ -78,7 +86,8 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
     EpiOps eops;
     double2 qn[NSUB][3];   // Q fragment of the NEXT tile
     double2 ws[NST];       // this thread's share of the NEXT W tile
-    auto load_q = [&](int t) {
+    auto load_q = [&](int t, auto ntag) {
+        constexpr bool NT = decltype(ntag)::value;
         const int64_t c0 = (int64_t)t * TILE;
 #pragma unroll
         for (int u = 0; u < NSUB; ++u) {
@@ -87,9 +96,13 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const double2 *qp = reinterpret_cast<const double2 *>(q0 + (size_t)r * ld + c);
-                    // a Q larger than the 256 MB Infinity Cache is a pure stream: non-temporal loads keep it from thrashing the
-                    // cache (measured at 349 MB: 78.9 us default policy); a Q that fits stays cacheable across iterations
-                    if (NT) qn[u][r] = make_double2(__builtin_nontemporal_load(&qp->x), __builtin_nontemporal_load(&qp->y));
+                    // a Q larger than the 256 MB Infinity Cache: the rows of the first nt_cam0 cameras (a cache-sized prefix) keep the default
+                    // policy and stay resident across products, the rest is a pure stream -- non-temporal loads keep it from evicting the
+                    // prefix (a 349 MB matrix with the default policy everywhere: 78.9 us, the stream evicts its own head); a Q that fits
+                    // stays cacheable as a whole (nt_cam0 = nloc).  The policy is a compile-time property of the LOOP (two copies of it
+                    // under one workgroup-uniform branch): a load whose hint is chosen by a run-time branch next to it is merged by the
+                    // compiler with its twin into one plain load -- the hint is metadata and does not survive the merge.
+                    if (NT) qn[u][r] = nt_load16(qp);
                     else qn[u][r] = *qp;
                 }
             } else {
@@ -125,12 +138,13 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
             return;
         }
     }
-    load_q(tile_at(0));
+    auto stream = [&](auto ntag) -> bool {
+    load_q(tile_at(0), ntag);
     load_w(tile_at(0));
     if (EPI == EPI_HESS) {
         // tCG already terminated: the enqueued-ahead launch becomes a no-op.  Checked only after the first tile's loads are
         // in flight, so that a live launch does not start with an exposed dependent load (uniform over the grid).
-        if (a.scal->status != 0) return;
+        if (a.scal->status != 0) return false;
     }
     store_w(0);
     __syncthreads();
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
             for (int r = 0; r < 3; ++r) q[u][r] = qn[u][r];
         const bool more = (t + 1 < ntiles);
         if (more) {  // uniform
-            load_q(tile_at(t + 1));
+            load_q(tile_at(t + 1), ntag);
             load_w(tile_at(t + 1));
         } else {
             epi_prefetch<O, EPI>(eops, cam, lane, active, a);
@@ -166,6 +180,10 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
         if (more) store_w((t + 1) & 1);
         __syncthreads();
     }
+    return true;
+    };
+    const bool alive = nt ? stream(std::true_type{}) : stream(std::false_type{});
+    if (!alive) return;
     qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
 }
 
@@ -331,8 +349,8 @@ __global__ __launch_bounds__(256) void qw_dense_ks_kernel(const double *__restri
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int kSvStrip = 256;
 constexpr int kSvTraceSlots = 24;
-template <int O, bool NT, bool TRACE = false>
-__global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc, int Kc, int Kf, int ysplit,
+template <int O, bool TRACE = false>
+__global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc, int Kc, int Kf, int ysplit, int nt_step0,
                                                         const TcgScal *__restrict__ scal, double *__restrict__ Prow,
                                                         double *__restrict__ Pcol, unsigned long long *__restrict__ trace, int rev) {
     constexpr int OP = pitch_of(O), V = 6 * O;
@@ -381,7 +399,10 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
 
     double wc[2][2][O], ca[2][2][O];
 
-    auto load_q = [&](int j, double2 (&q)[6][2]) {
+    // chunks that start at a step >= nt_step0 stream non-temporally (a matrix beyond the Infinity Cache keeps its top rows resident:
+    // symv_nt_step0).  The policy is a compile-time property of the sweep loop (two copies under one wave-uniform branch, see qw_dense_kernel).
+    auto load_q = [&](int j, double2 (&q)[6][2], auto ntag) __attribute__((always_inline)) {
+        constexpr bool NT = decltype(ntag)::value;
         const int64_t r0 = (int64_t)6 * j;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -390,12 +411,12 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const double2 *qp = reinterpret_cast<const double2 *>(row + (h ? cB : cA));
-                if (NT) q[r][h] = make_double2(__builtin_nontemporal_load(&qp->x), __builtin_nontemporal_load(&qp->y));
+                if (NT) q[r][h] = nt_load16(qp);
                 else q[r][h] = *qp;
             }
         }
     };
-    auto step = [&](int j, const double2 (&q)[6][2], auto masked) {
+    auto step = [&](int j, const double2 (&q)[6][2], auto masked) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(masked)::value;
         const int64_t r0 = (int64_t)6 * j;
         double mr[2] = {1.0, 1.0}, mc[2] = {1.0, 1.0};
@@ -454,7 +475,7 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
         __builtin_amdgcn_wave_barrier();
     };
     int nrun = 0;
-    auto run = [&](int j, const double2 (&q)[6][2]) {
+    auto run = [&](int j, const double2 (&q)[6][2]) __attribute__((always_inline)) {
         if (j < jfull) step(j, q, std::false_type{});
         else step(j, q, std::true_type{});
         if constexpr (TRACE) {
@@ -464,7 +485,8 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
     };
 
     double2 qA[6][2], qB[6][2];
-    if (jb < je) load_q(rev ? je - 1 : jb, qA);                // wave-uniform
+    auto sweep = [&](auto ntag) __attribute__((always_inline)) -> bool {
+    if (jb < je) load_q(rev ? je - 1 : jb, qA, ntag);                // wave-uniform
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -478,30 +500,34 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
     // the tCG's status word (written by the previous launch on another XCD: an L2 miss) is looked at only now, with the columns of W and the
     // first step of Q already requested: one round trip at the head of every wavefront instead of two
     if (scal != nullptr) {
-        if (scal->status != 0) return;
+        if (scal->status != 0) return false;
     }
     if constexpr (TRACE) { if (lane == 0) tr[1] = wall_clock64(); }
     // rev: the chunk is walked bottom-up (position i <-> step je - 1 - i).  Launches alternate the direction, so that a launch starts with
     // the steps the previous one ended with: they are still in this XCD's L2 (4 MB; block b runs on XCD b mod 8 in every launch)
-    auto at = [&](int i) { return rev ? je - 1 - i : jb + i; };
+    auto at = [&](int i) __attribute__((always_inline)) { return rev ? je - 1 - i : jb + i; };
     const int cnt = je - jb;
     if (cnt > 0) {
         int i = 0;
         while (i + 2 < cnt) {          // two more steps follow: both requests below are unconditional
-            load_q(at(i + 1), qB);
+            load_q(at(i + 1), qB, ntag);
             run(at(i), qA);
-            load_q(at(i + 2), qA);
+            load_q(at(i + 2), qA, ntag);
             run(at(i + 1), qB);
             i += 2;
         }
         if (i + 1 < cnt) {
-            load_q(at(i + 1), qB);
+            load_q(at(i + 1), qB, ntag);
             run(at(i), qA);
             run(at(i + 1), qB);
         } else {
             run(at(i), qA);
         }
     }
+    return true;
+    };
+    const bool alive = (jb >= nt_step0) ? sweep(std::true_type{}) : sweep(std::false_type{});
+    if (!alive) return;
     if constexpr (TRACE) { if (lane == 0) tr[kSvTraceSlots - 3] = wall_clock64(); }
 
     // column sums of the four chunks, added in wavefront order; wavefront h writes the h-th half of the strip (2 O contiguous doubles per lane)
@@ -1954,39 +1980,47 @@ int flat_grid(int64_t elems) {
 }
 
 
-static int g_qw_nt_override = -1;   // micro-benchmark only (xm_bench.h: xm_bench_dense_policy)
+// Load policy of the dense stream by the bytes of Q this GPU streams per product.  Up to 310 MB everything stays cacheable: the matrix lives
+// in the 256 MB Infinity Cache (+ 32 MB of L2) between products, and with the alternating direction a launch starts where the last one
+// ended (non-temporal loads cost 31.5 -> 36.1 us at Venice size, 44.1 -> 48.1 at 302 MB; at 354 MB the default policy collapses: the stream
+// evicts its own head).  Beyond, a prefix of kQwResidentMB stays cacheable and the rest streams non-temporally -- cameras >= the returned
+// index in the general kernel, chunks from symv_nt_step0 on in the symmetric sweep (profiles/r06_kbench_dense_prefix.txt, general kernel, us:
+// 472 MB 81.4 all non-temporal / 80.5 all cacheable / 74.3 prefix; 680 MB 106.9 / 106.1 / 96.0; 1.2 GB 179.4 / 192.6 / 175.2; 13.5 GB 2 003 / - / 1 998).
+constexpr int kQwResidentMB = 220;
+static int g_qw_nt_override = -1;
 void qw_bench_nt(int nt) { g_qw_nt_override = nt; }
-static bool qw_stream_nt(int nloc, int64_t ld) {
-    if (g_qw_nt_override >= 0) return g_qw_nt_override != 0;   // per-GPU Q beyond the Infinity Cache -> non-temporal stream (a matrix that fits keeps the default policy: nt costs 33.6 -> 36.8 us at Venice size)
-    return (size_t)nloc * 3 * (size_t)ld * sizeof(double) > (size_t)240 << 20;
+static int64_t qw_resident_bytes(size_t total_bytes) {      // bytes of the stream that stay cacheable; >= total: all of it
+    if (g_qw_nt_override == 0) return INT64_MAX;
+    if (g_qw_nt_override == 1) return 0;
+    if (g_qw_nt_override >= 2) return (int64_t)g_qw_nt_override << 20;
+    return total_bytes <= ((size_t)310 << 20) ? INT64_MAX : (int64_t)kQwResidentMB << 20;
 }
-template <int O, int NSUB, bool NT>
-static void qw_dense_epi2(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
-    const dim3 g(qw_grid(a.nloc)), b(256);
+static int qw_nt_cam0(int nloc, int64_t ld) {
+    const size_t row3 = (size_t)3 * (size_t)ld * sizeof(double);
+    const int64_t res = qw_resident_bytes((size_t)nloc * row3);
+    return (int)std::min<int64_t>(nloc, res / (int64_t)row3);
+}
+template <int O, int NSUB>
+static void qw_dense_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a0, hipStream_t st) {
+    const dim3 g(qw_grid(a0.nloc)), b(256);
+    CamArgs a = a0;
+    a.nt_cam0 = qw_nt_cam0(a.nloc, ld);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, NSUB, NT>), g, b, 0, st, Q, ld, W, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, NSUB, NT>), g, b, 0, st, Q, ld, W, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_HESS, NSUB, NT>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_HESS, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
         default: throw Error(-2, "bad epilogue");
     }
 }
-template <int O, int NSUB>
-static void qw_dense_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
-    if (qw_stream_nt(a.nloc, ld)) qw_dense_epi2<O, NSUB, true>(epi, Q, ld, W, alpha, a, st);
-    else qw_dense_epi2<O, NSUB, false>(epi, Q, ld, W, alpha, a, st);
-}
 // split launches (range_mode 1 / 2): plain or gradient epilogue, default tile width, default load policy by size
 template <int O>
-static void qw_dense_split_o(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
-    const dim3 g(qw_grid(a.nloc)), b(256);
-    const bool nt = qw_stream_nt(a.nloc, ld);
-    if (epi == EPI_PLAIN) {
-        if (nt) hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, 2, true, true>), g, b, 0, st, Q, ld, W, alpha, a);
-        else hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, 2, false, true>), g, b, 0, st, Q, ld, W, alpha, a);
-    } else if (epi == EPI_GRAD) {
-        if (nt) hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, 2, true, true>), g, b, 0, st, Q, ld, W, alpha, a);
-        else hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, 2, false, true>), g, b, 0, st, Q, ld, W, alpha, a);
-    } else throw Error(-2, "split dense product: plain or gradient epilogue only");
+static void qw_dense_split_o(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a0, hipStream_t st) {
+    const dim3 g(qw_grid(a0.nloc)), b(256);
+    CamArgs a = a0;
+    a.nt_cam0 = qw_nt_cam0(a.nloc, ld);
+    if (epi == EPI_PLAIN) hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, 2, true>), g, b, 0, st, Q, ld, W, alpha, a);
+    else if (epi == EPI_GRAD) hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, 2, true>), g, b, 0, st, Q, ld, W, alpha, a);
+    else throw Error(-2, "split dense product: plain or gradient epilogue only");
 }
 void launch_qw_dense_split(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st) {
     if (a.nloc <= 0) return;
@@ -2024,8 +2058,9 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
     }
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
-        if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2, true>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
-        else hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2, false>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, a);
+        CamArgs ac = a;
+        ac.nt_cam0 = qw_nt_cam0(a.nloc, ld);
+        hipLaunchKernelGGL((qw_dense_kernel<1, EPI_CERT, 2>), dim3(qw_grid(a.nloc)), dim3(256), 0, st, Q, ld, W, alpha, ac);
     } else {
         XM_DISPATCH_O(o, (qw_dense_epi<O_, kQwNsub>(epi, Q, ld, W, alpha, a, st)));
     }
@@ -2097,6 +2132,18 @@ void symv_plan_get(int nloc, int64_t ld, int out[4]) {   // host-only view of th
 }
 size_t sym_pcol_count(int nloc, int64_t ld, int o) { return (size_t)symv_plan(nloc, ld).nchunks * (size_t)ld * o; }
 
+// first step (two cameras, six rows) of the symmetric sweep that streams non-temporally: the upper triangle's rows above it hold the resident bytes
+static int symv_nt_step0(int nloc, int64_t ld) {
+    const double m = 3.0 * nloc;
+    const double tri = 8.0 * m * (m + 6.0) / 2.0;            // bytes the sweep streams (triangle incl. the 6-wide diagonal blocks)
+    const int64_t res = qw_resident_bytes((size_t)tri);
+    const int nsteps = (nloc + 1) / 2;
+    if ((double)res >= tri) return nsteps + 1;
+    // rows [0, r) of the triangle hold 8 (r m - r^2 / 2) bytes
+    const double disc = m * m - 2.0 * (double)res / 8.0;
+    const double r = m - std::sqrt(std::max(0.0, disc));
+    return (int)std::min<double>(nsteps + 1, std::max(0.0, r / 6.0));
+}
 template <int O>
 static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, double *Prow, double *Pcol,
                         hipStream_t st, int rev, unsigned long long *trace = nullptr) {
@@ -2106,10 +2153,10 @@ static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, d
     // the per-camera sum needs: steps per column-sum record (4 K: one record per workgroup), grid row from which the finer cut applies
     const int ys = pl.ysplit, rK = 4 * pl.K, rKf = 4 * pl.Kf, rys = ys;
     const dim3 gs(pl.gx, pl.gy);
+    const int nt0 = symv_nt_step0(a.nloc, ld);
     if (trace) {
-        if constexpr (O == 3 || O == 4) hipLaunchKernelGGL((qw_symv_kernel<O, false, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, sc, Prow, Pcol, trace, rev);
-    } else if (qw_stream_nt(a.nloc, ld)) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, sc, Prow, Pcol, trace, rev);
-    else hipLaunchKernelGGL((qw_symv_kernel<O, false>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, sc, Prow, Pcol, trace, rev);
+        if constexpr (O == 3 || O == 4) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, nt0, sc, Prow, Pcol, trace, rev);
+    } else hipLaunchKernelGGL((qw_symv_kernel<O>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, nt0, sc, Prow, Pcol, trace, rev);
     const dim3 g(qw_grid(a.nloc)), b(256);
     switch (epi) {
         case EPI_PLAIN: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break;
