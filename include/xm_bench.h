@@ -19,8 +19,9 @@ int xm_qw_dense_time(const double *dq, int64_t n, int o, const double *dW, doubl
 int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, double *dOut, int reps, double *ms_avg);
 /* micro-benchmark settings of the symmetric sweep: k > 0 overrides the chunk length of the plan (0 = the plan's own; set it BEFORE a context
  * or a timing call sizes its partial-result buffers); alternate = 0: xm_qw_dense_sym_time / xm_qw_dense_time walk the matrix in the same direction in every
- * launch instead of alternating it between consecutive products as the solver does */
-int xm_bench_symv_k(int k, int alternate);
+ * launch instead of alternating it between consecutive products as the solver does; kf > 0 (with k > 0): the last quarter of the grid rows is cut
+ * into chunks of kf steps whatever the size (the plan does that by itself only for sweeps of several residency rounds) */
+int xm_bench_symv_k(int k, int alternate, int kf);
 /* load policy of the dense stream in the micro-benchmarks: -1 = by size (the product's rule), 0 = default (cacheable), 1 = non-temporal */
 int xm_bench_dense_policy(int nt);
 /* ONE traced launch of the sweep (o = 3 or 4, top-down): per wavefront `slots` 100 MHz timestamps -- [0] entry, [1] after the status word,

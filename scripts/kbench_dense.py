@@ -29,11 +29,11 @@ for o in a.o:
     reps = 200 if n < 5000 else 20
     for nt in a.nt:
         for alt in a.alt:
-            xmamd._chk(L.xm_bench_dense_policy(nt)); xmamd._chk(L.xm_bench_symv_k(0, alt))
+            xmamd._chk(L.xm_bench_dense_policy(nt)); xmamd._chk(L.xm_bench_symv_k(0, alt, 0))
             tag = f"nt={nt:2d} alt={alt}"
             xmamd._chk(L.xm_qw_dense_time(dq.ptr, n, o, dW.ptr, dO.ptr, reps, C.byref(ms)))
             print(f"n={n} o={o} {tag} {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s algorithmic  ({by/1e6:.1f} MB)", flush=True)
             if 3 <= o <= 5 and not a.no_sym:
                 xmamd._chk(L.xm_qw_dense_sym_time(dq.ptr, n, o, dW.ptr, dO.ptr, reps, C.byref(ms)))
                 print(f"n={n} o={o} {tag} SYM (upper triangle only): {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s of full-storage algorithmic bytes", flush=True)
-xmamd._chk(L.xm_bench_dense_policy(-1)); xmamd._chk(L.xm_bench_symv_k(0, 1))
+xmamd._chk(L.xm_bench_dense_policy(-1)); xmamd._chk(L.xm_bench_symv_k(0, 1, 0))

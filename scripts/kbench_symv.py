@@ -18,7 +18,6 @@ ap.add_argument("--trace", action="store_true")
 a = ap.parse_args()
 n = a.n
 L = xmamd.lib(); ld = xmamd.dense_ld(n)
-L.xm_bench_symv_k.argtypes = [C.c_int, C.c_int]
 L.xm_qw_dense_sym_trace.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]
 rng = np.random.default_rng(0)
 reps = 200 if n < 5000 else 20
@@ -45,7 +44,7 @@ for o in a.o:
     ref = Qh @ Wh if a.check else None
     for v in a.alt:
         for k in a.k:
-            xmamd._chk(L.xm_bench_symv_k(k, v))
+            xmamd._chk(L.xm_bench_symv_k(k, v, 0))
             p = (C.c_int32 * 4)(); xmamd._chk(L.xm_symv_plan(n, p))
             xmamd._chk(L.xm_qw_dense_sym_time(dq.ptr, n, o, dW.ptr, dO.ptr, reps, C.byref(ms)))
             line = f"n={n} o={o} SYM alternating {v} K={p[0]:3d} Kf={p[1]:3d} {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s full-storage"
@@ -56,7 +55,7 @@ for o in a.o:
             print(line, flush=True)
     if a.trace and o in (3, 4):
         for k in a.k:
-            xmamd._chk(L.xm_bench_symv_k(k, 1))
+            xmamd._chk(L.xm_bench_symv_k(k, 1, 0))
             grid = (C.c_int * 2)(); slots = C.c_int()
             xmamd._chk(L.xm_qw_dense_sym_trace(dq.ptr, n, o, dW.ptr, dO.ptr, None, 0, grid, C.byref(slots)))
             S = slots.value; nw = grid[0] * grid[1] * 4
@@ -86,4 +85,4 @@ for o in a.o:
             cnt = np.bincount(np.unique(key, return_inverse=True)[1])
             print(f"    wavefronts with steps per XCC: {np.bincount(xcc[work], minlength=8).tolist()}; distinct (xcc, se, cu) = {cnt.size}, wavefronts per CU "
                   f"min {cnt.min()} p50 {int(np.median(cnt))} max {cnt.max()}")
-    xmamd._chk(L.xm_bench_symv_k(0, 1))
+    xmamd._chk(L.xm_bench_symv_k(0, 1, 0))

@@ -1,5 +1,6 @@
 """GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of libxm_amd.so and is checked
 against the CPU oracle on the same seeded inputs, against the golden fixtures, and through size-independent invariants."""
+import ctypes as C
 import json
 import os
 
@@ -637,6 +638,37 @@ def test_qw_dense_symmetric_kernel_matches_oracle(xmamd, oracle, n, o):
     got = xmamd.qw_dense(Q, W, 2.0, sym=True)
     assert tl.rel_fro(got, ref) < 1e-13
     assert tl.rel_fro(xmamd.qw_dense(Q, W, 2.0), ref) < 1e-13
+
+
+@pytest.mark.parametrize("n,o,k,kf", [(700, 3, 16, 4), (700, 4, 8, 2), (1031, 3, 12, 5), (1031, 5, 7, 3), (343, 4, 5, 1), (2200, 3, 9, 2)])
+def test_qw_dense_symmetric_kernel_with_a_forced_finer_cut(xmamd, n, o, k, kf):
+    """the plan cuts the grid rows dispatched last into shorter chunks only for sweeps of several residency rounds (>= ~5 000 cameras); forced
+    here at small sizes (xm_bench_symv_k) so that the reducer's per-column record counts -- a camera's three columns can lie in two strips
+    that are cut differently -- meet numpy on every row, in both sweep directions"""
+    rng = np.random.default_rng(11 * n + o)
+    A = rng.standard_normal((3 * n, 3 * n)); Q = A + A.T; del A
+    W = rng.standard_normal((3 * n, o))
+    ref = 2.0 * (Q @ W)
+    L = xmamd.lib()
+    try:
+        xmamd._chk(L.xm_bench_symv_k(k, 1, kf))
+        p = (C.c_int32 * 4)(); xmamd._chk(L.xm_symv_plan(n, p))
+        assert p[0] == k and p[1] == kf
+        dq = xmamd.dense_upload(Q)
+        got = xmamd.qw_dense(Q, W, 2.0, dq=dq, sym=True)
+        err = np.abs(got - ref).max(axis=1) / np.abs(ref).max()
+        assert err.max() < 1e-13, f"worst row {int(err.argmax())} (camera {int(err.argmax()) // 3}): {err.max():.2e}"
+        # bottom-up sweep of every chunk (what odd tCG iterations do): xm_qw_dense_sym_time alternates, the functional entry sweeps top-down,
+        # so time two launches and read the output of the second
+        dW = xmamd.DevArray(xmamd.to_rm(W, rows=xmamd.dense_ld(n))); dO = xmamd.DevArray(nbytes=3 * n * xmamd.pitch_of(o) * 8)
+        ms = C.c_double()
+        xmamd._chk(L.xm_qw_dense_sym_time(dq.ptr, n, o, dW.ptr, dO.ptr, 1, C.byref(ms)))   # 3 warm-ups (rev 0 1 0) + 1 timed launch (rev 1)
+        out = xmamd.from_rm(dO.get(), 3 * n, o)
+        assert np.abs(out - 0.5 * ref).max() / np.abs(ref).max() < 1e-13
+        for b in (dq, dW, dO):
+            b.free()
+    finally:
+        xmamd._chk(L.xm_bench_symv_k(0, 1, 0))
 
 
 def test_new_products_are_bit_reproducible(xmamd):

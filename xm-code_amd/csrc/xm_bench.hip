@@ -78,8 +78,8 @@ int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, d
     return XM_OK;
     XM_CATCH
 }
-int xm_bench_symv_k(int k, int alternate) {
-    xm::symv_bench_k(k);
+int xm_bench_symv_k(int k, int alternate, int kf) {
+    xm::symv_bench_k(k, kf);
     g_sym_alternate = alternate;
     return XM_OK;
 }

@@ -143,7 +143,7 @@ int bsr_grid(int nloc);   // workgroups (= partial sums per epilogue slot) of th
 size_t sym_prow_count(int nloc, int64_t ld, int o);
 size_t sym_pcol_count(int nloc, int64_t ld, int o);
 void qw_bench_nt(int nt);                                  // micro-benchmark override of the load policy: -1 by size, 0 default, 1 non-temporal
-void symv_bench_k(int k);                                  // micro-benchmark override of the chunk length (xm_bench.h)
+void symv_bench_k(int k, int kf);                                  // micro-benchmark override of the chunk length (xm_bench.h)
 int symv_trace_slots();
 void launch_qw_sym_traced(int o, const double *Q, int64_t ld, const double *W, const CamArgs &a, double *Prow, double *Pcol, unsigned long long *trace,
                           int grid[2], hipStream_t st);

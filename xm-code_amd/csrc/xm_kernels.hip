@@ -551,74 +551,74 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
     if constexpr (TRACE) { if (lane == 0) tr[kSvTraceSlots - 2] = wall_clock64(); }
 }
 
-// second half: y_cam = sum_{strips s >= s_lo} Prow[s][rows of cam] + sum_{chunks above} Pcol[chunk][rows of cam] (fixed order), fused epilogue
+// second half: y_cam = sum_{strips s >= s_lo} Prow[s][rows of cam] + sum_{groups above} Pcol[group][rows of cam] (fixed order), fused epilogue.
+// One wavefront per camera.  A record is 3 * O contiguous doubles: SIXTEEN lanes read one record (lane e its element e), so that a load
+// instruction of the wavefront covers four records = four short contiguous runs -- with a lane per record (round 5) every instruction touched
+// 64 different cache lines, 9 .. 12 instructions per round, and the launch was bound by the address rate of the vector memory pipeline
+// (7.7 us in the Venice solve for 13 MB).  Round t of a block of 64 records: lane group g = lane / 16 reads record 4 t + g; all sixteen
+// requests of the first block go out before the tCG's status word is looked at (the launch is latency-bound: status word, partial sums and
+// epilogue operands were all written by earlier launches on other XCDs -- one round trip for all of them).  Loads are unconditional (a lane
+// without a record re-reads a valid one and selects zero): a predicated load becomes a branch the compiler drains the queue for.  Order of
+// the sum: per lane group the rounds in sequence, then (g0 + g1) + (g2 + g3) -- fixed.
 template <int O, int EPI>
 __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t ld,
                                                            int nstrips, int Kc, int Kf, int ysplit, double alpha, CamArgs a) {
+    constexpr int NE = 3 * O;          // elements of a record (<= 15)
+    static_assert(NE <= 16, "a record must fit a 16-lane group");
     __shared__ double red[kQwWaves][3];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cam = blockIdx.x * kQwWaves + wave;
     const bool active = cam < a.nloc;
     EpiOps eops;
     epi_prefetch<O, EPI>(eops, cam, lane, active, a);
-    double acc[3][O];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
-    // A camera adds nrow row-sum records and up to ncol column-sum records (~100 at Venice size), lane i the records i, i + 64, ... in that
-    // order, then the wavefront's fixed DPP tree.  The records of a PAIR of rounds are requested together, the first pair before the
-    // tCG's status word is looked at (the launch is latency-bound: status word, partial sums and epilogue operands were all written by
-    // earlier launches on other XCDs -- one round trip for all of them instead of three in a row).  Loads are unconditional (a lane
-    // without a record re-reads a valid one and selects zero): a predicated load becomes a branch the compiler drains the queue for.
+    const int e = lane & 15, g = lane >> 4;
+    const bool eok = e < NE;
     const int camc = active ? cam : 0;
     const int64_t R = (int64_t)6 * ((a.nloc + 1) >> 1);
     const int s_lo = (6 * (camc >> 1)) / kSvStrip;
     const int nrow = nstrips - s_lo;
-    int cnt[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int c = 3 * camc + r;
-        const int sc_ = c / kSvStrip, row = min(sc_, nstrips - 1 - sc_);   // grid row of the strip that owns column c (folded grid of the sweep)
-        const int K = (row >= ysplit) ? Kf : Kc;                  // steps per column-sum record there
-        cnt[r] = (c >= 6) ? (c - 6) / (6 * K) + 1 : 0;
-    }
-    const int ncol = max(cnt[0], max(cnt[1], cnt[2]));
-    const int tot = active ? nrow + ncol : 0;
-    auto fetch = [&](int i, double (&v)[3][O]) {
-        const int ic = min(i, nrow + ncol - 1);               // nrow >= 1: always a valid record
-        const double *p = (ic < nrow) ? Prow + ((size_t)(s_lo + ic) * (size_t)R + (size_t)camc * 3) * O
-                                      : Pcol + ((size_t)(ic - nrow) * (size_t)ld + (size_t)camc * 3) * O;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < O; ++k) v[r][k] = p[r * O + k];
+    // column-sum records: the three columns of a camera lie in one step, but they may lie in two STRIPS (256 is no multiple of 3) whose grid
+    // rows are cut differently (Kc / Kf), so the count belongs to the column -- lane e owns column 3 cam + e / O
+    auto ncol_of = [&](int c) -> int {
+        const int sc_ = c / kSvStrip, row = min(sc_, nstrips - 1 - sc_);   // grid row of the strip that owns the column (folded grid of the sweep)
+        const int K = (row >= ysplit) ? Kf : Kc;                          // steps per column-sum record there
+        return (c >= 6) ? (c - 6) / (6 * K) + 1 : 0;
     };
-    auto add = [&](int i, const double (&v)[3][O]) {
-        const bool row = i < nrow;
-        const int ch = i - nrow;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const bool ok = (i < tot) && (row || ch < cnt[r]);
-#pragma unroll
-            for (int k = 0; k < O; ++k) acc[r][k] += ok ? v[r][k] : 0.0;
-        }
+    const int ncol_l = ncol_of(3 * camc + (eok ? e / O : 0));
+    const int ncol = max(ncol_of(3 * camc), ncol_of(3 * camc + 2));   // wave-uniform (the count is monotone in the column)
+    const int nrec = nrow + ncol;                                     // nrow >= 1: always a valid record
+    const int tot = active ? nrec : 0, tot_l = active ? nrow + ncol_l : 0;
+    const size_t eo = (size_t)camc * 3 * O + (eok ? e : 0);
+    auto fetch = [&](int i) -> double {
+        const int ic = min(i, nrec - 1);
+        const double *p = (ic < nrow) ? Prow + (size_t)(s_lo + ic) * (size_t)R * O : Pcol + (size_t)(ic - nrow) * (size_t)ld * O;
+        return p[eo];
     };
-    double va[3][O], vb[3][O];
-    fetch(lane, va);
-    fetch(lane + 64, vb);
+    double v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = fetch(4 * t + g);
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
-    add(lane, va);
-    add(lane + 64, vb);
-    for (int i = lane + 128; i < tot + lane; i += 128) {      // wave-uniform trip count (i - lane < tot)
-        fetch(i, va);
-        fetch(i + 64, vb);
-        add(i, va);
-        add(i + 64, vb);
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc += (eok && 4 * t + g < tot_l) ? v[t] : 0.0;
+    for (int base = 64; base < tot; base += 64) {                    // wave-uniform trip count
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = fetch(base + 4 * t + g);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc += (eok && base + 4 * t + g < tot_l) ? v[t] : 0.0;
     }
-    qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
+    acc += __shfl_xor(acc, 16);        // g0 + g1 | g2 + g3 (a + b == b + a bit for bit: both lanes of a pair hold the same sum)
+    acc += __shfl_xor(acc, 32);
+    // element r * O + k of the sum sits in lane r * O + k (of every group): column k -> lane k, as the epilogues expect
+    Col3 h;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double t = __shfl(acc, (lane < O) ? r * O + lane : 0);
+        h.v[r] = (active && lane < O) ? alpha * t : 0.0;
+    }
+    qw_tail<O, EPI, 64, kQwWaves>(cam, lane, wave, active, h, a, eops, red);
 }
 
 // max |Q[r][c] - Q[c][r]| and max |Q| over the device layout (decides whether the symmetric path may be used).  Tile pairs (ti <= tj)
@@ -2101,8 +2101,8 @@ size_t sym_prow_count(int nloc, int64_t ld, int o) { return (size_t)((ld + kSvSt
 // work counter instead (workgroups pulling item numbers) was measured too: no steadier at 13.5 GB and 1.5 x slower at Venice size
 // (a barrier and an atomic per item).  The remaining +-6 % between MI355X boxes for one K (1 145 / 1 290 us) is not scheduling noise
 // of this kind: it repeats on a box.
-static int g_symv_k = 0;                                  // micro-benchmark override of the chunk length (xm_bench.h: xm_bench_symv_k)
-void symv_bench_k(int k) { g_symv_k = k; }
+static int g_symv_k = 0, g_symv_kf = 0;                   // micro-benchmark / test override of the chunk lengths (xm_bench.h: xm_bench_symv_k)
+void symv_bench_k(int k, int kf) { g_symv_k = k; g_symv_kf = kf; }
 // K: steps per chunk (a wavefront); Kf: the same in the grid rows >= ysplit (dispatched last: cut finer when the sweep takes several residency
 // rounds); nchunks: upper bound of column-sum records per column (sizes Pcol); gx, gy: the folded grid
 struct SymvPlan { int K, Kf, ysplit, nchunks, gx, gy; };
@@ -2111,7 +2111,10 @@ static SymvPlan symv_plan(int nloc, int64_t ld) {
     p.K = g_symv_k > 0 ? g_symv_k : symv_k(nloc, ld);
     const int nsteps = (nloc + 1) / 2, nstrips = (int)((ld + kSvStrip - 1) / kSvStrip);
     p.gy = (nstrips + 1) / 2;
-    if (p.K >= 8 && symv_live_groups(nsteps, nstrips, p.K) > 1100) {   // several residency rounds
+    if (g_symv_k > 0 && g_symv_kf > 0) {                               // forced finer cut of the last rows (tests of the index arithmetic at small sizes)
+        p.Kf = std::min(g_symv_kf, p.K);
+        p.ysplit = (int)(0.75 * p.gy);
+    } else if (p.K >= 8 && symv_live_groups(nsteps, nstrips, p.K) > 1100) {   // several residency rounds
         p.Kf = p.K / 4;
         p.ysplit = (int)(0.75 * p.gy);          // every row of the folded grid holds the same work: the last quarter of it is cut four times finer
     } else {

@@ -132,7 +132,7 @@ def lib():
         L.xm_qw_dense.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
         L.xm_qw_dense_sym.argtypes = L.xm_qw_dense.argtypes
         L.xm_qw_dense_sym_time.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-        L.xm_bench_symv_k.argtypes = [C.c_int, C.c_int]
+        L.xm_bench_symv_k.argtypes = [C.c_int, C.c_int, C.c_int]
         L.xm_qw_dense_sym_trace.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]
         L.xm_qw_bsr3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_double, C.c_void_p]
