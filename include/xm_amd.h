@@ -117,7 +117,10 @@ typedef struct {
     int32_t schur_dense_max;   /* 0 = 20000 */
     int32_t debug_drop_finalize; /* tests: the k-th outer iteration loses its result kernel (the host must come back with XM_ERR_HIP) */
     int32_t debug_peer_mute;   /* tests: rank 1 never publishes its tCG epoch (a dead peer: the bounded waits must expire) */
-    int32_t reserved[4];
+    int32_t schur_pcg_first;   /* XM_STORAGE_SCHUR, CG form: iterations enqueued in the first batch of the first product (0 = 26; tests force top-up batches) */
+    int32_t schur_pcg_hess_digits; /* ... relative residual 10^-d of the inner solve inside Hessian products: 0 = 9, 6 .. 13 (13 = as tight as the
+                                  gradient / cost / certificate products always are) */
+    int32_t reserved[2];
 } xm_tuning_t;
 
 typedef struct {
@@ -221,6 +224,10 @@ typedef struct {
                                        * invariant subspace was hit: beta below round-off under full re-orthogonalisation) and min_eig is the
                                        * smallest eigenvalue of the complete tridiagonal matrix -- the dense path of the reference
                                        * (Dense/eig.h:35-73 dsyevd, checkeig.h:303-318) with the reduction done matrix-free.  Set AFTER the run. */
+
+#define XM_CERT_INEXACT_OPERATOR 4     /* matrix-free storage, CG form: an inner solve of the reduced camera system stopped at its iteration cap without
+                                       * reaching the tolerance while the multipliers or the Lanczos products were formed -- S was applied inexactly and
+                                       * the certificate was NOT accepted (xm_ctx_schur_info counts such products over the context's life) */
 
 int xm_ctx_create(const xm_problem_t *prob, xm_ctx_t **out);          /* uploads / lays out Q on device 0 (or the rank's device) */
 int xm_ctx_solve(xm_ctx_t *ctx, const xm_options_t *opt, xm_result_t *res);

@@ -84,6 +84,9 @@ int xmo_solve_path(const char *dataset_path, unsigned max_rank, double tol, doub
 /* helpers exported for unit tests */
 void xmo_qw(int n, int o, const double *C, const double *W, double *out, double alpha);        /* Dense/matmul.h:42 */
 void xmo_mgs_rows(int n, int o, const double *A, double *Qm);                                   /* Dense/batchedQR.h:42-67 on 3n x o col-major */
+/* eigen step of xmo_checkeig: NULL = the restated tred2 / tql2 (default), else the caller's routine with the contract of xmo_syev_lower */
+typedef int (*xmo_syev_fn)(int m, double *A, double *w);
+void xmo_set_syev(xmo_syev_fn f);
 int  xmo_syev_lower(int m, double *A, double *w);                                               /* Dense/eig.h:35 (vectors overwrite A, ascending) */
 int  xmo_read_bin(const char *file, double **data, int *rows, int *cols);                       /* main.cu:18 */
 int  xmo_write_bin(const char *file, const double *data, int rows, int cols);                   /* main.cu:284-305 */

@@ -181,5 +181,35 @@ def solve_path(path, max_rank, tol, lam, max_time, mode=0, flags=0):
     return lib().xmo_solve_path(os.fsencode(path), int(max_rank), tol, lam, max_time, mode, flags)
 
 
+_SYEV_CB = None   # keeps the ctypes callback alive while the library holds it
+
+
+def use_lapack_eig(on=True):
+    """Eigen step of checkeig through LAPACK dsyevd (scipy) instead of the restated tred2 / tql2 -- the closest CPU analogue of
+    cusolverDnXsyevd (Dense/eig.h:35-73).  For bench.py's CPU wall-clock-to-KKT leg on the headline size (5334 rows: an hour -> seconds);
+    tests/test_oracle.py asserts that both give the same certificate on the small golden cases."""
+    global _SYEV_CB
+    L = lib()
+    FN = C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
+    L.xmo_set_syev.argtypes = [FN]
+    if not on:
+        L.xmo_set_syev(C.cast(None, FN))
+        _SYEV_CB = None
+        return
+    from scipy.linalg import lapack
+
+    def cb(m, a_ptr, w_ptr):
+        A = np.ctypeslib.as_array(a_ptr, shape=(m * m,)).reshape((m, m), order="F")     # column-major view of the caller's buffer
+        w, v, info = lapack.dsyevd(A, compute_v=1, lower=1, overwrite_a=0)
+        if info != 0:
+            return int(info)
+        A[:, :] = v
+        np.ctypeslib.as_array(w_ptr, shape=(m,))[:] = w
+        return 0
+
+    _SYEV_CB = FN(cb)
+    L.xmo_set_syev(_SYEV_CB)
+
+
 def num_threads():
     return lib().xmo_num_threads()

@@ -68,6 +68,24 @@ if b2:
     for k in ("transport", "fallback", "exchange", "rccl_leg"):
         if k in b2:
             out += [f"* `{k}`: `{json.dumps(b2[k])[:600]}`"]
+if tag.startswith("multi_"):
+    # scripts/first_multi_gpu_run.sh: the first run on real devices -- rung by rung, then the scaling legs of the same workload
+    out += ["", "## first multi-GPU run (`scripts/first_multi_gpu_run.sh`)", ""]
+    fp = os.path.join(P, f"{tag}_probe.log")
+    if os.path.exists(fp):
+        out += ["transport ladder, rung by rung (`%s_probe.log`):" % tag, "```"] + [l[:400] for l in open(fp).read().splitlines() if l.startswith("{")] + ["```", ""]
+    rows = []
+    for f in sorted(glob.glob(os.path.join(P, f"{tag}_bench_*.json")) + glob.glob(os.path.join(P, f"{tag}_scale_*.json"))):
+        try:
+            b = json.loads(open(f).read().strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            continue
+        rl = b.get("rccl_leg") or {}
+        rows.append(f"| `{os.path.basename(f)}` | {b.get('n_gpus')} | {g(b, 'value', fmt='{:.0f}')} | {g(b, 'ms_per_step', fmt='{:.1f}')} | {g(b, 'transport')} | {g(b, 'fallback')} | "
+                    f"{g(b, 'exchange', 'used')} | {g(rl, 'value', fmt='{:.0f}')} | {g(b, 'rome_scale', 'value', fmt='{:.0f}')} | {g(b, 'rome_scale_dense', 'value', fmt='{:.0f}')} | {g(b, 'error')} |")
+    if rows:
+        out += ["| file | GPUs | Venice tCG it/s | ms per solve | transport | fallback | exchange used | RCCL leg it/s | Final-13682 BSR it/s | Final-13682 dense it/s | error |",
+                "|---|---|---|---|---|---|---|---|---|---|---|"] + rows
 out += ["", "## stamped PMC legs (`%s_pmc_fetch_<leg>.json`; FETCH_SIZE x 1024 x 2 per MI355X_MICROARCH)" % tag, "",
         "| leg | what | real launches | counter traffic per launch (MB) | traced µs per launch |", "|---|---|---|---|---|"]
 for f in sorted(glob.glob(os.path.join(P, f"{tag}_pmc_fetch_*.json"))):

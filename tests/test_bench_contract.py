@@ -56,3 +56,31 @@ def test_rank0_reports_when_the_launcher_tears_the_job_down():
     """)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 4 and len(lines) == 1 and "another rank failed" in json.loads(lines[0])["error"]
+
+
+def test_first_multi_gpu_run_script_commands_parse():
+    """scripts/first_multi_gpu_run.sh is what runs in the first minutes on a real N-GPU node (nothing in this tree has seen more than one
+    physical GPU): its command list must at least parse here -- every script it names exists and accepts its flags at --help level."""
+    import shlex, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(["bash", os.path.join(root, "scripts", "first_multi_gpu_run.sh"), "--dry-run", "8", "multi_test"], capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr
+    cmds = [l for l in out.stdout.splitlines() if l.startswith("python ")]
+    assert len(cmds) >= 10 and any("torch.distributed.run" in c for c in cmds) and any("--exchange rccl" in c for c in cmds)
+    seen = set()
+    for c in cmds:
+        parts = shlex.split(c)
+        script = next((p for p in parts if p.endswith(".py")), None)
+        if script is None:                      # python -m pytest ...
+            continue
+        assert os.path.exists(os.path.join(root, script)), script
+        if script in seen or script.endswith("collect_profiles.py") or script.endswith("kbench_multi.py") or script.endswith("kbench_symw.py"):
+            continue                            # (those three import the GPU library at module level or take no flags)
+        seen.add(script)
+        flags = [p for p in parts[parts.index(script) + 1:] if p.startswith("--")]
+        h = subprocess.run([sys.executable, os.path.join(root, script), "--help"], capture_output=True, text=True, cwd=root)
+        assert h.returncode == 0, (script, h.stderr[-400:])
+        for fl in flags:
+            assert fl in h.stdout, (script, fl)
+    d = subprocess.run([sys.executable, os.path.join(root, "scripts", "multi_gpu_probe.py"), "--dry-run", "--gpus", "8"], capture_output=True, text=True, cwd=root)
+    assert d.returncode == 0 and '"gpus": 8' in d.stdout

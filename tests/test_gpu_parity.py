@@ -1327,6 +1327,43 @@ def test_matrix_free_cg_form_equals_the_dense_inverse(xmamd):
         ctx.close()
 
 
+def test_matrix_free_cg_batches_do_not_change_the_iteration(xmamd):
+    """the inner CG of the matrix-free product is enqueued in batches and topped up after a look at the state word; a top-up batch used to
+    repeat the direction update the closing launch of the previous batch had already applied (p = z + beta (z + beta p): no conjugate
+    direction).  A context whose first batch is one iteration long (xm_tuning_t.schur_pcg_first: every product is topped up at
+    least once) must need exactly the iterations of one that guesses generously, and produce the same bits; inside the tCG the Hessian
+    products stop at 1e-9 (schur_pcg_hess_digits) and take fewer inner iterations than the gradient products for the same optimum"""
+    S = tl.gen_scene(600, 60000, 6, seed=5)
+    obs = (S["cam"], S["lm"], S["p"], S["w"])
+    n = 600
+    W = [np.random.default_rng(10 + o).standard_normal((3 * n, o)) for o in (3, 4, 1)]
+    res = {}
+    for first in (1, 60):
+        ctx = xmamd.Context(obs=obs, tuning=dict(schur_solver=2, schur_pcg_first=first))
+        Y = [ctx.qw(w) for w in W]
+        si = ctx.schur_info()
+        ctx.close()
+        res[first] = (Y, si)
+    (Ya, sa), (Yb, sb) = res[1], res[60]
+    assert sa["capped"] == sb["capped"] == 0 and sa["products"] == sb["products"] == 3
+    assert sa["inner_iters"] == sb["inner_iters"], (sa, sb)
+    for a, b in zip(Ya, Yb):
+        assert np.array_equal(a, b)
+    lam = 1.5 * float(np.sum(S["w"] * np.sum(S["p"] ** 2, axis=1)) / (3 * n))
+    out = {}
+    for digits in (13, 0):
+        ctx = xmamd.Context(obs=obs, tuning=dict(schur_solver=2, schur_pcg_hess_digits=digits))
+        R, s, info = ctx.solve(5, 1e-8, lam)
+        out[digits] = (R, s, info, ctx.schur_info())
+        ctx.close()
+    (R13, s13, i13, q13), (R9, s9, i9, q9) = out[13], out[0]
+    assert i13["status"] == i9["status"] == 1 and i13["rank"] == i9["rank"]
+    assert i9["primal"] == pytest.approx(i13["primal"], rel=1e-9)
+    assert tl.rotation_parity(R9, s9, R13, s13) < 1e-7
+    assert q9["capped"] == q13["capped"] == 0
+    assert q9["inner_iters"] / q9["products"] < 0.85 * q13["inner_iters"] / q13["products"], (q9, q13)
+
+
 def test_matrix_free_50k_cameras_without_any_n_squared_array(xmamd):
     """a 50 000-camera synthetic scene (1.5 M landmarks, ~9 M observations): beyond the dense inverse's limit (kSchurMaxCams = 40 000;
     8 N^2 = 20 GB and an O(N^3) factorisation) the matrix-free storage selects the CG form by itself.  Set-up in seconds (dominated by

@@ -149,6 +149,31 @@ def test_staircase_escalates_and_certifies(oracle):
     assert i3["trace"][-1, 0] > exp["f_star"] + 1e-3             # escalation strictly improves the optimum
 
 
+@pytest.mark.parametrize("name", ["synth/dense49", "synth/vg40_stair", "synth/vg60_cert"])
+def test_lapack_eigen_step_gives_the_same_certificate_and_staircase(oracle, name):
+    """bench.py's CPU wall-clock-to-KKT leg runs the oracle's certificate with LAPACK dsyevd (xm_oracle.use_lapack_eig: the closest CPU analogue
+    of cusolverDnXsyevd, Dense/eig.h:35-73) instead of the restated tred2 / tql2, which needs an hour at 5334 rows.  Same ranks, same
+    acceptance, min_eig / dual / gap to 1e-10 (1e-9 behind an escalation), same solution up to the gauge -- also through a rank escalation, whose direction is the
+    eigenvector the eigen step returns"""
+    Q, exp = _case(os.path.join(G, name))
+    lam = exp["lam"]
+    a = oracle.solve(Q, exp["max_rank"], 1e-9, lam, 1000.0)
+    oracle.use_lapack_eig(True)
+    try:
+        b = oracle.solve(Q, exp["max_rank"], 1e-9, lam, 1000.0)
+    finally:
+        oracle.use_lapack_eig(False)
+    (Ra, sa, ia), (Rb, sb, ib) = a, b
+    assert ia["rank"] == ib["rank"] and ia["status"] == ib["status"] and ia["cert"]["accepted"] == ib["cert"]["accepted"]
+    # no escalation: the same point goes into both eigen steps (1e-10); after one, the two runs continue from eigenvectors that agree to
+    # round-off and stop |grad| < 1e-9 apart
+    tol = 1e-10 if ia["rank"] == 3 else 1e-9
+    for k in ("min_eig", "dual", "gap"):
+        assert abs(ia["cert"][k] - ib["cert"][k]) <= tol * max(1.0, abs(ia["cert"]["dual"])), k
+    assert tl.rel_fro(tl.gram(Rb, sb), tl.gram(Ra, sa)) < 1e-8
+    assert tl.rotation_parity(Rb, sb, Ra, sa) < 1e-8
+
+
 def test_gradtol_quirk_and_rank3_mode(oracle):
     Q, exp = _case(os.path.join(G, "synth/dense49"))
     n = 49

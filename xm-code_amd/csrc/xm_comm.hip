@@ -67,6 +67,9 @@ Settings Settings::resolve(const xm_tuning_t *t) {
     if (z.schur_solver < 0 || z.schur_solver > 2) throw Error(XM_ERR_ARG, "xm_tuning_t.schur_solver must be 0, 1 or 2");
     s.schur_solver = z.schur_solver;
     if (z.schur_dense_max > 0) s.schur_dense_max = z.schur_dense_max;
+    s.schur_pcg_first = z.schur_pcg_first > 0 ? z.schur_pcg_first : 0;
+    if (z.schur_pcg_hess_digits != 0 && (z.schur_pcg_hess_digits < 6 || z.schur_pcg_hess_digits > 13)) throw Error(XM_ERR_ARG, "xm_tuning_t.schur_pcg_hess_digits must be 0 or 6..13");
+    s.schur_pcg_hess_digits = z.schur_pcg_hess_digits;
     s.debug_drop_finalize = z.debug_drop_finalize > 0 ? z.debug_drop_finalize : -1;
     s.debug_peer_mute = z.debug_peer_mute;
     return s;

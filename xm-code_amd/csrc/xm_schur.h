@@ -40,6 +40,8 @@ struct SchurSettings {          // from xm_tuning_t (Settings::resolve)
     bool trace = false;         // set-up phase times on stderr (scripts/kbench_schur.py)
     int solver = 0;             // reduced camera system inside the product: 0 by size (dense inverse up to dense_max cameras, CG above) | 1 dense inverse | 2 preconditioned CG
     int64_t dense_max = 20000;  // (the dense inverse costs 8 (N-1)^2 bytes -- 3.2 GB here -- and an O(N^3) set-up; the CG form nothing but the observation lists)
+    int pcg_first = 0;          // CG form: iterations of the first batch of a context's first product (0 = 26; tests force top-up batches with a small one)
+    int pcg_hess_digits = 0;    // CG form: relative residual 10^-digits of the inner solve inside HESSIAN products (0 = 9; gradient, cost and certificate products: 13)
 };
 struct SchurLm;                 // xm_schur.hip
 
@@ -109,10 +111,10 @@ private:
     DevBuf<double> pcg_dinv_, pcg_r_, pcg_p_, pcg_ap_, pcg_parts_;
     DevBuf<int32_t> pcg_state_;
     struct PcgState *pcg_host_ = nullptr;   // pinned copy of the device state word
-    int pcg_grid_ = 1, pcg_last_iters_ = 24, pcg_max_iters_ = 1000;
-    double pcg_tol_ = 1e-13, pcg_last_relres_ = 0.0;
+    int pcg_grid_ = 1, pcg_last_iters_[2] = {24, 24}, pcg_max_iters_ = 1000;   // [0] products at the tight tolerance, [1] Hessian products
+    double pcg_tol_[2] = {1e-13, 1e-9}, pcg_last_relres_ = 0.0;
     int64_t pcg_products_ = 0, pcg_iters_total_ = 0, pcg_unconverged_ = 0;
-    template <int O> void pcg_solve(const SchurLm &L, const struct TcgScal *sc, hipStream_t st);
+    template <int O> void pcg_solve(const SchurLm &L, const struct TcgScal *sc, hipStream_t st, int kind);
 public:
     ~SchurOp();
     SchurOp(const SchurOp &) = delete;

@@ -591,7 +591,16 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     std::vector<int32_t> order((size_t)M);
     for (int64_t l = 0; l < M; ++l) order[(size_t)l] = (int32_t)l;
     auto deg_of = [&](int64_t l) { return lp_[(size_t)l + 1] - lp_[(size_t)l]; };
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return deg_of(x) > deg_of(y); });
+    // ... and, among equals, by the first camera that sees them (smallest index): the landmarks of neighbouring cameras get neighbouring
+    // numbers, so that a camera's gathers of landmark records (schur_cam_*, pcg_cam_kernel: one 128-byte line per 24 .. 40-byte record when
+    // the numbers are scattered) fall into few lines wherever the scene has locality (sequential capture; a scene whose landmarks are seen by
+    // cameras drawn at random has none to find)
+    std::vector<int32_t> first_cam((size_t)M, INT32_MAX);
+    for (int64_t e = 0; e < nobs; ++e) first_cam[(size_t)lm[e]] = std::min(first_cam[(size_t)lm[e]], cam[e]);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        const int64_t dx = deg_of(x), dy = deg_of(y);
+        return dx != dy ? dx > dy : first_cam[(size_t)x] < first_cam[(size_t)y];
+    });
     slot_of_.assign((size_t)M, 0);
     std::vector<int32_t> ldeg((size_t)M);
     nheavy_ = 0;
@@ -615,9 +624,20 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     lcam_.assign((size_t)nobs, 0);
     pos_c_.assign((size_t)nobs, 0); pos_l_.assign((size_t)nobs, 0); dpos_l_.assign((size_t)nobs, 0); cam_obs_.assign((size_t)nobs, 0);
     {
-        std::vector<int64_t> nc(cp_.begin(), cp_.end() - 1), nl(lp_.begin(), lp_.end() - 1);
+        // position of every observation in its camera's list: ascending landmark number (ties: input order), so that the lanes of a wavefront
+        // that walk a camera's list gather neighbouring landmark records
+        std::vector<int64_t> apos((size_t)nobs);
+        {
+            std::vector<int64_t> nc0(cp_.begin(), cp_.end() - 1), byc((size_t)nobs);
+            for (int64_t e = 0; e < nobs; ++e) byc[(size_t)nc0[(size_t)cam[e]]++] = e;
+            for (int64_t i = 0; i < N; ++i)
+                std::stable_sort(byc.begin() + cp_[(size_t)i], byc.begin() + cp_[(size_t)i + 1],
+                                 [&](int64_t x, int64_t y) { return slot_of_[(size_t)lm[x]] < slot_of_[(size_t)lm[y]]; });
+            for (int64_t q = 0; q < nobs; ++q) apos[(size_t)byc[(size_t)q]] = q;
+        }
+        std::vector<int64_t> nl(lp_.begin(), lp_.end() - 1);
         for (int64_t e = 0; e < nobs; ++e) {
-            const int64_t a2 = nc[(size_t)cam[e]]++, b2 = nl[(size_t)lm[e]]++;
+            const int64_t a2 = apos[(size_t)e], b2 = nl[(size_t)lm[e]]++;
             const int64_t sl = slot_of_[(size_t)lm[e]], k = b2 - lp_[(size_t)lm[e]];
             const int64_t d2 = (sl < nheavy_) ? hptr[(size_t)sl] + k : gbase[(size_t)((sl - nheavy_) >> 6)] + 64 * k + ((sl - nheavy_) & 63);
             pos_c_[(size_t)e] = a2; pos_l_[(size_t)e] = b2; dpos_l_[(size_t)e] = d2;
@@ -672,6 +692,8 @@ SchurOp::SchurOp(int64_t n, int64_t n_landmarks, int64_t nobs, const int32_t *ca
     nred_pad_ = nred_loc_ * world_;
     if (pcg_) {
         dup_pairs_ = false;   // (the host assembly exists for VT; a pair named twice only makes the Jacobi diagonal approximate)
+        if (cfg_.pcg_first > 0) pcg_last_iters_[0] = pcg_last_iters_[1] = std::max(1, cfg_.pcg_first - 2);
+        if (cfg_.pcg_hess_digits > 0) pcg_tol_[1] = std::pow(10.0, -(double)std::min(13, std::max(6, cfg_.pcg_hess_digits)));
         pcg_dinv_.alloc((size_t)std::max<int64_t>(mr, 1));
         XM_HIP_CHECK(hipHostMalloc((void **)&pcg_host_, sizeof(PcgState), hipHostMallocDefault));
         pcg_state_.alloc(sizeof(PcgState) / sizeof(int32_t) + 2);
@@ -970,7 +992,7 @@ void SchurOp::ensure(int o) {
 int64_t SchurOp::bytes_per_product(int o) const {
     // observation arrays are streamed twice by camera (w, landmark index; w, p, landmark index) and twice by landmark, VT^{-1} once
     // CG form: every iteration streams both observation lists once more (w + index each way); counted with the iterations of the last product
-    const int64_t inner = pcg_ ? (int64_t)std::max(1, pcg_last_iters_) * (2 * nobs_ * (8 + 4)) : 8 * (n_ - 1) * (n_ - 1);
+    const int64_t inner = pcg_ ? (int64_t)std::max(1, pcg_last_iters_[1]) * (2 * nobs_ * (8 + 4)) : 8 * (n_ - 1) * (n_ - 1);
     return nobs_ * (8 + 4) + nobs_ * (8 + 24 + 4) + nobs_ * (8 + 24 + 4) + nobs_ * (8 + 4) + inner + 2LL * 8 * 3 * n_ * o;
 }
 
@@ -1026,7 +1048,10 @@ void SchurOp::product(int o, int epi, const double *W, double alpha, const CamAr
     SchurLm L;
     L.m = m_; L.nheavy = nheavy_; L.total = ltotal_; L.ptr = lm_ptr_.p; L.gbase = gbase_.p; L.deg = ldeg_.p; L.cam = lm_cam_.p; L.w = lm_w_.p; L.p = lm_p_.p;
     std::function<void(const TcgScal *)> pcg;
-    if (pcg_) pcg = [&](const TcgScal *sc) { XM_DISPATCH_O(o, (pcg_solve<O_>(L, sc, st))); };
+    // inner tolerance by the kind of product: the truncated CG tolerates a Hessian applied to 1e-9 (its own stop rule is a RELATIVE residual of
+    // 1e-1 .. 1e-6, its recurrences never look at the true residual), the gradient that decides convergence and the certificate do not
+    const int kind = (epi == EPI_HESS) ? 1 : 0;
+    if (pcg_) pcg = [&](const TcgScal *sc) { XM_DISPATCH_O(o, (pcg_solve<O_>(L, sc, st, kind))); };
     XM_DISPATCH_O(o, (schur_product_o<O_>(epi, n_, nobs_, L, cam_ptr_.p, cam_lm_.p, cam_w_.p, cam_p_.p, Q1_.p,
                                          c_.p, q3inv_.p, vtinv_.p, nred_, ldv_, h_.p, r_.p, xc_.p, xl_.p, W, alpha, a, (vt_sym_ && !comm_) ? sym_prow_.p : (double *)nullptr, sym_pcol_.p, st,
                                          comm_, nred_loc_, pcg)));
@@ -1037,11 +1062,11 @@ void SchurOp::product(int o, int epi, const double *W, double alpha, const CamAr
 // the previous product needed (+ 2), then the host reads the state word and tops up in steps of 8 -- one host round trip per product in
 // the steady state, where consecutive right-hand sides of a truncated CG need the same number of iterations to within a few.
 template <int O>
-void SchurOp::pcg_solve(const SchurLm &L, const TcgScal *sc, hipStream_t st) {
+void SchurOp::pcg_solve(const SchurLm &L, const TcgScal *sc, hipStream_t st, int kind) {
     constexpr int OP = pitch_of(O);
     const int n1 = (int)(n_ - 1);
     PcgArgs a;
-    a.n1 = n1; a.grid = pcg_grid_; a.tol2 = pcg_tol_ * pcg_tol_;
+    a.n1 = n1; a.grid = pcg_grid_; a.tol2 = pcg_tol_[kind] * pcg_tol_[kind];
     a.b = r_.p; a.dinv = pcg_dinv_.p; a.q2 = q2_.p;
     a.x = xc_.p; a.r = pcg_r_.p; a.p = pcg_p_.p; a.Ap = pcg_ap_.p;
     const size_t seg = (size_t)pcg_grid_ * O;
@@ -1052,18 +1077,20 @@ void SchurOp::pcg_solve(const SchurLm &L, const TcgScal *sc, hipStream_t st) {
     const int64_t nlight = L.m - L.nheavy;
     const dim3 glm((unsigned)(L.nheavy + (nlight + kSchurHeavyThreads - 1) / kSchurHeavyThreads)), blm(kSchurHeavyThreads);
     hipLaunchKernelGGL((pcg_init_kernel<O>), gf, b, 0, st, a, sc);
-    int it = 0;
+    int it = 0, dir_applied = 0;   // dir_applied: the iteration whose direction update is already in the queue (iteration 0 needs none)
     auto enqueue = [&](int upto) {
         for (; it < upto; ++it) {
-            if (it > 0) hipLaunchKernelGGL((pcg_dir_kernel<O>), gf, b, 0, st, a, it);
+            if (it != dir_applied) hipLaunchKernelGGL((pcg_dir_kernel<O>), gf, b, 0, st, a, it);
             hipLaunchKernelGGL((pcg_lm_kernel<O>), glm, blm, 0, st, L, q3inv_.p, (const double *)a.p, (const PcgState *)a.st, xl_.p);
             hipLaunchKernelGGL((pcg_cam_kernel<O>), gc, b, 0, st, (int)n_, cam_ptr_.p, cam_lm_.p, cam_w_.p, (const double *)xl_.p, a);
             hipLaunchKernelGGL((pcg_upd_kernel<O>), gf, b, 0, st, a, it);
         }
-        hipLaunchKernelGGL((pcg_dir_kernel<O>), gf, b, 0, st, a, it);   // the convergence test of the last update (no-op once done); it is not advanced:
-                                                                       // a following batch repeats this launch as its first direction update
+        // the convergence test of the last update (no-op once done).  When the test fails the same launch IS the direction update of iteration
+        // `it`: a following batch must not repeat it (p = z + beta (z + beta p) is no conjugate direction -- ADVICE r5)
+        hipLaunchKernelGGL((pcg_dir_kernel<O>), gf, b, 0, st, a, it);
+        dir_applied = it;
     };
-    int target = std::min(pcg_max_iters_, std::max(4, pcg_last_iters_ + 2));
+    int target = std::min(pcg_max_iters_, std::max(4, pcg_last_iters_[kind] + 2));
     for (;;) {
         enqueue(target);
         check_launch("schur_pcg");
@@ -1072,7 +1099,7 @@ void SchurOp::pcg_solve(const SchurLm &L, const TcgScal *sc, hipStream_t st) {
         if (pcg_host_->done || target >= pcg_max_iters_) break;
         target = std::min(pcg_max_iters_, target + 8);
     }
-    if (pcg_host_->done && pcg_host_->iters > 0) pcg_last_iters_ = pcg_host_->iters;
+    if (pcg_host_->done && pcg_host_->iters > 0) pcg_last_iters_[kind] = pcg_host_->iters;
     pcg_last_relres_ = pcg_host_->relres;
     pcg_products_++;
     pcg_iters_total_ += pcg_host_->done ? pcg_host_->iters : target;

@@ -39,6 +39,7 @@ struct Settings {
     int debug_peer_mute = 0;              // tests: rank 1 never publishes its tCG epoch -> the peers' bounded wait must expire
     int exchange_lite = 1;                // 0 (xm_tuning_t.exchange_fence): the fused tCG exchange pushes with plain stores + a system-scope release fence instead of write-through stores
     bool schur_host_assembly = false, schur_trace = false;   // matrix-free storage (xm_schur.h: SchurSettings)
+    int schur_pcg_first = 0, schur_pcg_hess_digits = 0;   // CG form of the matrix-free storage (xm_schur.h: SchurSettings)
     int schur_solver = 0;                 // 0 by size | 1 dense inverse of the reduced camera Laplacian | 2 preconditioned CG inside the product
     int64_t schur_dense_max = 20000;
     static Settings resolve(const xm_tuning_t *t);

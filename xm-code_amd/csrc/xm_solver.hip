@@ -336,6 +336,7 @@ void Context::init(const xm_problem_t &prob_in) {
         SchurSettings sc;
         sc.host_assembly = cfg_.schur_host_assembly; sc.sym_min_rows = cfg_.sym_rows(1); sc.trace = cfg_.schur_trace;
         sc.solver = cfg_.schur_solver; sc.dense_max = cfg_.schur_dense_max;
+        sc.pcg_first = cfg_.schur_pcg_first; sc.pcg_hess_digits = cfg_.schur_pcg_hess_digits;
         schur_.reset(new SchurOp(n_, prob.n_landmarks, prob.nobs, prob.obs_cam, prob.obs_lm, prob.obs_p, prob.obs_w, st_, comm_.get(), sc));
         w_cur_.assign(prob.obs_w, prob.obs_w + prob.nobs);
     } else {
@@ -1309,6 +1310,8 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
 CertResult Context::certificate(int o, double primal, std::vector<double> &v_out) {
     CertResult cr;
     const auto t0 = clk::now();
+    int64_t pst0[3] = {0, 0, 0};
+    const int64_t pcg_unconverged_at_start = schur_info(pst0, nullptr) ? pst0[2] : 0;
     double *Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
     // Right-hand side pieces: C * sR  (checkeig.h:182 with the diagonal term folded into cert_prepare)
     launch_scale_rows(o, nloc_, R_.p, s_.p, Wloc, st_);
@@ -1343,7 +1346,16 @@ CertResult Context::certificate(int o, double primal, std::vector<double> &v_out
     log("Optimility gap: %g\n", gap);
     double bound = 1e-4;                                           // checkeig.h:349-358 (later branches unreachable)
     if (n_ > 2000) bound = 1e-3;
-    cr.accepted = !not_converged && (gap / primal < 1e-3 || theta > -bound);
+    // matrix-free storage: a product whose inner CG gave up is not the operator the certificate is about
+    int64_t pst[3] = {0, 0, 0};
+    const bool inexact = schur_info(pst, nullptr) && pst[2] > pcg_unconverged_at_start;
+    if (inexact) {
+        res_->cert_flags |= XM_CERT_INEXACT_OPERATOR;
+        log("warning: %lld matrix-free products of this certificate did not reach the inner tolerance: not accepted\n", (long long)(pst[2] - pcg_unconverged_at_start));
+    } else {
+        res_->cert_flags &= ~XM_CERT_INEXACT_OPERATOR;
+    }
+    cr.accepted = !not_converged && !inexact && (gap / primal < 1e-3 || theta > -bound);
     cr.min_eig = theta; cr.dual = dual; cr.gap = gap; cr.lanczos_iters = its;
     if (cr.accepted) log("BM finished with rank %d\n", o); else log("BM order plus one\n");
     res_->cert_seconds += secs_since(t0);

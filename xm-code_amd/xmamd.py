@@ -45,7 +45,8 @@ class Tuning(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("sym", "sym_min_rows", "sell", "sell_slabs", "sell_lmax", "sell_gather", "sell_codec", "overlap",
                                          "overlap_min_mb", "cert_dense_rows", "lanczos_mmax", "lanczos_restarts", "watchdog_s", "balance",
                                          "exchange", "split_k", "sell_wpad", "exchange_fence", "schur_host_assembly", "schur_trace",
-                                         "schur_solver", "schur_dense_max", "debug_drop_finalize", "debug_peer_mute")] + [("reserved", C.c_int32 * 4)]
+                                         "schur_solver", "schur_dense_max", "debug_drop_finalize", "debug_peer_mute", "schur_pcg_first",
+                                         "schur_pcg_hess_digits")] + [("reserved", C.c_int32 * 2)]
 
 
 class Problem(C.Structure):
