@@ -267,7 +267,7 @@ def cpu_kkt(Q, wl, budget_s, tl, gpu_sol, gpu_info):
                                       (budget_s, int(io["status"]), int(io.get("stop_reason", 0)), c_s)),
             "threads": xo.num_threads(), "rank": int(io["rank"]), "status": int(io["status"]), "tcg_iters": int(io["tcg_iters"]), "outer_iters": int(io["outer_iters"]),
             "primal": fo, "min_eig": float(io["cert"]["min_eig"]), "qw_products": int(io["qw_products"]),
-            "trust_region_s": float(io["seconds"]), "qw_s": float(io["qw_seconds"]), "certificate_and_rest_s": c_s - float(io["seconds"]),
+            "trust_region_s_total": float(io["seconds"]), "qw_s_total": float(io["qw_seconds"]), "certificates_and_rest_s": c_s - float(io["seconds"]),
             "eigen_step": "LAPACK dsyevd through scipy (xm_oracle.use_lapack_eig); trust region, multipliers, acceptance rule: oracle/xm_oracle.c",
             "gpu_wallclock_to_kkt_s": gpu_info["seconds_last_timed_solve"], "gpu_tcg_iters": gpu_info["tcg_iters"],
             "parity_vs_timed_gpu_solution": {"rotations_rel_fro": tl.rotation_parity(R, s, Ro, so), "gram_rel_fro": tl.rel_fro(tl.gram(R, s), tl.gram(Ro, so)),

@@ -401,9 +401,17 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
 
     // chunks that start at a step >= nt_step0 stream non-temporally (a matrix beyond the Infinity Cache keeps its top rows resident:
     // symv_nt_step0).  The policy is a compile-time property of the sweep loop (two copies under one wave-uniform branch, see qw_dense_kernel).
-    auto load_q = [&](int j, double2 (&q)[6][2], auto ntag) __attribute__((always_inline)) {
+    // W of the step's six rows travels with the step's Q: lane l requests element l of the 6 * OP contiguous doubles (one more request behind
+    // the twelve), and the multiply reads w_row out of that register with v_readlane.  Scalar loads at the point of use (round 5) were waited
+    // for one by one inside the step -- up to six exposed round trips to L2 per step at o = 4, where a row's four values are a load of their own.
+    const int64_t wlim = (int64_t)nrows * OP - 1;
+    auto load_q = [&](int j, double2 (&q)[6][2], double &wl, auto ntag) __attribute__((always_inline)) {
         constexpr bool NT = decltype(ntag)::value;
         const int64_t r0 = (int64_t)6 * j;
+        {
+            const int64_t wi = r0 * OP + (lane < 6 * OP ? lane : 0);
+            wl = W[wi < wlim ? wi : wlim];
+        }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int64_t rr = (r0 + r < nrows) ? r0 + r : nrows - 1;   // wave-uniform clamp (odd camera count: three rows of the last step)
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
             }
         }
     };
-    auto step = [&](int j, const double2 (&q)[6][2], auto masked) __attribute__((always_inline)) {
+    auto step = [&](int j, const double2 (&q)[6][2], const double wl, auto masked) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(masked)::value;
         const int64_t r0 = (int64_t)6 * j;
         double mr[2] = {1.0, 1.0}, mc[2] = {1.0, 1.0};
@@ -430,12 +438,11 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             double wr[O];
-            const bool ok = r0 + r < nrows;                              // wave-uniform: scalar loads, scalar select
-            const int64_t rw = ok ? r0 + r : nrows - 1;
+            const bool ok = r0 + r < nrows;                              // wave-uniform: scalar select
 #pragma unroll
             for (int k = 0; k < O; ++k) {
-                const double t = W[(size_t)rw * OP + k];
-                wr[k] = ok ? t : 0.0;
+                const int lo = __builtin_amdgcn_readlane(__double2loint(wl), r * OP + k), hi = __builtin_amdgcn_readlane(__double2hiint(wl), r * OP + k);
+                wr[k] = ok ? __hiloint2double(hi, lo) : 0.0;
             }
             double qr[2][2], qc[2][2];
 #pragma unroll
@@ -475,9 +482,9 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
         __builtin_amdgcn_wave_barrier();
     };
     int nrun = 0;
-    auto run = [&](int j, const double2 (&q)[6][2]) __attribute__((always_inline)) {
-        if (j < jfull) step(j, q, std::false_type{});
-        else step(j, q, std::true_type{});
+    auto run = [&](int j, const double2 (&q)[6][2], const double wl) __attribute__((always_inline)) {
+        if (j < jfull) step(j, q, wl, std::false_type{});
+        else step(j, q, wl, std::true_type{});
         if constexpr (TRACE) {
             if (lane == 0 && 2 + nrun < kSvTraceSlots - 3) tr[2 + nrun] = wall_clock64();
             ++nrun;
@@ -485,8 +492,9 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
     };
 
     double2 qA[6][2], qB[6][2];
+    double wA = 0.0, wB = 0.0;
     auto sweep = [&](auto ntag) __attribute__((always_inline)) -> bool {
-    if (jb < je) load_q(rev ? je - 1 : jb, qA, ntag);                // wave-uniform
+    if (jb < je) load_q(rev ? je - 1 : jb, qA, wA, ntag);                // wave-uniform
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -510,18 +518,18 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
     if (cnt > 0) {
         int i = 0;
         while (i + 2 < cnt) {          // two more steps follow: both requests below are unconditional
-            load_q(at(i + 1), qB, ntag);
-            run(at(i), qA);
-            load_q(at(i + 2), qA, ntag);
-            run(at(i + 1), qB);
+            load_q(at(i + 1), qB, wB, ntag);
+            run(at(i), qA, wA);
+            load_q(at(i + 2), qA, wA, ntag);
+            run(at(i + 1), qB, wB);
             i += 2;
         }
         if (i + 1 < cnt) {
-            load_q(at(i + 1), qB, ntag);
-            run(at(i), qA);
-            run(at(i + 1), qB);
+            load_q(at(i + 1), qB, wB, ntag);
+            run(at(i), qA, wA);
+            run(at(i + 1), qB, wB);
         } else {
-            run(at(i), qA);
+            run(at(i), qA, wA);
         }
     }
     return true;
