@@ -402,6 +402,7 @@ def main():
                          "With auto and --gpus N > 1 a second, RCCL-timed leg follows the default one (rccl_leg)")
     ap.add_argument("--no-rccl-leg", action="store_true", help="skip the second (RCCL) leg of a multi-GPU run")
     ap.add_argument("--sell", default="auto", choices=["auto", "on", "off"], help="sliced-ELL copy of block-sparse storage (xm_tuning_t.sell)")
+    ap.add_argument("--model-recurrence", action="store_true", help="xm_options_t.flags |= XM_FLAG_MODEL_RECURRENCE: the tCG keeps no accumulated H v (default off: last bits of the model value differ)")
     ap.add_argument("--sym-min-rows", type=int, default=0, help="rows (3n) from which an exactly symmetric dense Q is multiplied by the half-traffic "
                     "kernel (xm_tuning_t.sym_min_rows; 0 = the library's measured default)")
     args = ap.parse_args()
@@ -571,7 +572,10 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         if world > 1:
             dist.barrier()
 
+    mflag = xmamd.FLAG_MODEL_RECURRENCE if args.model_recurrence else 0
+
     def one_solve(flags=0, grouping=0):
+        flags |= mflag
         return ctx.solve(wl["max_rank"], wl["tol"], wl["lam"], flags=flags, retraction=retr, grouping=grouping)
 
     _PHASE[0] = "warm-up solves"
@@ -632,7 +636,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         "build": library_build_stamp(),
         "config": {"workload": wl["desc"], "n_cameras": n, "storage": storage_desc,
                    "max_rank": wl["max_rank"], "tol": wl["tol"], "lam": wl["lam"],
-                   "retraction": args.retraction,
+                   "retraction": args.retraction, **({"model_value": "from the CG recurrences (XM_FLAG_MODEL_RECURRENCE)"} if args.model_recurrence else {}),
                    "summation_groupings": "step i uses xm_options_t.sum_grouping = i mod 3; tcg_iters_by_step lists what each drew",
                    "parallelism": ("single GPU" if ngp == 1 else
                                    (f"camera row partition x{world}, one process per GPU, " +

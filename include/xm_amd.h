@@ -166,6 +166,10 @@ typedef struct {
 #define XM_FLAG_FIX_STALE_SR   2u   /* recompute sR after the escalation line search (reference does not, trustregion.h:394-422) */
 #define XM_FLAG_PROFILE_QW     4u   /* time every 8th Q*W launch with HIP events (result.qw_*) */
 #define XM_FLAG_HOST_STEPPED   8u   /* debugging: synchronise after every tCG iteration instead of run-ahead polling */
+#define XM_FLAG_MODEL_RECURRENCE 32u /* the model decrease of a truncated CG from its own recurrences (m -= step <r,r> - step^2 <p,Hp> / 2) instead of from the
+                                     * accumulated vectors v, Hv as the reference forms it (trustregion.h:605-610, 667-668): the tCG neither reads nor writes
+                                     * Hv (2 x 24 n o bytes per iteration -- it shows from ~50 k cameras on, where cg_step is bound by its bytes).  Equal in
+                                     * exact arithmetic; the last bits of the model value, hence possibly the path, differ: default OFF */
 #define XM_FLAG_WARM_R        16u   /* XM_MODE_REBUTTLE: start the rank-3 stage from opt.R_ini instead of the identity stack.  The reference
                                        reads R_ini.bin and then overwrites it with the identity (XM_main.cu:41,95-103); this flag honours it,
                                        which is what makes the second solve of the XM^2 loop cheap */

@@ -45,6 +45,7 @@ struct TcgScal {
     double delta;     // trust-region radius
     double gradnorm;  // sqrt(rdotr[0])                                     (trustregion.h:485)
     double last_step; // alpha or tau of the last iteration (diagnostics)
+    double model;     // XM_FLAG_MODEL_RECURRENCE: model value m(v) = <g,v> + <v,Hv>/2 by recurrence (m -= step * rr - step^2 <p,Hp> / 2); else 0
     int32_t status;   // 0 running | 1 negative curvature | 2 boundary | 3 norm tolerance | 5 rdotr<1e-15 | 6 max iterations | 7 a peer never arrived
                       // | 9 dormant: a speculatively enqueued tCG whose outer iteration did not go the predicted way (SpecCtl)
     int32_t iter;     // inner iteration index i (== completed iterations)

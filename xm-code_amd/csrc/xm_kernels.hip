@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         TcgScal sc;
-        sc.rr = rr; sc.vv = 0.0; sc.vp = 0.0; sc.pp = rr; sc.delta = delta; sc.gradnorm = sqrt(rr); sc.last_step = 0.0;
+        sc.rr = rr; sc.vv = 0.0; sc.vp = 0.0; sc.pp = rr; sc.delta = delta; sc.gradnorm = sqrt(rr); sc.last_step = 0.0; sc.model = 0.0;
         sc.status = 0; sc.iter = 0; sc.seq = seq; sc.pad_ = 0;
         *scal0 = sc;
         publish_host(hstat, pack_stat(seq, 0, 0));
@@ -1003,8 +1003,11 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
     const int camf = (int)(i / (3 * OP));
     const bool own0 = in0 && (i % (3 * OP) == 0);
     double hp = 0, pv = 0, vv0 = 0, hv = 0, rv = 0, Rv = 0, hs = 0, psv = 0, rsv = 0, sv = 1, vsv = 0, hvs = 0;
-    if (in0) { hp = HpR[i]; pv = pR[i]; vv0 = vR[i]; hv = HvR[i]; rv = rR[i]; Rv = R[i]; hs = Hps[camf]; psv = ps_cur[camf]; rsv = rs_cur[camf]; sv = s[camf]; }
-    if (own0) { vsv = vs[camf]; hvs = Hvs[camf]; }
+    // XM_FLAG_MODEL_RECURRENCE (HvR == nullptr): H v is not accumulated -- the model value travels in the scalar block instead (below): 2 x 3 n OP
+    // doubles less read and written per iteration (28.8 MB of the launch's 93 MB at 100 k cameras, o = 3)
+    const bool keep_hv = HvR != nullptr;
+    if (in0) { hp = HpR[i]; pv = pR[i]; vv0 = vR[i]; if (keep_hv) hv = HvR[i]; rv = rR[i]; Rv = R[i]; hs = Hps[camf]; psv = ps_cur[camf]; rsv = rs_cur[camf]; sv = s[camf]; }
+    if (own0) { vsv = vs[camf]; if (keep_hv) hvs = Hvs[camf]; }
     // ... and so are the first rounds of rank 0's partial sums (single GPU: all of them up to 512 workgroups): scalar block and partial sums
     // were written by the previous launches on other XCDs -- one memory round trip for both instead of two in a row
     // (not with the fused peer exchange: there the peers' chunks arrive DURING this launch)
@@ -1131,7 +1134,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
     double acc = 0.0;
     if (in0) {
         vR[i] = vv0 + step * pv;
-        HvR[i] = hv + step * hp;
+        if (keep_hv) HvR[i] = hv + step * hp;
         if (cg) {
             const double rn = rv + step * hp;
             const double rsn = rsv + step * hs;
@@ -1150,14 +1153,14 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
             }
             if (own0) { rs_next[camf] = rsn; const double q = rsn / sv; acc += q * q; }
         }
-        if (own0) { vs[camf] = vsv + step * psv; Hvs[camf] = hvs + step * hs; }
+        if (own0) { vs[camf] = vsv + step * psv; if (keep_hv) Hvs[camf] = hvs + step * hs; }
     }
     for (i += stride; i < total; i += stride) {
         const int cam = (int)(i / (3 * OP));
         const bool own = (i % (3 * OP) == 0);
         const double hpi = HpR[i], pi = pR[i], hsi = Hps[cam], psi = ps_cur[cam];
         vR[i] += step * pi;
-        HvR[i] += step * hpi;
+        if (keep_hv) HvR[i] += step * hpi;
         if (cg) {
             const double rn = rR[i] + step * hpi;
             const double rsn = rs_cur[cam] + step * hsi;
@@ -1176,7 +1179,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
             }
             if (own) { rs_next[cam] = rsn; const double q = rsn / s[cam]; acc += q * q; }
         }
-        if (own) { vs[cam] += step * psi; Hvs[cam] += step * hsi; }
+        if (own) { vs[cam] += step * psi; if (keep_hv) Hvs[cam] += step * hsi; }
     }
     if (Afull && newdir) {
         // Multi-rank tCG with ONE exchange per iteration.  The next product input is W+ = s.*p+ + ps+.*R with p+ = beta p - r+,
@@ -1202,6 +1205,10 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
     if (lead) {
         TcgScal nx = sc;
         nx.last_step = step;
+        // m(v + step p) - m(v) = step <p, r> + step^2 <p,Hp> / 2 with <p, r> = -<r, r> (CG: r is orthogonal to the previous direction), for the
+        // interior step (step = rr / <p,Hp>: -step rr / 2) and for the boundary / negative-curvature step alike (trustregion.h:605-610, 667-668
+        // compute the same number from the accumulated vectors)
+        if (!keep_hv) nx.model = sc.model - step * sc.rr + 0.5 * step * step * pHp;
         if (!cg) {
             nx.status = d.mode;
         } else {
@@ -1234,9 +1241,10 @@ __global__ __launch_bounds__(256) void outer_finalize_kernel(const double *__res
         f += sum_partials256(partsA + (size_t)r * 2 * nA_loc, nA_loc, sh, grp);
         rr += sum_partials256(partsA + (size_t)r * 2 * nA_loc + nA_loc, nA_loc, sh, grp);
     }
-    const double m = sum_partials256(partsM, nM, sh, grp);
+    const double m_vec = (nM > 0) ? sum_partials256(partsM, nM, sh, grp) : 0.0;
     if (threadIdx.x == 0) {
         const TcgScal sc = *scal;
+        const double m = (nM > 0) ? m_vec : sc.model;     // XM_FLAG_MODEL_RECURRENCE: no partial sums of the model were formed
         __hip_atomic_store(hres + 0, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(hres + 1, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(hres + 2, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2333,6 +2341,12 @@ void launch_retract_model(int o, int nloc, int cam0, const double *R, const doub
                           hipStream_t st, int polar) {
     const ModelArgs mv = {HvR, Hvs, rgR, rgs, parts};
     const dim3 g(retract_grid(nloc)), b(256);
+    if (HvR == nullptr) {   // XM_FLAG_MODEL_RECURRENCE: the model value is in the tCG's scalar block
+        if (polar) { XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 1, false>), g, b, 0, st, nloc, cam0, R, s, vR, vs, 1.0, Rout, sout, Wloc, Wpad, mv)); }
+        else { XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 0, false>), g, b, 0, st, nloc, cam0, R, s, vR, vs, 1.0, Rout, sout, Wloc, Wpad, mv)); }
+        check_launch("retract");
+        return;
+    }
     if (polar) { XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 1, true>), g, b, 0, st, nloc, cam0, R, s, vR, vs, 1.0, Rout, sout, Wloc, Wpad, mv)); }
     else { XM_DISPATCH_O(o, hipLaunchKernelGGL((retract_kernel<O_, 0, true>), g, b, 0, st, nloc, cam0, R, s, vR, vs, 1.0, Rout, sout, Wloc, Wpad, mv)); }
     check_launch("retract_model");

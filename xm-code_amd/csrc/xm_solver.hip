@@ -821,6 +821,7 @@ void Context::tcg_enqueue_iteration(int i, bool profile) {
     a.Bout = comm_->active() ? pcur + (size_t)rank * chunk : nullptr;
     const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
     if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
+    const bool model_rec = opt_ && (opt_->flags & XM_FLAG_MODEL_RECURRENCE);
     sym_rev_ = par;        // consecutive tCG iterations sweep the symmetric matrix in opposite directions (launch_qw_sym)
     product(EPI_HESS, o_, 2.0, a);
     sym_rev_ = 1;          // every other product (gradient, cost): bottom-up, the direction iteration 0 of a tCG does not use
@@ -828,7 +829,7 @@ void Context::tcg_enqueue_iteration(int i, bool profile) {
     hess_launches_++;
     if (lockstep) comm_->allgather(pcur, chunk, st_);
     launch_cg_step(o_, nloc_, scal_.p + par, scal_.p + (par ^ 1), pcur, nA_loc, nB_loc, comm_->world, HpR_.p, Hps_.p, R_.p,
-                   s_.p, pR_.p, par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, vR_.p, vs_.p, HvR_.p, Hvs_.p, rR_.p,
+                   s_.p, pR_.p, par ? psB_.p : psA_.p, par ? psA_.p : psB_.p, vR_.p, vs_.p, model_rec ? nullptr : HvR_.p, model_rec ? nullptr : Hvs_.p, rR_.p,
                    par ? rsB_.p : rs_.p, par ? rs_.p : rsB_.p, Wloc, pnext + (size_t)rank * chunk + b_off + 3 * nA_loc, hstat_dev_,
                    (int)b_off, (int64_t)mat, comm_->active() ? Afull_.p : nullptr, W_.p, grouping_, xchg_, st_, wpad());
 }
@@ -1039,9 +1040,10 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         // the step's model decrease comes out of the retraction launch (the anchor's scale part of the step is zero by construction, as in
         // the flat kernel this replaces); the quad-per-camera form of the retraction is a micro-benchmark alternative only
         const int nB_loc = retract_grid(nloc_);
-        launch_retract_model(o, nloc_, cam0_, R_.p, s_.p, vR_.p, vs_.p, Rc_.p, sc_.p, Wloc, wpad(), HvR_.p, Hvs_.p, P.rgR.p, P.rgs.p,
+        const bool model_rec = (opt_->flags & XM_FLAG_MODEL_RECURRENCE) != 0;   // the model value sits in the tCG's scalar block: no sums, no gather
+        launch_retract_model(o, nloc_, cam0_, R_.p, s_.p, vR_.p, vs_.p, Rc_.p, sc_.p, Wloc, wpad(), model_rec ? nullptr : HvR_.p, Hvs_.p, P.rgR.p, P.rgs.p,
                              partsM_.p + (size_t)comm_->rank * nB_loc, st_, retraction_ == XM_RETRACT_POLAR ? 1 : 0);
-        if (comm_->active()) comm_->allgather(partsM_.p, (size_t)nB_loc, st_);
+        if (comm_->active() && !model_rec) comm_->allgather(partsM_.p, (size_t)nB_loc, st_);
         gather_W();
         wpad_next_ = wpad();   // the gradient product below may gather from the padded copy the retraction has just written
         {
@@ -1061,7 +1063,7 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         const OuterArgs oa = {loss, delta, delta_bar, gradtol, shrink_count, (k + 1 >= kMaxOuter) ? 1 : 0};
         if (drop_at >= 0 && (long long)outer_seq_ + 1 == drop_at) ++outer_seq_;
         else
-        launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, nB_loc * comm_->world, scal_.p + (enq & 1),
+        launch_outer_finalize(partsA_.p, nA_loc, comm_->world, partsM_.p, model_rec ? 0 : nB_loc * comm_->world, scal_.p + (enq & 1),
                               reinterpret_cast<double *>(hstat_dev_) + 8, ++outer_seq_, grouping_, st_, spec ? &oa : nullptr, spec_.p);
         const int n_spec = spec ? enqueue_spec_tcg() : 0;
         volatile double *hres = wait_outer_result();

@@ -22,6 +22,7 @@ FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 CERT_EIG_NOT_CONVERGED = 1
 CERT_EIG_EXACT = 2           # small problem: the certificate's tridiagonalisation ran to completion (dense route)
 FLAG_WARM_R = 16
+FLAG_MODEL_RECURRENCE = 32     # model decrease of a tCG from its recurrences instead of from accumulated H v (xm_amd.h)
 
 EXPORTS = [
     "xm_last_error", "xm_version", "xm_abi_revision", "xm_solve", "xm_solve_rank3", "xm_solve_rebuttle", "xm_ctx_create", "xm_ctx_solve",
