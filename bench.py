@@ -660,7 +660,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                   "tcg_iters_by_step": [i["tcg_iters"] for i in infos], "exchange": last.get("exchange")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_kind": ("recorded" if traffic is not None else None),   # PMC passes are separate runs (gpurun / the guide): never measured inside this one
-                     "traffic_source": traffic_source, "traced_avg_launch_us": traced_us, "kernel": kname + ("; Q is exactly symmetric and has >= 5120 rows: the rank-3 / rank-4 stages multiply it through the half-traffic pair "
+                     "traffic_source": traffic_source, "traced_avg_launch_us": traced_us, "kernel": kname + ("; Q is exactly symmetric and has >= 4096 rows: the rank-3 / rank-4 stages multiply it through the half-traffic pair "
                                                 "qw_symv_kernel + symv_reduce_kernel<o, EPI_HESS> (one product = both launches, upper triangle streamed once), rank 5 through "
                                                 "qw_dense_kernel; achieved / frac count the FULL-storage bytes of SURVEY 8d per product, traffic is what the counters saw"
                                                 if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,

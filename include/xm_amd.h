@@ -87,7 +87,7 @@ typedef struct xm_ctx xm_ctx_t;
  * XM_COMM_PEER, XM_COMM_TRACE, XM_FORCE_COMM, XM_SHM_TIMEOUT, XM_SHM_ASYNC for the process-level communicator set-up of section 4). */
 typedef struct {
     int32_t sym;               /* half-traffic symmetric dense product: 0 auto (3n >= sym_min_rows, exactly symmetric Q), 1 force (1e-9 asymmetry accepted), -1 off */
-    int32_t sym_min_rows;      /* 0 = measured: 5120 on one GPU (also where the matrix-free storage starts applying its inverse with the symmetric kernel), 6144 for the multi-rank window */
+    int32_t sym_min_rows;      /* 0 = measured: 4096 on one GPU (also where the matrix-free storage starts applying its inverse with the symmetric kernel), 6144 for the multi-rank window */
     int32_t sell;              /* sliced-ELL copy of a block-sparse Q: 0 auto (by size, xm_solver.hip), 1 force, -1 off */
     int32_t sell_slabs;        /* 0 = 4 (1, 2, 4, 8) */
     int32_t sell_lmax;         /* 0 = 64 */

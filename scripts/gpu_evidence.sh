@@ -46,6 +46,12 @@ for leg in "venice1778:--steps 3 --warmup 1 --cpu-seconds 0 --no-hbm-check --no-
 done
 cd $R
 [ -n "$QUICK" ] && exit 0
+# the symmetric sweep: plan, alternation on / off, chunk lengths around the plan's, per-wavefront timestamps; sizes up to 13.5 GB
+(python scripts/kbench_symv.py 1778 --o 3 4 --alt 1 0 --k 0 4 6 8 --check --trace; for n in 1536 2048 2560 3072 4096 8192 13682; do python scripts/kbench_symv.py $n --o 3 4; done) > $O/${TAG}_kbench_symv.txt 2>&1
+# general kernel: alternating tile direction and load policy (all cacheable / all non-temporal / resident prefix) between one and five Infinity-Cache sizes
+(for n in 1778 2048 2560 3072 4096; do python scripts/kbench_dense.py $n 3 --alt 0 1 --nt -1 0 1 --no-sym; done; python scripts/kbench_dense.py 13682 3 --nt -1 1 --no-sym) > $O/${TAG}_kbench_dense_policy.txt 2>&1
+timeout 300 python scripts/stage_iters.py --gpu 2>&1 | grep -v amdgpu > $O/${TAG}_stage_iters.txt
+timeout 600 python bench.py --workload vg100k --storage vg --steps 6 --warmup 1 --no-rome --no-hbm-check --cpu-seconds 0 --model-recurrence 2>/dev/null | tail -1 > $O/${TAG}_bench_vg100k_vg_model_recurrence.json
 (python scripts/kbench_dense.py 1778 3 4 5 10; python scripts/kbench_dense.py 13682 3 4
  python scripts/kbench_bsr.py 13682 30 3 4 5
  python scripts/kbench_retract.py; python scripts/kbench_recover.py) > $O/${TAG}_kbench.txt 2>&1

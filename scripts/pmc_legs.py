@@ -15,7 +15,7 @@ LEGS = {
                "Hessian products of the headline solve: qw_symv_kernel + symv_reduce_kernel<o, EPI_HESS> at rank 3 / 4 (half-traffic symmetric pair; "
                "the main launch also serves the few gradient products), qw_dense_kernel<5, EPI_HESS> at rank 5"),
     "hbm13682": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-rome"],
-                 {"plain": ["qw_dense_kernel<3, 0, 2, true"]}, "roofline_hbm leg: qw_dense_kernel<3, EPI_PLAIN> on the 13.5 GB matrix (non-temporal stream)"),
+                 {"plain": ["qw_dense_kernel<3, 0, 2, false"]}, "roofline_hbm leg: qw_dense_kernel<3, EPI_PLAIN> on the 13.5 GB matrix (220 MB prefix cacheable, the rest a non-temporal stream)"),
     "rome_dense": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-hbm-check"],
                    {"main": ["qw_symv_kernel<3"], "reduce": ["symv_reduce_kernel<3, 2"]},
                    "rome_scale_dense leg: Hessian products of the 13.5 GB dense Q through the half-traffic symmetric path (main + reduce launch)"),

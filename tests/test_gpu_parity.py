@@ -697,7 +697,7 @@ def test_new_products_are_bit_reproducible(xmamd):
 
 
 def test_symmetry_check_decides_the_dense_path(xmamd):
-    """the half-traffic product reads the upper triangle only, so it is taken (3n >= 5120 rows on one GPU) for an EXACTLY symmetric Q alone: one
+    """the half-traffic product reads the upper triangle only, so it is taken (3n >= 4096 rows on one GPU) for an EXACTLY symmetric Q alone: one
     entry of the lower triangle off by 1e-9, or a NaN, and the general kernel runs (asym_kernel: tiled transposed compare, sticky NaN)"""
     rng = np.random.default_rng(5)
     n = 2100

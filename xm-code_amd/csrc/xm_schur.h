@@ -36,7 +36,7 @@ void rank1_sub_device(int n, double *A, const double *u, double q, hipStream_t s
 
 struct SchurSettings {          // from xm_tuning_t (Settings::resolve)
     bool host_assembly = false; // assemble the reduced camera Laplacian on the host (the reference's route, utils/creatematrix.py:137-260; tests)
-    int64_t sym_min_rows = 5120; // VT^-1 is applied with the half-traffic symmetric kernel from this many rows on
+    int64_t sym_min_rows = 4096; // VT^-1 is applied with the half-traffic symmetric kernel from this many rows on
     bool trace = false;         // set-up phase times on stderr (scripts/kbench_schur.py)
     int solver = 0;             // reduced camera system inside the product: 0 by size (dense inverse up to dense_max cameras, CG above) | 1 dense inverse | 2 preconditioned CG
     int64_t dense_max = 20000;  // (the dense inverse costs 8 (N-1)^2 bytes -- 3.2 GB here -- and an O(N^3) set-up; the CG form nothing but the observation lists)

@@ -978,7 +978,7 @@ void SchurOp::ensure(int o) {
         pcg_grid_ = flat_grid(std::max<int64_t>(n_ - 1, 1));
         pcg_parts_.alloc(((size_t)4 * pcg_grid_ + (size_t)qw_grid((int)n_)) * (size_t)o + 16);
     }
-    // VT^-1 is symmetric: from xm_tuning_t.sym_min_rows rows on (default 5120, the measured threshold of the dense solver) the chain applies it
+    // VT^-1 is symmetric: from xm_tuning_t.sym_min_rows rows on (default 4096, the measured threshold of the dense solver) the chain applies it
     // with the half-traffic kernel (upper triangle only; o = 3, 4)
     vt_sym_ = !pcg_ && 3 * nred_ >= cfg_.sym_min_rows;
     if (vt_sym_ && o >= 3) {

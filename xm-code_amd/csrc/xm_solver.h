@@ -17,11 +17,12 @@ namespace xm {
 struct Settings {
     int sym = 0;                 // 0 auto | 1 force | -1 off
     int64_t sym_min_rows = 0;    // 0 = the measured default: sym_rows()
-    // Rows (3n) from which an exactly symmetric dense Q goes through the half-traffic kernels.  One GPU: the two-launch symmetric product
-    // overtakes the general kernel between 1536 and 1778 cameras (profiles/r05_kbench_dense_sym_crossover.txt, us, general / symmetric:
-    // n = 1536 o = 3 26.6 / 27.7, o = 4 28.2 / 31.4; n = 1778 33.8 / 30.2, 34.9 / 34.2; n = 2048 49.0 / 41.8, 48.9 / 45.8) -> 5120 rows;
-    // in the Venice-1778 solve 230 -> 220 ms.  Several ranks (cyclic half window, xm_symw.h): measured at Final-13682 size only -> 6144.
-    int64_t sym_rows(int world) const { return sym_min_rows > 0 ? sym_min_rows : (world <= 1 ? 5120 : 6144); }
+    // Rows (3n) from which an exactly symmetric dense Q goes through the half-traffic kernels.  One GPU: the two-launch symmetric product ties
+    // with the general kernel at 1280 cameras and wins from there on (round 6, both with the alternating direction, us, general / symmetric:
+    // n = 1024 o = 3 14.1 / 13.9, o = 4 15.5 / 14.8; n = 1280 18.3 / 18.4, 20.8 / 19.8; n = 1536 24.1 / 20.7, 25.4 / 21.7; n = 1778 31.9 / 25.8,
+    // 33.2 / 27.2; n = 2048 44.4 / 33.0; profiles/r06_kbench_dense_sym_crossover.txt) -> 4096 rows (round 5: 5120, round 2: 6144).
+    // Several ranks (cyclic half window, xm_symw.h): measured at Final-13682 size only -> 6144.
+    int64_t sym_rows(int world) const { return sym_min_rows > 0 ? sym_min_rows : (world <= 1 ? 4096 : 6144); }
     int sell = 0;                // 0 auto | 1 force | -1 off
     int sell_slabs = 4, sell_lmax = 64, sell_gather = 1;   // sell_gather: the kernels' gather mode (0 a record of W per lane | 1 records fetched element-per-lane and transposed through LDS, the default)
     int sell_codec = 0;          // 0 auto | 1 full | 2 quaternion

@@ -342,8 +342,8 @@ void Context::init(const xm_problem_t &prob_in) {
     } else {
         throw Error(XM_ERR_ARG, "unknown storage");
     }
-    // Symmetric half-traffic product: dense, Q exactly symmetric.  It pays from ~1700 cameras on (Settings::sym_rows: measured cross-over;
-    // 13682 cameras 2017 -> 1147 us at o = 3, 1778 cameras 33.8 -> 30.2 us).  Settings.sym: auto = on for 3n >= sym_rows() and o <= 4; 1 forces
+    // Symmetric half-traffic product: dense, Q exactly symmetric.  It pays from ~1300 cameras on (Settings::sym_rows: measured cross-over;
+    // 13682 cameras 2000 -> 1110 us at o = 3, 1778 cameras 31.9 -> 25.8 us).  Settings.sym: auto = on for 3n >= sym_rows() and o <= 4; 1 forces
     // it for every size (o <= 5, 1e-9 relative asymmetry accepted); -1 disables it.  Single rank only: the kernel sweeps the upper
     // triangle of the WHOLE matrix (a rank's row strip is a rectangle).
     sym_ok_ = false;
