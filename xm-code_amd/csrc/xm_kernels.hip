@@ -1397,7 +1397,8 @@ __global__ __launch_bounds__(256) void retract_kernel(int nloc, int cam0, const 
             if (Wloc) Wloc[base + r * OP + k] = sn * q[r][k];
             if (Wpad) Wpad[(size_t)cam * 16 + r * OP + k] = sn * q[r][k];
         }
-        if (OP > O) { Rout[base + r * OP + O] = 0.0; if (Wloc) Wloc[base + r * OP + O] = 0.0; }
+        // the pad column of an even rank (pitch o + 1) is written too, in every copy: no kernel relies on another having zeroed it
+        if (OP > O) { Rout[base + r * OP + O] = 0.0; if (Wloc) Wloc[base + r * OP + O] = 0.0; if (Wpad) Wpad[(size_t)cam * 16 + r * OP + O] = 0.0; }
     }
 }
 

@@ -86,7 +86,7 @@ void Context::ensure_pinned(size_t doubles) {
 Context::Context(const xm_problem_t &prob, std::shared_ptr<Comm> comm) {
     comm_ = comm ? std::move(comm) : default_comm();
     cfg_ = Settings::resolve(prob.tuning);
-    if (!cfg_.exchange_lite) comm_->set_exchange_fence(true);
+    comm_->set_exchange_fence(!cfg_.exchange_lite);   // unconditionally: the communicator may be shared, the setting must not stick from an earlier context
     try {
         init(prob);
     } catch (...) {   // a later allocation failed (e.g. the 13.5 GB slab): release what the destructor would have released
@@ -1102,6 +1102,11 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         } else {
             trstatus = 3;  // keep point, state, loss and rr
         }
+        // Speculative launches that were not adopted found a dormant scalar block and returned at once: they are no products.
+        // Invariant for the ones that WERE adopted when the loop is left right after (time limit, |grad| < gradtol by a rounding of the sqrt): a live
+        // tcg_init + iteration from the new point may still be in the queue; they write only the tCG's own vectors (v, Hv, r, p, W and the
+        // padded copy), which every later user re-creates before reading (certificate and line search rebuild W; tcg_seq_ guards the progress word).
+        if (n_spec > 0 && adopted != n_spec && res_) res_->qw_products -= n_spec;
     }
     log("\nTotal iteration:     %lld\n", totalite);
     const double secs = secs_since(start);
