@@ -403,6 +403,9 @@ def main():
     ap.add_argument("--no-rccl-leg", action="store_true", help="skip the second (RCCL) leg of a multi-GPU run")
     ap.add_argument("--sell", default="auto", choices=["auto", "on", "off"], help="sliced-ELL copy of block-sparse storage (xm_tuning_t.sell)")
     ap.add_argument("--model-recurrence", action="store_true", help="xm_options_t.flags |= XM_FLAG_MODEL_RECURRENCE: the tCG keeps no accumulated H v (default off: last bits of the model value differ)")
+    ap.add_argument("--outer", default="device", choices=["device", "host"],
+                    help="outer iteration of the trust region: device = decided on the GPU, the host only enqueues a repeating pair of launches (the library's "
+                         "default on one GPU with dense / block-CSR products); host = xm_options_t.flags |= XM_FLAG_HOST_OUTER (the form of rounds 1-5)")
     ap.add_argument("--sym-min-rows", type=int, default=0, help="rows (3n) from which an exactly symmetric dense Q is multiplied by the half-traffic "
                     "kernel (xm_tuning_t.sym_min_rows; 0 = the library's measured default)")
     args = ap.parse_args()
@@ -572,7 +575,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         if world > 1:
             dist.barrier()
 
-    mflag = xmamd.FLAG_MODEL_RECURRENCE if args.model_recurrence else 0
+    mflag = (xmamd.FLAG_MODEL_RECURRENCE if args.model_recurrence else 0) | (xmamd.FLAG_HOST_OUTER if args.outer == "host" else 0)
 
     def one_solve(flags=0, grouping=0):
         flags |= mflag
@@ -636,7 +639,11 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         "build": library_build_stamp(),
         "config": {"workload": wl["desc"], "n_cameras": n, "storage": storage_desc,
                    "max_rank": wl["max_rank"], "tol": wl["tol"], "lam": wl["lam"],
-                   "retraction": args.retraction, **({"model_value": "from the CG recurrences (XM_FLAG_MODEL_RECURRENCE)"} if args.model_recurrence else {}),
+                   "retraction": args.retraction,
+                   "outer_iteration": ("on the device (outer_step_kernel: retraction, accept / reject, radius, stop tests and the next tCG's start decided by the GPU; "
+                                       "the host enqueues one repeating (product, step) pair of launches ahead)" if (args.outer == "device" and ngp == 1)
+                                      else "on the host (XM_FLAG_HOST_OUTER or several ranks)"),
+                   **({"model_value": "from the CG recurrences (XM_FLAG_MODEL_RECURRENCE)"} if args.model_recurrence else {}),
                    "summation_groupings": "step i uses xm_options_t.sum_grouping = i mod 3; tcg_iters_by_step lists what each drew",
                    "parallelism": ("single GPU" if ngp == 1 else
                                    (f"camera row partition x{world}, one process per GPU, " +
@@ -668,7 +675,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                      # what really moved, next to the contract's algorithmic figure: counter bytes per product / traced duration per product
                      "streamed": ({"bytes_per_product": traffic, "GBs": traffic / (traced_us * 1e-6) / 1e9, "frac": traffic / (traced_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                    "traced_frac_algorithmic": alg_bytes / (traced_us * 1e-6) / 1e9 / HBM_PEAK_GBS} if (traffic and traced_us) else None),
-                     "note": "HIP events around every 8th Hessian Q*W launch inside the timed solves (no-op samples dropped); " + (
+                     "note": "HIP events around every 32nd tCG Q*W launch inside the timed solves (no-op samples dropped); " + (
                              "per-rank Q is %.0f MB, inside the 256 MB Infinity Cache: the figure is cache-assisted, see roofline_hbm for the "
                              "HBM-bound run of the same kernel" % (alg_bytes / 1e6) if alg_bytes < 250e6 else
                              "per-rank Q is %.0f MB, beyond the 256 MB Infinity Cache: HBM-bound" % (alg_bytes / 1e6))},
@@ -682,10 +689,10 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         Pr = tl.gen_vg(wr["n"], deg=wr["deg"], sigma=wr["sigma"], seed=wr["seed"], dense=False)
         cr = xmamd.Context(bsr=(Pr["rowptr"], Pr["colidx"], Pr["blocks"]), **tkw)
         rome_kind = cr.product_kind(3)
-        cr.solve(wr["max_rank"], wr["tol"], wr["lam"])
+        cr.solve(wr["max_rank"], wr["tol"], wr["lam"], flags=mflag)
         barrier()
         t0 = time.perf_counter()
-        ri = [cr.solve(wr["max_rank"], wr["tol"], wr["lam"], flags=xmamd.FLAG_PROFILE_QW)[2] for _ in range(2)]
+        ri = [cr.solve(wr["max_rank"], wr["tol"], wr["lam"], flags=xmamd.FLAG_PROFILE_QW | mflag)[2] for _ in range(2)]
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         barrier()
@@ -714,7 +721,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
             cd.solve(wr["max_rank"], wr["tol"], wr["lam"], max_time=-1.0)   # warm-up: every rank level stops at its first time check (clocks, first-touch of the workspaces)
             barrier()
             t0 = time.perf_counter()
-            di = cd.solve(wr["max_rank"], wr["tol"], wr["lam"], flags=xmamd.FLAG_PROFILE_QW)[2]
+            di = cd.solve(wr["max_rank"], wr["tol"], wr["lam"], flags=xmamd.FLAG_PROFILE_QW | mflag)[2]
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             barrier()

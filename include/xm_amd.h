@@ -164,12 +164,20 @@ typedef struct {
 
 #define XM_FLAG_VERBOSE        1u   /* reference-style progress lines on stdout (trustregion.h:504, checkeig.h:317-337) */
 #define XM_FLAG_FIX_STALE_SR   2u   /* recompute sR after the escalation line search (reference does not, trustregion.h:394-422) */
-#define XM_FLAG_PROFILE_QW     4u   /* time every 8th Q*W launch with HIP events (result.qw_*) */
+#define XM_FLAG_PROFILE_QW     4u   /* time every 32nd tCG Q*W launch with HIP events (result.qw_*) */
 #define XM_FLAG_HOST_STEPPED   8u   /* debugging: synchronise after every tCG iteration instead of run-ahead polling */
 #define XM_FLAG_MODEL_RECURRENCE 32u /* the model decrease of a truncated CG from its own recurrences (m -= step <r,r> - step^2 <p,Hp> / 2) instead of from the
                                      * accumulated vectors v, Hv as the reference forms it (trustregion.h:605-610, 667-668): the tCG neither reads nor writes
                                      * Hv (2 x 24 n o bytes per iteration -- it shows from ~50 k cameras on, where cg_step is bound by its bytes).  Equal in
                                      * exact arithmetic; the last bits of the model value, hence possibly the path, differ: default OFF */
+#define XM_FLAG_HOST_OUTER    64u   /* keep the outer iteration of the trust region on the HOST (the form of rounds 1-5: the host notices the end of a truncated
+                                     * CG, enqueues retraction / candidate gradient / result kernel and confirms a speculatively started next tCG).  Default on
+                                     * one GPU with dense or block-CSR products (not: sliced ELL, matrix-free, several ranks, XM_FLAG_VERBOSE, XM_FLAG_HOST_STEPPED)
+                                     * is the DEVICE-driven form: everything trustregion.h:527-708 does between two truncated CGs (retraction, candidate's cost /
+                                     * gradient, accept / reject, radius, stop tests, start of the next tCG) is decided on the device, the host enqueues one
+                                     * repeating pair of launches ahead and watches a progress word.  Same decisions from the same numbers: bit-identical
+                                     * paths in block-CSR storage; the dense products alternate their sweep direction by launch pair instead of by tCG
+                                     * iteration, so dense paths differ in the last bits */
 #define XM_FLAG_WARM_R        16u   /* XM_MODE_REBUTTLE: start the rank-3 stage from opt.R_ini instead of the identity stack.  The reference
                                        reads R_ini.bin and then overwrites it with the identity (XM_main.cu:41,95-103); this flag honours it,
                                        which is what makes the second solve of the XM^2 loop cheap */
@@ -222,6 +230,9 @@ typedef struct {
     int32_t exchange;          /* multi-GPU tCG exchange used: 1 RCCL all-gather, 2 direct peer writes (0 single GPU) */
     int64_t qw_stream_bytes;   /* bytes of Q one tCG product actually streams (== the matrix part of qw_bytes unless a compressed or
                                   symmetric path is used) */
+    int32_t outer_on_device;   /* trust regions (rank levels) of this solve whose outer iteration was driven by the device (0: all by the host --
+                                  XM_FLAG_HOST_OUTER, or a configuration the device-driven form does not cover); appended in round 6 */
+    int32_t reserved_;
 } xm_result_t;
 #define XM_CERT_EIG_NOT_CONVERGED 1   /* Lanczos hit its iteration cap: min_eig is only an upper bound, the certificate was NOT accepted on it */
 #define XM_CERT_EIG_EXACT 2           /* small problem (3n <= cert_dense_rows, default 384): the Krylov space of S was EXHAUSTED (3n steps, or an

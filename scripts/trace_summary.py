@@ -34,3 +34,15 @@ tot = sum(v[1] for v in gaps.values())
 print(f"\nidle {tot / 1e6:.3f} ms = {tot / (t1 - t0):.3f} of the span, by the kernel that follows the gap:")
 for k, (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
     print(f"{t / 1e3:10.1f} us total {c:7d} gaps {t / c / 1e3:8.2f} us avg  {k}")
+
+# optional: a window of consecutive launches (python trace_summary.py trace.csv 0.7 --window N): offset from the first one, duration, gap to the previous end
+if "--window" in sys.argv:
+    n = int(sys.argv[sys.argv.index("--window") + 1])
+    mid = len(rows) // 2
+    w = rows[mid:mid + n]
+    base = int(w[0]["Start_Timestamp"]); pe = None
+    print(f"\n{n} consecutive launches from the middle of the window: start (us), duration (us), gap to the end of the previous launch (us; negative = overlap)")
+    for r in w:
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        print(f"{(st - base) / 1e3:10.2f} {(en - st) / 1e3:8.2f} {((st - pe) / 1e3 if pe is not None else 0.0):8.2f}  {r['Kernel_Name'][:70]}")
+        pe = en

@@ -34,6 +34,10 @@ constexpr int kColPad = 128;      // dense leading dimension is a multiple of th
 constexpr int kMaxRank = 10;      // template instantiations cover o = 1 and 3..10
 constexpr int kMaxInner = 1000;   // trustregion.h:416
 constexpr int kMaxOuter = 1000;   // trustregion.h:417
+// XM_FLAG_PROFILE_QW: every kProfileStride-th tCG product is bracketed by a pair of HIP events.  Each record is a barrier packet of its own: the
+// kernel trace shows ~6 us of idle queue in front of the product and again in front of the launch behind it (11.5 us per sample) -- with a
+// stride of 8 that was 1.4 us per tCG iteration, 3-5 % of the solve the measurement is about; 32 leaves 140 samples per headline solve
+constexpr int kProfileStride = 32;
 
 inline int64_t dense_ld(int64_t n_total) { return ((3 * n_total + kColPad - 1) / kColPad) * kColPad; }
 
@@ -50,8 +54,25 @@ struct TcgScal {
                       // | 9 dormant: a speculatively enqueued tCG whose outer iteration did not go the predicted way (SpecCtl)
     int32_t iter;     // inner iteration index i (== completed iterations)
     int32_t seq;      // which truncated-CG run of this context this is (travels in the host-mapped progress word: a word of an earlier run is stale)
+    int32_t phase;    // device-driven outer iteration only (Phase below); 0 in every other mode
+    // ---- device-driven outer iteration (Context::trust_region_device): the trust-region state of trustregion.h:416-718 travels with the
+    // block, so that the launch that ends a truncated CG can retract, the next product can take the candidate's gradient and the launch
+    // behind it can accept or reject, update the radius and start the next truncated CG -- without the host in between
+    double loss;          // f at the current point                                 (loss[k])
+    double rr_point;      // <rg, rg> at the current point                          (rdotr[0] of the truncated CG that starts there)
+    int64_t totalite;     // the reference's "Total iteration"
+    int32_t shrink_count; // consecutive radius shrinks                             (trustregion.h:683-694)
+    int32_t k;            // outer iteration index
+    int32_t stop_reason;  // 5 | 10 | 11 | 12 | 13 | 14 as Context::trust_region reports them; 0 while running
+    int32_t time_up;      // the host's time limit has expired (sticky; looked at where the reference looks at its clock: top of an outer iteration)
+    int32_t slots;        // (product, step) launch pairs that did work so far
     int32_t pad_;
 };
+// what a (product, step) pair of the device-driven outer iteration does, decided by the step launch before it
+enum Phase { PH_TCG = 0,    // product: Hessian product of tCG iteration `iter`; step: cg_step -- and, when that ends the tCG, the retraction of the step
+             PH_CAND = 1,   // product: cost / gradient at the candidate point; step: trust-region update, accept / reject, stop tests, start of the next tCG
+             PH_STOP = 2,   // the trust region has ended (stop_reason): both launches return at once
+             PH_INIT = 3 }; // first launch of a run: start the first tCG from the state the host uploaded (product launches return)
 
 // Hand-over between the end of an outer iteration and a SPECULATIVELY enqueued start of the next truncated CG (single GPU): outer_finalize_kernel
 // evaluates the trust-region update (trustregion.h:680-708) with the same formulas the host uses and, when the step is accepted and no stop test
@@ -110,9 +131,19 @@ struct CamArgs {
     int nt_cam0;          // dense product: cameras >= this stream their rows non-temporally (set by the launcher from the size rule, not by callers)
     int rev;              // dense product (unsplit): 1 = the column tiles are walked right to left.  Consecutive products alternate it so that a
                           // launch starts with the tiles the previous one ended with (still in the L2s / the Infinity Cache); see launch_qw_sym
+    // EPI_AUTO (device-driven outer iteration): the launch takes its role from scal->phase -- PH_TCG: Hessian epilogue with the fields above;
+    // PH_CAND: gradient epilogue at the CANDIDATE point, whose buffers are these (cand_args()); otherwise it returns
+    struct Cand { const double *R, *s; double *G, *egs, *S0, *rgR, *rgs, *partials; } cand;
 };
 
-enum Epilogue { EPI_PLAIN = 0, EPI_GRAD = 1, EPI_HESS = 2, EPI_CERT = 3 };
+enum Epilogue { EPI_PLAIN = 0, EPI_GRAD = 1, EPI_HESS = 2, EPI_CERT = 3, EPI_AUTO = 4 };
+// the arguments an EPI_AUTO launch works with in the gradient role
+__host__ __device__ inline CamArgs cand_args(const CamArgs &a) {
+    CamArgs b = a;
+    b.R = a.cand.R; b.s = a.cand.s; b.G = a.cand.G; b.egs = a.cand.egs; b.S0 = a.cand.S0; b.rgR = a.cand.rgR; b.rgs = a.cand.rgs;
+    b.partials = a.cand.partials;
+    return b;
+}
 
 // Direct peer-write exchange of the truncated CG (peer communicators, xm_comm.hip): device-visible description, by value into
 // cg_step_kernel.  world == 0: no exchange (single GPU, or a communicator that gathers between the launches).
@@ -128,6 +159,41 @@ struct PeerXchg {
     int mute = 0;                               // tests: this rank never publishes its epoch (a dead peer)
     int lite = 0;                               // 1: payload through write-through (system-scope) stores + s_waitcnt instead of a release fence
 };
+
+// Arguments of the step launch of the device-driven outer iteration (outer_step_kernel, xm_kernels.hip), by value.  Buffers with a "cur" and a
+// "next" flavour are the two parity copies of the truncated CG (the host passes them by the parity of the SLOT, the launch pair's index).
+struct PointPtrs { double *G, *egs, *S0, *rgR, *rgs; };
+struct OuterStepArgs {
+    int nloc, cam0;
+    const TcgScal *scal_cur;
+    TcgScal *scal_next;
+    const double *parts;     // this slot's tCG partial sums [<p,Hp> | <r,Hp> | <Hp,Hp> (nA each, Hessian epilogue) | |r|^2 of the previous step (nB)]
+    double *partsB_out;      // |r|^2 partial sums of this step, in the other parity's chunk
+    int nA, nB;
+    const double *HpR, *Hps;
+    double *R, *s;           // current point (overwritten with the candidate when it is accepted: the buffers keep their roles, nothing is swapped)
+    double *Rc, *sc;         // candidate point
+    double *pR;
+    const double *ps_cur;
+    double *ps_next;
+    double *vR, *vs, *HvR, *Hvs, *rR;   // HvR == nullptr: XM_FLAG_MODEL_RECURRENCE
+    const double *rs_cur;
+    double *rs_next;
+    double *Wloc, *Wpad;
+    PointPtrs cur, cand;     // what the gradient epilogue wrote for the current / the candidate point
+    const double *partsA;    // [f | <rg,rg>] partial sums of the candidate's gradient epilogue (nA each)
+    double *partsM;          // model-decrease partial sums of the retraction
+    int nM;
+    double delta_bar, gradtol;
+    int max_outer;
+    double *trace;           // device copy of the per-outer-iteration trace (6 doubles per record), record k written at the top of iteration k
+    int trace_cap;
+    const int *stop_req;     // device word the host sets when its time limit has expired
+    unsigned long long *hprog;   // host-mapped progress word [run : 32 | slots done : 24 | phase : 8]
+    unsigned int run;
+    int slot, grp;
+};
+void launch_outer_step(int o, int polar, const OuterStepArgs &A, int grid, hipStream_t st);
 
 // ---- launchers implemented in xm_kernels.hip -------------------------------------------------------------------
 // Q*W products.  grid = ceil(nloc / kQwWaves).  Q rows are the local cameras' rows; W has `ld` rows (all cameras).

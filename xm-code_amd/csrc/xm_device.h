@@ -130,6 +130,12 @@ __device__ __forceinline__ void sum_partials256_x4_pre(const double *p0, const d
     for (int k = 0; k < 4; ++k) out[k] = (sh16[k * 4] + sh16[k * 4 + 1]) + (sh16[k * 4 + 2] + sh16[k * 4 + 3]);
 }
 
+// From here on (the per-camera algebra of the epilogues) floating-point contraction is OFF: every product and every sum below is rounded
+// on its own, so an expression gives the same bits in EVERY kernel it is inlined into.  With hipcc's default (contract = fast) the back end
+// decides per kernel which multiply-add pairs become FMAs -- the cost f of a candidate point came out one ulp apart from the gradient
+// instantiation and from the role-switching instantiation (EPI_AUTO) of the same product kernel, enough to send two runs of the same solve
+// down different paths.  The streaming loops of the products keep the default; this is a few hundred flops per camera.
+#pragma clang fp contract(off)
 // ----------------------------------------------------------------------------------------------------------------
 // fused epilogues, column-distributed: after the wave reduction lane k (< O) owns column k of the camera's 3 x O
 // block; every 3-vector below is "that column".  Reductions over k are wave_sum()s with lanes >= O contributing 0,
@@ -185,13 +191,35 @@ struct EpiOps {
     double S0[9];
 };
 template <int O, int EPI>
-__device__ __forceinline__ void epi_prefetch(EpiOps &e, int cam, int lane, bool active, const CamArgs &a) {
+__device__ __forceinline__ void epi_prefetch(EpiOps &e, int cam, int lane, bool active, const CamArgs &a, int role = EPI) {
+    // EPI_AUTO: the role of this launch (EPI_HESS or EPI_GRAD) is run-time state, uniform over the grid; the gradient role works on the CANDIDATE
+    // point's buffers (CamArgs.cand).  The kernel argument block itself is never copied or modified: only the fields a role uses are read, where it uses them
     if (!active) return;
-    if (EPI == EPI_GRAD) {
+    if (EPI == EPI_AUTO) {
+        const bool grad = (role == EPI_GRAD);
+        const double *Rp = grad ? a.cand.R : a.R, *sp = grad ? a.cand.s : a.s;   // both roles want the point they work at
+        e.s = sp[cam];
+        e.R = load_col<O>(Rp, cam, lane);
+        if (grad) {
+            e.Wl = load_col<O>(a.Wloc, cam, lane);
+        } else {
+            e.ps = a.ps[cam];
+            e.egs = a.egs[cam];
+            e.P = load_col<O>(a.pR, cam, lane);
+            e.G = load_col<O>(a.G, cam, lane);
+            e.Rr = load_col<O>(a.rR, cam, lane);
+            e.rs = a.rs[cam];
+            const double *s0 = a.S0 + (size_t)cam * 9;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) e.S0[j] = s0[j];
+        }
+        return;
+    }
+    if (role == EPI_GRAD) {
         e.s = a.s[cam];
         e.R = load_col<O>(a.R, cam, lane);
         e.Wl = load_col<O>(a.Wloc, cam, lane);
-    } else if (EPI == EPI_HESS) {
+    } else if (role == EPI_HESS) {
         e.s = a.s[cam];
         e.ps = a.ps[cam];
         e.egs = a.egs[cam];
@@ -208,13 +236,15 @@ __device__ __forceinline__ void epi_prefetch(EpiOps &e, int cam, int lane, bool 
 
 // Gradient / point-state epilogue: trustregion.h:186-194 (grad), :307-317 (projection), :162-170 (objc) fused.
 // h = 2*C*sR rows.  Produces G, egs, S0, rg and this camera's share of {f, <rg,rg>_metric} (uniform on return).
+// (the output buffers are explicit arguments: the role-switching instantiation writes the candidate's, a.cand.*, without copying the argument block)
+struct GradOut { double *G, *egs, *S0, *rgR, *rgs; };
 template <int O, int GW>
-__device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const EpiOps &e, const CamArgs &a, double &p0, double &p1) {
+__device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const EpiOps &e, const CamArgs &a, const GradOut &o, double &p0, double &p1) {
     const bool anchor = (a.cam0 + cam) == 0;
     const double s = e.s;
     const Col3 &R = e.R;
     const Col3 &Wl = e.Wl;
-    store_col<O>(h, a.G, cam, lane);
+    store_col<O>(h, o.G, cam, lane);
     // f = <C sR, sR> + lam * sum_{i>=1} (s_i^2-1)^2 ;  <C sR, sR> = 0.5 * <G, sR>
     const double q = s * s - 1.0;
     const double hW = group_sum<GW>(dot3(h, Wl));
@@ -228,15 +258,15 @@ __device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const
     sym_abt<GW>(R, eg, S0);
     sub_s_times(eg, S0, R);  // eg is now the Riemannian gradient column
     const double rgs = egs * (s * s);
-    store_col<O>(eg, a.rgR, cam, lane);
+    store_col<O>(eg, o.rgR, cam, lane);
     if (lane == 0) {
-        double *so = a.S0 + (size_t)cam * 9;
+        double *so = o.S0 + (size_t)cam * 9;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) so[r * 3 + c] = S0[r][c];
-        a.egs[cam] = egs;
-        a.rgs[cam] = rgs;
+        o.egs[cam] = egs;
+        o.rgs[cam] = rgs;
     }
     const double rsds = rgs / s;
     p1 = group_sum<GW>(dot3(eg, eg)) + rsds * rsds;
@@ -291,7 +321,7 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
 // ----------------------------------------------------------------------------------------------------------------
 // tail shared by every product kernel: h = this camera's 3 x O block of alpha * Q * W, column k in lane k of the camera's lane group
 template <int O, int EPI, int GW, int NSLOT>
-__device__ __forceinline__ void qw_tail(int cam, int lane, int slot, bool active, Col3 h, const CamArgs &a, const EpiOps &e, double (*red)[3]) {
+__device__ __forceinline__ void qw_tail(int cam, int lane, int slot, bool active, Col3 h, const CamArgs &a, const EpiOps &e, double (*red)[3], int role = EPI) {
     // `lane` = position inside the camera's lane group (0..GW-1), `slot` = index of that group inside the workgroup
     constexpr int OP = pitch_of(O);
     double p0 = 0.0, p1 = 0.0, p2 = 0.0;
@@ -299,9 +329,13 @@ __device__ __forceinline__ void qw_tail(int cam, int lane, int slot, bool active
         if (EPI == EPI_PLAIN) {
             store_col<O>(h, a.out, cam, lane);
         } else if (EPI == EPI_GRAD) {
-            epi_grad<O, GW>(cam, lane, h, e, a, p0, p1);
+            const GradOut go = {a.G, a.egs, a.S0, a.rgR, a.rgs};
+            epi_grad<O, GW>(cam, lane, h, e, a, go, p0, p1);
         } else if (EPI == EPI_HESS) {
             epi_hess<O, GW>(cam, lane, h, e, a, p0, p1, p2);
+        } else if (EPI == EPI_AUTO) {
+            if (role == EPI_GRAD) { const GradOut go = {a.cand.G, a.cand.egs, a.cand.S0, a.cand.rgR, a.cand.rgs}; epi_grad<O, GW>(cam, lane, h, e, a, go, p0, p1); }
+            else epi_hess<O, GW>(cam, lane, h, e, a, p0, p1, p2);
         } else if (EPI == EPI_CERT) {
             // y_i = (Q x)_i + dz_i * x[3i] e_0 - Lam_i x_i      (O == 1, lane 0 owns the column)
             const double *x = a.Wloc + (size_t)cam * 3 * OP;
@@ -313,16 +347,17 @@ __device__ __forceinline__ void qw_tail(int cam, int lane, int slot, bool active
             store_col<O>(h, a.out, cam, lane);
         }
     }
-    if (EPI == EPI_GRAD || EPI == EPI_HESS) {
+    if (EPI == EPI_GRAD || EPI == EPI_HESS || EPI == EPI_AUTO) {
         if (lane == 0) { red[slot][0] = p0; red[slot][1] = p1; red[slot][2] = p2; }
         __syncthreads();
         if (threadIdx.x == 0) {
             double t0 = 0.0, t1 = 0.0, t2 = 0.0;
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) { t0 += red[q][0]; t1 += red[q][1]; t2 += red[q][2]; }
-            a.partials[blockIdx.x] = t0;
-            a.partials[gridDim.x + blockIdx.x] = t1;
-            if (EPI == EPI_HESS) a.partials[2 * gridDim.x + blockIdx.x] = t2;
+            double *parts = (EPI == EPI_AUTO && role == EPI_GRAD) ? a.cand.partials : a.partials;
+            parts[blockIdx.x] = t0;
+            parts[gridDim.x + blockIdx.x] = t1;
+            if (EPI == EPI_HESS || (EPI == EPI_AUTO && role == EPI_HESS)) parts[2 * gridDim.x + blockIdx.x] = t2;
         }
     }
 }
@@ -332,17 +367,20 @@ __device__ __forceinline__ void qw_tail(int cam, int lane, int slot, bool active
 // ----------------------------------------------------------------------------------------------------------------
 template <int O, int EPI, int GW, int NSLOT>
 __device__ __forceinline__ void qw_finish(int cam, int lane, int slot, bool active, double (&acc)[3][O], double alpha,
-                                          const CamArgs &a, const EpiOps &e, double (*red)[3]) {
-    Col3 h;
-    h.v[0] = h.v[1] = h.v[2] = 0.0;
+                                          const CamArgs &a, const EpiOps &e, double (*red)[3], int role = EPI) {
+    double hv[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < O; ++k) {
             const double t = alpha * group_sum<GW>(acc[r][k]);
-            if (lane == k) h.v[r] = t;
+            hv[r] = (lane == k) ? t : hv[r];
         }
-    qw_tail<O, EPI, GW, NSLOT>(cam, lane, slot, active, h, a, e, red);
+    Col3 h;
+    h.v[0] = hv[0]; h.v[1] = hv[1]; h.v[2] = hv[2];
+    qw_tail<O, EPI, GW, NSLOT>(cam, lane, slot, active, h, a, e, red, (EPI == EPI_AUTO) ? role : (int)EPI);
 }
+
+#pragma clang fp contract(fast)   // (the including translation unit's streaming loops keep the compiler's default)
 
 }  // namespace xm

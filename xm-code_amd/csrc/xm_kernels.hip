@@ -50,6 +50,7 @@ template <int O, int EPI, int NSUB, bool SPLIT = false>
 __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict__ Q, int64_t ld,
                                                         const double *__restrict__ W, double alpha, CamArgs a) {
     constexpr int OP = pitch_of(O);
+    int role = EPI;   // EPI_AUTO: EPI_HESS or EPI_GRAD, from the phase of the device-driven outer iteration
     constexpr int TILE = NSUB * 128;                 // columns per tile
     constexpr int TILE2 = TILE * OP / 2;             // double2 elements of one W tile
     constexpr int NST = (TILE2 + 255) / 256;         // staging registers (double2) per thread
@@ -146,6 +147,11 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
         // in flight, so that a live launch does not start with an exposed dependent load (uniform over the grid).
         if (a.scal->status != 0) return false;
     }
+    if (EPI == EPI_AUTO) {   // device-driven outer iteration: Hessian product of the running tCG, or cost / gradient at the candidate point
+        const int ph = a.scal->phase;
+        if (ph >= PH_STOP) return false;
+        role = (ph == PH_CAND) ? EPI_GRAD : EPI_HESS;
+    }
     store_w(0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
             load_q(tile_at(t + 1), ntag);
             load_w(tile_at(t + 1));
         } else {
-            epi_prefetch<O, EPI>(eops, cam, lane, active, a);
+            epi_prefetch<O, EPI>(eops, cam, lane, active, a, (EPI == EPI_AUTO) ? role : (int)EPI);
         }
         const double2 *wbase = reinterpret_cast<const double2 *>(wt[t & 1]);
 #pragma unroll
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
     };
     const bool alive = nt ? stream(std::true_type{}) : stream(std::false_type{});
     if (!alive) return;
-    qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red);
+    qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red, (EPI == EPI_AUTO) ? role : (int)EPI);
 }
 
 // Column-split variant for SMALL ROW STRIPS (a rank of a multi-GPU run: Venice-1778 over 8 GPUs leaves 223 cameras = 56 workgroups for
@@ -352,7 +358,7 @@ constexpr int kSvTraceSlots = 24;
 template <int O, bool TRACE = false>
 __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__ Q, int64_t ld, const double *__restrict__ W, int nloc, int Kc, int Kf, int ysplit, int nt_step0,
                                                         const TcgScal *__restrict__ scal, double *__restrict__ Prow,
-                                                        double *__restrict__ Pcol, unsigned long long *__restrict__ trace, int rev) {
+                                                        double *__restrict__ Pcol, unsigned long long *__restrict__ trace, int rev, int by_phase) {
     constexpr int OP = pitch_of(O), V = 6 * O;
     __shared__ __attribute__((aligned(16))) double lds[4][V * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -507,8 +513,8 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
             }
     // the tCG's status word (written by the previous launch on another XCD: an L2 miss) is looked at only now, with the columns of W and the
     // first step of Q already requested: one round trip at the head of every wavefront instead of two
-    if (scal != nullptr) {
-        if (scal->status != 0) return false;
+    if (scal != nullptr) {   // by_phase (device-driven outer iteration): live in the phases PH_TCG and PH_CAND, whatever the tCG's status says
+        if (by_phase ? (scal->phase >= PH_STOP) : (scal->status != 0)) return false;
     }
     if constexpr (TRACE) { if (lane == 0) tr[1] = wall_clock64(); }
     // rev: the chunk is walked bottom-up (position i <-> step je - 1 - i).  Launches alternate the direction, so that a launch starts with
@@ -571,6 +577,7 @@ __global__ __launch_bounds__(256) void qw_symv_kernel(const double *__restrict__
 template <int O, int EPI>
 __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t ld,
                                                            int nstrips, int Kc, int Kf, int ysplit, double alpha, CamArgs a) {
+    int role = (EPI == EPI_AUTO) ? (int)EPI_HESS : EPI;   // (see qw_dense_kernel)
     constexpr int NE = 3 * O;          // elements of a record (<= 15)
     static_assert(NE <= 16, "a record must fit a 16-lane group");
     __shared__ double red[kQwWaves][3];
@@ -578,7 +585,9 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restri
     const int cam = blockIdx.x * kQwWaves + wave;
     const bool active = cam < a.nloc;
     EpiOps eops;
-    epi_prefetch<O, EPI>(eops, cam, lane, active, a);
+    // EPI_AUTO: the Hessian role's operands are requested up front like everybody's (most launches of a solve are Hessian products); a launch
+    // that finds itself in the gradient role asks again below
+    epi_prefetch<O, EPI == EPI_AUTO ? EPI_HESS : EPI>(eops, cam, lane, active, a);
     const int e = lane & 15, g = lane >> 4;
     const bool eok = e < NE;
     const int camc = active ? cam : 0;
@@ -608,6 +617,11 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restri
     if (EPI == EPI_HESS) {
         if (a.scal->status != 0) return;
     }
+    if (EPI == EPI_AUTO) {
+        const int ph = a.scal->phase;
+        if (ph >= PH_STOP) return;
+        if (ph == PH_CAND) { role = EPI_GRAD; epi_prefetch<O, EPI>(eops, cam, lane, active, a, (EPI == EPI_AUTO) ? role : (int)EPI); }
+    }
     double acc = 0.0;
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc += (eok && 4 * t + g < tot_l) ? v[t] : 0.0;
@@ -626,7 +640,7 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restri
         const double t = __shfl(acc, (lane < O) ? r * O + lane : 0);
         h.v[r] = (active && lane < O) ? alpha * t : 0.0;
     }
-    qw_tail<O, EPI, 64, kQwWaves>(cam, lane, wave, active, h, a, eops, red);
+    qw_tail<O, EPI, 64, kQwWaves>(cam, lane, wave, active, h, a, eops, red, (EPI == EPI_AUTO) ? role : (int)EPI);
 }
 
 // max |Q[r][c] - Q[c][r]| and max |Q| over the device layout (decides whether the symmetric path may be used).  Tile pairs (ti <= tj)
@@ -689,6 +703,7 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
                                                        const double *__restrict__ blocks, const double *__restrict__ W,
                                                        double alpha, CamArgs a) {
     constexpr int OP = pitch_of(O);
+    int role = EPI;   // (see qw_dense_kernel)
     constexpr int REC = 3 * OP;                                   // doubles of one camera's rows of W
     constexpr int SW = (VAR == 2 && REC > 9) ? REC : 9;           // LDS doubles per lane (blocks and W share the window)
     __shared__ double red[kBsrRows][3];
@@ -706,6 +721,11 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     if (active) { b0 = rowptr[cam]; b1 = rowptr[cam + 1]; }
     if (EPI == EPI_HESS) {   // the tCG's status word (written by the previous cg_step on another XCD: an L2 miss) travels WITH the row pointers:
         if (a.scal->status != 0) return;   // the dependent chain of this latency-bound kernel is one round trip shorter
+    }
+    if (EPI == EPI_AUTO) {
+        const int ph = a.scal->phase;
+        if (ph >= PH_STOP) return;
+        role = (ph == PH_CAND) ? EPI_GRAD : EPI_HESS;
     }
     // the four groups of a wavefront loop together (wave-level trip count = the longest of their rows)
     int64_t span = b1 - b0;
@@ -864,8 +884,8 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     // regime (13 682 cameras, 856 workgroups): requested up front they save a round trip but drop the kernel from three to two wavefronts per
     // SIMD, 22.5 against 20.3 us per Hessian product and 31.3 against 28.8 ms per solve on one box (profiles/r05_ab_rome.txt, lib_x)
     EpiOps eops;
-    epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a);
-    qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red);
+    epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a, (EPI == EPI_AUTO) ? role : (int)EPI);
+    qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red, (EPI == EPI_AUTO) ? role : (int)EPI);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -904,6 +924,9 @@ __global__ void dense_from_bsr_kernel(const int64_t *__restrict__ rowptr, const 
 // ----------------------------------------------------------------------------------------------------------------
 // flat kernels (grid-stride over the nloc*3*OP elements; the row -> camera map is idx / (3*OP))
 // ----------------------------------------------------------------------------------------------------------------
+// (floating-point contraction stays off through the truncated-CG, trust-region and retraction kernels -- see xm_device.h: the host-driven
+// kernels and the device-driven outer iteration evaluate the same expressions in different kernels and must get the same bits)
+#pragma clang fp contract(off)
 __device__ __forceinline__ unsigned long long pack_stat(int seq, int iter, int status) {   // [seq : 32 | iter : 24 | status : 8]
     return ((unsigned long long)(unsigned)seq << 32) | ((unsigned long long)((unsigned)iter & 0xffffffu) << 8) | (unsigned long long)(unsigned)(status & 0xff);
 }
@@ -966,9 +989,9 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
         if (i % (3 * OP) == 0) { rs[cam] = gs; ps[cam] = -gs; vs[cam] = 0.0; Hvs[cam] = 0.0; }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        TcgScal sc;
+        TcgScal sc = {};
         sc.rr = rr; sc.vv = 0.0; sc.vp = 0.0; sc.pp = rr; sc.delta = delta; sc.gradnorm = sqrt(rr); sc.last_step = 0.0; sc.model = 0.0;
-        sc.status = 0; sc.iter = 0; sc.seq = seq; sc.pad_ = 0;
+        sc.status = 0; sc.iter = 0; sc.seq = seq;
         *scal0 = sc;
         publish_host(hstat, pack_stat(seq, 0, 0));
     }
@@ -1330,6 +1353,32 @@ __device__ __forceinline__ void polar_rows(double (&X)[3][O]) {
     }
 }
 
+// the rows of one camera's 3 x O block back onto the manifold: modified Gram-Schmidt (Dense/batchedQR.h:42-67) or the polar factor
+template <int O, int POLAR>
+__device__ __forceinline__ void retract_rows(double (&q)[3][O]) {
+    if constexpr (POLAR) {
+        polar_rows<O>(q);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double qq = 0.0;
+#pragma unroll
+            for (int k = 0; k < O; ++k) qq += q[i][k] * q[i][k];
+            qq = sqrt(qq);
+#pragma unroll
+            for (int k = 0; k < O; ++k) q[i][k] /= qq;
+#pragma unroll
+            for (int j = i + 1; j < 3; ++j) {
+                double uu = 0.0;
+#pragma unroll
+                for (int k = 0; k < O; ++k) uu += q[i][k] * q[j][k];
+#pragma unroll
+                for (int k = 0; k < O; ++k) q[j][k] -= uu * q[i][k];
+            }
+        }
+    }
+}
+
 // MV: the same launch also delivers the model decrease of the step D = v it retracts, m = <v,Hv>/2 + <v,rg> in the product metric
 // (trustregion.h:667-668): this camera's share, summed per workgroup into mv.parts[blockIdx.x] (fixed order: threads, then the DPP tree).
 // The step is in registers anyway; a launch of its own (model_value_kernel: 4.5-8 us per outer iteration) reads it a second time.
@@ -1365,27 +1414,7 @@ __global__ __launch_bounds__(256) void retract_kernel(int nloc, int cam0, const 
         if (threadIdx.x == 0) mv.parts[blockIdx.x] = tot;
         if (!live) return;
     }
-    if constexpr (POLAR) {
-        polar_rows<O>(q);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double qq = 0.0;
-#pragma unroll
-            for (int k = 0; k < O; ++k) qq += q[i][k] * q[i][k];
-            qq = sqrt(qq);
-#pragma unroll
-            for (int k = 0; k < O; ++k) q[i][k] /= qq;
-#pragma unroll
-            for (int j = i + 1; j < 3; ++j) {
-                double uu = 0.0;
-#pragma unroll
-                for (int k = 0; k < O; ++k) uu += q[i][k] * q[j][k];
-#pragma unroll
-                for (int k = 0; k < O; ++k) q[j][k] -= uu * q[i][k];
-            }
-        }
-    }
+    retract_rows<O, POLAR>(q);
     const double so = s[cam];
     const double sn = ((cam0 + cam) == 0 || ds == nullptr) ? so : so * exp(t * ds[cam] / so);
     if (sout) sout[cam] = sn;
@@ -1399,6 +1428,317 @@ __global__ __launch_bounds__(256) void retract_kernel(int nloc, int cam0, const 
         }
         // the pad column of an even rank (pitch o + 1) is written too, in every copy: no kernel relies on another having zeroed it
         if (OP > O) { Rout[base + r * OP + O] = 0.0; if (Wloc) Wloc[base + r * OP + O] = 0.0; if (Wpad) Wpad[(size_t)cam * 16 + r * OP + O] = 0.0; }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Device-driven outer iteration (Context::trust_region_device): the step launch of a (product, step) pair.
+// The host enqueues the SAME two launches over and over, several pairs ahead, and only watches a progress word; what a pair does is decided
+// on the device (TcgScal.phase):
+//   PH_TCG   product = Hessian product of tCG iteration i (EPI_AUTO in the Hessian role); this launch = cg_step_kernel's arithmetic, and when
+//            that iteration ENDS the truncated CG (trustregion.h:572-600, 627, 664) the retraction of the step and its model decrease
+//            (:667-678) follow in the same launch, per camera, from v + step p still in registers  -> PH_CAND
+//   PH_CAND  product = cost / gradient at the candidate (EPI_AUTO in the gradient role); this launch = the trust-region update of
+//            trustregion.h:680-708 evaluated by every workgroup from the same partial sums (the formulas of Context::trust_region),
+//            the candidate copied over the current point when it is accepted, the stop tests of the next iteration's top (:527-543), and
+//            tcg_init_kernel's work for the next truncated CG                                       -> PH_TCG or PH_STOP
+// No launch is ever a run-ahead no-op, nothing waits for the host between an outer iteration's pieces (round 5: the host noticed the end
+// of a tCG, enqueued retraction / product / result kernel and confirmed a speculative start: 16 % of the span idle at Final-13682 size in
+// block CSR, and two to four no-op launches per outer iteration).  Every sum keeps the order the host-driven kernels use.
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long pack_prog(unsigned int run, int slots, int phase) {
+    return ((unsigned long long)run << 32) | ((unsigned long long)((unsigned)slots & 0xffffffu) << 8) | (unsigned long long)(unsigned)(phase & 0xff);
+}
+// two sums of `count` partials and one of `count3` partials, each in the order of sum_partials256 -- where entry i of the third list is itself
+// (w[4i] + w[4i+1]) + (w[4i+2] + w[4i+3]) of per-wavefront partials w[0 .. nw) (absent ones count 0): what block_sum256 makes of four wavefronts
+__device__ __forceinline__ void sum_partials256_x4q(const double *p0, const double *p1, int count, const double *w, int count3, int nw, double *sh16,
+                                                    double (&out)[4], int grp) {
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < count; i += 256) { const int j = sum_perm(i, count, grp); v[0] += p0[j]; v[1] += p1[j]; }
+    for (int i = threadIdx.x; i < count3; i += 256) {
+        const int j = 4 * sum_perm(i, count3, grp);
+        const double a = w[j], b = (j + 1 < nw) ? w[j + 1] : 0.0, c = (j + 2 < nw) ? w[j + 2] : 0.0, d = (j + 3 < nw) ? w[j + 3] : 0.0;
+        v[3] += (a + b) + (c + d);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh16[k * 4 + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (sh16[k * 4] + sh16[k * 4 + 1]) + (sh16[k * 4 + 2] + sh16[k * 4 + 3]);
+}
+
+template <int O>
+__device__ __forceinline__ void outer_decide(const OuterStepArgs &A, const TcgScal &sc0, bool lead, int time_up, double *sh16) {
+    constexpr int OP = pitch_of(O);
+    const int64_t total = (int64_t)A.nloc * 3 * OP;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    double loss = sc0.loss, rr = sc0.rr_point, delta = sc0.delta;
+    int shrink = sc0.shrink_count, k = sc0.k, stop = 0;
+    long long totalite = sc0.totalite;
+    bool accept = false, start = true;
+    if (sc0.phase == PH_CAND) {
+        // same grouping as outer_finalize_kernel (rank by rank, one rank here)
+        // (the three sums with all their loads in flight together and one pair of barriers; each keeps the tree of sum_partials256)
+        double f = 0.0, rr_new = 0.0, t[4];
+        sum_partials256_x4q(A.partsA, A.partsA + A.nA, A.nA, A.partsM, (A.HvR != nullptr) ? A.nM : 0, (A.nloc + 63) >> 6, sh16, t, A.grp);
+        f += t[0];
+        rr_new += t[1];
+        const double m = (A.HvR != nullptr) ? t[3] : sc0.model;
+        const int endreason = (sc0.status == 0) ? 6 : sc0.status;
+        const int inner_print = sc0.iter + 1;
+        int trstatus = 4;
+        totalite += sc0.iter + 1;
+        if (m >= 0.0) {   // "loss_qu is larger than 0": the point stays
+            stop = 12; start = false;
+        } else {
+            const double rou = (f - loss) / m;   // trustregion.h:680-701
+            if (rou < 0.25) { delta *= 0.25; trstatus = 1; shrink++; }
+            else if (rou > 0.75 && endreason <= 2) { delta = fmin(delta * 2, A.delta_bar); trstatus = 2; shrink = 0; }
+            else shrink = 0;
+            bool stop_delta = false;
+            if (shrink > 3) { delta *= 1e-3; shrink = 0; if (delta < 1e-20) stop_delta = true; }
+            const bool reject = (f > loss || rou < 0.1);   // trustregion.h:702
+            accept = stop_delta || !reject;
+            if (stop_delta) {   // the reference leaves the new point in place but reports loss[k]
+                stop = 13; start = false;
+            } else {
+                if (!reject) { loss = f; rr = rr_new; } else trstatus = 3;
+                k += 1;
+                if (k >= A.max_outer) { stop = 14; start = false; }
+                else {
+                    if (lead && A.trace != nullptr && k < A.trace_cap) {
+                        double *t = A.trace + (size_t)k * 6;
+                        t[0] = loss; t[1] = sqrt(rr); t[2] = (double)inner_print; t[3] = (double)endreason; t[4] = (double)trstatus; t[5] = delta;
+                    }
+                    if (endreason == 5) stop = 5;
+                    else if (sqrt(rr) < A.gradtol) stop = 10;
+                    else if (sc0.time_up) stop = 11;
+                    start = (stop == 0);
+                }
+            }
+        }
+    }
+    if (accept || start) {
+        const double *srcR = accept ? A.Rc : A.R, *srcs = accept ? A.sc : A.s;
+        const double *srcg = accept ? A.cand.rgR : A.cur.rgR, *srcgs = accept ? A.cand.rgs : A.cur.rgs;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+            const int cam = (int)(i / (3 * OP));
+            const bool own = (i % (3 * OP) == 0);
+            const double Rv = srcR[i], sv = srcs[cam], g = srcg[i], gs = srcgs[cam];
+            if (accept) {   // the candidate becomes the current point: buffers keep their roles (no pointer travels back to the host)
+                A.R[i] = Rv; A.cur.G[i] = A.cand.G[i]; A.cur.rgR[i] = g;
+                if (own) {
+                    A.s[cam] = sv; A.cur.egs[cam] = A.cand.egs[cam]; A.cur.rgs[cam] = gs;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) A.cur.S0[(size_t)cam * 9 + j] = A.cand.S0[(size_t)cam * 9 + j];
+                }
+            }
+            if (start) {    // tcg_init_kernel: r = rg, p = -rg, v = Hv = 0, W = s.*p + ps.*R
+                A.rR[i] = g; A.pR[i] = -g; A.vR[i] = 0.0;
+                if (A.HvR) A.HvR[i] = 0.0;
+                const double wv = sv * (-g) + (-gs) * Rv;
+                if (A.Wloc) A.Wloc[i] = wv;
+                if (A.Wpad) A.Wpad[(size_t)cam * 16 + (i - (int64_t)cam * (3 * OP))] = wv;
+                if (own) { A.rs_next[cam] = gs; A.ps_next[cam] = -gs; A.vs[cam] = 0.0; if (A.Hvs) A.Hvs[cam] = 0.0; }
+            }
+        }
+    }
+    if (lead) {
+        TcgScal nx = {};
+        nx.rr = rr; nx.pp = rr; nx.delta = delta; nx.gradnorm = sqrt(rr);
+        nx.seq = sc0.seq;
+        nx.phase = start ? PH_TCG : PH_STOP;
+        nx.loss = loss; nx.rr_point = rr; nx.totalite = totalite; nx.shrink_count = shrink; nx.k = k; nx.stop_reason = stop;
+        nx.time_up = time_up;
+        nx.slots = sc0.slots + ((sc0.phase == PH_CAND) ? 1 : 0);
+        *A.scal_next = nx;
+        publish_host(A.hprog, pack_prog(A.run, A.slot + 1, nx.phase));
+    }
+}
+
+template <int O, int POLAR>
+__global__ __launch_bounds__(256) void outer_step_kernel(OuterStepArgs A) {
+    constexpr int OP = pitch_of(O);
+    __shared__ double sh[4];
+    __shared__ double sh16[16];
+    const int64_t total = (int64_t)A.nloc * 3 * OP;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // as cg_step_kernel: operands of the thread's first element and the first rounds of the partial sums are requested before the scalar block
+    const bool in0 = i < total;
+    const int camf = (int)(i / (3 * OP));
+    const bool own0 = in0 && (i % (3 * OP) == 0);
+    const bool keep_hv = A.HvR != nullptr;
+    double hp = 0, pv = 0, vv0 = 0, hv = 0, rv = 0, Rv = 0, hs = 0, psv = 0, rsv = 0, sv = 1, vsv = 0, hvs = 0;
+    if (in0) { hp = A.HpR[i]; pv = A.pR[i]; vv0 = A.vR[i]; if (keep_hv) hv = A.HvR[i]; rv = A.rR[i]; Rv = A.R[i]; hs = A.Hps[camf]; psv = A.ps_cur[camf]; rsv = A.rs_cur[camf]; sv = A.s[camf]; }
+    if (own0) { vsv = A.vs[camf]; if (keep_hv) hvs = A.Hvs[camf]; }
+    PartialsPre pre;
+    sum_partials_prefetch(A.parts, A.parts + A.nA, A.parts + 2 * A.nA, A.nA, A.parts + 3 * A.nA, A.nB, pre, A.grp);
+    const TcgScal sc0 = *A.scal_cur;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    int time_up = 0;
+    if (lead) time_up = sc0.time_up | *A.stop_req;
+    if (sc0.phase == PH_STOP) {
+        if (lead) *A.scal_next = sc0;
+        return;
+    }
+    if (sc0.phase != PH_TCG) {   // PH_CAND, PH_INIT
+        outer_decide<O>(A, sc0, lead, time_up, sh16);
+        return;
+    }
+    double pHp = 0.0, rHp = 0.0, HpHp = 0.0, rr_prev = 0.0;
+    {
+        double t[4];
+        sum_partials256_x4_pre(A.parts, A.parts + A.nA, A.parts + 2 * A.nA, A.nA, A.parts + 3 * A.nA, A.nB, sc0.iter > 0, pre, sh16, t, A.grp);
+        pHp += t[0]; rHp += t[1]; HpHp += t[2];
+        if (sc0.iter > 0) rr_prev += t[3];
+    }
+    TcgScal sc = sc0;
+    if (sc0.iter > 0) sc.rr = rr_prev;   // exact |r|^2 summed by the previous iteration
+    const StepDecision d = tcg_decide(sc, pHp);
+    const bool stop5 = (d.mode == 5);
+    const double step = d.step;
+    const bool cg = (d.mode == 0);
+    double rr_est = sc.rr + 2.0 * step * rHp + step * step * HpHp;
+    if (rr_est < 0.0) rr_est = 0.0;
+    const bool conv = cg && (sqrt(rr_est) < sc.gradnorm * fmin(sc.gradnorm, 0.1));   // trustregion.h:627
+    const double beta = rr_est / sc.rr;
+    const bool last = stop5 || !cg || conv || (sc.iter + 1 >= kMaxInner);            // this iteration ends the truncated CG
+    if (!last) {
+        // cg_step_kernel's update with a new direction
+        double acc = 0.0;
+        if (in0) {
+            A.vR[i] = vv0 + step * pv;
+            if (keep_hv) A.HvR[i] = hv + step * hp;
+            const double rn = rv + step * hp;
+            const double rsn = rsv + step * hs;
+            A.rR[i] = rn;
+            acc += rn * rn;
+            const double pn = beta * pv - rn;
+            const double psn = beta * psv - rsn;
+            A.pR[i] = pn;
+            const double wv = sv * pn + psn * Rv;
+            if (A.Wloc) A.Wloc[i] = wv;
+            if (A.Wpad) A.Wpad[(size_t)camf * 16 + (i - (int64_t)camf * (3 * OP))] = wv;
+            if (own0) { A.ps_next[camf] = psn; A.rs_next[camf] = rsn; const double q = rsn / sv; acc += q * q; A.vs[camf] = vsv + step * psv; if (keep_hv) A.Hvs[camf] = hvs + step * hs; }
+        }
+        for (i += stride; i < total; i += stride) {
+            const int cam = (int)(i / (3 * OP));
+            const bool own = (i % (3 * OP) == 0);
+            const double hpi = A.HpR[i], pi = A.pR[i], hsi = A.Hps[cam], psi = A.ps_cur[cam];
+            A.vR[i] += step * pi;
+            if (keep_hv) A.HvR[i] += step * hpi;
+            const double rn = A.rR[i] + step * hpi;
+            const double rsn = A.rs_cur[cam] + step * hsi;
+            A.rR[i] = rn;
+            acc += rn * rn;
+            const double pn = beta * pi - rn;
+            const double psn = beta * psi - rsn;
+            A.pR[i] = pn;
+            const double wv = A.s[cam] * pn + psn * A.R[i];
+            if (A.Wloc) A.Wloc[i] = wv;
+            if (A.Wpad) A.Wpad[(size_t)cam * 16 + (i - (int64_t)cam * (3 * OP))] = wv;
+            if (own) { A.ps_next[cam] = psn; A.rs_next[cam] = rsn; const double q = rsn / A.s[cam]; acc += q * q; A.vs[cam] += step * psi; if (keep_hv) A.Hvs[cam] += step * hsi; }
+        }
+        const double tot = block_sum256(acc, sh);
+        if (threadIdx.x == 0) A.partsB_out[blockIdx.x] = tot;
+        if (lead) {
+            TcgScal nx = sc;
+            nx.last_step = step;
+            if (!keep_hv) nx.model = sc.model - step * sc.rr + 0.5 * step * step * pHp;
+            nx.rr = rr_est;
+            nx.vv = sc.vv + 2.0 * step * sc.vp + step * step * sc.pp;  // trustregion.h:642-644
+            nx.vp = beta * (sc.vp + step * sc.pp);
+            nx.pp = beta * beta * sc.pp + rr_est;
+            nx.iter = sc.iter + 1;
+            nx.status = 0;
+            nx.phase = PH_TCG;
+            nx.slots = sc0.slots + 1;
+            nx.time_up = time_up;
+            *A.scal_next = nx;
+            publish_host(A.hprog, pack_prog(A.run, A.slot + 1, PH_TCG));
+        }
+        return;
+    }
+    // The truncated CG ends here: the step eta = v + step p (v itself when the residual was already below 1e-15) is retracted straight
+    // away, one thread per camera with the expressions of retract_kernel<O, POLAR, MV>; the tCG's vectors are not written back -- nothing reads
+    // them before the next tcg_init.  A thread's loads are 72 .. 240 bytes apart from its neighbour's: a wavefront's load touches ~40 cache
+    // lines, and four wavefronts per CU on 54 CUs (retract_kernel's shape at 13 682 cameras) queue up behind the CU's address unit -- here
+    // only the FIRST wavefront of a workgroup takes 64 cameras, so that the work spreads over four times as many CUs.  The model decrease goes
+    // out as one partial sum per WAVEFRONT; outer_decide adds four of them in block_sum256's order before it sums the list, which gives
+    // retract_kernel's partial sums bit for bit.
+    const double stp = stop5 ? 0.0 : step;
+    const int nwave = (A.nloc + 63) >> 6;
+    if ((threadIdx.x >> 6) == 0) {
+        for (int gw = blockIdx.x; gw < nwave; gw += gridDim.x) {
+            const int cam = gw * 64 + (int)threadIdx.x;
+            const bool live = cam < A.nloc;
+            const int c = live ? cam : 0;
+            const size_t base = (size_t)c * 3 * OP;
+            double q[3][O];
+            double macc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    const size_t idx = base + r * OP + k;
+                    const double dv = A.vR[idx] + stp * A.pR[idx];
+                    q[r][k] = A.R[idx] + dv;
+                    if (keep_hv) {
+                        const double hvv = A.HvR[idx] + stp * A.HpR[idx];
+                        macc += dv * (0.5 * hvv + A.cur.rgR[idx]);
+                    }
+                }
+            const double so = A.s[c];
+            const double dsv = A.vs[c] + stp * A.ps_cur[c];
+            if (keep_hv) {
+                const double hvsv = A.Hvs[c] + stp * A.Hps[c];
+                const double vsds = dsv / (so * so);
+                macc += vsds * (0.5 * hvsv + A.cur.rgs[c]);
+                const double tot = wave_sum(live ? macc : 0.0);
+                if (threadIdx.x == 0) A.partsM[gw] = tot;
+            }
+            if (live) {
+                retract_rows<O, POLAR>(q);
+                const double sn = ((A.cam0 + cam) == 0) ? so : so * exp(dsv / so);
+                A.sc[cam] = sn;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int k = 0; k < O; ++k) {
+                        A.Rc[base + r * OP + k] = q[r][k];
+                        if (A.Wloc) A.Wloc[base + r * OP + k] = sn * q[r][k];
+                        if (A.Wpad) A.Wpad[(size_t)cam * 16 + r * OP + k] = sn * q[r][k];
+                    }
+                    if (OP > O) { A.Rc[base + r * OP + O] = 0.0; if (A.Wloc) A.Wloc[base + r * OP + O] = 0.0; if (A.Wpad) A.Wpad[(size_t)cam * 16 + r * OP + O] = 0.0; }
+                }
+            }
+        }
+    }
+    if (lead) {
+        TcgScal nx = sc;
+        nx.last_step = stop5 ? 0.0 : step;
+        if (!keep_hv && !stop5) nx.model = sc.model - step * sc.rr + 0.5 * step * step * pHp;
+        if (stop5) nx.status = 5;
+        else if (!cg) nx.status = d.mode;
+        else {
+            nx.rr = rr_est;
+            nx.vv = sc.vv + 2.0 * step * sc.vp + step * step * sc.pp;
+            nx.vp = beta * (sc.vp + step * sc.pp);
+            nx.pp = beta * beta * sc.pp + rr_est;
+            if (conv) nx.status = 3;
+            else { nx.iter = sc.iter + 1; nx.status = 6; }
+        }
+        nx.phase = PH_CAND;
+        nx.slots = sc0.slots + 1;
+        nx.time_up = time_up;
+        *A.scal_next = nx;
+        publish_host(A.hprog, pack_prog(A.run, A.slot + 1, PH_CAND));
     }
 }
 
@@ -1481,6 +1821,7 @@ __device__ __forceinline__ void gen_matrix(int cam_is_anchor, int g, double (&A)
     }
 }
 
+#pragma clang fp contract(fast)
 template <int O>
 __global__ __launch_bounds__(256) void cert_prepare_kernel(int nloc, int cam0, double lam, const double *__restrict__ QsR,
                                                             const double *__restrict__ R, const double *__restrict__ s,
@@ -2026,6 +2367,9 @@ static void qw_dense_epi(int epi, const double *Q, int64_t ld, const double *W, 
         case EPI_PLAIN: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_PLAIN, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
         case EPI_GRAD: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_GRAD, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
         case EPI_HESS: hipLaunchKernelGGL((qw_dense_kernel<O, EPI_HESS, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break;
+        case EPI_AUTO:
+            if constexpr (O >= 3) { hipLaunchKernelGGL((qw_dense_kernel<O, EPI_AUTO, NSUB>), g, b, 0, st, Q, ld, W, alpha, a); break; }
+            throw Error(-2, "bad epilogue");
         default: throw Error(-2, "bad epilogue");
     }
 }
@@ -2169,19 +2513,23 @@ static void qw_symv_epi(int epi, const double *Q, int64_t ld, const double *W, d
                         hipStream_t st, int rev, unsigned long long *trace = nullptr) {
     const SymvPlan pl = symv_plan(a.nloc, ld);
     const int nstrips = (int)((ld + kSvStrip - 1) / kSvStrip);
-    const TcgScal *sc = (epi == EPI_HESS) ? a.scal : (const TcgScal *)nullptr;
+    const TcgScal *sc = (epi == EPI_HESS || epi == EPI_AUTO) ? a.scal : (const TcgScal *)nullptr;
+    const int by_phase = (epi == EPI_AUTO) ? 1 : 0;
     // the per-camera sum needs: steps per column-sum record (4 K: one record per workgroup), grid row from which the finer cut applies
     const int ys = pl.ysplit, rK = 4 * pl.K, rKf = 4 * pl.Kf, rys = ys;
     const dim3 gs(pl.gx, pl.gy);
     const int nt0 = symv_nt_step0(a.nloc, ld);
     if (trace) {
-        if constexpr (O == 3 || O == 4) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, nt0, sc, Prow, Pcol, trace, rev);
-    } else hipLaunchKernelGGL((qw_symv_kernel<O>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, nt0, sc, Prow, Pcol, trace, rev);
+        if constexpr (O == 3 || O == 4) hipLaunchKernelGGL((qw_symv_kernel<O, true>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, nt0, sc, Prow, Pcol, trace, rev, by_phase);
+    } else hipLaunchKernelGGL((qw_symv_kernel<O>), gs, dim3(256), 0, st, Q, ld, W, a.nloc, pl.K, pl.Kf, ys, nt0, sc, Prow, Pcol, trace, rev, by_phase);
     const dim3 g(qw_grid(a.nloc)), b(256);
     switch (epi) {
         case EPI_PLAIN: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_PLAIN>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break;
         case EPI_GRAD: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_GRAD>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break;
         case EPI_HESS: hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_HESS>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break;
+        case EPI_AUTO:
+            if constexpr (O >= 3) { hipLaunchKernelGGL((symv_reduce_kernel<O, EPI_AUTO>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break; }
+            throw Error(-2, "bad epilogue");
         case EPI_CERT:   // certificate operator (rank-1 input): the Lanczos products of a large dense Q at half the traffic too
             if constexpr (O == 1) { hipLaunchKernelGGL((symv_reduce_kernel<1, EPI_CERT>), g, b, 0, st, Prow, Pcol, ld, nstrips, rK, rKf, rys, alpha, a); break; }
             throw Error(-2, "certificate operator needs o == 1");
@@ -2266,6 +2614,9 @@ static void qw_bsr3_epi(int epi, const int64_t *rp, const int32_t *ci, const dou
         case EPI_PLAIN: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_PLAIN, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
         case EPI_GRAD: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
         case EPI_HESS: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_HESS, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
+        case EPI_AUTO:
+            if constexpr (O >= 3) { hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_AUTO, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break; }
+            throw Error(-2, "bad epilogue");
         default: throw Error(-2, "bad epilogue");
     }
 }
@@ -2334,6 +2685,16 @@ void launch_outer_finalize(const double *partsA, int nA_loc, int world, const do
     hipLaunchKernelGGL(outer_finalize_kernel, dim3(1), dim3(256), 0, st, partsA, nA_loc, world, partsM, nM, scal, hres, seq, grouping, oa ? *oa : z,
                        (oa != nullptr) ? spec_out : (SpecCtl *)nullptr);
     check_launch("outer_finalize");
+}
+void launch_outer_step(int o, int polar, const OuterStepArgs &A, int grid, hipStream_t st) {
+    switch (o) {
+#define XM_OS_CASE(OO) case OO: if (polar) hipLaunchKernelGGL((outer_step_kernel<OO, 1>), dim3(grid), dim3(256), 0, st, A); \
+                                else hipLaunchKernelGGL((outer_step_kernel<OO, 0>), dim3(grid), dim3(256), 0, st, A); break;
+        XM_OS_CASE(3) XM_OS_CASE(4) XM_OS_CASE(5) XM_OS_CASE(6) XM_OS_CASE(7) XM_OS_CASE(8) XM_OS_CASE(9) XM_OS_CASE(10)
+#undef XM_OS_CASE
+        default: throw Error(-2, "device-driven outer iteration: rank o must be 3..10, got " + std::to_string(o));
+    }
+    check_launch("outer_step");
 }
 int retract_grid(int nloc) { return (nloc + 255) / 256; }
 // the outer iteration's retraction: + model decrease of the step (partial sums parts[retract_grid(nloc)]) + the padded copy of the product input

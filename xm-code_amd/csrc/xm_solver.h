@@ -318,6 +318,13 @@ private:
     void drain_events();
     void finish_profile();
     TrResult trust_region(int o, double &gradtol, double linesearch_step, const std::vector<double> &v_dir, double max_time);
+    // the same loop with the outer iteration on the DEVICE (xm_kernels.hip: outer_step_kernel): the host enqueues (product, step) launch pairs ahead
+    // and watches a progress word; entered from trust_region() after the first cost / gradient (f, rr at the starting point)
+    bool device_outer_applies(int o) const;
+    TrResult trust_region_device(int o, double &gradtol, double f, double rr, double delta, double delta_bar, double max_time);
+    DevBuf<double> trace_dev_;           // device copy of the outer-iteration trace (kMaxOuter records)
+    DevBuf<int> stop_req_;               // set by the host when its time limit has expired
+    unsigned int outer_run_ = 0;         // run number in the progress word (hstat_[24])
     CertResult certificate(int o, double primal, std::vector<double> &v_out);
     int lanczos_min(std::vector<double> &x_out, double &theta, int &iters, double &resid);   // 0 converged, 1 not
     void log(const char *fmt, ...) const;

@@ -504,7 +504,7 @@ void Context::setup_rank(int o) {
         partsB_.ensure(pb, st_, (size_t)2 * ((comm_->active() ? mat_top : 0) * world + 3 * nA_ + nB_));
     }
     if (comm_->active()) Afull_.ensure(mat * world, st_, mat_top * world); else Afull_.release();
-    partsM_.ensure((size_t)std::max(std::max(nB_, flat_grid((int64_t)mat_top) * world), 2 * ((nloc_ + 255) / 256) * world), st_);
+    partsM_.ensure((size_t)std::max(std::max(nB_, flat_grid((int64_t)mat_top) * world), 4 * ((nloc_ + 255) / 256) * world), st_);   // (device-driven outer iteration: one model partial per wavefront of 64 cameras)
     if (sym_ok_ && o >= 3 && o <= sym_max_o_) {
         Prow_.alloc(sym_prow_count(nloc_, ld_, o));
         Pcol_.alloc(sym_pcol_count(nloc_, ld_, o), false);
@@ -819,7 +819,7 @@ void Context::tcg_enqueue_iteration(int i, bool profile) {
     double *pcur = pB + (size_t)par * chunk * comm_->world, *pnext = pB + (size_t)(par ^ 1) * chunk * comm_->world;
     a.partials = pcur + (size_t)rank * chunk + b_off;
     a.Bout = comm_->active() ? pcur + (size_t)rank * chunk : nullptr;
-    const bool timed = profile && (hess_launches_ % 8 == 0) && ev_used_ < ev_pool_.size();
+    const bool timed = profile && (hess_launches_ % kProfileStride == 0) && ev_used_ < ev_pool_.size();
     if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
     const bool model_rec = opt_ && (opt_->flags & XM_FLAG_MODEL_RECURRENCE);
     sym_rev_ = par;        // consecutive tCG iterations sweep the symmetric matrix in opposite directions (launch_qw_sym)
@@ -1000,6 +1000,7 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
         gather_W();
     }
     eval_point(cur_, R_.p, s_.p, f, rr);  // loss[0] and the gradient state of the first outer iteration
+    if (device_outer_applies(o)) return trust_region_device(o, gradtol, f, rr, delta, delta_bar, max_time);
     double loss = f;
 
     int endreason = 6, trstatus = 4, shrink_count = 0, inner_print = 1, k = 0;
@@ -1111,6 +1112,166 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
     log("\nTotal iteration:     %lld\n", totalite);
     const double secs = secs_since(start);
     log("Time taken by function1: %lld ms\n", (long long)(secs * 1e3));
+    res_->tcg_iters += totalite;
+    res_->outer_iters += k;
+    res_->tr_seconds += secs;
+    res_->last_stop_reason = stop_reason;
+    out.primal = loss;
+    out.outer_iters = k;
+    out.stop_reason = stop_reason;
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same trust region with the OUTER ITERATION ON THE DEVICE (single GPU; dense, symmetric-dense and block-CSR products).
+// The host's part: the first cost / gradient (done by the caller), the tests at the top of outer iteration 0, the initial scalar block, and
+// then one and the same pair of launches -- product(EPI_AUTO), outer_step -- enqueued `ahead` pairs in front of the progress word, until
+// the word says PH_STOP.  Everything trustregion.h:527-708 decides between two truncated CGs is decided by outer_step_kernel from the same
+// partial sums with the same formulas as trust_region() above; the candidate is COPIED over the current point when it is accepted, so R_ / s_ /
+// ps_[cur_] are the current point before and after, and no buffer role ever depends on what the device decided.
+// Buffers with two parity copies (tCG scalar block, scale parts of p and r, partial sums) go by the parity of the SLOT (the pair's index),
+// and so does the sweep direction of the dense products: every launch of the sequence is fixed when it is enqueued.
+// ------------------------------------------------------------------------------------------------------------------
+bool Context::device_outer_applies(int o) const {
+    if (!opt_ || (opt_->flags & (XM_FLAG_HOST_OUTER | XM_FLAG_HOST_STEPPED)) || verbose_) return false;
+    if (comm_->active() || symw_ || storage_ == XM_STORAGE_SCHUR || o < 3 || cfg_.debug_drop_finalize >= 0) return false;
+    if (storage_ == XM_STORAGE_BSR3 && sell_ && sell_supports(o)) return false;   // (the sliced-ELL pair of launches has no EPI_AUTO form)
+    if (storage_ == XM_STORAGE_DENSE && ks_ > 1) return false;
+    return true;
+}
+
+TrResult Context::trust_region_device(int o, double &gradtol, double f, double rr, double delta, double delta_bar, double max_time) {
+    TrResult out;
+    const auto start = clk::now();
+    const bool profile = (opt_->flags & XM_FLAG_PROFILE_QW) != 0;
+    const bool model_rec = (opt_->flags & XM_FLAG_MODEL_RECURRENCE) != 0;
+    const int nA = prod_grid(), nB = tcg_blocks(), nM = retract_grid(nloc_);
+    double loss = f;
+    int stop_reason = 14, k = 0;
+    long long totalite = 0;
+    int trace0 = res_->trace_len;   // the trace of this trust region starts here (the staircase appends stage after stage)
+    if (opt_->trace && res_->trace_len < opt_->trace_cap) {
+        double *tr = opt_->trace + (size_t)res_->trace_len * 6;
+        tr[0] = loss; tr[1] = std::sqrt(rr); tr[2] = 1; tr[3] = 6; tr[4] = 4; tr[5] = delta;
+        res_->trace_len++;
+    }
+    bool run = true;
+    if (std::sqrt(rr) < gradtol) { stop_reason = 10; run = false; }
+    else if ((double)(long long)secs_since(start) > max_time) { stop_reason = 11; run = false; }
+    long long slots_live = 0, slots_enq = 0;
+    if (run) {
+        if (trace_dev_.count < (size_t)kMaxOuter * 6) trace_dev_.alloc((size_t)kMaxOuter * 6);
+        if (stop_req_.count < 1) stop_req_.alloc(1);
+        XM_HIP_CHECK(hipMemsetAsync(stop_req_.p, 0, sizeof(int), st_));
+        TcgScal init;
+        std::memset(&init, 0, sizeof(init));
+        init.phase = PH_INIT; init.loss = loss; init.rr_point = rr; init.delta = delta; init.seq = (int)++tcg_seq_;
+        to_dev(scal_.p + 1, &init, sizeof(init));   // slot -1 has parity 1
+        const unsigned int runid = ++outer_run_;
+        volatile unsigned long long *hp = hstat_ + 24;
+        *hp = 0;
+        const size_t chunk = (size_t)3 * nA + nB;
+        double *Wloc = W_.p + (size_t)cam0_ * 3 * OP_;
+        const PointState &Pc = ps_[cur_], &Pn = ps_[cur_ ^ 1];
+        auto step_args = [&](int slot) {
+            const int par = slot & 1;
+            OuterStepArgs A;
+            std::memset(&A, 0, sizeof(A));
+            A.nloc = nloc_; A.cam0 = cam0_;
+            A.scal_cur = scal_.p + par; A.scal_next = scal_.p + (par ^ 1);
+            A.parts = partsB_.p + (size_t)par * chunk;
+            A.partsB_out = partsB_.p + (size_t)(par ^ 1) * chunk + (size_t)3 * nA;
+            A.nA = nA; A.nB = nB;
+            A.HpR = HpR_.p; A.Hps = Hps_.p;
+            A.R = R_.p; A.s = s_.p; A.Rc = Rc_.p; A.sc = sc_.p;
+            A.pR = pR_.p; A.ps_cur = par ? psB_.p : psA_.p; A.ps_next = par ? psA_.p : psB_.p;
+            A.vR = vR_.p; A.vs = vs_.p; A.HvR = model_rec ? nullptr : HvR_.p; A.Hvs = model_rec ? nullptr : Hvs_.p; A.rR = rR_.p;
+            A.rs_cur = par ? rsB_.p : rs_.p; A.rs_next = par ? rs_.p : rsB_.p;
+            A.Wloc = Wloc; A.Wpad = nullptr;
+            A.cur = {Pc.G.p, Pc.egs.p, Pc.S0.p, Pc.rgR.p, Pc.rgs.p};
+            A.cand = {Pn.G.p, Pn.egs.p, Pn.S0.p, Pn.rgR.p, Pn.rgs.p};
+            A.partsA = partsA_.p; A.partsM = partsM_.p; A.nM = nM;
+            A.delta_bar = delta_bar; A.gradtol = gradtol; A.max_outer = kMaxOuter;
+            A.trace = trace_dev_.p; A.trace_cap = kMaxOuter;
+            A.stop_req = stop_req_.p;
+            A.hprog = hstat_dev_ + 24;
+            A.run = runid; A.slot = slot; A.grp = grouping_;
+            return A;
+        };
+        const int polar = retraction_ == XM_RETRACT_POLAR ? 1 : 0;
+        auto enqueue_slot = [&](int slot) {
+            const int par = slot & 1;
+            CamArgs a = cam_args(cur_);
+            a.scal = scal_.p + par;
+            a.ps = par ? psB_.p : psA_.p;
+            a.rs = par ? rsB_.p : rs_.p;
+            a.partials = partsB_.p + (size_t)par * chunk;
+            a.cand.R = Rc_.p; a.cand.s = sc_.p;
+            a.cand.G = Pn.G.p; a.cand.egs = Pn.egs.p; a.cand.S0 = Pn.S0.p; a.cand.rgR = Pn.rgR.p; a.cand.rgs = Pn.rgs.p;
+            a.cand.partials = partsA_.p;
+            // sampled like the host-driven loop's Hessian launches; a pair in the gradient role moves the same bytes, a drained pair after the
+            // end is dropped by finish_profile() like a run-ahead no-op
+            const bool timed = profile && (hess_launches_ % kProfileStride == 0) && ev_used_ < ev_pool_.size();
+            if (timed) XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].first, st_));
+            sym_rev_ = par;
+            product(EPI_AUTO, o_, 2.0, a);
+            sym_rev_ = 1;
+            if (timed) { XM_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].second, st_)); ev_used_++; }
+            hess_launches_++;
+            launch_outer_step(o_, polar, step_args(slot), nB, st_);
+        };
+        launch_outer_step(o_, polar, step_args(-1), nB, st_);
+        const int ahead = 4;
+        int enq = 0;
+        bool time_sent = false;
+        auto last_progress = clk::now();
+        auto last_change = last_progress;
+        unsigned long long seen = ~0ull;
+        for (;;) {
+            const unsigned long long v = *hp;
+            if (v != seen) { seen = v; last_progress = clk::now(); last_change = last_progress; }
+            const bool valid = (unsigned int)(v >> 32) == runid;
+            const int done = valid ? (int)((v >> 8) & 0xffffff) : 0;
+            const int phase = valid ? (int)(v & 0xff) : (int)PH_INIT;
+            if (phase == PH_STOP) break;
+            if (enq - done < ahead) { enqueue_slot(enq++); continue; }
+            __builtin_ia32_pause();
+            if (!time_sent && (double)(long long)secs_since(start) > max_time) {
+                XM_HIP_CHECK(hipMemsetAsync(stop_req_.p, 1, sizeof(int), st_));   // (any non-zero pattern; lands within `ahead` pairs)
+                time_sent = true;
+            }
+            if (secs_since(last_progress) > 200e-6) {
+                // nothing new for a while: if the stream has drained the word is stale (or device writes to mapped host memory are not
+                // visible promptly on this platform) -> read the truth from the device
+                if (stream_idle(last_change, "the outer-iteration progress word")) {
+                    TcgScal sc;
+                    to_host(&sc, scal_.p + (enq & 1), sizeof(TcgScal));
+                    if (sc.phase == PH_STOP) break;
+                    *hp = ((unsigned long long)runid << 32) | ((unsigned long long)(unsigned)enq << 8) | (unsigned long long)(unsigned)sc.phase;
+                }
+                last_progress = clk::now();
+            }
+        }
+        XM_HIP_CHECK(hipStreamSynchronize(st_));
+        TcgScal fin;
+        to_host(&fin, scal_.p + (enq & 1), sizeof(TcgScal));
+        if (fin.phase != PH_STOP) throw Error(XM_ERR_HIP, "device-driven outer iteration: the final scalar block is not in the stop phase");
+        k = fin.k; totalite = fin.totalite; loss = fin.loss; stop_reason = fin.stop_reason;
+        slots_live = fin.slots; slots_enq = enq;
+        // trace records 1 .. k (record k exists when iteration k's top was reached: always, except when the iteration cap ended the loop)
+        const int last_rec = std::min(k, kMaxOuter - 1);
+        if (opt_->trace && last_rec >= 1 && res_->trace_len < opt_->trace_cap) {
+            const int take = std::min(last_rec, opt_->trace_cap - res_->trace_len);
+            to_host(opt_->trace + (size_t)res_->trace_len * 6, trace_dev_.p + 6, (size_t)take * 6 * sizeof(double));
+            res_->trace_len += take;
+        }
+        if (profile) drain_events();
+        res_->qw_products -= (slots_enq - slots_live);   // pairs drained after the end were no products
+    }
+    (void)trace0;
+    if (stop_reason == 10) gradtol /= 10;
+    const double secs = secs_since(start);
+    res_->outer_on_device++;
     res_->tcg_iters += totalite;
     res_->outer_iters += k;
     res_->tr_seconds += secs;

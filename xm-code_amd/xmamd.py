@@ -22,6 +22,7 @@ FLAG_VERBOSE, FLAG_FIX_STALE_SR, FLAG_PROFILE_QW, FLAG_HOST_STEPPED = 1, 2, 4, 8
 CERT_EIG_NOT_CONVERGED = 1
 CERT_EIG_EXACT = 2           # small problem: the certificate's tridiagonalisation ran to completion (dense route)
 FLAG_WARM_R = 16
+FLAG_HOST_OUTER = 64           # outer iteration of the trust region on the host instead of the device (xm_amd.h)
 FLAG_MODEL_RECURRENCE = 32     # model decrease of a tCG from its recurrences instead of from accumulated H v (xm_amd.h)
 
 EXPORTS = [
@@ -73,7 +74,8 @@ class Result(C.Structure):
                 ("cert_seconds", C.c_double), ("qw_ms_sum", C.c_double), ("qw_ms_count", C.c_int64),
                 ("qw_bytes", C.c_int64), ("trace_len", C.c_int32), ("last_stop_reason", C.c_int32),
                 ("sym_product", C.c_int32), ("cert_flags", C.c_int32), ("eig_residual", C.c_double),
-                ("n_gpus", C.c_int32), ("exchange", C.c_int32), ("qw_stream_bytes", C.c_int64)]
+                ("n_gpus", C.c_int32), ("exchange", C.c_int32), ("qw_stream_bytes", C.c_int64),
+                ("outer_on_device", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Xm2Info(C.Structure):
