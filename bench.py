@@ -610,13 +610,16 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
     # per-rank algorithmic bytes of one tCG product: this rank's rows of Q + W in/out (SURVEY §8d dense formula / world)
     n = wl["n"]
     o_fin = max(3, last["rank"])
+    # outer iteration on the device: the tCG products run the role-switching instantiation (EPI_AUTO: Hessian epilogue, or -- one launch per outer
+    # iteration -- the candidate's gradient epilogue; the same bytes either way)
+    epi_name = "AUTO" if last.get("outer_on_device") else "HESS"
     if wl["kind"] == "dense" or args.storage == "dense":
         alg_bytes = (8.0 * (3 * n) ** 2) / ngp + 2 * 8 * 3 * n * o_fin
-        kname = "qw_dense_kernel<o, EPI_HESS>"
+        kname = "qw_dense_kernel<o, EPI_%s>" % epi_name
     else:
         alg_bytes = (76.0 * nb + 4 * (n + 1)) / ngp + 2 * 8 * 3 * n * o_fin      # FULL-storage accounting whatever is streamed
         pk = ctx.product_kind(o_fin)
-        kname = "qw_bsr3_kernel<o, EPI_HESS>"
+        kname = "qw_bsr3_kernel<o, EPI_%s>" % epi_name
         if pk in ("sell", "sell_quat"):
             kname = "qw_sell_kernel<o> + sell_reduce_kernel<o, EPI_HESS> (sliced-ELL over per-XCD column slabs; one product = both launches)"
             if team == 1 and world == 1 and ctx.sell_wpad():
@@ -668,7 +671,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_kind": ("recorded" if traffic is not None else None),   # PMC passes are separate runs (gpurun / the guide): never measured inside this one
                      "traffic_source": traffic_source, "traced_avg_launch_us": traced_us, "kernel": kname + ("; Q is exactly symmetric and has >= 4096 rows: the rank-3 / rank-4 stages multiply it through the half-traffic pair "
-                                                "qw_symv_kernel + symv_reduce_kernel<o, EPI_HESS> (one product = both launches, upper triangle streamed once), rank 5 through "
+                                                "qw_symv_kernel + symv_reduce_kernel<o, EPI_%s> (one product = both launches, upper triangle streamed once), rank 5 through " % epi_name +
                                                 "qw_dense_kernel; achieved / frac count the FULL-storage bytes of SURVEY 8d per product, traffic is what the counters saw"
                                                 if last.get("sym_product") else ""), "avg_launch_ms": qw_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,

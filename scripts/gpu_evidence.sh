@@ -45,6 +45,9 @@ for leg in "venice1778:--steps 3 --warmup 1 --cpu-seconds 0 --no-hbm-check --no-
   rm -rf $O/prof_$name $O/prof_$name.log
 done
 cd $R
+# outer iteration on the device (default) against XM_FLAG_HOST_OUTER on this box, alternating; kernel traces of the host-driven form next to the default's above
+scripts/ab_outer.sh 2 > $O/${TAG}_ab_outer.txt 2>&1
+OUTERS=host scripts/trace_outer.sh $TAG > /dev/null 2>&1
 [ -n "$QUICK" ] && exit 0
 # the symmetric sweep: plan, alternation on / off, chunk lengths around the plan's, per-wavefront timestamps; sizes up to 13.5 GB
 (python scripts/kbench_symv.py 1778 --o 3 4 --alt 1 0 --k 0 4 6 8 --check --trace; for n in 1536 2048 2560 3072 4096 8192 13682; do python scripts/kbench_symv.py $n --o 3 4; done) > $O/${TAG}_kbench_symv.txt 2>&1

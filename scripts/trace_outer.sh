@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel traces of the headline and the Final-13682 block-CSR solve, outer iteration on the device / on the host -> gpurun_out/<tag>_trace_<leg>_<outer>.txt
-TAG=${1:-dbg}; R=$(pwd); O=$R/gpurun_out; mkdir -p $O
+TAG=${1:-dbg}; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 for outer in ${OUTERS:-device host}; do

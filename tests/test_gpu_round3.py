@@ -826,7 +826,14 @@ def test_rome13682_dense_storage_vs_recorded_oracle(xmamd):
     P = tl.gen_vg(c["n"], deg=c["deg"], sigma=c["sigma"], seed=c["n"], dense=False)
     ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]), densify=True)
     R, s, info = ctx.solve(5, c["tol"], c["lam"])
+    # the time limit inside a device-driven trust region: the host raises a flag, the device looks at it where the reference looks at its
+    # clock (top of an outer iteration, whole seconds: trustregion.h:540) -- with max_time = 0 that is the first boundary after one second of
+    # this ~1 s solve, or never; either way a valid point of lower cost than the start comes back, and a run that was cut short says so
+    Rt, st, it = ctx.solve(3, 1e-30, c["lam"], max_time=0.0, trace=400)
     ctx.close()
+    assert it["outer_on_device"] == 1 and it["last_stop_reason"] in (5, 11) and it["primal"] < it["trace"][0, 0]
+    if it["last_stop_reason"] == 11:
+        assert it["seconds"] >= 1.0 and it["trace"].shape[0] == it["outer_iters"] + 1
     assert info["sym_product"] == 1 and info["rank"] == 3 and info["status"] == 1
     assert info["qw_stream_bytes"] == 4 * (3 * c["n"]) ** 2            # half the matrix per product
     assert info["primal"] == pytest.approx(c["f"], rel=1e-9)

@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
         if (more) {  // uniform
             load_q(tile_at(t + 1), ntag);
             load_w(tile_at(t + 1));
-        } else {
-            epi_prefetch<O, EPI>(eops, cam, lane, active, a, (EPI == EPI_AUTO) ? role : (int)EPI);
+        } else if (EPI != EPI_AUTO) {
+            epi_prefetch<O, EPI>(eops, cam, lane, active, a, (int)EPI);
         }
         const double2 *wbase = reinterpret_cast<const double2 *>(wt[t & 1]);
 #pragma unroll
@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256) void qw_dense_kernel(const double *__restrict_
     };
     const bool alive = nt ? stream(std::true_type{}) : stream(std::false_type{});
     if (!alive) return;
+    // (EPI_AUTO asks for its epilogue operands only here: requested inside the last tile, the two roles' operand sets cost the loop 60 VGPRs and a
+    // wavefront per SIMD -- 36.9 against 32.5 us per product at Venice size)
+    if (EPI == EPI_AUTO) epi_prefetch<O, EPI>(eops, cam, lane, active, a, role);
     qw_finish<O, EPI, 64, kQwWaves>(cam, lane, wave, active, acc, alpha, a, eops, red, (EPI == EPI_AUTO) ? role : (int)EPI);
 }
 
