@@ -172,7 +172,7 @@ typedef struct {
                                      * exact arithmetic; the last bits of the model value, hence possibly the path, differ: default OFF */
 #define XM_FLAG_HOST_OUTER    64u   /* keep the outer iteration of the trust region on the HOST (the form of rounds 1-5: the host notices the end of a truncated
                                      * CG, enqueues retraction / candidate gradient / result kernel and confirms a speculatively started next tCG).  Default on
-                                     * one GPU with dense or block-CSR products (not: sliced ELL, matrix-free, several ranks, XM_FLAG_VERBOSE, XM_FLAG_HOST_STEPPED)
+                                     * one GPU with dense or block-CSR products (not: sliced ELL, matrix-free, several ranks, XM_FLAG_HOST_STEPPED; with XM_FLAG_VERBOSE a stage's progress lines appear when its trust region has ended)
                                      * is the DEVICE-driven form: everything trustregion.h:527-708 does between two truncated CGs (retraction, candidate's cost /
                                      * gradient, accept / reject, radius, stop tests, start of the next tCG) is decided on the device, the host enqueues one
                                      * repeating pair of launches ahead and watches a progress word.  Same decisions from the same numbers: bit-identical

@@ -57,6 +57,10 @@ int xm_peer_allgather_bench(int world, int gpu_map, int64_t count, int reps, dou
  * multiple of nloc, cam0 / nloc < world and o in 1, 3..5 */
 int xm_qw_symw_time(int64_t ntot, int nloc, int cam0, int o, int world, int reps, double ms[2], int64_t *bytes);
 
+/* a grid-wide barrier inside one launch against a kernel boundary (`blocks` resident workgroups, `rounds` rounds of write / meet / check): us[0] =
+ * microseconds per round inside ONE launch, us[1] = per round as separate launches, us[2] = failed checks or expired waits (must be 0) */
+int xm_bench_grid_barrier(int blocks, int rounds, int reps, double us[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,7 @@ timeout 600 python bench.py --workload vg100k --storage vg --steps 6 --warmup 1 
 (python scripts/kbench_sell.py 100000 50 --o 3 4 5 --slabs 4 --gather 1 --codec 0 1 --no-csr
  python scripts/kbench_sell.py 100000 50 --o 3 4 5 --slabs 4 --gather 1 --codec 0 1 --no-csr --padded
  python scripts/kbench_sell.py 100000 50 --o 3 --band --codec 1 --no-csr) > $O/${TAG}_kbench_sell.txt 2>&1
+python scripts/kbench_barrier.py > $O/${TAG}_kbench_barrier.txt 2>&1
 python scripts/kbench_symw.py 13682 --worlds 2 8 > $O/${TAG}_kbench_symw.txt 2>&1
 # general kernel against the half-traffic symmetric pair around the cross-over (Settings::sym_rows, xm_solver.h)
 (for n in 1024 1280 1536 1664 1778 2048 2560; do python scripts/kbench_dense.py $n 3 4; done) 2>&1 | grep -v amdgpu > $O/${TAG}_kbench_dense_sym_crossover.txt

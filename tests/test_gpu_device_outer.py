@@ -155,3 +155,21 @@ def test_device_outer_at_baseline_sizes_vs_recorded_oracle(xmamd):
     assert i["rank"] == 3 and i["status"] == 1 and i["primal"] == pytest.approx(c["f"], rel=1e-9)
     rot, _ = tl.recover_rotations(R, s)
     assert tl.rel_fro(rot, np.load(os.path.join(G, "synth", "rome13682_oracle_rot.npy"))) < 1e-6
+
+
+def test_verbose_progress_lines_are_the_same_text(xmamd, capfd):
+    """XM_FLAG_VERBOSE (the file surface's default, like the reference): the device-driven loop prints a stage's progress lines from its trace
+    records when the stage has ended -- the same text the host-driven loop prints line by line (the wall-clock line aside)"""
+    P = tl.gen_vg(40, deg=3, sigma=1.5, seed=40)
+    ctx = xmamd.Context(bsr=(P["rowptr"], P["colidx"], P["blocks"]))
+    out = []
+    for fl in (xmamd.FLAG_VERBOSE, xmamd.FLAG_VERBOSE | xmamd.FLAG_HOST_OUTER):
+        capfd.readouterr()
+        R, s, info = ctx.solve(6, 1e-9, 3.0, flags=fl)
+        txt = capfd.readouterr().out
+        out.append(([l for l in txt.splitlines() if not l.startswith("Time taken")], info))
+    ctx.close()
+    (dev, idev), (host, ihost) = out
+    assert idev["outer_on_device"] == 4 and ihost["outer_on_device"] == 0
+    assert len(dev) > 100 and any("nagative curvature" in l for l in dev) and any(l.startswith("TR+ ") for l in dev)
+    assert dev == host

@@ -231,4 +231,67 @@ int xm_qw_symw_time(int64_t ntot, int nloc, int cam0, int o, int world, int reps
     XM_CATCH
 }
 
+// What does a GRID-WIDE BARRIER inside one launch cost against a kernel boundary?  ("open": folding the step of a tCG iteration into
+// the launch before it needs one.)  `blocks` workgroups of 256 threads, all resident; per round every thread writes a value, the workgroups meet
+// (release fence, arrival counter, bounded spin, acquire fence) and every thread checks a value another workgroup wrote.  us[0] = microseconds per
+// round inside ONE launch, us[1] = per round as `rounds` launches of the same work split at the barrier, us[2] = mismatches seen (must be 0).
+int xm_bench_grid_barrier(int blocks, int rounds, int reps, double us[3]);
+
+}  // extern "C"
+
+namespace {
+__global__ __launch_bounds__(256) void grid_barrier_kernel(unsigned int *counter, double *buf, int rounds, int round0, int do_barrier, long long spin_ticks,
+                                                          unsigned int *bad) {
+    __shared__ int ok;
+    const int n = gridDim.x * 256, gid = blockIdx.x * 256 + threadIdx.x;
+    for (int r = round0; r < round0 + rounds; ++r) {
+        if (r > round0 || round0 > 0) {   // check what the round before left (another workgroup's element, 7 workgroups away)
+            const int j = (gid + 7 * 256) % n;
+            if (buf[(size_t)((r - 1) & 1) * n + j] != (double)(r - 1) * 0.5 + j) atomicAdd(bad, 1u);
+        }
+        buf[(size_t)(r & 1) * n + gid] = (double)r * 0.5 + gid;
+        if (!do_barrier) continue;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int target = (unsigned int)(r - round0 + 1) * gridDim.x;
+            const long long t0 = wall_clock64();
+            int good = 1;
+            while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (wall_clock64() - t0 > spin_ticks) { good = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ok = good;
+        }
+        __syncthreads();
+        if (!ok) { if (threadIdx.x == 0) atomicAdd(bad, 1u << 20); return; }
+    }
+}
+}  // namespace
+
+extern "C" int xm_bench_grid_barrier(int blocks, int rounds, int reps, double us[3]) {
+    XM_TRY
+    require_device();
+    if (blocks < 1 || blocks > 1024 || rounds < 1 || reps < 1 || !us) throw xm::Error(XM_ERR_ARG, "bad argument");
+    xm::DevBuf<double> buf;
+    xm::DevBuf<unsigned int> cnt;
+    buf.alloc((size_t)2 * blocks * 256);
+    cnt.alloc(2);
+    const long long spin = 100000000ll / 20;   // 50 ms at 100 MHz: a workgroup that is not resident would otherwise hang the launch
+    auto fused = [&]() {
+        XM_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(unsigned int), nullptr));
+        hipLaunchKernelGGL(grid_barrier_kernel, dim3(blocks), dim3(256), 0, nullptr, cnt.p, buf.p, rounds, 0, 1, spin, cnt.p + 1);
+    };
+    auto split = [&]() {
+        for (int r = 0; r < rounds; ++r) hipLaunchKernelGGL(grid_barrier_kernel, dim3(blocks), dim3(256), 0, nullptr, cnt.p, buf.p, 1, r, 0, spin, cnt.p + 1);
+    };
+    const double ms_f = time_launches(2, reps, fused), ms_s = time_launches(2, reps, split);
+    unsigned int bad = 0;
+    XM_HIP_CHECK(hipMemcpy(&bad, cnt.p + 1, sizeof(bad), hipMemcpyDeviceToHost));
+    us[0] = ms_f * 1e3 / rounds; us[1] = ms_s * 1e3 / rounds; us[2] = (double)bad;
+    return XM_OK;
+    XM_CATCH
+}
+
+extern "C" {
 }  // extern "C"

@@ -1133,7 +1133,7 @@ TrResult Context::trust_region(int o, double &gradtol, double linesearch_step, c
 // and so does the sweep direction of the dense products: every launch of the sequence is fixed when it is enqueued.
 // ------------------------------------------------------------------------------------------------------------------
 bool Context::device_outer_applies(int o) const {
-    if (!opt_ || (opt_->flags & (XM_FLAG_HOST_OUTER | XM_FLAG_HOST_STEPPED)) || verbose_) return false;
+    if (!opt_ || (opt_->flags & (XM_FLAG_HOST_OUTER | XM_FLAG_HOST_STEPPED))) return false;
     if (comm_->active() || symw_ || storage_ == XM_STORAGE_SCHUR || o < 3 || cfg_.debug_drop_finalize >= 0) return false;
     if (storage_ == XM_STORAGE_BSR3 && sell_ && sell_supports(o)) return false;   // (the sliced-ELL pair of launches has no EPI_AUTO form)
     if (storage_ == XM_STORAGE_DENSE && ks_ > 1) return false;
@@ -1154,6 +1154,21 @@ TrResult Context::trust_region_device(int o, double &gradtol, double f, double r
         double *tr = opt_->trace + (size_t)res_->trace_len * 6;
         tr[0] = loss; tr[1] = std::sqrt(rr); tr[2] = 1; tr[3] = 6; tr[4] = 4; tr[5] = delta;
         res_->trace_len++;
+    }
+    // XM_FLAG_VERBOSE: the reference's progress lines (trustregion.h:504-525) are printed from the trace records -- the same text, but a
+    // stage's lines appear together when its trust region has ended instead of one by one
+    auto progress_line = [&](int kk, const double *rec, double delta_prev) {
+        static const char *trn[] = {"", "TR- ", "TR+ ", "REJ ", "TR "};
+        const int er = (int)rec[3], ts = (int)rec[4];
+        if (kk > 0 && rec[5] < delta_prev * 0.25 * 0.5) log("delta shrinked to %1.3e\n", rec[5]);   // (the 1e-3 cut after four shrinks in a row)
+        if (kk > 0) log("%s", trn[(ts >= 0 && ts <= 4) ? ts : 0]);
+        log("%d   %d   %1.3e   %1.3e", kk, (int)rec[2], rec[0], rec[1]);
+        if (kk > 0) log("   %s\n", er == 1 ? "nagative curvature" : er == 2 ? "exceed trust region" : er == 3 ? "reached norm tolerance" : er == 5 ? "numerical issue" : "max iteration");
+        else log("\n");
+    };
+    {
+        const double rec0[6] = {loss, std::sqrt(rr), 1, 6, 4, delta};
+        progress_line(0, rec0, delta);
     }
     bool run = true;
     if (std::sqrt(rr) < gradtol) { stop_reason = 10; run = false; }
@@ -1265,10 +1280,23 @@ TrResult Context::trust_region_device(int o, double &gradtol, double f, double r
             to_host(opt_->trace + (size_t)res_->trace_len * 6, trace_dev_.p + 6, (size_t)take * 6 * sizeof(double));
             res_->trace_len += take;
         }
+        if (verbose_ && last_rec >= 1) {
+            std::vector<double> recs((size_t)last_rec * 6);
+            to_host(recs.data(), trace_dev_.p + 6, recs.size() * sizeof(double));
+            double dprev = delta;
+            for (int kk = 1; kk <= last_rec; ++kk) { progress_line(kk, &recs[(size_t)(kk - 1) * 6], dprev); dprev = recs[(size_t)(kk - 1) * 6 + 5]; }
+        }
         if (profile) drain_events();
         res_->qw_products -= (slots_enq - slots_live);   // pairs drained after the end were no products
     }
     (void)trace0;
+    if (stop_reason == 5) log("Terminate because of rdotr touched machine precise\n");
+    else if (stop_reason == 10) log("Terminate because of small gradient norm\n");
+    else if (stop_reason == 11) log("Terminate because of time limit\n");
+    else if (stop_reason == 12) log("error! loss_qu is larger than 0\n");
+    else if (stop_reason == 13) log("delta is too small, BM stopped!\n");
+    log("\nTotal iteration:     %lld\n", totalite);
+    log("Time taken by function1: %lld ms\n", (long long)(secs_since(start) * 1e3));
     if (stop_reason == 10) gradtol /= 10;
     const double secs = secs_since(start);
     res_->outer_on_device++;

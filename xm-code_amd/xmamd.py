@@ -35,7 +35,7 @@ EXPORTS = [
 ]
 # include/xm_bench.h: timing hooks of the micro-benchmarks (same library, not part of the product ABI)
 BENCH_EXPORTS = ["xm_bench_last_error", "xm_qw_dense_time", "xm_qw_dense_sym_time", "xm_bench_symv_k", "xm_bench_dense_policy", "xm_qw_dense_sym_trace", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_qw_bsr3_time", "xm_qw_sell_time",
-                 "xm_retract_variant", "xm_recover_rotations_variant", "xm_peer_allgather_bench", "xm_qw_symw_time"]
+                 "xm_retract_variant", "xm_recover_rotations_variant", "xm_peer_allgather_bench", "xm_qw_symw_time", "xm_bench_grid_barrier"]
 PRODUCT_KINDS = {0: "dense", 1: "dense_sym", 2: "bsr3", 3: "sell", 4: "sell_quat", 5: "schur"}
 
 
@@ -126,6 +126,7 @@ def lib():
         L.xm_symw_plan.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.xm_symw_use.argtypes = [C.c_int, C.c_int, C.c_int]
         L.xm_qw_symw_time.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
+        L.xm_bench_grid_barrier.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.xm_dev_count.argtypes = [C.POINTER(C.c_int)]
         L.xm_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         L.xm_dev_free.argtypes = [C.c_void_p]
