@@ -55,9 +55,13 @@ struct TcgScal {
     int32_t iter;     // inner iteration index i (== completed iterations)
     int32_t seq;      // which truncated-CG run of this context this is (travels in the host-mapped progress word: a word of an earlier run is stale)
     int32_t phase;    // device-driven outer iteration only (Phase below); 0 in every other mode
-    // ---- device-driven outer iteration (Context::trust_region_device): the trust-region state of trustregion.h:416-718 travels with the
-    // block, so that the launch that ends a truncated CG can retract, the next product can take the candidate's gradient and the launch
-    // behind it can accept or reject, update the radius and start the next truncated CG -- without the host in between
+};
+// Trust-region state of the DEVICE-DRIVEN outer iteration (Context::trust_region_device; trustregion.h:416-718), double-buffered by parity next to
+// TcgScal: with it the launch that ends a truncated CG can retract, the next product can take the candidate's gradient and the launch behind it
+// can accept or reject, update the radius and start the next truncated CG -- without the host in between.  (A block of its own: folded into
+// TcgScal it made cg_step_kernel copy a 128-byte struct through private memory -- 56 bytes of scratch, 13 KB of LDS, and 18.7 instead of 5.7 us
+// per launch at Venice size, on the host-driven path that never looks at these fields.)
+struct OuterScal {
     double loss;          // f at the current point                                 (loss[k])
     double rr_point;      // <rg, rg> at the current point                          (rdotr[0] of the truncated CG that starts there)
     int64_t totalite;     // the reference's "Total iteration"
@@ -167,6 +171,8 @@ struct OuterStepArgs {
     int nloc, cam0;
     const TcgScal *scal_cur;
     TcgScal *scal_next;
+    const OuterScal *os_cur;
+    OuterScal *os_next;
     const double *parts;     // this slot's tCG partial sums [<p,Hp> | <r,Hp> | <Hp,Hp> (nA each, Hessian epilogue) | |r|^2 of the previous step (nB)]
     double *partsB_out;      // |r|^2 partial sums of this step, in the other parity's chunk
     int nA, nB;

@@ -201,7 +201,8 @@ __device__ __forceinline__ void epi_prefetch(EpiOps &e, int cam, int lane, bool 
         e.s = sp[cam];
         e.R = load_col<O>(Rp, cam, lane);
         if (grad) {
-            e.Wl = load_col<O>(a.Wloc, cam, lane);
+            // (the candidate's rows of W are fetched inside epi_grad: held here they are three more live doubles next to the Hessian role's
+            // operand set, which the register allocator answers with a spill to scratch -- and a kernel that uses scratch pays for it at every dispatch)
         } else {
             e.ps = a.ps[cam];
             e.egs = a.egs[cam];
@@ -238,12 +239,12 @@ __device__ __forceinline__ void epi_prefetch(EpiOps &e, int cam, int lane, bool 
 // h = 2*C*sR rows.  Produces G, egs, S0, rg and this camera's share of {f, <rg,rg>_metric} (uniform on return).
 // (the output buffers are explicit arguments: the role-switching instantiation writes the candidate's, a.cand.*, without copying the argument block)
 struct GradOut { double *G, *egs, *S0, *rgR, *rgs; };
-template <int O, int GW>
+template <int O, int GW, bool LATE_WL = false>
 __device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const EpiOps &e, const CamArgs &a, const GradOut &o, double &p0, double &p1) {
     const bool anchor = (a.cam0 + cam) == 0;
     const double s = e.s;
     const Col3 &R = e.R;
-    const Col3 &Wl = e.Wl;
+    const Col3 Wl = LATE_WL ? load_col<O>(a.Wloc, cam, lane) : e.Wl;
     store_col<O>(h, o.G, cam, lane);
     // f = <C sR, sR> + lam * sum_{i>=1} (s_i^2-1)^2 ;  <C sR, sR> = 0.5 * <G, sR>
     const double q = s * s - 1.0;
@@ -334,7 +335,7 @@ __device__ __forceinline__ void qw_tail(int cam, int lane, int slot, bool active
         } else if (EPI == EPI_HESS) {
             epi_hess<O, GW>(cam, lane, h, e, a, p0, p1, p2);
         } else if (EPI == EPI_AUTO) {
-            if (role == EPI_GRAD) { const GradOut go = {a.cand.G, a.cand.egs, a.cand.S0, a.cand.rgR, a.cand.rgs}; epi_grad<O, GW>(cam, lane, h, e, a, go, p0, p1); }
+            if (role == EPI_GRAD) { const GradOut go = {a.cand.G, a.cand.egs, a.cand.S0, a.cand.rgR, a.cand.rgs}; epi_grad<O, GW, true>(cam, lane, h, e, a, go, p0, p1); }
             else epi_hess<O, GW>(cam, lane, h, e, a, p0, p1, p2);
         } else if (EPI == EPI_CERT) {
             // y_i = (Q x)_i + dz_i * x[3i] e_0 - Lam_i x_i      (O == 1, lane 0 owns the column)

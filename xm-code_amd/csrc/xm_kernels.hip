@@ -1007,6 +1007,18 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
 // reduction; the directly summed |r|^2 (partsB_out) replaces that estimate as <r,r> of the NEXT iteration, so no error
 // accumulates.  Block 0 owns the scalar state (other parity buffer) and the host-mapped progress word.  The scale parts of
 // p and r are ping-ponged (cur -> next): every element thread of a camera reads them while one thread rewrites them.
+// entry i of a small pointer table that lives in the kernel's ARGUMENT block, by a chain of selects over constant indices.  Indexing such a table
+// with a run-time value makes the compiler copy it to private memory first -- cg_step_kernel carried 56 bytes of scratch and 13 KB of LDS for
+// PeerXchg's two tables, on the single-GPU path too, and a kernel with scratch pays for it at every dispatch: 5.7 us on one box, 18.7 on another
+// whose host was busy (same GPU, same launch; profiles/r06_trace_venice1778_host.txt)
+template <class T>
+__device__ __forceinline__ T pick_peer(const T (&tab)[kMaxPeers], int i) {
+    T p = tab[0];
+#pragma unroll
+    for (int q = 1; q < kMaxPeers; ++q) p = (i == q) ? tab[q] : p;
+    return p;
+}
+
 template <int O>
 __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *__restrict__ scal_cur, TcgScal *scal_next,
                                                        const double *__restrict__ parts, int nA_loc, int nB_loc, int world,
@@ -1057,14 +1069,14 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
         const size_t chunk_d = (size_t)b_off + 3 * (size_t)nA_loc + nB_loc;
         const size_t off = ((size_t)par * x.world + x.rank) * chunk_d;
         const unsigned long long epoch = x.epoch_base + (unsigned long long)sc0.iter + 1ull;
-        const double *src = x.buf[x.rank] + off;
+        const double *src = pick_peer(x.buf, x.rank) + off;
         if (x.lite) {
             // write-through form: every payload store is itself a system-scope (sc0 sc1) store, acknowledged by its destination
             // before s_waitcnt vmcnt(0) lets the wave go on -- nothing of it is left in this device's L2, so the hand-off needs no
             // release fence (which writes back the WHOLE L2 of the XCD: the column-split product measured 39 vs 14 us for that)
             for (int p = 0; p < x.world; ++p) {
                 if (p == x.rank) continue;
-                double *dst = x.buf[p] + off;
+                double *dst = pick_peer(x.buf, p) + off;
                 for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < chunk_d; j += (size_t)stride)
                     __hip_atomic_store(dst + j, src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -1077,11 +1089,11 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
             }
             __syncthreads();
             if (sh_flag && !x.mute && threadIdx.x < x.world && (int)threadIdx.x != x.rank)
-                __hip_atomic_store(x.flag[threadIdx.x] + par * kMaxPeers + x.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(pick_peer(x.flag, (int)threadIdx.x) + par * kMaxPeers + x.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             for (int p = 0; p < x.world; ++p) {
                 if (p == x.rank) continue;
-                double *dst = x.buf[p] + off;
+                double *dst = pick_peer(x.buf, p) + off;
                 for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < chunk_d; j += (size_t)stride) dst[j] = src[j];
             }
             __threadfence_system();
@@ -1096,14 +1108,14 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
             if (sh_flag && !x.mute && threadIdx.x < x.world && (int)threadIdx.x != x.rank) {
                 __threadfence_system();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(x.flag[threadIdx.x] + par * kMaxPeers + x.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(pick_peer(x.flag, (int)threadIdx.x) + par * kMaxPeers + x.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             int good = 1;
             const long long t0 = wall_clock64();
-            const unsigned long long *f = x.flag[x.rank] + par * kMaxPeers;
+            const unsigned long long *f = pick_peer(x.flag, x.rank) + par * kMaxPeers;
             for (int p = 0; p < x.world && good; ++p) {
                 if (p == x.rank) continue;
                 while (__hip_atomic_load(f + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
@@ -1476,13 +1488,13 @@ __device__ __forceinline__ void sum_partials256_x4q(const double *p0, const doub
 }
 
 template <int O>
-__device__ __forceinline__ void outer_decide(const OuterStepArgs &A, const TcgScal &sc0, bool lead, int time_up, double *sh16) {
+__device__ __forceinline__ void outer_decide(const OuterStepArgs &A, const TcgScal &sc0, const OuterScal &os0, bool lead, int time_up, double *sh16) {
     constexpr int OP = pitch_of(O);
     const int64_t total = (int64_t)A.nloc * 3 * OP;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    double loss = sc0.loss, rr = sc0.rr_point, delta = sc0.delta;
-    int shrink = sc0.shrink_count, k = sc0.k, stop = 0;
-    long long totalite = sc0.totalite;
+    double loss = os0.loss, rr = os0.rr_point, delta = sc0.delta;
+    int shrink = os0.shrink_count, k = os0.k, stop = 0;
+    long long totalite = os0.totalite;
     bool accept = false, start = true;
     if (sc0.phase == PH_CAND) {
         // same grouping as outer_finalize_kernel (rank by rank, one rank here)
@@ -1520,7 +1532,7 @@ __device__ __forceinline__ void outer_decide(const OuterStepArgs &A, const TcgSc
                     }
                     if (endreason == 5) stop = 5;
                     else if (sqrt(rr) < A.gradtol) stop = 10;
-                    else if (sc0.time_up) stop = 11;
+                    else if (os0.time_up) stop = 11;
                     start = (stop == 0);
                 }
             }
@@ -1556,10 +1568,12 @@ __device__ __forceinline__ void outer_decide(const OuterStepArgs &A, const TcgSc
         nx.rr = rr; nx.pp = rr; nx.delta = delta; nx.gradnorm = sqrt(rr);
         nx.seq = sc0.seq;
         nx.phase = start ? PH_TCG : PH_STOP;
-        nx.loss = loss; nx.rr_point = rr; nx.totalite = totalite; nx.shrink_count = shrink; nx.k = k; nx.stop_reason = stop;
-        nx.time_up = time_up;
-        nx.slots = sc0.slots + ((sc0.phase == PH_CAND) ? 1 : 0);
+        OuterScal on = {};
+        on.loss = loss; on.rr_point = rr; on.totalite = totalite; on.shrink_count = shrink; on.k = k; on.stop_reason = stop;
+        on.time_up = time_up;
+        on.slots = os0.slots + ((sc0.phase == PH_CAND) ? 1 : 0);
         *A.scal_next = nx;
+        *A.os_next = on;
         publish_host(A.hprog, pack_prog(A.run, A.slot + 1, nx.phase));
     }
 }
@@ -1583,15 +1597,16 @@ __global__ __launch_bounds__(256) void outer_step_kernel(OuterStepArgs A) {
     PartialsPre pre;
     sum_partials_prefetch(A.parts, A.parts + A.nA, A.parts + 2 * A.nA, A.nA, A.parts + 3 * A.nA, A.nB, pre, A.grp);
     const TcgScal sc0 = *A.scal_cur;
+    const OuterScal os0 = *A.os_cur;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     int time_up = 0;
-    if (lead) time_up = sc0.time_up | *A.stop_req;
+    if (lead) time_up = os0.time_up | *A.stop_req;
     if (sc0.phase == PH_STOP) {
-        if (lead) *A.scal_next = sc0;
+        if (lead) { *A.scal_next = sc0; *A.os_next = os0; }
         return;
     }
     if (sc0.phase != PH_TCG) {   // PH_CAND, PH_INIT
-        outer_decide<O>(A, sc0, lead, time_up, sh16);
+        outer_decide<O>(A, sc0, os0, lead, time_up, sh16);
         return;
     }
     double pHp = 0.0, rHp = 0.0, HpHp = 0.0, rr_prev = 0.0;
@@ -1661,9 +1676,11 @@ __global__ __launch_bounds__(256) void outer_step_kernel(OuterStepArgs A) {
             nx.iter = sc.iter + 1;
             nx.status = 0;
             nx.phase = PH_TCG;
-            nx.slots = sc0.slots + 1;
-            nx.time_up = time_up;
+            OuterScal on = os0;
+            on.slots = os0.slots + 1;
+            on.time_up = time_up;
             *A.scal_next = nx;
+            *A.os_next = on;
             publish_host(A.hprog, pack_prog(A.run, A.slot + 1, PH_TCG));
         }
         return;
@@ -1738,9 +1755,11 @@ __global__ __launch_bounds__(256) void outer_step_kernel(OuterStepArgs A) {
             else { nx.iter = sc.iter + 1; nx.status = 6; }
         }
         nx.phase = PH_CAND;
-        nx.slots = sc0.slots + 1;
-        nx.time_up = time_up;
+        OuterScal on = os0;
+        on.slots = os0.slots + 1;
+        on.time_up = time_up;
         *A.scal_next = nx;
+        *A.os_next = on;
         publish_host(A.hprog, pack_prog(A.run, A.slot + 1, PH_CAND));
     }
 }

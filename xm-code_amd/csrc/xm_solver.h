@@ -324,6 +324,7 @@ private:
     TrResult trust_region_device(int o, double &gradtol, double f, double rr, double delta, double delta_bar, double max_time);
     DevBuf<double> trace_dev_;           // device copy of the outer-iteration trace (kMaxOuter records)
     DevBuf<int> stop_req_;               // set by the host when its time limit has expired
+    DevBuf<OuterScal> oscal_;            // trust-region state of the device-driven outer iteration, two parity copies next to scal_
     unsigned int outer_run_ = 0;         // run number in the progress word (hstat_[24])
     CertResult certificate(int o, double primal, std::vector<double> &v_out);
     int lanczos_min(std::vector<double> &x_out, double &theta, int &iters, double &resid);   // 0 converged, 1 not

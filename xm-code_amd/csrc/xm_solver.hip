@@ -1178,10 +1178,15 @@ TrResult Context::trust_region_device(int o, double &gradtol, double f, double r
         if (trace_dev_.count < (size_t)kMaxOuter * 6) trace_dev_.alloc((size_t)kMaxOuter * 6);
         if (stop_req_.count < 1) stop_req_.alloc(1);
         XM_HIP_CHECK(hipMemsetAsync(stop_req_.p, 0, sizeof(int), st_));
+        if (oscal_.count < 2) oscal_.alloc(2);
         TcgScal init;
         std::memset(&init, 0, sizeof(init));
-        init.phase = PH_INIT; init.loss = loss; init.rr_point = rr; init.delta = delta; init.seq = (int)++tcg_seq_;
+        init.phase = PH_INIT; init.delta = delta; init.seq = (int)++tcg_seq_;
+        OuterScal oinit;
+        std::memset(&oinit, 0, sizeof(oinit));
+        oinit.loss = loss; oinit.rr_point = rr;
         to_dev(scal_.p + 1, &init, sizeof(init));   // slot -1 has parity 1
+        to_dev(oscal_.p + 1, &oinit, sizeof(oinit));
         const unsigned int runid = ++outer_run_;
         volatile unsigned long long *hp = hstat_ + 24;
         *hp = 0;
@@ -1194,6 +1199,7 @@ TrResult Context::trust_region_device(int o, double &gradtol, double f, double r
             std::memset(&A, 0, sizeof(A));
             A.nloc = nloc_; A.cam0 = cam0_;
             A.scal_cur = scal_.p + par; A.scal_next = scal_.p + (par ^ 1);
+            A.os_cur = oscal_.p + par; A.os_next = oscal_.p + (par ^ 1);
             A.parts = partsB_.p + (size_t)par * chunk;
             A.partsB_out = partsB_.p + (size_t)(par ^ 1) * chunk + (size_t)3 * nA;
             A.nA = nA; A.nB = nB;
@@ -1269,10 +1275,12 @@ TrResult Context::trust_region_device(int o, double &gradtol, double f, double r
         }
         XM_HIP_CHECK(hipStreamSynchronize(st_));
         TcgScal fin;
+        OuterScal ofin;
         to_host(&fin, scal_.p + (enq & 1), sizeof(TcgScal));
+        to_host(&ofin, oscal_.p + (enq & 1), sizeof(OuterScal));
         if (fin.phase != PH_STOP) throw Error(XM_ERR_HIP, "device-driven outer iteration: the final scalar block is not in the stop phase");
-        k = fin.k; totalite = fin.totalite; loss = fin.loss; stop_reason = fin.stop_reason;
-        slots_live = fin.slots; slots_enq = enq;
+        k = ofin.k; totalite = ofin.totalite; loss = ofin.loss; stop_reason = ofin.stop_reason;
+        slots_live = ofin.slots; slots_enq = enq;
         // trace records 1 .. k (record k exists when iteration k's top was reached: always, except when the iteration cap ended the loop)
         const int last_rec = std::min(k, kMaxOuter - 1);
         if (opt_->trace && last_rec >= 1 && res_->trace_len < opt_->trace_cap) {
