@@ -1007,18 +1007,6 @@ __global__ __launch_bounds__(256) void tcg_init_kernel(int nloc, const double *_
 // reduction; the directly summed |r|^2 (partsB_out) replaces that estimate as <r,r> of the NEXT iteration, so no error
 // accumulates.  Block 0 owns the scalar state (other parity buffer) and the host-mapped progress word.  The scale parts of
 // p and r are ping-ponged (cur -> next): every element thread of a camera reads them while one thread rewrites them.
-// entry i of a small pointer table that lives in the kernel's ARGUMENT block, by a chain of selects over constant indices.  Indexing such a table
-// with a run-time value makes the compiler copy it to private memory first -- cg_step_kernel carried 56 bytes of scratch and 13 KB of LDS for
-// PeerXchg's two tables, on the single-GPU path too, and a kernel with scratch pays for it at every dispatch: 5.7 us on one box, 18.7 on another
-// whose host was busy (same GPU, same launch; profiles/r06_trace_venice1778_host.txt)
-template <class T>
-__device__ __forceinline__ T pick_peer(const T (&tab)[kMaxPeers], int i) {
-    T p = tab[0];
-#pragma unroll
-    for (int q = 1; q < kMaxPeers; ++q) p = (i == q) ? tab[q] : p;
-    return p;
-}
-
 template <int O>
 __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *__restrict__ scal_cur, TcgScal *scal_next,
                                                        const double *__restrict__ parts, int nA_loc, int nB_loc, int world,
@@ -1069,14 +1057,14 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
         const size_t chunk_d = (size_t)b_off + 3 * (size_t)nA_loc + nB_loc;
         const size_t off = ((size_t)par * x.world + x.rank) * chunk_d;
         const unsigned long long epoch = x.epoch_base + (unsigned long long)sc0.iter + 1ull;
-        const double *src = pick_peer(x.buf, x.rank) + off;
+        const double *src = x.buf[x.rank] + off;
         if (x.lite) {
             // write-through form: every payload store is itself a system-scope (sc0 sc1) store, acknowledged by its destination
             // before s_waitcnt vmcnt(0) lets the wave go on -- nothing of it is left in this device's L2, so the hand-off needs no
             // release fence (which writes back the WHOLE L2 of the XCD: the column-split product measured 39 vs 14 us for that)
             for (int p = 0; p < x.world; ++p) {
                 if (p == x.rank) continue;
-                double *dst = pick_peer(x.buf, p) + off;
+                double *dst = x.buf[p] + off;
                 for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < chunk_d; j += (size_t)stride)
                     __hip_atomic_store(dst + j, src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -1089,11 +1077,11 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
             }
             __syncthreads();
             if (sh_flag && !x.mute && threadIdx.x < x.world && (int)threadIdx.x != x.rank)
-                __hip_atomic_store(pick_peer(x.flag, (int)threadIdx.x) + par * kMaxPeers + x.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(x.flag[threadIdx.x] + par * kMaxPeers + x.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             for (int p = 0; p < x.world; ++p) {
                 if (p == x.rank) continue;
-                double *dst = pick_peer(x.buf, p) + off;
+                double *dst = x.buf[p] + off;
                 for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < chunk_d; j += (size_t)stride) dst[j] = src[j];
             }
             __threadfence_system();
@@ -1108,14 +1096,14 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int nloc, const TcgScal *_
             if (sh_flag && !x.mute && threadIdx.x < x.world && (int)threadIdx.x != x.rank) {
                 __threadfence_system();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(pick_peer(x.flag, (int)threadIdx.x) + par * kMaxPeers + x.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(x.flag[threadIdx.x] + par * kMaxPeers + x.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             int good = 1;
             const long long t0 = wall_clock64();
-            const unsigned long long *f = pick_peer(x.flag, x.rank) + par * kMaxPeers;
+            const unsigned long long *f = x.flag[x.rank] + par * kMaxPeers;
             for (int p = 0; p < x.world && good; ++p) {
                 if (p == x.rank) continue;
                 while (__hip_atomic_load(f + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
