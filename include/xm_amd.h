@@ -74,7 +74,7 @@ typedef struct xm_ctx xm_ctx_t;
                                   each rank builds only its own camera rows (a >= 10k-camera Q never exists on the host) */
 #define XM_STORAGE_VIEWGRAPH 4 /* the north_star workload described by its EDGE LIST: Q = sum_e w_e G_e over view-graph edges e = (i, j), Q_ii += w_e I,
                                   Q_jj += w_e I, Q_ij = -w_e M_e, Q_ji = Q_ij^T with M_e the measured relative rotation (what xm_ctx_attach_edges takes).
-                                  Stored as 3x3-block CSR; with >= 1.5 M blocks per GPU (xm_tuning_t.sell) the products stream the compressed sliced-ELL copy
+                                  Stored as 3x3-block CSR; with >= 2.2 M blocks per GPU (xm_tuning_t.sell) the products stream the compressed sliced-ELL copy
                                   (quaternion per off-diagonal block, one double per diagonal block: 36 B per stored block instead of 76,
                                   xm-code_amd/csrc/xm_sell.h).  The edges are attached for the XM^2 calls at creation. */
 #define XM_STORAGE_SCHUR 3     /* MATRIX-FREE: Q is never formed.  The problem is the observation list the reference's

@@ -35,6 +35,8 @@ int xm_qw_dense_strip_time(const double *dq, int64_t nloc, int64_t n, int o, con
  * out = alpha * Q_strip * W (also a functional entry: tests compare it with the unsplit product); with reps > 0 also the average launch time */
 int xm_qw_dense_strip_ks(const double *dq, int64_t nloc, int64_t n, int o, const double *dW, double *dOut, double alpha, int ks, int reps,
                          double *ms_avg, int *ks_used);
+/* xm_qw_bsr3_time multiplies with every workgroup's 16 rows ordered by their number of 16-block windows, as a solve does (1, default), or in camera order (0) */
+int xm_bench_bsr_binned(int on);
 int xm_qw_bsr3_time(const int64_t *d_rowptr, const int32_t *d_colidx, const double *d_blocks, int64_t n, int o, const double *dW,
                     double *dOut, int reps, double *ms_avg);
 /* sliced-ELL product (both launches); dWpad16 = the input at a record pitch of 16 doubles or NULL (xm_qw_sell_padded) */

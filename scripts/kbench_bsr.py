@@ -1,9 +1,9 @@
-"""micro-benchmark of the BSR3 Q*W kernel: python scripts/kbench_bsr.py n deg o [o ...]"""
+"""micro-benchmark of the BSR3 Q*W kernel: python scripts/kbench_bsr.py n deg o [o ...] [--policy]   (--policy: also with the block stream's load policy forced)"""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "xm-code_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, xmamd, xm_testlib as tl
-n = int(sys.argv[1]); deg = int(sys.argv[2]); os_ = [int(x) for x in sys.argv[3:]] or [3]
+n = int(sys.argv[1]); deg = int(sys.argv[2]); os_ = [int(x) for x in sys.argv[3:] if not x.startswith("--")] or [3]
 if os.environ.get("XM_KB_BAND") == "1":   # view graph WITH locality: camera i sees cameras i-deg/2 .. i+deg/2 (sequential capture)
     h = deg // 2
     lo = np.maximum(np.arange(n) - h, 0); hi = np.minimum(np.arange(n) + h, n - 1)
@@ -25,4 +25,17 @@ for o in os_:
     ms = C.c_double()
     xmamd._chk(L.xm_qw_bsr3_time(drp.ptr, dci.ptr, dbl.ptr, n, o, dW.ptr, dO.ptr, 100, C.byref(ms)))
     by = 76.0 * nb + 4 * (n + 1) + 2 * 8 * 3 * n * o
-    print(f"BSR n={n} deg={deg} nb={nb} o={o}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s algorithmic ({by/1e6:.1f} MB)")
+    pol = ""
+    if "--order" in sys.argv:   # rows in camera order instead of binned by their number of windows
+        xmamd._chk(L.xm_bench_bsr_binned(0)); m2 = C.c_double()
+        xmamd._chk(L.xm_qw_bsr3_time(drp.ptr, dci.ptr, dbl.ptr, n, o, dW.ptr, dO.ptr, 100, C.byref(m2)))
+        xmamd._chk(L.xm_bench_bsr_binned(1))
+        pol += f"   [rows in camera order {m2.value*1e3:.1f} us]"
+    if "--policy" in sys.argv or os.environ.get("XM_KB_POLICY"):   # the block stream's load policy forced: all cacheable / all non-temporal
+        tt = []
+        for nt in (0, 1):
+            xmamd._chk(L.xm_bench_dense_policy(nt)); m2 = C.c_double()
+            xmamd._chk(L.xm_qw_bsr3_time(drp.ptr, dci.ptr, dbl.ptr, n, o, dW.ptr, dO.ptr, 100, C.byref(m2))); tt.append(m2.value * 1e3)
+        xmamd._chk(L.xm_bench_dense_policy(-1))
+        pol += f"   [blocks all cacheable {tt[0]:.1f} us, all non-temporal {tt[1]:.1f} us]"
+    print(f"BSR n={n} deg={deg} nb={nb} o={o}: {ms.value*1e3:8.1f} us  {by/ms.value/1e6:8.1f} GB/s algorithmic ({by/1e6:.1f} MB){pol}")

@@ -58,6 +58,35 @@ def test_qw_bsr3_banded(xmamd, o):
     assert tl.rel_fro(got, ref) < 1e-13
 
 
+@pytest.mark.parametrize("o", [3, 5, 7])
+def test_qw_bsr3_rows_ordered_by_window_count(xmamd, o):
+    """inside a solve the block-CSR kernel takes the 16 rows of a workgroup in the order of their number of 16-block windows (one 16-byte
+    row record instead of two row pointers; a wavefront's four rows then have similar lengths).  Same product bit for bit as in camera order:
+    a row's sum does not depend on which lane group computes it.  Ragged rows incl. empty ones and a last workgroup that is not full"""
+    import ctypes as C
+    rng = np.random.default_rng(40 + o)
+    n = 16 * 23 + 5
+    cnt = rng.integers(0, 70, n); cnt[rng.integers(0, n, 25)] = 0
+    rowptr = np.zeros(n + 1, dtype=np.int64); rowptr[1:] = np.cumsum(cnt)
+    colidx = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in cnt] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+    blocks = rng.standard_normal((int(rowptr[-1]), 3, 3))
+    W = rng.standard_normal((3 * n, o))
+    ref = tl.bsr_to_dense(n, rowptr, colidx, blocks) @ W
+    L = xmamd.lib()
+    drp = xmamd.DevArray(rowptr); dci = xmamd.DevArray(colidx); dbl = xmamd.DevArray(blocks.reshape(-1))
+    dW = xmamd.DevArray(xmamd.to_rm(W))
+    outs = []
+    for binned in (1, 0):
+        dO = xmamd.DevArray(np.full(3 * n * xmamd.pitch_of(o), np.nan)); ms = C.c_double()
+        xmamd._chk(L.xm_bench_bsr_binned(binned))
+        xmamd._chk(L.xm_qw_bsr3_time(drp.ptr, dci.ptr, dbl.ptr, n, o, dW.ptr, dO.ptr, 1, C.byref(ms)))
+        outs.append(xmamd.from_rm(dO.get(), 3 * n, o)); dO.free()
+    xmamd._chk(L.xm_bench_bsr_binned(1))
+    for b in (drp, dci, dbl, dW): b.free()
+    assert np.array_equal(outs[0], outs[1])
+    assert tl.rel_fro(outs[0], ref) < 1e-13
+
+
 def test_qw_empty_rows_bsr(xmamd):
     # ragged: cameras without any stored block
     n = 9

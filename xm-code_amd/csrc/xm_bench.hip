@@ -140,11 +140,25 @@ int xm_qw_dense_strip_ks(const double *dq, int64_t nloc, int64_t n, int o, const
     return XM_OK;
     XM_CATCH
 }
+static int g_bsr_binned = 1;
+int xm_bench_bsr_binned(int on) { g_bsr_binned = on; return XM_OK; }
 int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int64_t n, int o, const double *dW, double *dOut, int reps,
                     double *ms_avg) {
     XM_TRY
     const xm::CamArgs a = plain_args(n, dOut);
-    const double ms = time_launches(3, reps, [&] { xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr); });
+    // as in a solve: the block count decides the load policy of the block stream (xm_bench_dense_policy overrides it) and the rows are
+    // binned by their number of windows (xm_bench_bsr_binned(0): camera order)
+    std::vector<int64_t> rph((size_t)n + 1);
+    XM_HIP_CHECK(hipMemcpy(rph.data(), rp, rph.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t nb = rph[(size_t)n];
+    xm::DevBuf<int4> dri;
+    if (g_bsr_binned) {
+        std::vector<int4> ri;
+        xm::bsr_build_rowinfo(rph.data(), (int)n, ri);
+        dri.alloc(std::max<size_t>(ri.size(), 1));
+        if (!ri.empty()) XM_HIP_CHECK(hipMemcpy(dri.p, ri.data(), ri.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
+    const double ms = time_launches(3, reps, [&] { xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr, nb, g_bsr_binned ? dri.p : nullptr); });
     if (ms_avg) *ms_avg = ms;
     return XM_OK;
     XM_CATCH

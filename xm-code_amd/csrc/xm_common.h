@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace xm {
 
@@ -205,8 +206,11 @@ void launch_outer_step(int o, int polar, const OuterStepArgs &A, int grid, hipSt
 // Q*W products.  grid = ceil(nloc / kQwWaves).  Q rows are the local cameras' rows; W has `ld` rows (all cameras).
 void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a,
                      hipStream_t st);
+// nb = stored blocks of the nloc rows (0: unknown): decides the load policy of the block stream (cacheable below the Infinity Cache's size)
+// rowinfo (device, nloc entries, may be nullptr = camera order): the rows binned by their number of 16-block windows (bsr_build_rowinfo)
 void launch_qw_bsr3(int o, int epi, const int64_t *rowptr, const int32_t *colidx, const double *blocks, const double *W,
-                    double alpha, const CamArgs &a, hipStream_t st);
+                    double alpha, const CamArgs &a, hipStream_t st, int64_t nb = 0, const int4 *rowinfo = nullptr);
+void bsr_build_rowinfo(const int64_t *rowptr_host, int nloc, std::vector<int4> &out);
 int qw_grid(int nloc);
 // the same product restricted to a range of column tiles (CamArgs.range_mode / t_lo / t_hi / addend); plain or gradient epilogue
 void launch_qw_dense_split(int o, int epi, const double *Q, int64_t ld, const double *W, double alpha, const CamArgs &a, hipStream_t st);

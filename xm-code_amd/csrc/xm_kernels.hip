@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void asym_kernel(const double *__restrict__ Q,
 template <int O, int EPI, int VAR>
 __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                                        const double *__restrict__ blocks, const double *__restrict__ W,
-                                                       double alpha, CamArgs a) {
+                                                       const int4 *__restrict__ rowinfo, double alpha, CamArgs a) {
     constexpr int OP = pitch_of(O);
     int role = EPI;   // (see qw_dense_kernel)
     constexpr int REC = 3 * OP;                                   // doubles of one camera's rows of W
@@ -713,15 +713,27 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     __shared__ double stage[(VAR >= 1) ? kBsrRows * 16 * SW : 1]; // VAR >= 1: blocks pass through LDS (coalesced loads)
     const int gl = threadIdx.x & 15;          // lane inside the group
     const int slot = threadIdx.x >> 4;        // group inside the workgroup (0..15)
-    const int cam = blockIdx.x * kBsrRows + slot;
-    const bool active = cam < a.nloc;
+    // rowinfo (may be nullptr: rows in camera order): the workgroup's 16 rows ORDERED BY THEIR NUMBER OF WINDOWS, longest first (bsr_build_rowinfo) --
+    // entry = {first block (64 bit), row length, camera}.  The four groups of a wavefront loop together, so in camera order a wavefront runs as
+    // many windows as its longest row needs: with ~31 +- 5 blocks per row 82 % of the wavefronts ran three windows where 35 % of the rows need
+    // them (13.0 us against 11.2 for the same number of blocks in rows of equal length).  One 16-byte load instead of the two row pointers.
+    const int rslot = blockIdx.x * kBsrRows + slot;
+    const bool active = rslot < a.nloc;
+    int cam = rslot;
     double acc[3][O];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
     int64_t b0 = 0, b1 = 0;
-    if (active) { b0 = rowptr[cam]; b1 = rowptr[cam + 1]; }
+    if (rowinfo) {
+        if (active) {
+            const int4 ri = rowinfo[rslot];
+            b0 = (int64_t)(((unsigned long long)(unsigned)ri.y << 32) | (unsigned long long)(unsigned)ri.x);
+            b1 = b0 + ri.z;
+            cam = ri.w;
+        }
+    } else if (active) { b0 = rowptr[cam]; b1 = rowptr[cam + 1]; }
     if (EPI == EPI_HESS) {   // the tCG's status word (written by the previous cg_step on another XCD: an L2 miss) travels WITH the row pointers:
         if (a.scal->status != 0) return;   // the dependent chain of this latency-bound kernel is one round trip shorter
     }
@@ -752,6 +764,13 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
         // window k+1 in flight since window k-1.  Window k first issues cols(k+2), blocks(k+1) and - with the indices that have
         // had a whole window to arrive - W-records(k+1), and only then consumes its own data: no load waits on a load issued
         // in the same window, so a window costs one memory latency instead of the chained two (index, then gather).
+        // The blocks' load policy is a compile-time property of the pipeline's copy (a hint chosen by a branch next to the load is merged
+        // into one plain load by the compiler): below the Infinity Cache's size the blocks are read with the DEFAULT policy -- they stay in the
+        // L2s / the Infinity Cache between products: 13.0 -> 11.9 us at 425 k blocks (34 MB), 25.7 -> 21.8 at 929 k, 36.5 -> 30.9 at 1.39 M --
+        // beyond it non-temporally, a pure stream (402 MB: 127.4 against 136.5 us); profiles/r06_kbench_bsr_policy.txt.  CamArgs.nt_cam0
+        // (0 or nloc: set by the launcher from the size rule of the dense kernel) is the camera where the stream starts.
+        auto pipeline = [&](auto ntflag) {
+        constexpr bool NT = decltype(ntflag)::value;
         int jn = 0, jnn = 0, nd = 0, ndn = 0;
         d2u t[5], tn[5], tw[NP], twn[NP];
         auto load_cols = [&](int64_t off, int &jj) {
@@ -767,7 +786,8 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
             // back to align every load was measured and changed nothing: 131.2 vs 131.1 us)
 #pragma unroll
             for (int i = 0; i < 5; ++i)
-                tt[i] = __builtin_nontemporal_load((const d2u *)(src + max(min(2 * (gl + 16 * i), ndd - 2), 0)));   // pure stream
+                tt[i] = NT ? __builtin_nontemporal_load((const d2u *)(src + max(min(2 * (gl + 16 * i), ndd - 2), 0)))
+                           : *(const d2u *)(src + max(min(2 * (gl + 16 * i), ndd - 2), 0));
         };
         auto load_w = [&](int jj, d2u (&ww)[NP]) {
 #pragma unroll
@@ -840,6 +860,9 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
             for (; off + 16 < span; off += 16) window(off, std::true_type{});
             window(off, std::false_type{});
         }
+        };
+        if ((int)(blockIdx.x * kBsrRows) >= a.nt_cam0) pipeline(std::true_type{});
+        else pipeline(std::false_type{});
     } else
     for (int64_t off = 0; off < span; off += 16) {
         const int64_t base = b0 + off;
@@ -2617,37 +2640,67 @@ void launch_asym(const double *Q, int64_t ld, int64_t m, double *out, int grid, 
 }
 
 template <int O, int VAR>
-static void qw_bsr3_epi(int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, double alpha,
+static void qw_bsr3_epi(int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, const int4 *ri, double alpha,
                         const CamArgs &a, hipStream_t st) {
     const dim3 g((a.nloc + kBsrRows - 1) / kBsrRows), b(256);
     switch (epi) {
-        case EPI_PLAIN: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_PLAIN, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
-        case EPI_GRAD: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
-        case EPI_HESS: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_HESS, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break;
+        case EPI_PLAIN: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_PLAIN, VAR>), g, b, 0, st, rp, ci, bl, W, ri, alpha, a); break;
+        case EPI_GRAD: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_GRAD, VAR>), g, b, 0, st, rp, ci, bl, W, ri, alpha, a); break;
+        case EPI_HESS: hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_HESS, VAR>), g, b, 0, st, rp, ci, bl, W, ri, alpha, a); break;
         case EPI_AUTO:
-            if constexpr (O >= 3) { hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_AUTO, VAR>), g, b, 0, st, rp, ci, bl, W, alpha, a); break; }
+            if constexpr (O >= 3) { hipLaunchKernelGGL((qw_bsr3_kernel<O, EPI_AUTO, VAR>), g, b, 0, st, rp, ci, bl, W, ri, alpha, a); break; }
             throw Error(-2, "bad epilogue");
         default: throw Error(-2, "bad epilogue");
     }
 }
+// nb: stored blocks of these nloc rows, or 0 when the caller does not know -- then, and up to the size the dense kernel's rule keeps cacheable, the
+// blocks are read with the default policy; a larger matrix streams all of them non-temporally (a cacheable prefix as in the dense kernel
+// loses here: 402 MB 133.5 us with a 220 MB prefix, 127.4 all non-temporal, 136.5 all cacheable)
+static int bsr_nt_cam0(int nloc, int64_t nb) {
+    const size_t bytes = (size_t)std::max<int64_t>(nb, 0) * 76;
+    return qw_resident_bytes(bytes) >= (int64_t)bytes ? nloc : 0;
+}
+// The 16 rows of every workgroup (cameras 16 b .. 16 b + 15) ordered by their number of 16-block windows, most windows first, camera order among
+// equals (stable): entry = {first block lo, hi, length, camera}.  A wavefront then carries four rows of similar length out of its workgroup's
+// sixteen, and the workgroup still owns sixteen CONSECUTIVE cameras: the epilogue's vectors stay contiguous per workgroup (binning over the whole
+// matrix is 0.9 us faster in the bare product at 13 682 cameras and loses all of it again in the Hessian epilogue, whose five vectors it scatters)
+void bsr_build_rowinfo(const int64_t *rowptr_host, int nloc, std::vector<int4> &out) {
+    out.resize((size_t)std::max(nloc, 0));
+    for (int c0 = 0; c0 < nloc; c0 += kBsrRows) {
+        const int m = std::min(kBsrRows, nloc - c0);
+        int order[kBsrRows];
+        for (int j = 0; j < m; ++j) order[j] = c0 + j;
+        std::stable_sort(order, order + m, [&](int x, int y) {
+            return (rowptr_host[x + 1] - rowptr_host[x] + 15) / 16 > (rowptr_host[y + 1] - rowptr_host[y] + 15) / 16;
+        });
+        for (int j = 0; j < m; ++j) {
+            const int i = order[j];
+            const int64_t b0 = rowptr_host[i], len = rowptr_host[i + 1] - b0;
+            if (len >= ((int64_t)1 << 31)) throw Error(-2, "block-CSR row with 2^31 or more blocks");
+            out[(size_t)c0 + j] = make_int4((int)(unsigned)(b0 & 0xffffffffll), (int)(unsigned)((unsigned long long)b0 >> 32), (int)len, i);
+        }
+    }
+}
 void launch_qw_bsr3(int o, int epi, const int64_t *rp, const int32_t *ci, const double *bl, const double *W, double alpha,
-                    const CamArgs &a, hipStream_t st) {
-    if (a.nloc <= 0) return;
+                    const CamArgs &a0, hipStream_t st, int64_t nb, const int4 *ri) {
+    if (a0.nloc <= 0) return;
+    CamArgs a = a0;
+    a.nt_cam0 = bsr_nt_cam0(a.nloc, nb);
     if (epi == EPI_CERT) {
         if (o != 1) throw Error(-2, "certificate operator needs o == 1");
-        hipLaunchKernelGGL((qw_bsr3_kernel<1, EPI_CERT, 0>), dim3((a.nloc + kBsrRows - 1) / kBsrRows), dim3(256), 0, st, rp, ci, bl, W, alpha, a);
+        hipLaunchKernelGGL((qw_bsr3_kernel<1, EPI_CERT, 0>), dim3((a.nloc + kBsrRows - 1) / kBsrRows), dim3(256), 0, st, rp, ci, bl, W, ri, alpha, a);
     } else {
         // o <= 6: blocks AND the gathered records of W staged through LDS (VAR 2); above that the records no longer fit: blocks only (VAR 1)
         switch (o) {
-            case 3: qw_bsr3_epi<3, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
-            case 4: qw_bsr3_epi<4, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
-            case 5: qw_bsr3_epi<5, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
-            case 6: qw_bsr3_epi<6, 2>(epi, rp, ci, bl, W, alpha, a, st); break;
-            case 1: qw_bsr3_epi<1, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
-            case 7: qw_bsr3_epi<7, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
-            case 8: qw_bsr3_epi<8, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
-            case 9: qw_bsr3_epi<9, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
-            case 10: qw_bsr3_epi<10, 1>(epi, rp, ci, bl, W, alpha, a, st); break;
+            case 3: qw_bsr3_epi<3, 2>(epi, rp, ci, bl, W, ri, alpha, a, st); break;
+            case 4: qw_bsr3_epi<4, 2>(epi, rp, ci, bl, W, ri, alpha, a, st); break;
+            case 5: qw_bsr3_epi<5, 2>(epi, rp, ci, bl, W, ri, alpha, a, st); break;
+            case 6: qw_bsr3_epi<6, 2>(epi, rp, ci, bl, W, ri, alpha, a, st); break;
+            case 1: qw_bsr3_epi<1, 1>(epi, rp, ci, bl, W, ri, alpha, a, st); break;
+            case 7: qw_bsr3_epi<7, 1>(epi, rp, ci, bl, W, ri, alpha, a, st); break;
+            case 8: qw_bsr3_epi<8, 1>(epi, rp, ci, bl, W, ri, alpha, a, st); break;
+            case 9: qw_bsr3_epi<9, 1>(epi, rp, ci, bl, W, ri, alpha, a, st); break;
+            case 10: qw_bsr3_epi<10, 1>(epi, rp, ci, bl, W, ri, alpha, a, st); break;
             default: throw Error(-2, "rank o must be 1 or 3..10, got " + std::to_string(o));
         }
     }

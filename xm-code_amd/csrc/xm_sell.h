@@ -62,7 +62,7 @@ void sell_build_host(const int64_t *rowptr, const int32_t *colidx, int64_t nloc,
 //                    36 bytes per stored block instead of 76: the HBM stream of the product is 0.47x.  w_e = 0 (an edge removed by
 //                    the XM^2 filter) is the zero quaternion.
 enum { SELL_CODEC_FULL = 0, SELL_CODEC_QUAT = 1 };
-constexpr int64_t kSellMinBlocks = 1500000;   // stored blocks per GPU from which a context builds the sliced-ELL copy by itself (measured cross-over, xm_solver.hip)
+constexpr int64_t kSellMinBlocks = 2200000;   // stored blocks per GPU from which a context builds the sliced-ELL copy by itself (measured cross-over, xm_solver.hip)
 
 struct SellArgs {   // what the kernels see
     const int64_t *slice_off;

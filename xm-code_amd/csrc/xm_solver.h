@@ -220,6 +220,7 @@ private:
     DevBuf<int32_t> colidx_;
     DevBuf<double> blocks_;
     int64_t nb_loc_ = 0;
+    DevBuf<int4> rowinfo_;   // block-CSR kernel: the local rows binned by their number of 16-block windows (bsr_build_rowinfo)
     std::unique_ptr<SellMatrix> sell_;   // large block-sparse Q: sliced-ELL layout (xm_sell.h); the CSR arrays stay for the fallback kernels
     int sell_gm_ = 0;
     std::unique_ptr<SchurOp> schur_;     // XM_STORAGE_SCHUR: matrix-free Q (xm_schur.h)

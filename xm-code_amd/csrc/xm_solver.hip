@@ -313,13 +313,20 @@ void Context::init(const xm_problem_t &prob_in) {
         colidx_.alloc((size_t)std::max<int64_t>(nb_loc_, 1));
         blocks_.alloc((size_t)std::max<int64_t>(nb_loc_, 1) * 9);
         XM_HIP_CHECK(hipMemcpy(rowptr_.p, rp.data(), rp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        {
+            std::vector<int4> ri;
+            bsr_build_rowinfo(rp.data(), nloc_, ri);
+            rowinfo_.alloc(std::max<size_t>(ri.size(), 1));
+            if (!ri.empty()) XM_HIP_CHECK(hipMemcpy(rowinfo_.p, ri.data(), ri.size() * sizeof(int4), hipMemcpyHostToDevice));
+        }
         if (nb_loc_ > 0) {
             XM_HIP_CHECK(hipMemcpy(colidx_.p, ci.data(), (size_t)nb_loc_ * sizeof(int32_t), hipMemcpyHostToDevice));
             XM_HIP_CHECK(hipMemcpy(blocks_.p, prob.blocks + b0 * 9, (size_t)nb_loc_ * 9 * sizeof(double), hipMemcpyHostToDevice));
         }
-        // Large problems: sliced-ELL over per-XCD column slabs (xm_sell.h).  Below ~1.5 M blocks per GPU the product is in the
-        // launch-latency regime and the one-launch CSR kernel wins -- measured (profiles/r05_kbench_sell_crossover.txt, o = 3, us):
-        // 425 k blocks CSR 13.2 / sliced ELL 23.0, 929 k blocks 25.5 / 32.0, 2.05 M blocks 53.1 / 46.8; inside the solve at 425 k blocks
+        // Large problems: sliced-ELL over per-XCD column slabs (xm_sell.h).  Below ~2.2 M blocks per GPU the one-launch CSR kernel wins --
+        // measured (profiles/r06_kbench_bsr_policy.txt, o = 3, us; the CSR kernel reads its blocks with the default cache policy at these sizes):
+        // 1.39 M blocks CSR 31.5 / sliced ELL 39.3, 2.05 M blocks 49.3 / 52.2, 2.79 M blocks 72.4 / 66.1 (round 5, non-temporal blocks:
+        // 425 k 13.2 / 23.0, 929 k 25.5 / 32.0, 2.05 M 53.1 / 46.8); inside the solve at 425 k blocks
         // (Hessian epilogue, HIP events) 20.4 / 28.9 and 22.4 k / 18.3 k tCG iterations per second (r05_bench_rome_bsr*.json).  View-graph storage compresses the
         // stream with the quaternion codec (36 instead of 76 bytes per stored block).  Settings: sell, sell_slabs, sell_lmax,
         // sell_gather, sell_codec (xm_tuning_t).
@@ -649,7 +656,7 @@ void Context::product(int epi, int o, double alpha, const CamArgs &a) {
         wpad_next_ = nullptr;
         launch_qw_sell(o, epi, *sell_, W_.p, alpha, a, sell_gm_, st_, wp);
     } else {
-        launch_qw_bsr3(o, epi, rowptr_.p, colidx_.p, blocks_.p, W_.p, alpha, a, st_);
+        launch_qw_bsr3(o, epi, rowptr_.p, colidx_.p, blocks_.p, W_.p, alpha, a, st_, nb_loc_, rowinfo_.p);
     }
     if (res_) res_->qw_products++;
 }
@@ -1462,7 +1469,7 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 else if (storage_ == XM_STORAGE_DENSE) launch_qw_dense(1, EPI_CERT, dQ_, ld_, vj, 1.0, a, st_);
                 else if (storage_ == XM_STORAGE_SCHUR) schur_->product(1, EPI_CERT, vj, 1.0, a, st_);
                 else if (sell_) launch_qw_sell(1, EPI_CERT, *sell_, vj, 1.0, a, 0, st_);
-                else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_);
+                else launch_qw_bsr3(1, EPI_CERT, rowptr_.p, colidx_.p, blocks_.p, vj, 1.0, a, st_, nb_loc_, rowinfo_.p);
                 res_->qw_products++;
                 if (comm_->active()) comm_->allgather(w.p, (size_t)nloc_ * 3, st_);
                 // classical Gram-Schmidt twice against V(:,0..j); alpha_j = c1[j] + c2[j]; beta_j = |w|; v_{j+1} = w / beta_j

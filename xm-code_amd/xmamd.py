@@ -34,7 +34,7 @@ EXPORTS = [
     "xm_ctx_attach_edges", "xm_ctx_edge_residuals", "xm_ctx_edge_residuals_recovered", "xm_ctx_xm2_filter", "xm_ctx_xm2_round", "xm_ctx_set_edge_weights", "xm_ctx_recover_tp", "xm_ctx_schur_info", "xm_ctx_qw", "xm_spd_inverse", "xm_ctx_transport", "xm_ctx_sell_wpad", "xm_ctx_product_kind", "xm_symw_plan", "xm_symw_use",
 ]
 # include/xm_bench.h: timing hooks of the micro-benchmarks (same library, not part of the product ABI)
-BENCH_EXPORTS = ["xm_bench_last_error", "xm_qw_dense_time", "xm_qw_dense_sym_time", "xm_bench_symv_k", "xm_bench_dense_policy", "xm_qw_dense_sym_trace", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_qw_bsr3_time", "xm_qw_sell_time",
+BENCH_EXPORTS = ["xm_bench_last_error", "xm_qw_dense_time", "xm_qw_dense_sym_time", "xm_bench_symv_k", "xm_bench_dense_policy", "xm_qw_dense_sym_trace", "xm_qw_dense_strip_time", "xm_qw_dense_strip_ks", "xm_qw_bsr3_time", "xm_bench_bsr_binned", "xm_qw_sell_time",
                  "xm_retract_variant", "xm_recover_rotations_variant", "xm_peer_allgather_bench", "xm_qw_symw_time", "xm_bench_grid_barrier"]
 PRODUCT_KINDS = {0: "dense", 1: "dense_sym", 2: "bsr3", 3: "sell", 4: "sell_quat", 5: "schur"}
 
