@@ -1,4 +1,6 @@
-"""experiment: per-wavefront timestamps of the plain block-CSR product (needs a -DXM_BSR_TRACE build: XMAMD_LIB=xm-code_amd/lib_x/libxm_amd.so)"""
+"""per-wavefront 100 MHz timestamps of ONE launch of the plain block-CSR product (entry, row record in, each window's data in, end of the loop, end).
+   Needs an experiment build:  make -C xm-code_amd OBJDIR=obj_x LIBDIR=lib_x EXTRA=-DXM_BSR_TRACE lib_x/libxm_amd.so
+   XMAMD_LIB=xm-code_amd/lib_x/libxm_amd.so python scripts/kbench_bsr_trace.py n deg o"""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "xm-code_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))

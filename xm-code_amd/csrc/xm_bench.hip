@@ -163,6 +163,35 @@ int xm_qw_bsr3_time(const int64_t *rp, const int32_t *ci, const double *bl, int6
     return XM_OK;
     XM_CATCH
 }
+#ifdef XM_BSR_TRACE
+void xm_bsr_trace_set(unsigned long long *p);
+// experiment builds only (-DXM_BSR_TRACE): one traced launch of the plain block-CSR product as a solve runs it; trace_host[grid * 4 wavefronts][8]
+int xm_qw_bsr3_trace(const int64_t *rp, const int32_t *ci, const double *bl, int64_t n, int o, const double *dW, double *dOut,
+                     unsigned long long *trace_host) {
+    XM_TRY
+    const xm::CamArgs a = plain_args(n, dOut);
+    std::vector<int64_t> rph((size_t)n + 1);
+    XM_HIP_CHECK(hipMemcpy(rph.data(), rp, rph.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    std::vector<int4> ri;
+    xm::bsr_build_rowinfo(rph.data(), (int)n, ri);
+    xm::DevBuf<int4> dri;
+    dri.alloc(std::max<size_t>(ri.size(), 1));
+    if (!ri.empty()) XM_HIP_CHECK(hipMemcpy(dri.p, ri.data(), ri.size() * sizeof(int4), hipMemcpyHostToDevice));
+    const int4 *rip = g_bsr_binned ? dri.p : nullptr;
+    const size_t need = (size_t)((n + xm::kBsrRows - 1) / xm::kBsrRows) * 4 * 8;
+    xm::DevBuf<unsigned long long> tr;
+    tr.alloc(need);
+    for (int i = 0; i < 3; ++i) xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr, rph[(size_t)n], rip);
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    xm_bsr_trace_set(tr.p);
+    xm::launch_qw_bsr3(o, xm::EPI_PLAIN, rp, ci, bl, dW, 1.0, a, nullptr, rph[(size_t)n], rip);
+    XM_HIP_CHECK(hipDeviceSynchronize());
+    xm_bsr_trace_set(nullptr);
+    XM_HIP_CHECK(hipMemcpy(trace_host, tr.p, need * 8, hipMemcpyDeviceToHost));
+    return XM_OK;
+    XM_CATCH
+}
+#endif
 // handle: what xm_sell_create / xm_sell_create2 returned; dWpad16 may be NULL (include/xm_amd.h: xm_qw_sell_padded)
 int xm_qw_sell_time(void *handle, int o, const double *dW, const double *dWpad16, double *dOut, int gather_mode, int reps, double *ms_avg) {
     XM_TRY

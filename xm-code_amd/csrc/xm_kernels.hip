@@ -701,8 +701,18 @@ __global__ __launch_bounds__(256) void asym_kernel(const double *__restrict__ Q,
 // The row sums and the whole fused epilogue run inside the 16-lane row with four DPP steps per reduction.
 // ----------------------------------------------------------------------------------------------------------------
 
+#ifdef XM_BSR_TRACE
+// experiment builds only (make EXTRA=-DXM_BSR_TRACE OBJDIR=obj_x LIBDIR=lib_x; scripts/kbench_bsr_trace.py): 100 MHz timestamps per wavefront --
+// entry, row record in, the data of window 0 / 1 / >= 2 in, end of the loop, end.  What they showed at 13 682 cameras (profiles/r06_kbench_bsr_trace.txt):
+// a wavefront lives ~10 us = 0.4 (row pointers) + 3.0 + 2.6 + 2.0 (one window's loads after the other) + 0.9 + 0.8, and requesting two windows
+// at once moves the arrivals without shortening their sum: the windows' loads queue in the CU's load path (~45 cycles per 64-lane 16-byte load)
+__device__ unsigned long long *g_bsr_trace = nullptr;
+#define BSR_TS(slot_) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (g_bsr_trace && (threadIdx.x & 63) == 0) g_bsr_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot_)] = wall_clock64(); } while (0)
+#else
+#define BSR_TS(slot_) do { } while (0)
+#endif
 template <int O, int EPI, int VAR>
-__global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VAR == 2 && O == 3) ? 4 : 1, 8))) void qw_bsr3_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                                        const double *__restrict__ blocks, const double *__restrict__ W,
                                                        const int4 *__restrict__ rowinfo, double alpha, CamArgs a) {
     constexpr int OP = pitch_of(O);
@@ -726,6 +736,7 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
     int64_t b0 = 0, b1 = 0;
+    BSR_TS(0);
     if (rowinfo) {
         if (active) {
             const int4 ri = rowinfo[rslot];
@@ -744,6 +755,10 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     }
     // the four groups of a wavefront loop together (wave-level trip count = the longest of their rows)
     int64_t span = b1 - b0;
+#ifdef XM_BSR_TRACE
+    int widx = 0;
+#endif
+    BSR_TS(1);
     span = max(span, (int64_t)__shfl_xor((long long)span, 16, 64));
     span = max(span, (int64_t)__shfl_xor((long long)span, 32, 64));
     double *st = stage + slot * 16 * SW;
@@ -760,104 +775,106 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
         // every load is UNCONDITIONAL (idle lanes re-read a valid neighbour, clamped addresses): predicated loads become
         // exec-mask branches whose outstanding-load count the compiler cannot track, and it then drains the next window's loads
         // (s_waitcnt vmcnt(0)) right after issuing them.
-        // Pipeline state at the top of window k: blocks(k) and W-records(k) in flight since window k-1, column indices of
-        // window k+1 in flight since window k-1.  Window k first issues cols(k+2), blocks(k+1) and - with the indices that have
-        // had a whole window to arrive - W-records(k+1), and only then consumes its own data: no load waits on a load issued
-        // in the same window, so a window costs one memory latency instead of the chained two (index, then gather).
+        // Pipeline state at the top of window k: blocks(k) and W-records(k) in flight since window k-1, column indices of window k+1 in flight
+        // since window k-1.  Window k stages its data in LDS, requests cols(k+2), blocks(k+1) and - with the indices that have had a whole
+        // window to arrive - W-records(k+1), and multiplies: no load waits on a load issued in the same window.
         // The blocks' load policy is a compile-time property of the pipeline's copy (a hint chosen by a branch next to the load is merged
         // into one plain load by the compiler): below the Infinity Cache's size the blocks are read with the DEFAULT policy -- they stay in the
         // L2s / the Infinity Cache between products: 13.0 -> 11.9 us at 425 k blocks (34 MB), 25.7 -> 21.8 at 929 k, 36.5 -> 30.9 at 1.39 M --
         // beyond it non-temporally, a pure stream (402 MB: 127.4 against 136.5 us); profiles/r06_kbench_bsr_policy.txt.  CamArgs.nt_cam0
         // (0 or nloc: set by the launcher from the size rule of the dense kernel) is the camera where the stream starts.
+        // ONE set of load registers: a window first moves what has arrived (its blocks, then its records of W -- they share the LDS window) out
+        // of the registers and requests the next window into them; its own arithmetic follows.  The requests leave a few dozen cycles later
+        // than with a second register set, which costs nothing: the windows' loads queue in the CU's load path anyway (per-wavefront timestamps,
+        // profiles/r06_kbench_bsr_trace.txt: requesting two windows at once moved their arrivals, not the sum).  The lane's position inside its
+        // group is made opaque once per window -- derived from one loop-invariant value, the two dozen clamped offsets, record / piece numbers and
+        // LDS addresses were all kept in registers across the loop.  Together: 124 instead of 160 VGPRs at o = 3, a FOURTH wavefront per SIMD
+        // (1024 resident workgroups: the 856 of a 13 682-camera product in one round), three instead of two at o = 4, 5, two instead of one at
+        // o = 6: 11.6 -> 11.1 us at 13 682 cameras (deg 12: 7.4 -> 6.5), same sums in the same order.  Offsets inside a row are 32-bit.
         auto pipeline = [&](auto ntflag) {
         constexpr bool NT = decltype(ntflag)::value;
-        int jn = 0, jnn = 0, nd = 0, ndn = 0;
-        d2u t[5], tn[5], tw[NP], twn[NP];
-        auto load_cols = [&](int64_t off, int &jj) {
-            const int64_t bj = (b0 + off + gl < b1) ? b0 + off + gl : ((b1 > 0) ? b1 - 1 : 0);
-            jj = colidx[bj];
-        };
-        auto load_blocks = [&](int64_t off, d2u (&tt)[5], int &ndd) {
-            const int64_t base = b0 + off;
-            const int64_t left = b1 - base;
-            ndd = (int)((left < 16) ? ((left > 0) ? left : 0) : 16) * 9;   // doubles of this group's window
-            const double *src = (ndd > 0) ? blocks + base * 9 : blocks;
-            // (windows start 72*base bytes into the array, 16-byte aligned only for even base; shifting odd windows one double
-            // back to align every load was measured and changed nothing: 131.2 vs 131.1 us)
+        int jn = 0, jnn = 0, nd = 0;
+        d2u t[5], tw[NP];
+        const int len = (int)(b1 - b0);
+        const double *rowblocks = blocks + b0 * 9;
+        const int32_t *rowcols = colidx + b0;
+        const int wbase = threadIdx.x & 48;
+        auto load_cols = [&](int glo, int off, int &jj) { jj = (len > 0) ? rowcols[max(min(off + glo, len - 1), 0)] : 0; };
+        auto load_blocks = [&](int glo, int off, int &ndd) {
+            ndd = max(min(len - off, 16), 0) * 9;
+            const double *src = (ndd > 0) ? rowblocks + off * 9 : blocks;
 #pragma unroll
             for (int i = 0; i < 5; ++i)
-                tt[i] = NT ? __builtin_nontemporal_load((const d2u *)(src + max(min(2 * (gl + 16 * i), ndd - 2), 0)))
-                           : *(const d2u *)(src + max(min(2 * (gl + 16 * i), ndd - 2), 0));
+                t[i] = NT ? __builtin_nontemporal_load((const d2u *)(src + max(min(2 * (glo + 16 * i), ndd - 2), 0)))
+                          : *(const d2u *)(src + max(min(2 * (glo + 16 * i), ndd - 2), 0));
         };
-        auto load_w = [&](int jj, d2u (&ww)[NP]) {
+        auto load_w = [&](int glo, int jj) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int g = gl + 16 * i;
+                const int g = glo + 16 * i;
                 const int sl = g / NP;
                 const int start = min(2 * (g - sl * NP), REC - 2);
-                const int js = __shfl(jj, (threadIdx.x & 48) + sl, 64);
-                ww[i] = *(const d2u *)(W + (size_t)js * REC + start);
+                const int js = __shfl(jj, wbase + sl, 64);
+                tw[i] = *(const d2u *)(W + (size_t)((unsigned)js * (unsigned)REC + (unsigned)start));
             }
         };
-        // `prefetch` is a compile-time flag: no run-time branch may surround a load, or the compiler loses count of the
-        // outstanding ones and drains them all; hence the peeled last window.
-        auto window = [&](int64_t off, auto prefetch) {
-            if constexpr (decltype(prefetch)::value) {
-                load_cols(off + 32, jnn);
-                load_blocks(off + 16, tn, ndn);
-                load_w(jn, twn);
-            }
+        auto window = [&](int off, auto prefetch) {
+#ifdef XM_BSR_TRACE
+            BSR_TS(2 + min(widx, 2)); widx++;   // (this window's blocks and records have arrived)
+#endif
+            int glo = gl;
+            asm volatile("" : "+v"(glo));
             double q[9], w[3][O];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {   // clamped lanes rewrite identical data
-                const int pos = max(min(2 * (gl + 16 * i), nd - 2), 0);
+            for (int i = 0; i < 5; ++i) {
+                const int pos = max(min(2 * (glo + 16 * i), nd - 2), 0);
                 st[pos] = t[i].x; st[pos + 1] = t[i].y;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int e = 0; e < 9; ++e) q[e] = st[gl * 9 + e];
+            for (int e = 0; e < 9; ++e) q[e] = st[glo * 9 + e];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int g = gl + 16 * i;
+                const int g = glo + 16 * i;
                 const int sl = g / NP;
                 const int start = min(2 * (g - sl * NP), REC - 2);
                 st[sl * REC + start] = tw[i].x;
                 st[sl * REC + start + 1] = tw[i].y;
+            }
+            if constexpr (decltype(prefetch)::value) {
+                load_cols(glo, off + 32, jnn);
+                load_blocks(glo, off + 16, nd);
+                load_w(glo, jn);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int k = 0; k < O; ++k) w[c][k] = st[gl * REC + c * OP + k];
+                for (int k = 0; k < O; ++k) w[c][k] = st[glo * REC + c * OP + k];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const bool keep = b0 + off + gl < b1;   // idle lanes hold stale LDS contents: select, never multiply (NaN * 0)
+            const bool keep = off + glo < len;
 #pragma unroll
             for (int e = 0; e < 9; ++e) q[e] = keep ? q[e] : 0.0;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int k = 0; k < O; ++k) acc[r][k] += q[3 * r] * w[0][k] + q[3 * r + 1] * w[1][k] + q[3 * r + 2] * w[2][k];
-            if constexpr (decltype(prefetch)::value) {
-                jn = jnn; nd = ndn;
-#pragma unroll
-                for (int i = 0; i < 5; ++i) t[i] = tn[i];
-#pragma unroll
-                for (int i = 0; i < NP; ++i) tw[i] = twn[i];
-            }
+            if constexpr (decltype(prefetch)::value) jn = jnn;
         };
-        if (span > 0) {
+        const int wspan = (int)span;
+        if (wspan > 0) {
             int j0;
-            load_cols(0, j0);
-            load_cols(16, jn);
-            load_blocks(0, t, nd);
-            load_w(j0, tw);
-            int64_t off = 0;
-            for (; off + 16 < span; off += 16) window(off, std::true_type{});
+            load_cols(gl, 0, j0);
+            load_cols(gl, 16, jn);
+            load_blocks(gl, 0, nd);
+            load_w(gl, j0);
+            int off = 0;
+            for (; off + 16 < wspan; off += 16) window(off, std::true_type{});
             window(off, std::false_type{});
         }
         };
@@ -910,9 +927,14 @@ __global__ __launch_bounds__(256) void qw_bsr3_kernel(const int64_t *__restrict_
     // regime (13 682 cameras, 856 workgroups): requested up front they save a round trip but drop the kernel from three to two wavefronts per
     // SIMD, 22.5 against 20.3 us per Hessian product and 31.3 against 28.8 ms per solve on one box (profiles/r05_ab_rome.txt, lib_x)
     EpiOps eops;
+    BSR_TS(5);
     epi_prefetch<O, EPI>(eops, active ? cam : 0, gl, active, a, (EPI == EPI_AUTO) ? role : (int)EPI);
     qw_finish<O, EPI, 16, kBsrRows>(cam, gl, slot, active, acc, alpha, a, eops, red, (EPI == EPI_AUTO) ? role : (int)EPI);
+    BSR_TS(6);
 }
+#ifdef XM_BSR_TRACE
+extern "C" void xm_bsr_trace_set(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bsr_trace), &p, sizeof(p)); }
+#endif
 
 // ----------------------------------------------------------------------------------------------------------------
 // layout helpers
