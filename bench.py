@@ -408,6 +408,8 @@ def main():
                          "default on one GPU with dense / block-CSR products); host = xm_options_t.flags |= XM_FLAG_HOST_OUTER (the form of rounds 1-5)")
     ap.add_argument("--sym-min-rows", type=int, default=0, help="rows (3n) from which an exactly symmetric dense Q is multiplied by the half-traffic "
                     "kernel (xm_tuning_t.sym_min_rows; 0 = the library's measured default)")
+    ap.add_argument("--stream-policy", type=int, default=None, help="measurement aid (include/xm_bench.h: xm_bench_dense_policy): cache policy of the matrix "
+                    "streams forced -- 0 all cacheable, 1 all non-temporal, >= 2 a cacheable prefix of that many MB; default: the library's size rules")
     args = ap.parse_args()
     _claim_stdout()
 
@@ -444,6 +446,8 @@ def main():
     retr = xmamd.RETRACT_POLAR if args.retraction == "polar" else xmamd.RETRACT_QR
     xmamd.require_gpu()
     torch.cuda.set_device(local)
+    if args.stream_policy is not None:
+        xmamd._chk(xmamd.lib().xm_bench_dense_policy(args.stream_policy))
     wl = workload(args.workload)
     guard = _arm_guards(rank, ngp, args, wl["desc"]) if ngp > 1 else None
     try:

@@ -210,6 +210,9 @@ void launch_qw_dense(int o, int epi, const double *Q, int64_t ld, const double *
 // rowinfo (device, nloc entries, may be nullptr = camera order): the rows binned by their number of 16-block windows (bsr_build_rowinfo)
 void launch_qw_bsr3(int o, int epi, const int64_t *rowptr, const int32_t *colidx, const double *blocks, const double *W,
                     double alpha, const CamArgs &a, hipStream_t st, int64_t nb = 0, const int4 *rowinfo = nullptr);
+// sliced-ELL stream: bytes of its prefix that are read with the default cache policy (found in the Infinity Cache by the next product) when an
+// iteration moves `other` bytes besides the matrix; the rest streams non-temporally (xm_bench_dense_policy overrides the rule)
+int64_t sell_resident_bytes(int64_t stream, int64_t other);
 void bsr_build_rowinfo(const int64_t *rowptr_host, int nloc, std::vector<int4> &out);
 int qw_grid(int nloc);
 // the same product restricted to a range of column tiles (CamArgs.range_mode / t_lo / t_hi / addend); plain or gradient epilogue

@@ -77,6 +77,7 @@ struct SellArgs {   // what the kernels see
     int S;
     int wstride;           // doubles between camera records in the W the kernel reads (3 * pitch natively; 16 = one cache line per record)
     int coalesced_store;   // 1: partial results stored at slice * 64 + lane AND written as one contiguous run per slice (through LDS)
+    int64_t nt_off;        // slices whose stream offset (slice_off, in step units) is >= this are read non-temporally, the others with the default policy
 };
 
 class SellMatrix {
@@ -91,6 +92,7 @@ public:
                hipStream_t st, int codec = SELL_CODEC_FULL, int64_t row0 = 0);
     int codec() const { return codec_; }
     int64_t stream_bytes() const;   // bytes of block + index stream one product reads
+    int64_t nt_off(int o, int64_t nloc) const;   // SellArgs.nt_off of a rank-o product over nloc cameras (xm_sell.hip)
     SellArgs args() const;
     void refill(const int32_t *d_colidx, const double *d_blocks, hipStream_t st);   // values changed on the device (XM^2 re-weighting)
     double *parts(int o);

@@ -295,7 +295,18 @@ SellArgs SellMatrix::args() const {
     a.row0 = row0_;
     a.wstride = 0;   // set per rank by the launcher (wstride(o))
     a.coalesced_store = coalesced_ ? 1 : 0;
+    a.nt_off = 0;      // set per product by the launcher (nt_off(o, nloc))
     return a;
+}
+// Stream offset (in step units of 64 blocks) from which the main launch reads non-temporally.  Inside a solve the Infinity Cache is shared with
+// what an iteration moves besides the matrix -- the partial results (S records of 16 doubles per camera), about ten vectors of 3 x pitch doubles
+// per camera and the padded copy of W -- so the prefix of the stream that can stay from product to product is the cache's size minus that;
+// the rest is a pure stream (xm_bench_dense_policy overrides: 0 all cacheable, 1 all non-temporal, >= 2 a prefix of that many MB).
+int64_t SellMatrix::nt_off(int o, int64_t nloc) const {
+    const int64_t unit = 64 * (4 + 8 * (int64_t)(codec_ == SELL_CODEC_QUAT ? 4 : 9));
+    const int64_t vec = nloc * ((int64_t)S_ * 128 + 10 * 24 * (int64_t)pitch_of(o) + 128);
+    const int64_t prefix = sell_resident_bytes(stream_bytes(), vec);
+    return prefix >= stream_bytes() ? INT64_MAX : prefix / unit;
 }
 
 // Record pitch of W as the kernels see it: the native 3 x pitch_of(o) doubles, or 16 when the caller hands over a padded copy
@@ -334,22 +345,21 @@ struct SellBuf {   // one pipeline stage: two steps of blocks and the two gather
     d2u raw[2][(GM == 1) ? NPR : 1];
 };
 
-template <int O, int GM, int PIPE = 0, int CODEC = 0>   // GM 0: a record of W per lane | 1: records fetched element-per-lane, transposed through LDS.  PIPE 1: block loads run one pair ahead.  CODEC: SELL_CODEC_*
+// the stream's load policy is a compile-time property of the kernel (a hint picked by a branch next to a load is merged into one plain load):
+// NT = non-temporal -- a stream beyond the Infinity Cache; otherwise the default policy: the stream is found in the Infinity Cache / the L2s by
+// the next product (100 k cameras, quaternion codec, 204 MB: 82.7 -> 65.8 us; 60 k cameras, full blocks, 250 MB: 68.3 -> 55.0; 100 k, full
+// blocks, 402 MB: 110.1 non-temporal against 115.4; profiles/r06_kbench_sell_policy.txt).  The launcher applies the dense kernel's size rule.
+template <bool NT, class T>
+__device__ __forceinline__ T sell_ld(const T *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int O, int GM, int PIPE = 0, int CODEC = 0, bool NT = true>   // GM 0: a record of W per lane | 1: records fetched element-per-lane, transposed through LDS.  PIPE 1: block loads run one pair ahead.  CODEC: SELL_CODEC_*
 __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
-                                             double *__restrict__ parts) {
+                                             double *__restrict__ parts, double *lds, int c, int64_t off) {
     constexpr int OP = pitch_of(O), REC = 3 * OP, NPR = (REC + 1) / 2, RECP = (REC + 1) & ~1;
     constexpr int NQ = (CODEC == SELL_CODEC_QUAT) ? 4 : 9;   // doubles per stored block
-    // ONE transposition buffer per wavefront (the two steps of a pair go through it one after the other; transpose1 ends with a wavefront
-    // fence): 20 KB per workgroup at o = 3, 32 KB at o = 4 / 5 -- with one buffer per step (40 / 64 KB) the LDS, not the registers, capped
-    // the resident workgroups per CU (o = 4 / 5: two)
-    __shared__ __attribute__((aligned(16))) double lds[(GM != 0) ? 4 * 64 * RECP : 2];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int per = 8 / m.S;
-    const int x = blockIdx.x & 7, bi = blockIdx.x >> 3;
-    const int slab = x / per, sub = x - slab * per;
-    const int c = m.slab_start[slab] + (bi * per + sub) * 4 + wave;
-    if (c >= m.slab_start[slab + 1]) return;   // wave-uniform
-    const int64_t off = m.slice_off[c];
     const int w = (int)(m.slice_off[c + 1] - off);
     if (scal != nullptr) {   // the tCG's status word (an L2 miss: written by the previous cg_step) is waited for only after the slice look-ups
         if (scal->status != 0) return;   // have been requested
@@ -366,11 +376,11 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
 #pragma unroll
         for (int k = 0; k < O; ++k) acc[r][k] = 0.0;
 
-    auto load_cols = [&](int p) -> i2a { return __builtin_nontemporal_load(reinterpret_cast<const i2a *>(cb) + (size_t)p * 64 + lane); };
+    auto load_cols = [&](int p) -> i2a { return sell_ld<NT>(reinterpret_cast<const i2a *>(cb) + (size_t)p * 64 + lane); };
     auto load_blk = [&](int p, d2a (&q)[NQ]) {
         const d2a *b = reinterpret_cast<const d2a *>(bb) + (size_t)p * (64 * NQ) + lane;
 #pragma unroll
-        for (int e = 0; e < NQ; ++e) q[e] = __builtin_nontemporal_load(b + e * 64);
+        for (int e = 0; e < NQ; ++e) q[e] = sell_ld<NT>(b + e * 64);
     };
     // stored planes of one pair -> the two 3x3 blocks (codec 0: the planes ARE the blocks; quaternion codec: -R(q), 23 flops each)
     auto expand = [&](const d2a (&q)[NQ], double (&q0)[9], double (&q1)[9]) {
@@ -513,17 +523,17 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
         }
     }
     if (tail) {
-        const int jt = __builtin_nontemporal_load(cb + (size_t)np * 128 + lane);
+        const int jt = sell_ld<NT>(cb + (size_t)np * 128 + lane);
         double qt[9];
         const double *b = bb + (size_t)np * (128 * NQ) + lane;
         if constexpr (CODEC == SELL_CODEC_QUAT) {
             double t4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t4[e] = __builtin_nontemporal_load(b + e * 64);
+            for (int e = 0; e < 4; ++e) t4[e] = sell_ld<NT>(b + e * 64);
             quat_to_block(t4[0], t4[1], t4[2], t4[3], qt);
         } else {
 #pragma unroll
-            for (int e = 0; e < 9; ++e) qt[e] = __builtin_nontemporal_load(b + e * 64);
+            for (int e = 0; e < 9; ++e) qt[e] = sell_ld<NT>(b + e * 64);
         }
         if constexpr (GM == 0) {
             double wt[REC];
@@ -569,10 +579,29 @@ __device__ __forceinline__ void qw_sell_body(const SellArgs &m, const double *__
     }
 }
 
+// the slice of this wavefront, and which copy of the body streams it: slices whose stream offset lies below SellArgs.nt_off are read with the
+// default cache policy (a prefix of the stream that the Infinity Cache keeps from product to product), the rest non-temporally
+template <int O, int GM, int PIPE, int CODEC>
+__device__ __forceinline__ void qw_sell_entry(const SellArgs &m, const double *__restrict__ W, const TcgScal *__restrict__ scal, double *__restrict__ parts) {
+    constexpr int RECP = (3 * pitch_of(O) + 1) & ~1;
+    // ONE transposition buffer per wavefront (the two steps of a pair go through it one after the other; transpose1 ends with a wavefront
+    // fence): 20 KB per workgroup at o = 3, 32 KB at o = 4 / 5 -- with one buffer per step (40 / 64 KB) the LDS, not the registers, capped
+    // the resident workgroups per CU (o = 4 / 5: two)
+    __shared__ __attribute__((aligned(16))) double lds[(GM != 0) ? 4 * 64 * RECP : 2];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per = 8 / m.S;
+    const int x = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int slab = x / per, sub = x - slab * per;
+    const int c = m.slab_start[slab] + (bi * per + sub) * 4 + wave;
+    if (c >= m.slab_start[slab + 1]) return;   // wave-uniform
+    const int64_t off = m.slice_off[c];
+    if (off >= m.nt_off) qw_sell_body<O, GM, PIPE, CODEC, true>(m, W, scal, parts, lds, c, off);
+    else qw_sell_body<O, GM, PIPE, CODEC, false>(m, W, scal, parts, lds, c, off);
+}
 template <int O, int GM, int PIPE = 0, int CODEC = 0>
 __global__ __launch_bounds__(256) void qw_sell_kernel(SellArgs m, const double *__restrict__ W, const TcgScal *__restrict__ scal,
                                                        double *__restrict__ parts) {
-    qw_sell_body<O, GM, PIPE, CODEC>(m, W, scal, parts);
+    qw_sell_entry<O, GM, PIPE, CODEC>(m, W, scal, parts);
 }
 // quaternion codec at o = 3 compiled for FOUR wavefronts per SIMD (the blocks of a pair are 16 registers instead of 36), no software pipeline:
 // 81.9 us against 82.4 (two wavefronts, no pipeline) / 84.2 (block loads one pair ahead) at 100 k cameras (profiles/r03_kbench_sell.txt)
@@ -580,7 +609,7 @@ template <int GM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void qw_sell_kernel_q_occ4(SellArgs m, const double *__restrict__ W,
                                                                                                       const TcgScal *__restrict__ scal,
                                                                                                       double *__restrict__ parts) {
-    qw_sell_body<3, GM, 0, SELL_CODEC_QUAT>(m, W, scal, parts);
+    qw_sell_entry<3, GM, 0, SELL_CODEC_QUAT>(m, W, scal, parts);
 }
 
 // per camera: partial results added in list order (fixed -> bit-reproducible), then the common tail of the Q*W kernels
@@ -685,6 +714,7 @@ static void qw_sell_o(int epi, SellMatrix &m, const double *W, double alpha, con
         // Kernel variant by codec and rank (measured at 100 k cameras, profiles/r03_kbench_sell.txt).  Full blocks: the block loads run one
         // pair ahead at o = 3 (worth 2-3 us); beyond that the second block buffer costs the occupancy (o = 5: 256 VGPRs).  Quaternion
         // codec: four wavefronts per SIMD without software pipeline at o = 3, the plain body at o = 4, 5.
+        sa.nt_off = m.nt_off(O, a.nloc);
         if (quat) {
             if constexpr (O == 3) {
                 if (gm == 1) hipLaunchKernelGGL((qw_sell_kernel_q_occ4<1>), g, b, 0, st, sa, W, sc, parts);
@@ -719,6 +749,7 @@ void launch_qw_sell(int o, int epi, SellMatrix &m, const double *W, double alpha
         SellArgs sa = m.args();
         sa.wstride = 3;
         if (m.grid() > 0) {
+            sa.nt_off = m.nt_off(1, a.nloc);
             if (m.codec() == SELL_CODEC_QUAT) hipLaunchKernelGGL((qw_sell_kernel<1, 0, 0, SELL_CODEC_QUAT>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
             else hipLaunchKernelGGL((qw_sell_kernel<1, 0>), dim3(m.grid()), dim3(256), 0, st, sa, W, (const TcgScal *)nullptr, parts);
         }
