@@ -56,7 +56,7 @@ OUTERS=host scripts/trace_outer.sh $TAG > /dev/null 2>&1
 timeout 300 python scripts/stage_iters.py --gpu 2>&1 | grep -v amdgpu > $O/${TAG}_stage_iters.txt
 timeout 600 python bench.py --workload vg100k --storage vg --steps 6 --warmup 1 --no-rome --no-hbm-check --cpu-seconds 0 --model-recurrence 2>/dev/null | tail -1 > $O/${TAG}_bench_vg100k_vg_model_recurrence.json
 (python scripts/kbench_dense.py 1778 3 4 5 10; python scripts/kbench_dense.py 13682 3 4
- python scripts/kbench_bsr.py 13682 30 3 4 5
+ python scripts/kbench_bsr.py 13682 30 3 4 5 --policy --order; python scripts/kbench_bsr.py 30000 30 3 --policy --order; python scripts/kbench_bsr.py 66000 30 3 --policy
  python scripts/kbench_retract.py; python scripts/kbench_recover.py) > $O/${TAG}_kbench.txt 2>&1
 (python scripts/kbench_sell.py 100000 50 --o 3 4 5 --slabs 4 --gather 1 --codec 0 1 --no-csr
  python scripts/kbench_sell.py 100000 50 --o 3 4 5 --slabs 4 --gather 1 --codec 0 1 --no-csr --padded

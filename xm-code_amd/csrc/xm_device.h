@@ -48,6 +48,24 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// The same sum when only the first O lanes of the group hold non-zero values (the column-distributed epilogues: lane k < O owns column k, the
+// others contribute exact zeros) and the result is needed in those lanes only: a 16-lane group stops after the butterfly steps that cover O lanes
+// (O <= 4: the two quad steps) -- the steps left out would add zeros, so the bits are the same (up to the sign of a zero sum).  The block-CSR
+// kernel's Hessian epilogue makes 14 such sums per camera: 84 of its ~550 instructions per wavefront.
+// A whole wavefront per camera (GW = 64: dense products, the per-camera sum of the symmetric pair): the two quad steps and a broadcast of lane 0
+// instead of six steps -- these sums are a dependent chain at the very end of a launch (14 of them in the Hessian epilogue).
+template <int GW, int O>
+__device__ __forceinline__ double group_sum_cols(double v) {
+    if ((GW != 16 && GW != 64) || O > 4) return group_sum<GW>(v);
+    if (O > 1) v += dpp_mov<0xb1, 0xf>(v);
+    if (O > 2) v += dpp_mov<0x4e, 0xf>(v);
+    if (GW == 64) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), 0), hi = __builtin_amdgcn_readlane(__double2hiint(v), 0);
+        return __hiloint2double(hi, lo);
+    }
+    return v;
+}
+
 // sum over the 256 threads of a block; result valid in every thread.  `sh` must hold >= 4 doubles.
 __device__ __forceinline__ double block_sum256(double v, double *sh) {
     v = wave_sum(v);
@@ -165,13 +183,13 @@ __device__ __forceinline__ void store_col(const Col3 &c, double *base, int cam, 
 __device__ __forceinline__ double dot3(const Col3 &x, const Col3 &y) { return x.v[0] * y.v[0] + x.v[1] * y.v[1] + x.v[2] * y.v[2]; }
 
 // S = sym(A B^T) with A, B 3 x O blocks held column-per-lane: 9 wave reductions, result uniform across the wave
-template <int GW>
+template <int GW, int O>
 __device__ __forceinline__ void sym_abt(const Col3 &A, const Col3 &B, double (&S)[3][3]) {
     double M[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) M[a][b] = group_sum<GW>(A.v[a] * B.v[b]);
+        for (int b = 0; b < 3; ++b) M[a][b] = group_sum_cols<GW, O>(A.v[a] * B.v[b]);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -248,15 +266,15 @@ __device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const
     store_col<O>(h, o.G, cam, lane);
     // f = <C sR, sR> + lam * sum_{i>=1} (s_i^2-1)^2 ;  <C sR, sR> = 0.5 * <G, sR>
     const double q = s * s - 1.0;
-    const double hW = group_sum<GW>(dot3(h, Wl));
-    const double hR = group_sum<GW>(dot3(h, R));
+    const double hW = group_sum_cols<GW, O>(dot3(h, Wl));
+    const double hR = group_sum_cols<GW, O>(dot3(h, R));
     p0 = 0.5 * hW + (anchor ? 0.0 : a.lam * q * q);
     const double egs = anchor ? 0.0 : hR + 4.0 * a.lam * (q * s);
     Col3 eg;
 #pragma unroll
     for (int r = 0; r < 3; ++r) eg.v[r] = h.v[r] * s;
     double S0[3][3];
-    sym_abt<GW>(R, eg, S0);
+    sym_abt<GW, O>(R, eg, S0);
     sub_s_times(eg, S0, R);  // eg is now the Riemannian gradient column
     const double rgs = egs * (s * s);
     store_col<O>(eg, o.rgR, cam, lane);
@@ -270,7 +288,7 @@ __device__ __forceinline__ void epi_grad(int cam, int lane, const Col3 &h, const
         o.rgs[cam] = rgs;
     }
     const double rsds = rgs / s;
-    p1 = group_sum<GW>(dot3(eg, eg)) + rsds * rsds;
+    p1 = group_sum_cols<GW, O>(dot3(eg, eg)) + rsds * rsds;
 }
 
 // Hessian epilogue: trustregion.h:227-255 (ehess) + :277-295 (ehess2rhess) fused.  h = 2*C*(s.*Ru + su.*R) rows.
@@ -285,7 +303,7 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
     const Col3 &P = e.P;
     const Col3 &G = e.G;
     // hs = sum(CsRu.*R) + sum(CsR.*Ru) + 4 lam (3 s^2 - 1) su
-    const double hRGP = group_sum<GW>(dot3(h, R)) + group_sum<GW>(dot3(G, P));
+    const double hRGP = group_sum_cols<GW, O>(dot3(h, R)) + group_sum_cols<GW, O>(dot3(G, P));
     const double hs = anchor ? 0.0 : hRGP + 4.0 * a.lam * ((3.0 * s * s - 1.0) * ps);
     // hr = CsRu.*s + CsR.*su
     Col3 rh;
@@ -297,7 +315,7 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
 #pragma unroll
         for (int c = 0; c < 3; ++c) S0[r][c] = e.S0[r * 3 + c];
     sub_s_times(rh, S0, P);   // rhr = ehessR - Ru * sym(R' egradR)
-    sym_abt<GW>(R, rh, S1);
+    sym_abt<GW, O>(R, rh, S1);
     sub_s_times(rh, S1, R);   // rhr -= R * sym(R' rhr)
     const double rhs = anchor ? 0.0 : hs * (s * s) + (ps * s) * e.egs;
     store_col<O>(rh, a.HpR, cam, lane);
@@ -308,13 +326,13 @@ __device__ __forceinline__ void epi_hess(int cam, int lane, const Col3 &h, const
         for (int r = 0; r < 3; ++r) b.v[r] = s * rh.v[r] + rhs * R.v[r];
         store_col<O>(b, a.Bout, cam, lane);
     }
-    p0 = group_sum<GW>(dot3(P, rh)) + ps * (rhs / (s * s));
+    p0 = group_sum_cols<GW, O>(dot3(P, rh)) + ps * (rhs / (s * s));
     // <r,Hp> and <Hp,Hp> in the same metric: with them the residual norm after the CG step follows without a second
     // global reduction, |r + alpha Hp|^2 = <r,r> + 2 alpha <r,Hp> + alpha^2 <Hp,Hp>   (one flat kernel per iteration)
     const double rsv = anchor ? 0.0 : e.rs;
-    p1 = group_sum<GW>(dot3(e.Rr, rh)) + rsv * (rhs / (s * s));
+    p1 = group_sum_cols<GW, O>(dot3(e.Rr, rh)) + rsv * (rhs / (s * s));
     const double hq = rhs / s;
-    p2 = group_sum<GW>(dot3(rh, rh)) + hq * hq;
+    p2 = group_sum_cols<GW, O>(dot3(rh, rh)) + hq * hq;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
