@@ -403,9 +403,10 @@ def main():
     ap.add_argument("--no-rccl-leg", action="store_true", help="skip the second (RCCL) leg of a multi-GPU run")
     ap.add_argument("--sell", default="auto", choices=["auto", "on", "off"], help="sliced-ELL copy of block-sparse storage (xm_tuning_t.sell)")
     ap.add_argument("--model-recurrence", action="store_true", help="xm_options_t.flags |= XM_FLAG_MODEL_RECURRENCE: the tCG keeps no accumulated H v (default off: last bits of the model value differ)")
-    ap.add_argument("--outer", default="device", choices=["device", "host"],
-                    help="outer iteration of the trust region: device = decided on the GPU, the host only enqueues a repeating pair of launches (the library's "
-                         "default on one GPU with dense / block-CSR products); host = xm_options_t.flags |= XM_FLAG_HOST_OUTER (the form of rounds 1-5)")
+    ap.add_argument("--outer", default="auto", choices=["auto", "device", "host"],
+                    help="outer iteration of the trust region: auto = the library's choice (on the device with block-CSR products, on the host with dense "
+                         "ones: the measured faster form of each); device = xm_options_t.flags |= XM_FLAG_DEVICE_OUTER (decided on the GPU also with dense "
+                         "products; the host only enqueues a repeating pair of launches); host = XM_FLAG_HOST_OUTER (the form of rounds 1-5)")
     ap.add_argument("--sym-min-rows", type=int, default=0, help="rows (3n) from which an exactly symmetric dense Q is multiplied by the half-traffic "
                     "kernel (xm_tuning_t.sym_min_rows; 0 = the library's measured default)")
     ap.add_argument("--stream-policy", type=int, default=None, help="measurement aid (include/xm_bench.h: xm_bench_dense_policy): cache policy of the matrix "
@@ -579,7 +580,8 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
         if world > 1:
             dist.barrier()
 
-    mflag = (xmamd.FLAG_MODEL_RECURRENCE if args.model_recurrence else 0) | (xmamd.FLAG_HOST_OUTER if args.outer == "host" else 0)
+    mflag = ((xmamd.FLAG_MODEL_RECURRENCE if args.model_recurrence else 0) | (xmamd.FLAG_HOST_OUTER if args.outer == "host" else 0) |
+             (xmamd.FLAG_DEVICE_OUTER if args.outer == "device" else 0))
 
     def one_solve(flags=0, grouping=0):
         flags |= mflag
@@ -648,8 +650,10 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                    "max_rank": wl["max_rank"], "tol": wl["tol"], "lam": wl["lam"],
                    "retraction": args.retraction,
                    "outer_iteration": ("on the device (outer_step_kernel: retraction, accept / reject, radius, stop tests and the next tCG's start decided by the GPU; "
-                                       "the host enqueues one repeating (product, step) pair of launches ahead)" if (args.outer == "device" and ngp == 1)
-                                      else "on the host (XM_FLAG_HOST_OUTER or several ranks)"),
+                                       "the host enqueues one repeating (product, step) pair of launches ahead)" if last.get("outer_on_device")
+                                      else "on the host (the library's default with dense / sliced-ELL / matrix-free products and with several ranks: the host "
+                                           "notices the end of a truncated CG and confirms a speculatively started next one; XM_FLAG_DEVICE_OUTER / --outer device "
+                                           "moves it to the GPU for dense products, measured 1.5-2 % slower there)"),
                    **({"model_value": "from the CG recurrences (XM_FLAG_MODEL_RECURRENCE)"} if args.model_recurrence else {}),
                    "summation_groupings": "step i uses xm_options_t.sum_grouping = i mod 3; tcg_iters_by_step lists what each drew",
                    "parallelism": ("single GPU" if ngp == 1 else

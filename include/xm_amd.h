@@ -172,12 +172,18 @@ typedef struct {
                                      * exact arithmetic; the last bits of the model value, hence possibly the path, differ: default OFF */
 #define XM_FLAG_HOST_OUTER    64u   /* keep the outer iteration of the trust region on the HOST (the form of rounds 1-5: the host notices the end of a truncated
                                      * CG, enqueues retraction / candidate gradient / result kernel and confirms a speculatively started next tCG).  Default on
-                                     * one GPU with dense or block-CSR products (not: sliced ELL, matrix-free, several ranks, XM_FLAG_HOST_STEPPED; with XM_FLAG_VERBOSE a stage's progress lines appear when its trust region has ended)
+                                     * one GPU with block-CSR products -- and with dense products when XM_FLAG_DEVICE_OUTER asks for it -- (not: sliced ELL,
+                                     * matrix-free, several ranks, XM_FLAG_HOST_STEPPED; with XM_FLAG_VERBOSE a stage's progress lines appear when its trust region has ended)
                                      * is the DEVICE-driven form: everything trustregion.h:527-708 does between two truncated CGs (retraction, candidate's cost /
                                      * gradient, accept / reject, radius, stop tests, start of the next tCG) is decided on the device, the host enqueues one
                                      * repeating pair of launches ahead and watches a progress word.  Same decisions from the same numbers: bit-identical
                                      * paths in block-CSR storage; the dense products alternate their sweep direction by launch pair instead of by tCG
                                      * iteration, so dense paths differ in the last bits */
+#define XM_FLAG_DEVICE_OUTER 128u   /* the device-driven outer iteration also for DENSE products (one GPU), where the host-driven form is the default because
+                                     * it measures 1.5-2 % faster there (the role-switching product kernels are 0.3-0.8 us dearer per launch and the host-driven
+                                     * loop's round trips are hidden behind the speculative start of the next tCG: 41.7 against 42.4 us per tCG iteration on
+                                     * the Venice-1778-size problem); in block-CSR storage the device-driven form is the faster one (34.7 against 35.5 us at
+                                     * 13 682 cameras) and the default.  XM_FLAG_HOST_OUTER wins over this flag */
 #define XM_FLAG_WARM_R        16u   /* XM_MODE_REBUTTLE: start the rank-3 stage from opt.R_ini instead of the identity stack.  The reference
                                        reads R_ini.bin and then overwrites it with the identity (XM_main.cu:41,95-103); this flag honours it,
                                        which is what makes the second solve of the XM^2 loop cheap */
@@ -231,7 +237,8 @@ typedef struct {
     int64_t qw_stream_bytes;   /* bytes of Q one tCG product actually streams (== the matrix part of qw_bytes unless a compressed or
                                   symmetric path is used) */
     int32_t outer_on_device;   /* trust regions (rank levels) of this solve whose outer iteration was driven by the device (0: all by the host --
-                                  XM_FLAG_HOST_OUTER, or a configuration the device-driven form does not cover); appended in round 6 */
+                                  XM_FLAG_HOST_OUTER, dense products without XM_FLAG_DEVICE_OUTER, or a configuration the device-driven form does not
+                                  cover); appended in round 6 */
     int32_t reserved_;
 } xm_result_t;
 #define XM_CERT_EIG_NOT_CONVERGED 1   /* Lanczos hit its iteration cap: min_eig is only an upper bound, the certificate was NOT accepted on it */

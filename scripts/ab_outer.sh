@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the outer iteration on the device (default) against XM_FLAG_HOST_OUTER on ONE box, alternating: headline + Final-13682 block-CSR leg
+# A/B of the outer iteration on the device (bench.py --outer device: the library's default with block-CSR products) against the host-driven form (--outer host: its default with dense products) on ONE box, alternating: headline + Final-13682 block-CSR leg
 #   scripts/ab_outer.sh [rounds] > gpurun_out/<tag>_ab_outer.txt
 rounds=${1:-2}
 for r in $(seq 1 $rounds); do for o in host device; do

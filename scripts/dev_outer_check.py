@@ -1,4 +1,4 @@
-"""the device-driven outer iteration (default) against the host-driven one (XM_FLAG_HOST_OUTER): same problems solved both ways, results, iteration counts and time side by side
+"""the device-driven outer iteration (XM_FLAG_DEVICE_OUTER; the default with block-CSR products) against the host-driven one (XM_FLAG_HOST_OUTER; the default with dense products): same problems solved both ways, results, iteration counts and time side by side
    python scripts/dev_outer_check.py [quick]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 
 def cmp(name, ctx, max_rank, tol, lam, reps=1, extra=0, **kw):
     out = []
-    for fl in (extra | xmamd.FLAG_HOST_OUTER, extra):
+    for fl in (extra | xmamd.FLAG_HOST_OUTER, extra | xmamd.FLAG_DEVICE_OUTER):
         ctx.solve(max_rank, tol, lam, flags=fl, **kw)   # warm-up
         t0 = time.perf_counter()
         for _ in range(reps):

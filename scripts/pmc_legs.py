@@ -11,14 +11,14 @@ LEGS = {
     # the headline solve multiplies an exactly symmetric Q of 5334 rows through the half-traffic pair at rank 3 / 4 and through the general kernel
     # at rank 5 (xm_solver.h: sym_rows): per_product = the launch-count-weighted mean of the two kinds of product (MIX below)
     "venice": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-hbm-check", "--no-rome", "--no-kkt-pair"],
-               {"hess": ["qw_dense_kernel<", ", 4, 2, "], "main": ["qw_symv_kernel<"], "reduce": ["symv_reduce_kernel<", ", 4>"]},
-               "tCG products of the headline solve (outer iteration on the device: the role-switching instantiations, EPI_AUTO = 4 -- Hessian products "
-               "and, one per outer iteration, the candidate's gradient product: the same bytes): qw_symv_kernel + symv_reduce_kernel<o, EPI_AUTO> at "
-               "rank 3 / 4 (half-traffic symmetric pair), qw_dense_kernel<5, EPI_AUTO> at rank 5"),
+               {"hess": ["qw_dense_kernel<", ", 2, 2, "], "main": ["qw_symv_kernel<"], "reduce": ["symv_reduce_kernel<", ", 2>"]},
+               "Hessian products of the headline solve (dense products: outer iteration on the host, EPI_HESS = 2): qw_symv_kernel + "
+               "symv_reduce_kernel<o, EPI_HESS> at rank 3 / 4 (half-traffic symmetric pair; the main launch also serves the few gradient products), "
+               "qw_dense_kernel<5, EPI_HESS> at rank 5"),
     "hbm13682": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-rome"],
                  {"plain": ["qw_dense_kernel<3, 0, 2, false"]}, "roofline_hbm leg: qw_dense_kernel<3, EPI_PLAIN> on the 13.5 GB matrix (220 MB prefix cacheable, the rest a non-temporal stream)"),
     "rome_dense": (["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-hbm-check"],
-                   {"main": ["qw_symv_kernel<3"], "reduce": ["symv_reduce_kernel<3, 4"]},
+                   {"main": ["qw_symv_kernel<3"], "reduce": ["symv_reduce_kernel<3, 2"]},
                    "rome_scale_dense leg: Hessian products of the 13.5 GB dense Q through the half-traffic symmetric path (main + reduce launch)"),
     "rome_bsr": (["--workload", "final13682", "--storage", "bsr", "--steps", "1", "--warmup", "0", "--no-hbm-check", "--cpu-seconds", "0"],
                  {"hess": ["qw_bsr3_kernel<3, 4, 2"]},

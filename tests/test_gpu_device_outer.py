@@ -1,8 +1,9 @@
 """GPU tests of round 6's device-driven outer iteration (run with -m gpu on an MI355X), through the C ABI of libxm_amd.so.
 
 The trust region of trustregion.h:416-718 has two loops.  Since round 1 the inner one (truncated CG) runs without the host; since round 6 the
-outer one does too (xm_kernels.hip: outer_step_kernel, xm_solver.hip: Context::trust_region_device): the host enqueues one repeating pair of
-launches and watches a progress word.  XM_FLAG_HOST_OUTER keeps the round-5 form, which is what these tests compare with: the two forms
+outer one can too (xm_kernels.hip: outer_step_kernel, xm_solver.hip: Context::trust_region_device): the host enqueues one repeating pair of
+launches and watches a progress word -- the default with block-CSR products, on request (XM_FLAG_DEVICE_OUTER) with dense ones, where the
+host-driven form measures faster.  XM_FLAG_HOST_OUTER keeps the round-5 form, which is what these tests compare with: the two forms
 evaluate the same formulas on the same numbers, so in block-CSR storage (no sweep direction to alternate) they must agree BIT FOR BIT --
 solution, per-iteration trace, iteration counts, stop reason; dense products alternate their sweep direction by launch pair instead of by
 tCG iteration, there the two agree like two summation groupings do (same certified optimum, rotations <= 1e-6)."""
@@ -19,7 +20,7 @@ G = tl.GOLDEN
 
 
 def _both(ctx, xmamd, *a, flags=0, **kw):
-    dev = ctx.solve(*a, flags=flags, trace=2000, **kw)
+    dev = ctx.solve(*a, flags=flags | xmamd.FLAG_DEVICE_OUTER, trace=2000, **kw)   # (dense products run it on request only)
     host = ctx.solve(*a, flags=flags | xmamd.FLAG_HOST_OUTER, trace=2000, **kw)
     return dev, host
 
@@ -76,7 +77,7 @@ def test_device_outer_model_recurrence_and_stop_tests_in_block_csr(xmamd):
 
 @pytest.mark.parametrize("name", ["simple1", "simple2", "synth/dense49", "synth/vg60_cert", "synth/vg40_stair"])
 def test_device_outer_reaches_the_golden_optimum_in_dense_storage(xmamd, name):
-    """the five golden cases through the dense kernels, device-driven (default) and host-driven: rank, status, certified optimum (1e-9 of the
+    """the five golden cases through the dense kernels, device-driven (XM_FLAG_DEVICE_OUTER) and host-driven (the default for dense products): rank, status, certified optimum (1e-9 of the
     fixture), rotations within 1e-6 of each other; problems of one column tile have no sweep direction and agree bit for bit"""
     Q = tl.load_bin(os.path.join(G, name, "Q.bin")); exp = json.load(open(os.path.join(G, name, "expected.json")))
     ctx = xmamd.Context(Q=Q)
@@ -112,9 +113,10 @@ def test_device_outer_is_bit_reproducible(xmamd):
     index, and the pairs a solve needs are a function of its arithmetic)"""
     D = tl.gen_dense(356, seed=356)
     ctx = xmamd.Context(Q=D["Q"], tuning=dict(sym=1, sym_min_rows=256))
-    a = ctx.solve(5, 1e-6, 0.0, trace=2000)
-    b = ctx.solve(5, 1e-6, 0.0, trace=2000)
+    a = ctx.solve(5, 1e-6, 0.0, trace=2000, flags=xmamd.FLAG_DEVICE_OUTER)
+    b = ctx.solve(5, 1e-6, 0.0, trace=2000, flags=xmamd.FLAG_DEVICE_OUTER)
     ctx.close()
+    assert a[2]["outer_on_device"] >= 1
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2]["trace"], b[2]["trace"])
 
 
@@ -137,11 +139,20 @@ def test_host_driven_configurations_stay_on_the_host(xmamd):
     R3, s3, i3 = ctx.solve(4, 1e-8, 10.0)
     ctx.close()
     assert i3["outer_on_device"] == 0 and i3["status"] == 1 and tl.rotation_parity(R3, s3, R1, s1) < 1e-7
+    # dense products: host-driven by default (measured 1.5-2 % faster there), device-driven on request, host-driven when both flags are given
+    D = tl.gen_dense(60, seed=60)
+    ctx = xmamd.Context(Q=D["Q"])
+    i4 = ctx.solve(4, 1e-8, 0.0)[2]
+    i5 = ctx.solve(4, 1e-8, 0.0, flags=xmamd.FLAG_DEVICE_OUTER)[2]
+    i6 = ctx.solve(4, 1e-8, 0.0, flags=xmamd.FLAG_DEVICE_OUTER | xmamd.FLAG_HOST_OUTER)[2]
+    ctx.close()
+    assert i4["outer_on_device"] == 0 and i5["outer_on_device"] >= 1 and i6["outer_on_device"] == 0
+    assert i4["status"] == i5["status"] == 1 and i4["primal"] == pytest.approx(i5["primal"], rel=1e-9)
 
 
 def test_device_outer_at_baseline_sizes_vs_recorded_oracle(xmamd):
     """Final-13682 in block CSR, both forms bit-identical and within 1e-6 of the CPU oracle's recorded rotations; the headline's Venice-1778
-    is covered by test_venice1778_vs_recorded_oracle (default options = device-driven)"""
+    is covered by test_venice1778_vs_recorded_oracle (default options: dense products, host-driven)"""
     fj = os.path.join(G, "synth", "rome13682_oracle.json")
     if not os.path.exists(fj):
         pytest.skip("recorded oracle run not present")

@@ -829,7 +829,7 @@ def test_rome13682_dense_storage_vs_recorded_oracle(xmamd):
     # the time limit inside a device-driven trust region: the host raises a flag, the device looks at it where the reference looks at its
     # clock (top of an outer iteration, whole seconds: trustregion.h:540) -- with max_time = 0 that is the first boundary after one second of
     # this ~1 s solve, or never; either way a valid point of lower cost than the start comes back, and a run that was cut short says so
-    Rt, st, it = ctx.solve(3, 1e-30, c["lam"], max_time=0.0, trace=400)
+    Rt, st, it = ctx.solve(3, 1e-30, c["lam"], max_time=0.0, trace=400, flags=xmamd.FLAG_DEVICE_OUTER)
     ctx.close()
     assert it["outer_on_device"] == 1 and it["last_stop_reason"] in (5, 11) and it["primal"] < it["trace"][0, 0]
     if it["last_stop_reason"] == 11:

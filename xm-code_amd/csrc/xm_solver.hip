@@ -1144,6 +1144,9 @@ bool Context::device_outer_applies(int o) const {
     if (comm_->active() || symw_ || storage_ == XM_STORAGE_SCHUR || o < 3 || cfg_.debug_drop_finalize >= 0) return false;
     if (storage_ == XM_STORAGE_BSR3 && sell_ && sell_supports(o)) return false;   // (the sliced-ELL pair of launches has no EPI_AUTO form)
     if (storage_ == XM_STORAGE_DENSE && ks_ > 1) return false;
+    // dense products: the host-driven form is 1.5-2 % faster (profiles/r06_ab_outer.txt: 41.7 against 42.4 us per tCG iteration on the headline) --
+    // the device-driven one on request; block-CSR products: the device-driven form is the faster one (34.7 against 35.5 us at 13 682 cameras)
+    if (storage_ == XM_STORAGE_DENSE && !(opt_->flags & XM_FLAG_DEVICE_OUTER)) return false;
     return true;
 }
 

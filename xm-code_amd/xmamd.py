@@ -23,6 +23,7 @@ CERT_EIG_NOT_CONVERGED = 1
 CERT_EIG_EXACT = 2           # small problem: the certificate's tridiagonalisation ran to completion (dense route)
 FLAG_WARM_R = 16
 FLAG_HOST_OUTER = 64           # outer iteration of the trust region on the host instead of the device (xm_amd.h)
+FLAG_DEVICE_OUTER = 128        # ... on the device also with dense products, where the host-driven form is the (faster) default (xm_amd.h)
 FLAG_MODEL_RECURRENCE = 32     # model decrease of a tCG from its recurrences instead of from accumulated H v (xm_amd.h)
 
 EXPORTS = [
