@@ -282,6 +282,12 @@ void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int
 void launch_scale_copy(double *dst, const double *src, double a, int64_t len, hipStream_t st);
 void launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t st);   // bytes % 4 == 0; either side may be host-mapped memory
 void launch_lz_alpha(const double *c1j, const double *c2j, double *alpha_j, hipStream_t st);
+// the same Lanczos step in seven launches instead of eleven (the sums of the partial dots are taken inside the kernels that use them: same bits)
+void launch_dots_multi_parts(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *scratch, hipStream_t st);
+bool lz_fused_ok(int m);
+void launch_sub_vc_fin(double *w, const double *V, int64_t ldv, const double *parts, int m, int64_t len, double *c_out, const double *c_prev,
+                       double *alpha_j, hipStream_t st);
+void launch_lz_next_fin(double *dst, const double *w, const double *parts, double *beta_j, int64_t len, hipStream_t st);
 void launch_lz_next(double *dst, const double *w, const double *ww, double *beta_j, int64_t len, hipStream_t st);
 void launch_gemv_n(double *y, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st);  // y = V c
 

@@ -2014,6 +2014,40 @@ __global__ __launch_bounds__(256) void sub_vc_kernel(double *w, const double *__
         w[i] -= acc;
     }
 }
+// One Gram-Schmidt pass of a Lanczos step in TWO launches instead of three (+ the alpha kernel): dots_multi_seg_kernel leaves the per-segment partial
+// dots; this kernel adds them in segment order -- every workgroup for itself, into LDS: the sums of dots_multi_fin_kernel, bit for bit -- and
+// subtracts V c from w.  Workgroup 0 keeps the coefficients (c_out) and, in the second pass (c_prev != nullptr), writes alpha_j = c_prev[j] + c[j].
+// The Final-13682 certificate is 32 Lanczos steps of eleven launches at ~4-6 us each: launch-bound (profiles/r06_trace_summary_rome_bsr.txt).
+constexpr int kLzMaxCols = 1024;
+__global__ __launch_bounds__(256) void sub_vc_fin_kernel(double *w, const double *__restrict__ V, int64_t ldv, const double *__restrict__ part, int nseg,
+                                                          int m, int64_t len, double *c_out, const double *c_prev, double *alpha_j) {
+    __shared__ double cs[kLzMaxCols];
+    for (int j = threadIdx.x; j < m; j += 256) {
+        double t = 0.0;
+        for (int q = 0; q < nseg; ++q) t += part[(size_t)j * nseg + q];
+        cs[j] = t;
+        if (blockIdx.x == 0) {
+            c_out[j] = t;
+            if (c_prev != nullptr && j == m - 1) *alpha_j = c_prev[j] + t;
+        }
+    }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+        double acc = 0.0;
+        for (int j = 0; j < m; ++j) acc += V[(size_t)j * ldv + i] * cs[j];
+        w[i] -= acc;
+    }
+}
+// beta_j = sqrt(<w,w>) from the per-segment partial sums (added in segment order, as dots_multi_fin_kernel does), v_{j+1} = w / beta_j
+__global__ __launch_bounds__(256) void lz_next_fin_kernel(double *dst, const double *__restrict__ w, const double *__restrict__ part, int nseg, double *beta_j,
+                                                           int64_t len) {
+    double ww = 0.0;
+    for (int q = 0; q < nseg; ++q) ww += part[q];
+    const double beta = sqrt(fmax(ww, 0.0));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *beta_j = beta;
+    const double inv = (beta > 0.0) ? 1.0 / beta : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) dst[i] = w[i] * inv;
+}
 __global__ __launch_bounds__(256) void gemv_n_kernel(double *y, const double *__restrict__ V, int64_t ldv,
                                                       const double *__restrict__ c, int m, int64_t len) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
@@ -2856,6 +2890,26 @@ void launch_dots_multi(const double *V, int64_t ldv, int m, const double *w, int
         hipLaunchKernelGGL(dots_multi_fin_kernel, dim3((m + 255) / 256), dim3(256), 0, st, scratch, m, nseg, c);
     }
     check_launch("dots_multi");
+}
+// the per-segment partial dots only (scratch[m][nseg], nseg = dots_multi_segments(len)); the sums are taken by the kernels that use them
+void launch_dots_multi_parts(const double *V, int64_t ldv, int m, const double *w, int64_t len, double *scratch, hipStream_t st) {
+    if (m <= 0) return;
+    const int nseg = dots_multi_segments(len);
+    const int64_t seg = ((len + nseg - 1) / nseg + 255) / 256 * 256;
+    hipLaunchKernelGGL(dots_multi_seg_kernel, dim3(m, nseg), dim3(256), 0, st, V, ldv, w, len, seg, scratch);
+    check_launch("dots_multi_parts");
+}
+bool lz_fused_ok(int m) { return m <= kLzMaxCols; }
+// w -= V c with c = the sums of `parts` (launch_dots_multi_parts); c_out[0..m) keeps them; second pass: alpha_j = c_prev[m-1] + c[m-1]
+void launch_sub_vc_fin(double *w, const double *V, int64_t ldv, const double *parts, int m, int64_t len, double *c_out, const double *c_prev,
+                       double *alpha_j, hipStream_t st) {
+    if (m <= 0 || m > kLzMaxCols) throw Error(-2, "launch_sub_vc_fin: bad column count");
+    hipLaunchKernelGGL(sub_vc_fin_kernel, dim3(flat_grid(len)), dim3(256), 0, st, w, V, ldv, parts, dots_multi_segments(len), m, len, c_out, c_prev, alpha_j);
+    check_launch("sub_vc_fin");
+}
+void launch_lz_next_fin(double *dst, const double *w, const double *parts, double *beta_j, int64_t len, hipStream_t st) {
+    hipLaunchKernelGGL(lz_next_fin_kernel, dim3(flat_grid(len)), dim3(256), 0, st, dst, w, parts, dots_multi_segments(len), beta_j, len);
+    check_launch("lz_next_fin");
 }
 void launch_sub_vc(double *w, const double *V, int64_t ldv, const double *c, int m, int64_t len, hipStream_t st) {
     if (m <= 0) return;

@@ -1476,13 +1476,22 @@ int Context::lanczos_min(std::vector<double> &x_out, double &theta_out, int &ite
                 res_->qw_products++;
                 if (comm_->active()) comm_->allgather(w.p, (size_t)nloc_ * 3, st_);
                 // classical Gram-Schmidt twice against V(:,0..j); alpha_j = c1[j] + c2[j]; beta_j = |w|; v_{j+1} = w / beta_j
-                launch_dots_multi(V.p, len, j + 1, w.p, len, c.p, dscr.p, st_);
-                launch_sub_vc(w.p, V.p, len, c.p, j + 1, len, st_);
-                launch_dots_multi(V.p, len, j + 1, w.p, len, c2.p, dscr.p, st_);
-                launch_sub_vc(w.p, V.p, len, c2.p, j + 1, len, st_);
-                launch_lz_alpha(c.p + j, c2.p + j, ab.p + j, st_);
-                launch_dots_multi(w.p, len, 1, w.p, len, c.p + mmax + 1, dscr.p, st_);
-                launch_lz_next(V.p + (size_t)(j + 1) * len, w.p, c.p + mmax + 1, ab.p + (mmax + 1) + j, len, st_);
+                if (lz_fused_ok(j + 1)) {   // seven launches per step: the sums of the partial dots are taken by the kernels that use them (same bits)
+                    launch_dots_multi_parts(V.p, len, j + 1, w.p, len, dscr.p, st_);
+                    launch_sub_vc_fin(w.p, V.p, len, dscr.p, j + 1, len, c.p, nullptr, nullptr, st_);
+                    launch_dots_multi_parts(V.p, len, j + 1, w.p, len, dscr.p, st_);
+                    launch_sub_vc_fin(w.p, V.p, len, dscr.p, j + 1, len, c2.p, c.p, ab.p + j, st_);
+                    launch_dots_multi_parts(w.p, len, 1, w.p, len, dscr.p, st_);
+                    launch_lz_next_fin(V.p + (size_t)(j + 1) * len, w.p, dscr.p, ab.p + (mmax + 1) + j, len, st_);
+                } else {
+                    launch_dots_multi(V.p, len, j + 1, w.p, len, c.p, dscr.p, st_);
+                    launch_sub_vc(w.p, V.p, len, c.p, j + 1, len, st_);
+                    launch_dots_multi(V.p, len, j + 1, w.p, len, c2.p, dscr.p, st_);
+                    launch_sub_vc(w.p, V.p, len, c2.p, j + 1, len, st_);
+                    launch_lz_alpha(c.p + j, c2.p + j, ab.p + j, st_);
+                    launch_dots_multi(w.p, len, 1, w.p, len, c.p + mmax + 1, dscr.p, st_);
+                    launch_lz_next(V.p + (size_t)(j + 1) * len, w.p, c.p + mmax + 1, ab.p + (mmax + 1) + j, len, st_);
+                }
                 total++;
             }
             to_host(hab.data(), ab.p, hab.size() * sizeof(double));
