@@ -693,12 +693,13 @@ __global__ __launch_bounds__(256) void asym_kernel(const double *__restrict__ Q,
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// 3x3-block CSR Q*W: ONE 16-LANE GROUP (a DPP row) PER CAMERA ROW, ONE LANE PER STORED BLOCK.  The kernel is bound by the
-// dependent chain rowptr -> colidx -> gathered W rows, i.e. by how many camera rows are in flight, so a wavefront carries four
-// rows (16 per workgroup) instead of one; a lane fetches its column index, then (independently, all in flight together) its
-// 72-byte block and the 3 x O rows of W it multiplies and does the 9*O FMAs itself.  The blocks of a row are contiguous and
-// pass through LDS so that the global loads are perfectly coalesced (VAR 1; direct 72-byte-strided loads are 1.3x slower).
-// The row sums and the whole fused epilogue run inside the 16-lane row with four DPP steps per reduction.
+// 3x3-block CSR Q*W: ONE 16-LANE GROUP (a DPP row) PER CAMERA ROW, ONE LANE PER STORED BLOCK.  A wavefront carries four rows (16 per
+// workgroup); a lane fetches its column index, then (independently, all in flight together) its 72-byte block and the 3 x O rows of W
+// it multiplies and does the 9*O FMAs itself.  The blocks of a row are contiguous and pass through LDS so that the global loads are
+// perfectly coalesced (VAR 1; direct 72-byte-strided loads are 1.3x slower).  The row sums and the whole fused epilogue run inside the
+// 16-lane row with DPP steps.  What bounds it (round 6: per-wavefront timestamps, profiles/r06_kbench_bsr_trace.txt) is the CU's load
+// path -- ~45 cycles per 64-lane 16-byte load, the windows' loads queue whatever order they are issued in -- together with instruction
+// issue; rounds 1-5 had read it as a chain of dependent round trips (row pointers -> column indices -> gathered records).
 // ----------------------------------------------------------------------------------------------------------------
 
 #ifdef XM_BSR_TRACE
