@@ -22,7 +22,9 @@ int xm_qw_dense_sym_time(const double *dq, int64_t n, int o, const double *dW, d
  * launch instead of alternating it between consecutive products as the solver does; kf > 0 (with k > 0): the last quarter of the grid rows is cut
  * into chunks of kf steps whatever the size (the plan does that by itself only for sweeps of several residency rounds) */
 int xm_bench_symv_k(int k, int alternate, int kf);
-/* load policy of the dense stream in the micro-benchmarks: -1 = by size (the product's rule), 0 = default (cacheable), 1 = non-temporal */
+/* load policy of the matrix streams (dense, block-CSR, sliced ELL) in the micro-benchmarks and in solves of this process: -1 = by size (the
+ * products' rules), 0 = default (cacheable), 1 = non-temporal, n >= 2 = a cacheable prefix of n MB and the rest non-temporal, n <= -2 = a prefix of
+ * -n KB (mixed policies on the small matrices of the tests).  A cache hint only: results never depend on it (tests assert that) */
 int xm_bench_dense_policy(int nt);
 /* ONE traced launch of the sweep (o = 3 or 4, top-down): per wavefront `slots` 100 MHz timestamps -- [0] entry, [1] after the status word,
  * [2 + i] after step i, [slots - 3] loop done, [slots - 2] column sums written, [slots - 1] XCC_ID << 32 | HW_ID; trace_host = NULL: grid and slots only */

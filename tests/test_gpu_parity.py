@@ -152,6 +152,43 @@ def test_qw_sell_matches_dense(xmamd, oracle, n, deg, o, slabs, lmax, gather):
     assert tl.rel_fro(got, ref) < 1e-13 and np.array_equal(got, again) and tl.rel_fro(padded, ref) < 1e-13
 
 
+def test_stream_cache_policy_never_changes_a_result(xmamd):
+    """the matrix streams pick their cache policy by size (default below the Infinity Cache, non-temporal beyond, a cacheable prefix in
+    between); in the sliced-ELL and block-CSR kernels the two policies are two compiled copies of the loop under a uniform branch.  The test
+    matrices are small, so the rule never reaches the non-temporal copies: force every policy (xm_bench_dense_policy) -- all cacheable, all
+    non-temporal, a prefix that cuts the stream in the middle -- and compare bit for bit with the default.  Sliced ELL with full blocks and
+    with the quaternion codec, block CSR, dense (general kernel with a resident prefix)"""
+    import ctypes as C
+    L = xmamd.lib()
+    P = tl.gen_vg(3000, deg=24, sigma=0.3, seed=31)
+    W = np.random.default_rng(31).standard_normal((3 * 3000, 3))
+    D = tl.gen_dense(300, seed=7)
+    Wd = np.random.default_rng(8).standard_normal((900, 3))
+    def products():
+        out = []
+        for codec in (0, 1):
+            M = xmamd.SellMatrix(P["rowptr"], P["colidx"], P["blocks"], slabs=4, codec=codec)
+            out.append(M.qw(W, 1.0, gather=1)); out.append(M.qw(W, 1.0, gather=0)); M.close()
+        # block CSR through the timing hook: it knows the block count, as a solve does (the plain entry point does not and stays cacheable)
+        drp = xmamd.DevArray(P["rowptr"]); dci = xmamd.DevArray(P["colidx"]); dbl = xmamd.DevArray(P["blocks"].reshape(-1))
+        dW = xmamd.DevArray(xmamd.to_rm(W)); dO = xmamd.DevArray(np.full(3 * 3000 * 3, np.nan)); ms = C.c_double()
+        xmamd._chk(L.xm_qw_bsr3_time(drp.ptr, dci.ptr, dbl.ptr, 3000, 3, dW.ptr, dO.ptr, 1, C.byref(ms)))
+        out.append(xmamd.from_rm(dO.get(), 9000, 3))
+        for b in (drp, dci, dbl, dW, dO): b.free()
+        out.append(xmamd.qw_dense(D["Q"], Wd, 1.0))
+        return out
+    try:
+        ref = products()
+        for pol in (0, 1, -1024, -3000):     # (the sliced-ELL streams are ~9 MB / ~5 MB, the dense matrix 9 MB)
+            xmamd._chk(L.xm_bench_dense_policy(pol))
+            got = products()
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b), pol
+    finally:
+        xmamd._chk(L.xm_bench_dense_policy(-1))
+    assert tl.rel_fro(ref[0], tl.bsr_to_dense(3000, P["rowptr"], P["colidx"], P["blocks"]) @ W) < 1e-13
+
+
 def test_qw_sell_skewed_degrees_and_unsorted_rows(xmamd):
     """hub cameras (rows of ~n/4 blocks among rows of ~20: cut into virtual rows of <= lmax blocks, partial results added per camera),
     cameras without blocks, rows handed over in arbitrary column order; the block-CSR kernel runs the same skewed matrix"""

@@ -2441,6 +2441,7 @@ static int64_t qw_resident_bytes(size_t total_bytes) {      // bytes of the stre
     if (g_qw_nt_override == 0) return INT64_MAX;
     if (g_qw_nt_override == 1) return 0;
     if (g_qw_nt_override >= 2) return (int64_t)g_qw_nt_override << 20;
+    if (g_qw_nt_override <= -2) return (int64_t)(-g_qw_nt_override) << 10;   // (KB: mixed policies on the small matrices of the tests)
     return total_bytes <= ((size_t)310 << 20) ? INT64_MAX : (int64_t)kQwResidentMB << 20;
 }
 // sliced-ELL stream (xm_sell.hip): bytes of its prefix that stay cacheable when an iteration moves `other` bytes besides it
@@ -2449,6 +2450,7 @@ int64_t sell_resident_bytes(int64_t stream, int64_t other) {
     if (g_qw_nt_override == 0) return INT64_MAX;
     if (g_qw_nt_override == 1) return 0;
     if (g_qw_nt_override >= 2) return (int64_t)g_qw_nt_override << 20;
+    if (g_qw_nt_override <= -2) return (int64_t)(-g_qw_nt_override) << 10;
     return std::max<int64_t>(0, (kSellCacheBudgetMB << 20) - other);
 }
 static int qw_nt_cam0(int nloc, int64_t ld) {
