@@ -686,7 +686,7 @@ def _run(args, wl, tl, t0, Q, tkw, team, gpu_map, ngp, retr, rank, world, torch,
                      # what really moved, next to the contract's algorithmic figure: counter bytes per product / traced duration per product
                      "streamed": ({"bytes_per_product": traffic, "GBs": traffic / (traced_us * 1e-6) / 1e9, "frac": traffic / (traced_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                    "traced_frac_algorithmic": alg_bytes / (traced_us * 1e-6) / 1e9 / HBM_PEAK_GBS} if (traffic and traced_us) else None),
-                     "note": "HIP events around every 32nd tCG Q*W launch inside the timed solves (no-op samples dropped); " + (
+                     "note": "HIP events around every 64th tCG Q*W launch inside the timed solves (no-op samples dropped); " + (
                              "per-rank Q is %.0f MB, inside the 256 MB Infinity Cache: the figure is cache-assisted, see roofline_hbm for the "
                              "HBM-bound run of the same kernel" % (alg_bytes / 1e6) if alg_bytes < 250e6 else
                              "per-rank Q is %.0f MB, beyond the 256 MB Infinity Cache: HBM-bound" % (alg_bytes / 1e6))},

@@ -164,7 +164,7 @@ typedef struct {
 
 #define XM_FLAG_VERBOSE        1u   /* reference-style progress lines on stdout (trustregion.h:504, checkeig.h:317-337) */
 #define XM_FLAG_FIX_STALE_SR   2u   /* recompute sR after the escalation line search (reference does not, trustregion.h:394-422) */
-#define XM_FLAG_PROFILE_QW     4u   /* time every 32nd tCG Q*W launch with HIP events (result.qw_*) */
+#define XM_FLAG_PROFILE_QW     4u   /* time every 64th tCG Q*W launch with HIP events (result.qw_*) */
 #define XM_FLAG_HOST_STEPPED   8u   /* debugging: synchronise after every tCG iteration instead of run-ahead polling */
 #define XM_FLAG_MODEL_RECURRENCE 32u /* the model decrease of a truncated CG from its own recurrences (m -= step <r,r> - step^2 <p,Hp> / 2) instead of from the
                                      * accumulated vectors v, Hv as the reference forms it (trustregion.h:605-610, 667-668): the tCG neither reads nor writes

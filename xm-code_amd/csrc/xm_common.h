@@ -37,8 +37,9 @@ constexpr int kMaxInner = 1000;   // trustregion.h:416
 constexpr int kMaxOuter = 1000;   // trustregion.h:417
 // XM_FLAG_PROFILE_QW: every kProfileStride-th tCG product is bracketed by a pair of HIP events.  Each record is a barrier packet of its own: the
 // kernel trace shows ~6 us of idle queue in front of the product and again in front of the launch behind it (11.5 us per sample) -- with a
-// stride of 8 that was 1.4 us per tCG iteration, 3-5 % of the solve the measurement is about; 32 leaves 140 samples per headline solve
-constexpr int kProfileStride = 32;
+// stride of 8 that was 1.4 us per tCG iteration, 3-5 % of the solve the measurement is about; 32 was still 0.36 us (0.9 % of the headline's
+// 41 us per iteration); 64 leaves 70 samples per headline solve and 11 per Final-13682 solve (bench.py averages over six solves)
+constexpr int kProfileStride = 64;
 
 inline int64_t dense_ld(int64_t n_total) { return ((3 * n_total + kColPad - 1) / kColPad) * kColPad; }
 
